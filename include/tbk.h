@@ -1,0 +1,165 @@
+/* tbk.h -- C ABI of libtbk: the MI355X (gfx950) k-mesh tight-binding kernels.
+ *
+ * This is the drop-in boundary for PythTB's k-space hot path.  The reference
+ * (PythTB 1.8.0, one pure-Python file) has no FFI of its own, so each entry
+ * point below names the reference routine whose results it reproduces
+ * (file:line in /root/reference/pythtb.py).  The Python side that binds these
+ * with ctypes lives in pythtb_amd/_lib.py; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a TBK_E* code otherwise;
+ *     tbk_last_error() gives a thread-local message for the last failure.
+ *   - plain pointers and sizes only.  "c128" = interleaved (re,im) doubles.
+ *     Pointers are HOST pointers unless the parameter name ends in _dev.
+ *   - state index n = 2*orbital+spin for nspin=2 (the reshape of pythtb.py:933).
+ *   - a handle is bound to one device and one HIP stream; calls on a handle are
+ *     synchronous from the caller's view unless the name ends in _async.
+ *     Handles are not thread-safe (neither are the reference's objects).
+ */
+#ifndef TBK_H
+#define TBK_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBK_OK 0
+#define TBK_EINVAL 1   /* bad argument (shape, range, null)            */
+#define TBK_EHIP 2     /* a HIP runtime call failed                    */
+#define TBK_ENOMEM 3   /* device or host allocation failed             */
+#define TBK_EUNSUPPORTED 4 /* size outside what this build handles     */
+#define TBK_ECOMM 5    /* RCCL not loadable / communicator failure     */
+#define TBK_ENOCONV 6  /* an iterative kernel hit its sweep limit      */
+
+#define TBK_MAX_DIM 4      /* dim_k, dim_arr <= 4      (pythtb.py:99)   */
+#define TBK_MAX_NSTA 64    /* states per k in this build                */
+#define TBK_MAX_NOCC 16    /* bands in one Berry overlap matrix         */
+
+typedef struct tbk_ctx tbk_ctx;     /* device + stream + workspaces          */
+typedef struct tbk_model tbk_model; /* flattened hopping table on the device */
+typedef struct tbk_wfs tbk_wfs;     /* device-resident wf_array._wfs         */
+
+const char* tbk_last_error(void);
+int tbk_version(void);
+int tbk_device_count(int* count);
+
+/* ---- context -------------------------------------------------------- */
+int tbk_ctx_create(int device, tbk_ctx** out);
+int tbk_ctx_destroy(tbk_ctx* ctx);
+int tbk_ctx_sync(tbk_ctx* ctx);
+int tbk_ctx_device_info(tbk_ctx* ctx, char* name, int name_cap, int* compute_units,
+                        int64_t* hbm_bytes);
+
+/* raw device memory for callers that keep inputs/outputs resident (bench) */
+int tbk_dev_alloc(tbk_ctx* ctx, int64_t bytes, void** ptr_dev);
+int tbk_dev_free(tbk_ctx* ctx, void* ptr_dev);
+int tbk_dev_upload(tbk_ctx* ctx, void* dst_dev, const void* src, int64_t bytes);
+int tbk_dev_download(tbk_ctx* ctx, void* dst, const void* src_dev, int64_t bytes);
+
+/* HIP-event timing on the context's stream (the stream kernels run on).
+ * tbk_timer_*: one bracket around arbitrary calls.  tbk_prof_*: per-kernel
+ * brackets recorded inside the library around every launch while enabled. */
+int tbk_timer_begin(tbk_ctx* ctx);
+int tbk_timer_end(tbk_ctx* ctx, double* elapsed_ms);
+int tbk_prof_enable(tbk_ctx* ctx, int on);
+int tbk_prof_reset(tbk_ctx* ctx);
+int tbk_prof_count(tbk_ctx* ctx, int* n_kernels);
+int tbk_prof_get(tbk_ctx* ctx, int index, char* name, int name_cap, int64_t* launches,
+                 double* total_ms);
+
+/* ---- model tables (tb_model._site_energies/_hoppings, pythtb.py:171-180,
+ *      :475-478; consumed by _gen_ham :874-925) ------------------------ */
+/* orb:     norb x dim_k  reduced orbital coordinates, periodic components only
+ *          (_orb[:, _per], :912-914)
+ * onsite:  norb x nspin x nspin c128 (nspin=1: the real site energy as c128)
+ * hop_R:   nhop x dim_k  integer lattice vectors, periodic components only
+ * hop_amp: nhop x nspin x nspin c128 (the block of _val_to_block :517-560)  */
+int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, const double* orb,
+                     const double* onsite, int64_t nhop, const int32_t* hop_i,
+                     const int32_t* hop_j, const int32_t* hop_R, const double* hop_amp,
+                     tbk_model** out);
+int tbk_model_free(tbk_model* model);
+int tbk_model_info(tbk_model* model, int* dim_k, int* nsta, int64_t* nterm);
+
+/* ---- H(k) and eigen-solve ------------------------------------------- */
+/* _gen_ham (pythtb.py:874-925) for nk points: ham_out[nk][nsta][nsta] c128.
+ * k: nk x dim_k reduced coordinates (ignored when dim_k == 0).            */
+int tbk_gen_ham(tbk_model* model, const double* k, int64_t nk, double* ham_out);
+
+/* solve_all (pythtb.py:955-1079) = _gen_ham + _sol_ham (:927-953) fused:
+ * eval[nsta][nk] ascending per k; evec[nsta][nk][nsta] c128 (rows are
+ * eigenvectors, band-major) or NULL for eigenvalues only.                  */
+int tbk_solve_list(tbk_model* model, const double* k, int64_t nk, double* eval, double* evec);
+/* same, all buffers already on the device (no PCIe in the call)           */
+int tbk_solve_list_dev(tbk_model* model, const double* k_dev, int64_t nk, double* eval_dev,
+                       double* evec_dev);
+
+/* _sol_ham (pythtb.py:927-953) on caller-supplied Hermitian matrices
+ * ham[nk][n][n] c128 -> eval[n][nk], evec[n][nk][n] (or NULL).            */
+int tbk_eigh_batch(tbk_ctx* ctx, int n, const double* ham, int64_t nk, double* eval,
+                   double* evec);
+
+/* ---- wf_array storage (pythtb.py:2388-2419): _wfs[k1..kD][state][comp] */
+int tbk_wfs_create(tbk_ctx* ctx, int dim_arr, const int32_t* mesh, int nsta_arr, int ncomp,
+                   tbk_wfs** out);
+int tbk_wfs_free(tbk_wfs* wfs);
+int tbk_wfs_upload(tbk_wfs* wfs, const double* host_c128);
+int tbk_wfs_download(tbk_wfs* wfs, double* host_c128);
+int tbk_wfs_device_ptr(tbk_wfs* wfs, void** ptr_dev, int64_t* bytes);
+
+/* solve_on_grid (pythtb.py:2421-2532): every mesh point i_d < N_d-1 solved at
+ * start_k[d] + i_d/(N_d-1); the points with i_d == N_d-1 are the impose_pbc
+ * images (:2729-2747), produced in the same launch by solving k(i_d=0) again
+ * and multiplying by pbc_phase[d][comp] (c128, = exp(-2 pi i orb[:,per[d]])).
+ * min_gaps[nsta-1] = min over solved points of E[b+1]-E[b] (:2495,:2530).
+ * Slab form for k-sharding along mesh axis 0: the handle holds rows
+ * [row0, row0+mesh[0]) of a global mesh whose axis-0 size is global_n0
+ * (pass row0=0, global_n0=mesh[0] for the whole mesh).                     */
+int tbk_wfs_solve_grid(tbk_wfs* wfs, tbk_model* model, const double* start_k,
+                       const double* pbc_phase, int64_t row0, int64_t global_n0,
+                       double* min_gaps);
+/* Launch-only forms (no host synchronisation, no PCIe traffic): results stay
+ * in device buffers owned by the handle until the matching *_result call.  */
+int tbk_wfs_solve_grid_async(tbk_wfs* wfs, tbk_model* model, const double* start_k,
+                             const double* pbc_phase, int64_t row0, int64_t global_n0);
+int tbk_wfs_solve_grid_result(tbk_wfs* wfs, double* min_gaps);
+/* impose_pbc (:2674-2749) / impose_loop (:2751-2791) on a filled array:
+ * last slice along mesh_dir = first slice * phase[comp] (phase NULL: copy) */
+int tbk_wfs_impose(tbk_wfs* wfs, int mesh_dir, const double* phase_c128);
+
+/* ---- Berry quantities ----------------------------------------------- */
+/* berry_flux (pythtb.py:3068-3205) / _one_flux_plane (:3840-3865):
+ * plaquette phases on the (dir0,dir1) planes for bands occ[nocc].
+ * totals[n_slices]: sum over each plane (slices = remaining axes, row-major
+ * in original axis order).  plaq (nullable): [n_slices][N_dir0-1][N_dir1-1].
+ * The sum is a fixed-shape tree (no float atomics): bit-reproducible.       */
+int tbk_berry_flux(tbk_wfs* wfs, const int32_t* occ, int nocc, int dir0, int dir1,
+                   double* totals, double* plaq);
+
+int tbk_berry_flux_async(tbk_wfs* wfs, const int32_t* occ, int nocc, int dir0, int dir1,
+                         int want_plaq);
+int tbk_berry_flux_result(tbk_wfs* wfs, double* totals, double* plaq);
+
+/* berry_phase (pythtb.py:2863-3066) / _one_berry_loop (:3798-3838) for every
+ * string along `dir` (strings = remaining axes, row-major in original order).
+ * berry_evals == 0: out[n_strings]        = -arg det prod_i M_i
+ * berry_evals != 0: out[n_strings][nocc]  = sorted -arg eig prod_i polar(M_i)
+ * (the contin post-processing :3036-3065 is O(n_strings) host work).        */
+int tbk_berry_phase(tbk_wfs* wfs, const int32_t* occ, int nocc, int dir, int berry_evals,
+                    double* out);
+
+/* ---- multi-GPU: one process per GPU, k-points sharded, one gather ------
+ * Thin RCCL wrappers (librccl is dlopen'ed on first use).  The 128-byte id is
+ * created on rank 0 and distributed by the launcher (any out-of-band channel). */
+int tbk_comm_unique_id(unsigned char id_out[128]);
+int tbk_comm_init(tbk_ctx* ctx, const unsigned char id[128], int nranks, int rank);
+int tbk_comm_destroy(tbk_ctx* ctx);
+/* all ranks contribute count doubles from send_dev; recv_dev[nranks*count]   */
+int tbk_comm_allgather_f64(tbk_ctx* ctx, const double* send_dev, double* recv_dev,
+                           int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBK_H */

@@ -1,0 +1,747 @@
+// tbk_berry.hip -- Berry flux (plaquettes) and Berry phases (strings) on a
+// device-resident wf mesh, gfx950.
+//
+// Reproduces _wf_dpr (pythtb.py:3793-3796), _one_berry_loop (:3798-3838),
+// _one_flux_plane (:3840-3865) and the slicing of wf_array.berry_flux
+// (:3135-3202) / berry_phase (:2978-3029).
+//
+// Identities used (checked against the reference):
+//   det(M1 M2 ...) = det M1 * det M2 * ...      -> link determinants are scalars
+//   -angle(det prod) for a string / plaquette   -> one complex product, one atan2
+//   polar(M) = U Vh of svd(M)                   -> closed form (nocc<=2) or
+//                                                  one-sided Jacobi (nocc>2)
+// Ordered nocc x nocc products are split into per-thread segments and combined
+// in order (matrix products are associative, not commutative).
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include "tbk_internal.h"
+
+struct AxisSet {           // the axes that enumerate slices / strings
+    int n;                 // how many (<= 3)
+    int size[3];
+    int64_t stride[3];     // in mesh points
+};
+
+__device__ __forceinline__ int64_t axis_offset(const AxisSet& ax, int64_t s) {
+    int64_t off = 0;
+#pragma unroll
+    for (int a = 2; a >= 0; --a) {
+        if (a < ax.n) {
+            const int64_t q = s / ax.size[a];
+            off += (s - q * ax.size[a]) * ax.stride[a];
+            s = q;
+        }
+    }
+    return off;
+}
+
+// ---------------------------------------------------------------- overlaps
+// M_ab = <u_a(P) | u_b(Q)> over the ncomp components (pythtb.py:3815-3817)
+template <int NOCC>
+__device__ __forceinline__ void link_matrix(const cd* __restrict__ P, const cd* __restrict__ Q,
+                                            const int* occ, int ncomp, cd (&M)[NOCC][NOCC]) {
+#pragma unroll
+    for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+        for (int b = 0; b < NOCC; ++b) M[a][b] = cd{0.0, 0.0};
+    for (int o = 0; o < ncomp; ++o) {
+        cd pa[NOCC], qb[NOCC];
+#pragma unroll
+        for (int a = 0; a < NOCC; ++a) {
+            pa[a] = P[occ[a] * ncomp + o];
+            qb[a] = Q[occ[a] * ncomp + o];
+        }
+#pragma unroll
+        for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+            for (int b = 0; b < NOCC; ++b) cfmac(M[a][b], pa[a], qb[b]);
+    }
+}
+
+__device__ __forceinline__ cd det2(cd a, cd b, cd c, cd d) { return csub(cmul(a, d), cmul(b, c)); }
+
+template <int NOCC>
+__device__ __forceinline__ cd det_small(const cd (&M)[NOCC][NOCC]) {
+    if constexpr (NOCC == 1) {
+        return M[0][0];
+    } else if constexpr (NOCC == 2) {
+        return det2(M[0][0], M[0][1], M[1][0], M[1][1]);
+    } else if constexpr (NOCC == 3) {
+        cd d = cmul(M[0][0], det2(M[1][1], M[1][2], M[2][1], M[2][2]));
+        d = csub(d, cmul(M[0][1], det2(M[1][0], M[1][2], M[2][0], M[2][2])));
+        d = cadd(d, cmul(M[0][2], det2(M[1][0], M[1][1], M[2][0], M[2][1])));
+        return d;
+    } else {
+        // 4x4 through complementary 2x2 minors of rows (0,1) and (2,3)
+        auto top = [&](int i, int j) { return det2(M[0][i], M[0][j], M[1][i], M[1][j]); };
+        auto bot = [&](int i, int j) { return det2(M[2][i], M[2][j], M[3][i], M[3][j]); };
+        cd d = cmul(top(0, 1), bot(2, 3));
+        d = csub(d, cmul(top(0, 2), bot(1, 3)));
+        d = cadd(d, cmul(top(0, 3), bot(1, 2)));
+        d = cadd(d, cmul(top(1, 2), bot(0, 3)));
+        d = csub(d, cmul(top(1, 3), bot(0, 2)));
+        d = cadd(d, cmul(top(2, 3), bot(0, 1)));
+        return d;
+    }
+}
+
+// dynamic sizes: matrices live in per-thread local memory, row-major, leading dim n
+__device__ inline void link_matrix_dyn(const cd* __restrict__ P, const cd* __restrict__ Q, const int* occ,
+                                       int nocc, int ncomp, cd* M) {
+    for (int a = 0; a < nocc; ++a)
+        for (int b = 0; b < nocc; ++b) {
+            cd acc{0.0, 0.0};
+            const cd* pa = P + occ[a] * ncomp;
+            const cd* qb = Q + occ[b] * ncomp;
+            for (int o = 0; o < ncomp; ++o) cfmac(acc, pa[o], qb[o]);
+            M[a * nocc + b] = acc;
+        }
+}
+
+// determinant by LU with partial pivoting (destroys M)
+__device__ inline cd det_dyn(int n, cd* M) {
+    cd det{1.0, 0.0};
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        double best = cabs2(M[c * n + c]);
+        for (int r = c + 1; r < n; ++r) {
+            const double v = cabs2(M[r * n + c]);
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+        if (best == 0.0) return cd{0.0, 0.0};
+        if (piv != c) {
+            for (int j = c; j < n; ++j) {
+                const cd t = M[c * n + j];
+                M[c * n + j] = M[piv * n + j];
+                M[piv * n + j] = t;
+            }
+            det = cd{-det.x, -det.y};
+        }
+        const cd p = M[c * n + c];
+        det = cmul(det, p);
+        const double ip = 1.0 / cabs2(p);
+        const cd pinv{p.x * ip, -p.y * ip};
+        for (int r = c + 1; r < n; ++r) {
+            const cd f = cmul(M[r * n + c], pinv);
+            for (int j = c + 1; j < n; ++j) {
+                const cd s = cmul(f, M[c * n + j]);
+                M[r * n + j] = csub(M[r * n + j], s);
+            }
+        }
+    }
+    return det;
+}
+
+// unitary polar factor U Vh of svd(M) (pythtb.py:3825-3826) by one-sided
+// (Hestenes) Jacobi: G = M V with orthogonal columns, polar = sum_j g_j/|g_j| v_j^H.
+// G: in M, out W.  V, T: work.  All n x n row-major.
+__device__ inline void polar_dyn(int n, cd* G, cd* V, cd* T) {
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) V[a * n + b] = cd{a == b ? 1.0 : 0.0, 0.0};
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double alpha = 0.0, beta = 0.0;
+                cd gam{0.0, 0.0};
+                for (int r = 0; r < n; ++r) {
+                    const cd x = G[r * n + p], y = G[r * n + q];
+                    alpha += cabs2(x);
+                    beta += cabs2(y);
+                    cfmac(gam, x, y);
+                }
+                const double g2 = cabs2(gam);
+                if (g2 > 0.0 && g2 > 1.0e-31 * alpha * beta) {
+                    rotated = true;
+                    const double ga = sqrt(g2), inv = 1.0 / ga;
+                    const double tau = (beta - alpha) * (0.5 * inv);
+                    const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                    const cd sw{s * gam.x * inv, s * gam.y * inv};
+                    for (int r = 0; r < n; ++r) {
+                        cd x = G[r * n + p], y = G[r * n + q];
+                        G[r * n + p] = cd{c * x.x - (sw.x * y.x + sw.y * y.y), c * x.y - (sw.x * y.y - sw.y * y.x)};
+                        G[r * n + q] = cd{(sw.x * x.x - sw.y * x.y) + c * y.x, (sw.x * x.y + sw.y * x.x) + c * y.y};
+                        x = V[r * n + p];
+                        y = V[r * n + q];
+                        V[r * n + p] = cd{c * x.x - (sw.x * y.x + sw.y * y.y), c * x.y - (sw.x * y.y - sw.y * y.x)};
+                        V[r * n + q] = cd{(sw.x * x.x - sw.y * x.y) + c * y.x, (sw.x * x.y + sw.y * x.x) + c * y.y};
+                    }
+                }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < n; ++j) {
+        double nr = 0.0;
+        for (int r = 0; r < n; ++r) nr += cabs2(G[r * n + j]);
+        const double inv = nr > 0.0 ? 1.0 / sqrt(nr) : 0.0;
+        for (int r = 0; r < n; ++r) G[r * n + j] = cscale(G[r * n + j], inv);
+    }
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            cd acc{0.0, 0.0};
+            for (int j = 0; j < n; ++j) cfma(acc, G[a * n + j], cconj(V[b * n + j]));
+            T[a * n + b] = acc;
+        }
+    for (int e = 0; e < n * n; ++e) G[e] = T[e];
+}
+
+// closed-form 2x2 polar factor: W = M (M^+M)^(-1/2),
+//   (P)^(-1/2) = adj(P + s I) / (s t),  s = |det M|,  t = sqrt(tr P + 2 s)
+__device__ __forceinline__ void polar2(cd (&M)[2][2]) {
+    const cd dm = det2(M[0][0], M[0][1], M[1][0], M[1][1]);
+    const double s = sqrt(cabs2(dm));
+    const double a = cabs2(M[0][0]) + cabs2(M[1][0]);
+    const double d = cabs2(M[0][1]) + cabs2(M[1][1]);
+    cd b{0.0, 0.0};
+    cfmac(b, M[0][0], M[0][1]);
+    cfmac(b, M[1][0], M[1][1]);
+    const double t = sqrt(a + d + 2.0 * s);
+    if (!(s * t > 1.0e-280)) {  // singular overlap: fall back to the Jacobi SVD path
+        cd G[4] = {M[0][0], M[0][1], M[1][0], M[1][1]}, V[4], T[4];
+        polar_dyn(2, G, V, T);
+        M[0][0] = G[0]; M[0][1] = G[1]; M[1][0] = G[2]; M[1][1] = G[3];
+        return;
+    }
+    const double inv = 1.0 / (s * t);
+    const cd cb = cconj(b);
+    const cd w00 = csub(cscale(M[0][0], d + s), cmul(M[0][1], cb));
+    const cd w01 = csub(cscale(M[0][1], a + s), cmul(M[0][0], b));
+    const cd w10 = csub(cscale(M[1][0], d + s), cmul(M[1][1], cb));
+    const cd w11 = csub(cscale(M[1][1], a + s), cmul(M[1][0], b));
+    M[0][0] = cscale(w00, inv);
+    M[0][1] = cscale(w01, inv);
+    M[1][0] = cscale(w10, inv);
+    M[1][1] = cscale(w11, inv);
+}
+
+// eigenvalues of a general complex n x n matrix (destroys H): Householder
+// Hessenberg reduction, then explicit single-shift QR (all unitary similarities).
+// Returns false if an eigenvalue needs more than 60 iterations.
+__device__ inline bool eigvals_dyn(int n, cd* H, cd* ev, cd* rc, cd* rs) {
+    auto cdiv = [](cd a, cd b) {
+        const double ib = 1.0 / cabs2(b);
+        return cd{(a.x * b.x + a.y * b.y) * ib, (a.y * b.x - a.x * b.y) * ib};
+    };
+    auto csqrt_ = [](cd z) {
+        const double r = sqrt(cabs2(z));
+        if (r == 0.0) return cd{0.0, 0.0};
+        double re = sqrt(0.5 * (r + fabs(z.x)));
+        double im = 0.5 * z.y / re;
+        if (z.x < 0.0) {
+            const double t = re;
+            re = fabs(im);
+            im = copysign(t, z.y);
+        }
+        return cd{re, im};
+    };
+    // Householder reduction to Hessenberg form: unitary similarity, so a normal
+    // (here: unitary) matrix stays normal and repeated eigenvalues stay well
+    // conditioned.  rc[] doubles as the reflector until the QR phase starts.
+    for (int m = 0; m < n - 2; ++m) {
+        double nr2 = 0.0;
+        for (int i = m + 1; i < n; ++i) nr2 += cabs2(H[i * n + m]);
+        const cd x0 = H[(m + 1) * n + m];
+        if (nr2 - cabs2(x0) == 0.0) continue;
+        const double nr = sqrt(nr2), ax = sqrt(cabs2(x0));
+        const cd ph = ax > 0.0 ? cscale(x0, 1.0 / ax) : cd{1.0, 0.0};
+        for (int i = m + 1; i < n; ++i) rc[i] = H[i * n + m];
+        rc[m + 1] = cadd(x0, cscale(ph, nr));
+        double vn2 = 0.0;
+        for (int i = m + 1; i < n; ++i) vn2 += cabs2(rc[i]);
+        const double beta = 2.0 / vn2;
+        for (int j = 0; j < n; ++j) {  // H <- (I - beta v v^H) H
+            cd dot{0.0, 0.0};
+            for (int i = m + 1; i < n; ++i) cfmac(dot, rc[i], H[i * n + j]);
+            dot = cscale(dot, beta);
+            for (int i = m + 1; i < n; ++i) H[i * n + j] = csub(H[i * n + j], cmul(rc[i], dot));
+        }
+        for (int r = 0; r < n; ++r) {  // H <- H (I - beta v v^H)
+            cd dot{0.0, 0.0};
+            for (int i = m + 1; i < n; ++i) cfma(dot, H[r * n + i], rc[i]);
+            dot = cscale(dot, beta);
+            for (int i = m + 1; i < n; ++i) H[r * n + i] = csub(H[r * n + i], cmul(dot, cconj(rc[i])));
+        }
+    }
+    cd shift{0.0, 0.0};
+    int en = n - 1, its = 0;
+    bool ok = true;
+    while (en >= 0) {
+        int l = en;
+        for (; l > 0; --l) {
+            const double sub = fabs(H[l * n + l - 1].x) + fabs(H[l * n + l - 1].y);
+            // diagonal entries carry the accumulated explicit shift
+            const cd d0 = cadd(H[(l - 1) * n + l - 1], shift), d1 = cadd(H[l * n + l], shift);
+            const double dsum = fabs(d0.x) + fabs(d0.y) + fabs(d1.x) + fabs(d1.y);
+            if (sub <= 2.3e-16 * dsum || sub == 0.0) break;
+        }
+        if (l == en) {
+            ev[en] = cadd(H[en * n + en], shift);
+            --en;
+            its = 0;
+            continue;
+        }
+        if (its >= 60) {
+            ok = false;
+            ev[en] = cadd(H[en * n + en], shift);
+            --en;
+            its = 0;
+            continue;
+        }
+        cd s;
+        if (its == 10 || its == 20 || its == 40) {
+            s = cd{fabs(H[en * n + en - 1].x) + (en >= 2 ? fabs(H[(en - 1) * n + en - 2].x) : 0.0), 0.0};
+        } else {  // Wilkinson shift from the trailing 2x2
+            s = H[en * n + en];
+            const cd x = cmul(H[(en - 1) * n + en], H[en * n + en - 1]);
+            if (x.x != 0.0 || x.y != 0.0) {
+                const cd y = cscale(csub(H[(en - 1) * n + en - 1], s), 0.5);
+                cd z = csqrt_(cadd(cmul(y, y), x));
+                if (y.x * z.x + y.y * z.y < 0.0) z = cd{-z.x, -z.y};
+                s = csub(s, cdiv(x, cadd(y, z)));
+            }
+        }
+        for (int i = 0; i <= en; ++i) H[i * n + i] = csub(H[i * n + i], s);
+        shift = cadd(shift, s);
+        ++its;
+        // QR sweep on the active block [l,en]: R = G..G (H - sI), H' = R G^H..G^H
+        for (int i = l + 1; i <= en; ++i) {
+            const cd a = H[(i - 1) * n + i - 1], b = H[i * n + i - 1];
+            const double nr = sqrt(cabs2(a) + cabs2(b));
+            cd c{1.0, 0.0}, sn{0.0, 0.0};
+            if (nr > 0.0) {
+                c = cscale(a, 1.0 / nr);
+                sn = cscale(b, 1.0 / nr);
+            }
+            rc[i] = c;
+            rs[i] = sn;
+            for (int j = i - 1; j <= en; ++j) {
+                const cd u = H[(i - 1) * n + j], v = H[i * n + j];
+                H[(i - 1) * n + j] = cadd(cmulc(c, u), cmulc(sn, v));   // conj(c) u + conj(s) v
+                H[i * n + j] = csub(cmul(c, v), cmul(sn, u));           // -s u + c v
+            }
+        }
+        for (int i = l + 1; i <= en; ++i) {
+            const cd c = rc[i], sn = rs[i];
+            const int top = i + 1 <= en ? i + 1 : en;
+            for (int r = l; r <= top; ++r) {
+                const cd u = H[r * n + i - 1], v = H[r * n + i];
+                H[r * n + i - 1] = cadd(cmul(u, c), cmul(v, sn));       // u c + v s
+                H[r * n + i] = csub(cmul(v, cconj(c)), cmul(u, cconj(sn)));  // -conj(s) u + conj(c) v
+            }
+        }
+    }
+    return ok;
+}
+
+// ---------------------------------------------------------------- flux
+struct FluxArgs {
+    WfsView v;
+    int nocc;
+    int occ[TBK_MAX_NOCC];
+    int n0, n1;        // plaquettes along dir0, dir1
+    int64_t s0, s1;    // point strides of dir0, dir1
+    AxisSet other;     // slice axes
+    int bps;           // blocks per slice
+    double* plaq;      // nullable [nslices][n0][n1]
+    double* partial;   // [nslices][bps]
+};
+
+template <int NOCC, int MAXN>
+__device__ __forceinline__ cd one_link_det(const cd* P, const cd* Q, const int* occ, int nocc, int ncomp) {
+    if constexpr (NOCC > 0) {
+        cd M[NOCC][NOCC];
+        link_matrix<NOCC>(P, Q, occ, ncomp, M);
+        return det_small<NOCC>(M);
+    } else {
+        cd M[MAXN * MAXN];
+        link_matrix_dyn(P, Q, occ, nocc, ncomp, M);
+        return det_dyn(nocc, M);
+    }
+}
+
+// F(i,j) = -arg[ det<00|10> det<10|11> det<11|01> det<01|00> ]  (pythtb.py:3852-3863)
+template <int NOCC, int MAXN>
+__global__ __launch_bounds__(256) void k_flux(const FluxArgs A) {
+    const int slice = blockIdx.x / A.bps;
+    const int blk = blockIdx.x - slice * A.bps;
+    const unsigned p = (unsigned)blk * 256u + threadIdx.x;
+    const unsigned per = (unsigned)A.n0 * (unsigned)A.n1;
+    double pha = 0.0;
+    if (p < per) {
+        const unsigned i = p / (unsigned)A.n1, j = p - i * (unsigned)A.n1;
+        const int per_pt = A.v.nsta * A.v.ncomp;
+        const int64_t base = axis_offset(A.other, slice) + (int64_t)i * A.s0 + (int64_t)j * A.s1;
+        const cd* u00 = A.v.data + base * per_pt;
+        const cd* u10 = u00 + A.s0 * per_pt;
+        const cd* u01 = u00 + A.s1 * per_pt;
+        const cd* u11 = u10 + A.s1 * per_pt;
+        cd d = one_link_det<NOCC, MAXN>(u00, u10, A.occ, A.nocc, A.v.ncomp);
+        d = cmul(d, one_link_det<NOCC, MAXN>(u10, u11, A.occ, A.nocc, A.v.ncomp));
+        d = cmul(d, one_link_det<NOCC, MAXN>(u11, u01, A.occ, A.nocc, A.v.ncomp));
+        d = cmul(d, one_link_det<NOCC, MAXN>(u01, u00, A.occ, A.nocc, A.v.ncomp));
+        pha = -atan2(d.y, d.x);
+        if (A.plaq) A.plaq[(int64_t)slice * per + p] = pha;
+    }
+    // fixed-shape block sum (bit-reproducible: no atomics)
+    __shared__ double red[4];
+    double s = pha;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) A.partial[(int64_t)slice * A.bps + blk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one block per slice: ordered strided sums, then a fixed tree
+__global__ __launch_bounds__(256) void k_flux_reduce(const double* __restrict__ partial, int bps,
+                                                     double* __restrict__ totals) {
+    const double* p = partial + (int64_t)blockIdx.x * bps;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < bps; i += 256) s += p[i];
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = red[0];
+}
+
+static int fill_occ(const tbk_wfs* w, const int32_t* occ, int nocc, int* dst) {
+    TBK_REQUIRE(occ && nocc >= 1, TBK_EINVAL, "occ must list at least one state");
+    TBK_REQUIRE(nocc <= TBK_MAX_NOCC, TBK_EUNSUPPORTED, "nocc=%d exceeds this build's limit of %d", nocc, TBK_MAX_NOCC);
+    for (int i = 0; i < nocc; ++i) {
+        TBK_REQUIRE(occ[i] >= 0 && occ[i] < w->view.nsta, TBK_EINVAL, "occ[%d]=%d outside 0..%d", i, occ[i],
+                    w->view.nsta - 1);
+        dst[i] = occ[i];
+    }
+    return TBK_OK;
+}
+
+static void other_axes(const WfsView& v, int skip0, int skip1, AxisSet* ax, int64_t* count) {
+    ax->n = 0;
+    *count = 1;
+    for (int a = 0; a < 3; ++a) {
+        ax->size[a] = 1;
+        ax->stride[a] = 0;
+    }
+    for (int d = 0; d < v.dim_arr; ++d) {
+        if (d == skip0 || d == skip1) continue;
+        ax->size[ax->n] = v.mesh[d];
+        ax->stride[ax->n] = v.stride[d];
+        ax->n++;
+        *count *= v.mesh[d];
+    }
+}
+
+template <int NOCC, int MAXN>
+static void launch_flux(tbk_ctx* ctx, const FluxArgs& A, int64_t nslices) {
+    hipLaunchKernelGGL((k_flux<NOCC, MAXN>), dim3((unsigned)(nslices * A.bps)), dim3(256), 0, ctx->stream, A);
+}
+
+extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, int dir0, int dir1,
+                                    int want_plaq) {
+    TBK_REQUIRE(w, TBK_EINVAL, "tbk_berry_flux: null wfs");
+    const WfsView& v = w->view;
+    // pythtb.py:3126-3130
+    TBK_REQUIRE(dir0 != dir1, TBK_EINVAL, "Need to specify two different directions for Berry flux calculation.");
+    TBK_REQUIRE(dir0 >= 0 && dir1 >= 0 && dir0 < v.dim_arr && dir1 < v.dim_arr, TBK_EINVAL,
+                "Direction for Berry flux calculation out of bounds.");
+    FluxArgs A{};
+    int rc = fill_occ(w, occ, nocc, A.occ);
+    if (rc) return rc;
+    tbk_ctx* ctx = w->ctx;
+    TBK_HIP(hipSetDevice(ctx->device));
+    A.v = v;
+    A.nocc = nocc;
+    A.n0 = v.mesh[dir0] - 1;
+    A.n1 = v.mesh[dir1] - 1;
+    A.s0 = v.stride[dir0];
+    A.s1 = v.stride[dir1];
+    int64_t nslices = 1;
+    other_axes(v, dir0, dir1, &A.other, &nslices);
+    const int64_t per = (int64_t)A.n0 * A.n1;
+    TBK_REQUIRE(per < (int64_t)0xffffffffu, TBK_EUNSUPPORTED, "plane of %lld plaquettes is too large", (long long)per);
+    A.bps = (int)((per + 255) / 256);
+    TBK_REQUIRE(nslices * A.bps < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many plaquette blocks");
+    if (w->flux_nslices < nslices) {
+        if (w->flux_totals_dev) TBK_HIP(hipFree(w->flux_totals_dev));
+        w->flux_totals_dev = nullptr;
+        TBK_HIP(hipMalloc((void**)&w->flux_totals_dev, nslices * sizeof(double)));
+    }
+    w->flux_nslices = nslices;
+    if (w->flux_partial_cap < nslices * A.bps) {
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (w->flux_partial_dev) TBK_HIP(hipFree(w->flux_partial_dev));
+        w->flux_partial_dev = nullptr;
+        TBK_HIP(hipMalloc((void**)&w->flux_partial_dev, nslices * A.bps * sizeof(double)));
+        w->flux_partial_cap = nslices * A.bps;
+    }
+    w->flux_plaq_n = 0;
+    if (want_plaq) {
+        if (w->flux_plaq_cap < nslices * per) {
+            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            if (w->flux_plaq_dev) TBK_HIP(hipFree(w->flux_plaq_dev));
+            w->flux_plaq_dev = nullptr;
+            hipError_t e = hipMalloc((void**)&w->flux_plaq_dev, nslices * per * sizeof(double));
+            if (e != hipSuccess) {
+                w->flux_plaq_cap = 0;
+                tbk_set_error("tbk_berry_flux: plaquette buffer of %lld doubles: %s", (long long)(nslices * per),
+                              hipGetErrorString(e));
+                return TBK_ENOMEM;
+            }
+            w->flux_plaq_cap = nslices * per;
+        }
+        w->flux_plaq_n = nslices * per;
+        A.plaq = w->flux_plaq_dev;
+    }
+    A.partial = w->flux_partial_dev;
+    {
+        ProfScope ps(ctx, "berry_flux");
+        switch (nocc) {
+            case 1: launch_flux<1, 1>(ctx, A, nslices); break;
+            case 2: launch_flux<2, 1>(ctx, A, nslices); break;
+            case 3: launch_flux<3, 1>(ctx, A, nslices); break;
+            case 4: launch_flux<4, 1>(ctx, A, nslices); break;
+            default:
+                if (nocc <= 8) launch_flux<0, 8>(ctx, A, nslices);
+                else launch_flux<0, TBK_MAX_NOCC>(ctx, A, nslices);
+        }
+        TBK_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps(ctx, "flux_reduce");
+        hipLaunchKernelGGL(k_flux_reduce, dim3((unsigned)nslices), dim3(256), 0, ctx->stream,
+                           (const double*)w->flux_partial_dev, A.bps, w->flux_totals_dev);
+        TBK_HIP(hipGetLastError());
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_berry_flux_result(tbk_wfs* w, double* totals, double* plaq) {
+    TBK_REQUIRE(w && totals, TBK_EINVAL, "tbk_berry_flux_result: null argument");
+    TBK_REQUIRE(w->flux_nslices > 0, TBK_EINVAL, "tbk_berry_flux_result: no flux launch pending");
+    tbk_ctx* ctx = w->ctx;
+    TBK_HIP(hipMemcpyAsync(totals, w->flux_totals_dev, w->flux_nslices * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    if (plaq) {
+        TBK_REQUIRE(w->flux_plaq_n > 0, TBK_EINVAL, "tbk_berry_flux_result: plaquettes were not requested");
+        TBK_HIP(hipMemcpyAsync(plaq, w->flux_plaq_dev, w->flux_plaq_n * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    }
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    return TBK_OK;
+}
+
+extern "C" int tbk_berry_flux(tbk_wfs* w, const int32_t* occ, int nocc, int dir0, int dir1, double* totals,
+                              double* plaq) {
+    int rc = tbk_berry_flux_async(w, occ, nocc, dir0, dir1, plaq != nullptr);
+    if (rc) return rc;
+    return tbk_berry_flux_result(w, totals, plaq);
+}
+
+// ---------------------------------------------------------------- strings
+struct ChainArgs {
+    WfsView v;
+    int nocc;
+    int occ[TBK_MAX_NOCC];
+    int nlinks;        // mesh[dir]-1
+    int64_t sdir;      // point stride along dir
+    AxisSet other;     // string axes (original order)
+    int64_t nstrings;
+    int seg_len, nseg;
+    cd* partial;       // det: [nseg][nstrings]; evals: [nseg][nstrings][nocc*nocc]
+    double* out;       // det: [nstrings]; evals: [nstrings][nocc]
+    int* flags;
+};
+
+// ordered product over one segment of one string
+template <int NOCC, int MAXN, bool EVALS>
+__global__ __launch_bounds__(256) void k_chain_partial(const ChainArgs A) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= A.nstrings * A.nseg) return;
+    const int64_t seg = t / A.nstrings, s = t - seg * A.nstrings;
+    const int per_pt = A.v.nsta * A.v.ncomp;
+    const int i0 = (int)seg * A.seg_len;
+    const int i1 = min(i0 + A.seg_len, A.nlinks);
+    const cd* P = A.v.data + (axis_offset(A.other, s) + (int64_t)i0 * A.sdir) * per_pt;
+    const int64_t step = A.sdir * per_pt;
+    const int nocc = A.nocc, ncomp = A.v.ncomp;
+    if constexpr (!EVALS) {
+        cd acc{1.0, 0.0};
+        for (int i = i0; i < i1; ++i, P += step)
+            acc = cmul(acc, one_link_det<NOCC, MAXN>(P, P + step, A.occ, nocc, ncomp));
+        A.partial[seg * A.nstrings + s] = acc;
+    } else if constexpr (NOCC == 1) {
+        cd acc{1.0, 0.0};
+        for (int i = i0; i < i1; ++i, P += step) {
+            cd M[1][1];
+            link_matrix<1>(P, P + step, A.occ, ncomp, M);
+            const double r = sqrt(cabs2(M[0][0]));
+            acc = cmul(acc, r > 0.0 ? cscale(M[0][0], 1.0 / r) : cd{1.0, 0.0});
+        }
+        A.partial[seg * A.nstrings + s] = acc;
+    } else if constexpr (NOCC == 2) {
+        cd R[2][2] = {{cd{1.0, 0.0}, cd{0.0, 0.0}}, {cd{0.0, 0.0}, cd{1.0, 0.0}}};
+        for (int i = i0; i < i1; ++i, P += step) {
+            cd M[2][2];
+            link_matrix<2>(P, P + step, A.occ, ncomp, M);
+            polar2(M);
+            cd T[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) T[a][b] = cadd(cmul(R[a][0], M[0][b]), cmul(R[a][1], M[1][b]));
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) R[a][b] = T[a][b];
+        }
+        cd* o = A.partial + (seg * A.nstrings + s) * 4;
+        o[0] = R[0][0]; o[1] = R[0][1]; o[2] = R[1][0]; o[3] = R[1][1];
+    } else {
+        cd R[MAXN * MAXN], M[MAXN * MAXN], V[MAXN * MAXN], T[MAXN * MAXN];
+        for (int a = 0; a < nocc; ++a)
+            for (int b = 0; b < nocc; ++b) R[a * nocc + b] = cd{a == b ? 1.0 : 0.0, 0.0};
+        for (int i = i0; i < i1; ++i, P += step) {
+            link_matrix_dyn(P, P + step, A.occ, nocc, ncomp, M);
+            polar_dyn(nocc, M, V, T);
+            for (int a = 0; a < nocc; ++a)
+                for (int b = 0; b < nocc; ++b) {
+                    cd acc{0.0, 0.0};
+                    for (int j = 0; j < nocc; ++j) cfma(acc, R[a * nocc + j], M[j * nocc + b]);
+                    T[a * nocc + b] = acc;
+                }
+            for (int e = 0; e < nocc * nocc; ++e) R[e] = T[e];
+        }
+        cd* o = A.partial + (seg * A.nstrings + s) * (int64_t)(nocc * nocc);
+        for (int e = 0; e < nocc * nocc; ++e) o[e] = R[e];
+    }
+}
+
+// combine the segments of each string in order and finish
+template <int MAXN, bool EVALS>
+__global__ __launch_bounds__(64) void k_chain_final(const ChainArgs A) {
+    const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= A.nstrings) return;
+    const int nocc = A.nocc;
+    if constexpr (!EVALS) {
+        cd acc{1.0, 0.0};
+        for (int g = 0; g < A.nseg; ++g) acc = cmul(acc, A.partial[(int64_t)g * A.nstrings + s]);
+        A.out[s] = -atan2(acc.y, acc.x);   // -angle(det(prd))   (pythtb.py:3829-3831)
+    } else {
+        if (nocc == 1) {
+            cd acc{1.0, 0.0};
+            for (int g = 0; g < A.nseg; ++g) acc = cmul(acc, A.partial[(int64_t)g * A.nstrings + s]);
+            A.out[s] = -atan2(acc.y, acc.x);
+            return;
+        }
+        cd R[MAXN * MAXN], T[MAXN * MAXN], ev[MAXN], rc[MAXN], rs[MAXN];
+        const int nn = nocc * nocc;
+        for (int e = 0; e < nn; ++e) R[e] = A.partial[s * nn + e];
+        for (int g = 1; g < A.nseg; ++g) {
+            const cd* M = A.partial + ((int64_t)g * A.nstrings + s) * nn;
+            for (int a = 0; a < nocc; ++a)
+                for (int b = 0; b < nocc; ++b) {
+                    cd acc{0.0, 0.0};
+                    for (int j = 0; j < nocc; ++j) cfma(acc, R[a * nocc + j], M[j * nocc + b]);
+                    T[a * nocc + b] = acc;
+                }
+            for (int e = 0; e < nn; ++e) R[e] = T[e];
+        }
+        if (!eigvals_dyn(nocc, R, ev, rc, rs)) atomicExch(A.flags + 1, 1);
+        // sort(-angle(eigvals))   (pythtb.py:3834-3838)
+        double* o = A.out + s * nocc;
+        for (int j = 0; j < nocc; ++j) {
+            const double ph = -atan2(ev[j].y, ev[j].x);
+            int pos = j;
+            while (pos > 0 && o[pos - 1] > ph) {
+                o[pos] = o[pos - 1];
+                --pos;
+            }
+            o[pos] = ph;
+        }
+    }
+}
+
+extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir, int berry_evals, double* out) {
+    TBK_REQUIRE(w && out, TBK_EINVAL, "tbk_berry_phase: null argument");
+    const WfsView& v = w->view;
+    TBK_REQUIRE(dir >= 0 && dir < v.dim_arr, TBK_EINVAL, "Wrong direction for Berry phase calculation!");
+    ChainArgs A{};
+    int rc = fill_occ(w, occ, nocc, A.occ);
+    if (rc) return rc;
+    tbk_ctx* ctx = w->ctx;
+    TBK_HIP(hipSetDevice(ctx->device));
+    A.v = v;
+    A.nocc = nocc;
+    A.nlinks = v.mesh[dir] - 1;
+    A.sdir = v.stride[dir];
+    other_axes(v, dir, -1, &A.other, &A.nstrings);
+    // segment length: enough threads to fill the chip, segments no shorter than 8 links
+    const int64_t target = (int64_t)ctx->cus * 1024;
+    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + 7) / 8, target / std::max<int64_t>(A.nstrings, 1)));
+    A.seg_len = (int)((A.nlinks + nseg - 1) / nseg);
+    A.nseg = (A.nlinks + A.seg_len - 1) / A.seg_len;
+    const bool ev = berry_evals != 0;
+    const int64_t per = ev ? (int64_t)nocc * nocc : 1;
+    const int64_t nout = A.nstrings * (ev ? nocc : 1);
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t pb = al((size_t)A.nseg * A.nstrings * per * sizeof(cd));
+    const size_t ob = al((size_t)nout * sizeof(double));
+    void* base = nullptr;
+    rc = tbk_ctx_scratch(ctx, pb + ob, &base);
+    if (rc) return rc;
+    A.partial = (cd*)base;
+    A.out = (double*)((unsigned char*)base + pb);
+    A.flags = ctx->flags_dev;
+    const int64_t nthreads = A.nstrings * A.nseg;
+    const dim3 grid((unsigned)((nthreads + 255) / 256)), blk(256);
+    {
+        ProfScope ps(ctx, ev ? "chain_partial_evals" : "chain_partial_det");
+        if (!ev) {
+            switch (nocc) {
+                case 1: hipLaunchKernelGGL((k_chain_partial<1, 1, false>), grid, blk, 0, ctx->stream, A); break;
+                case 2: hipLaunchKernelGGL((k_chain_partial<2, 1, false>), grid, blk, 0, ctx->stream, A); break;
+                case 3: hipLaunchKernelGGL((k_chain_partial<3, 1, false>), grid, blk, 0, ctx->stream, A); break;
+                case 4: hipLaunchKernelGGL((k_chain_partial<4, 1, false>), grid, blk, 0, ctx->stream, A); break;
+                default:
+                    if (nocc <= 8) hipLaunchKernelGGL((k_chain_partial<0, 8, false>), grid, blk, 0, ctx->stream, A);
+                    else hipLaunchKernelGGL((k_chain_partial<0, TBK_MAX_NOCC, false>), grid, blk, 0, ctx->stream, A);
+            }
+        } else {
+            if (nocc == 1) hipLaunchKernelGGL((k_chain_partial<1, 1, true>), grid, blk, 0, ctx->stream, A);
+            else if (nocc == 2) hipLaunchKernelGGL((k_chain_partial<2, 1, true>), grid, blk, 0, ctx->stream, A);
+            else if (nocc <= 4) hipLaunchKernelGGL((k_chain_partial<0, 4, true>), grid, blk, 0, ctx->stream, A);
+            else if (nocc <= 8) hipLaunchKernelGGL((k_chain_partial<0, 8, true>), grid, blk, 0, ctx->stream, A);
+            else hipLaunchKernelGGL((k_chain_partial<0, TBK_MAX_NOCC, true>), grid, blk, 0, ctx->stream, A);
+        }
+        TBK_HIP(hipGetLastError());
+    }
+    {
+        ProfScope ps(ctx, "chain_final");
+        const dim3 g2((unsigned)((A.nstrings + 63) / 64)), b2(64);
+        if (!ev) hipLaunchKernelGGL((k_chain_final<1, false>), g2, b2, 0, ctx->stream, A);
+        else if (nocc <= 4) hipLaunchKernelGGL((k_chain_final<4, true>), g2, b2, 0, ctx->stream, A);
+        else if (nocc <= 8) hipLaunchKernelGGL((k_chain_final<8, true>), g2, b2, 0, ctx->stream, A);
+        else hipLaunchKernelGGL((k_chain_final<TBK_MAX_NOCC, true>), g2, b2, 0, ctx->stream, A);
+        TBK_HIP(hipGetLastError());
+    }
+    int flag = 0;
+    TBK_HIP(hipMemcpyAsync(out, A.out, (size_t)nout * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipMemcpyAsync(&flag, ctx->flags_dev + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        TBK_HIP(hipMemsetAsync(ctx->flags_dev + 1, 0, sizeof(int), ctx->stream));
+        tbk_set_error("tbk_berry_phase: QR iteration for Wilson-loop eigenvalues did not converge");
+        return TBK_ENOCONV;
+    }
+    return TBK_OK;
+}

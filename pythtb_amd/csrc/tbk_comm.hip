@@ -1,0 +1,97 @@
+// tbk_comm.hip -- one process per GPU, one gather: thin RCCL wrappers.
+//
+// k-points shard with no data-path collective (every k, plaquette and string is
+// computed from local data; slabs recompute their one halo row).  The only
+// exchange is the final gather of eigenvalues / phases / partial flux sums,
+// done with ncclAllGather over xGMI.  librccl is dlopen'ed on first use so a
+// single-GPU user never loads it.
+#include <dlfcn.h>
+#include <string.h>
+#include "tbk_internal.h"
+
+namespace {
+typedef struct { char internal[128]; } nccl_uid;
+typedef int (*fn_get_uid)(nccl_uid*);
+typedef int (*fn_init_rank)(void** comm, int nranks, nccl_uid id, int rank);
+typedef int (*fn_destroy)(void* comm);
+typedef int (*fn_allgather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t s);
+typedef const char* (*fn_errstr)(int);
+
+struct Rccl {
+    void* lib = nullptr;
+    fn_get_uid get_uid = nullptr;
+    fn_init_rank init_rank = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_allgather allgather = nullptr;
+    fn_errstr errstr = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.lib) return TBK_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (const char* n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    TBK_REQUIRE(lib, TBK_ECOMM, "cannot load librccl.so: %s", dlerror());
+    g_rccl.get_uid = (fn_get_uid)dlsym(lib, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
+    g_rccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
+    g_rccl.allgather = (fn_allgather)dlsym(lib, "ncclAllGather");
+    g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+    TBK_REQUIRE(g_rccl.get_uid && g_rccl.init_rank && g_rccl.destroy && g_rccl.allgather, TBK_ECOMM,
+                "librccl.so lacks an expected symbol");
+    g_rccl.lib = lib;
+    return TBK_OK;
+}
+const char* nccl_msg(int rc) { return g_rccl.errstr ? g_rccl.errstr(rc) : "?"; }
+}  // namespace
+
+extern "C" int tbk_comm_unique_id(unsigned char id_out[128]) {
+    TBK_REQUIRE(id_out, TBK_EINVAL, "tbk_comm_unique_id: null id");
+    int rc = load_rccl();
+    if (rc) return rc;
+    nccl_uid id;
+    memset(&id, 0, sizeof(id));
+    const int nrc = g_rccl.get_uid(&id);
+    TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclGetUniqueId: %s", nccl_msg(nrc));
+    memcpy(id_out, &id, 128);
+    return TBK_OK;
+}
+
+extern "C" int tbk_comm_init(tbk_ctx* ctx, const unsigned char id[128], int nranks, int rank) {
+    TBK_REQUIRE(ctx && id && nranks >= 1 && rank >= 0 && rank < nranks, TBK_EINVAL, "tbk_comm_init: bad argument");
+    TBK_REQUIRE(!ctx->comm, TBK_EINVAL, "tbk_comm_init: communicator already initialised");
+    int rc = load_rccl();
+    if (rc) return rc;
+    TBK_HIP(hipSetDevice(ctx->device));
+    nccl_uid uid;
+    memcpy(&uid, id, 128);
+    void* comm = nullptr;
+    const int nrc = g_rccl.init_rank(&comm, nranks, uid, rank);
+    TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, nccl_msg(nrc));
+    ctx->comm = comm;
+    return TBK_OK;
+}
+
+extern "C" int tbk_comm_destroy(tbk_ctx* ctx) {
+    TBK_REQUIRE(ctx, TBK_EINVAL, "tbk_comm_destroy: null ctx");
+    if (ctx->comm && g_rccl.destroy) {
+        (void)hipStreamSynchronize(ctx->stream);
+        g_rccl.destroy(ctx->comm);
+    }
+    ctx->comm = nullptr;
+    return TBK_OK;
+}
+
+extern "C" int tbk_comm_allgather_f64(tbk_ctx* ctx, const double* send_dev, double* recv_dev, int64_t count) {
+    TBK_REQUIRE(ctx && ctx->comm, TBK_ECOMM, "tbk_comm_allgather_f64: communicator not initialised");
+    TBK_REQUIRE(send_dev && recv_dev && count >= 0, TBK_EINVAL, "tbk_comm_allgather_f64: bad argument");
+    const int nccl_float64 = 8;  // ncclDouble
+    const int nrc = g_rccl.allgather(send_dev, recv_dev, (size_t)count, nccl_float64, ctx->comm, ctx->stream);
+    TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclAllGather: %s", nccl_msg(nrc));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    return TBK_OK;
+}

@@ -1,0 +1,488 @@
+// tbk_core.hip -- contexts, device memory, timing, model flattening, wf storage.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <new>
+#include "tbk_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void tbk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* tbk_last_error(void) { return g_err; }
+extern "C" int tbk_version(void) { return 100; }
+
+extern "C" int tbk_device_count(int* count) {
+    TBK_REQUIRE(count, TBK_EINVAL, "tbk_device_count: null argument");
+    TBK_HIP(hipGetDeviceCount(count));
+    return TBK_OK;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int tbk_ctx_create(int device, tbk_ctx** out) {
+    TBK_REQUIRE(out, TBK_EINVAL, "tbk_ctx_create: null out");
+    int n = 0;
+    TBK_HIP(hipGetDeviceCount(&n));
+    TBK_REQUIRE(device >= 0 && device < n, TBK_EINVAL, "tbk_ctx_create: device %d of %d", device, n);
+    TBK_HIP(hipSetDevice(device));
+    tbk_ctx* c = new (std::nothrow) tbk_ctx();
+    TBK_REQUIRE(c, TBK_ENOMEM, "tbk_ctx_create: out of host memory");
+    c->device = device;
+    hipDeviceProp_t prop;
+    TBK_HIP(hipGetDeviceProperties(&prop, device));
+    c->cus = prop.multiProcessorCount;
+    TBK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    TBK_HIP(hipEventCreate(&c->timer0));
+    TBK_HIP(hipEventCreate(&c->timer1));
+    TBK_HIP(hipMalloc((void**)&c->flags_dev, 64 * sizeof(int)));
+    TBK_HIP(hipMemsetAsync(c->flags_dev, 0, 64 * sizeof(int), c->stream));
+    TBK_HIP(hipStreamSynchronize(c->stream));
+    *out = c;
+    return TBK_OK;
+}
+
+extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
+    if (!c) return TBK_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->comm) tbk_comm_destroy(c);
+    for (auto& r : c->prof_pending) {
+        hipEventDestroy(r.t0);
+        hipEventDestroy(r.t1);
+    }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    if (c->scratch) hipFree(c->scratch);
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->flags_dev) hipFree(c->flags_dev);
+    hipEventDestroy(c->timer0);
+    hipEventDestroy(c->timer1);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return TBK_OK;
+}
+
+extern "C" int tbk_ctx_sync(tbk_ctx* c) {
+    TBK_REQUIRE(c, TBK_EINVAL, "tbk_ctx_sync: null ctx");
+    TBK_HIP(hipStreamSynchronize(c->stream));
+    return TBK_OK;
+}
+
+extern "C" int tbk_ctx_device_info(tbk_ctx* c, char* name, int cap, int* cus, int64_t* hbm) {
+    TBK_REQUIRE(c, TBK_EINVAL, "tbk_ctx_device_info: null ctx");
+    hipDeviceProp_t prop;
+    TBK_HIP(hipGetDeviceProperties(&prop, c->device));
+    if (name && cap > 0) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
+    return TBK_OK;
+}
+
+int tbk_ctx_scratch(tbk_ctx* c, size_t bytes, void** out) {
+    if (bytes > c->scratch_bytes) {
+        TBK_HIP(hipStreamSynchronize(c->stream));
+        if (c->scratch) TBK_HIP(hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratch_bytes = 0;
+        size_t want = std::max(bytes, (size_t)1 << 20);
+        hipError_t e = hipMalloc(&c->scratch, want);
+        if (e != hipSuccess) {
+            tbk_set_error("device scratch of %zu bytes: %s", want, hipGetErrorString(e));
+            return TBK_ENOMEM;
+        }
+        c->scratch_bytes = want;
+    }
+    *out = c->scratch;
+    return TBK_OK;
+}
+
+int tbk_ctx_pinned(tbk_ctx* c, size_t bytes, void** out) {
+    if (bytes > c->pinned_bytes) {
+        TBK_HIP(hipStreamSynchronize(c->stream));
+        if (c->pinned) TBK_HIP(hipHostFree(c->pinned));
+        c->pinned = nullptr;
+        size_t want = std::max(bytes, (size_t)1 << 16);
+        TBK_HIP(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+        c->pinned_bytes = want;
+    }
+    *out = c->pinned;
+    return TBK_OK;
+}
+
+extern "C" int tbk_dev_alloc(tbk_ctx* c, int64_t bytes, void** p) {
+    TBK_REQUIRE(c && p && bytes >= 0, TBK_EINVAL, "tbk_dev_alloc: bad argument");
+    TBK_HIP(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(p, (size_t)std::max<int64_t>(bytes, 16));
+    if (e != hipSuccess) {
+        tbk_set_error("hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+        return TBK_ENOMEM;
+    }
+    return TBK_OK;
+}
+extern "C" int tbk_dev_free(tbk_ctx* c, void* p) {
+    TBK_REQUIRE(c, TBK_EINVAL, "tbk_dev_free: null ctx");
+    if (p) {
+        TBK_HIP(hipStreamSynchronize(c->stream));
+        TBK_HIP(hipFree(p));
+    }
+    return TBK_OK;
+}
+extern "C" int tbk_dev_upload(tbk_ctx* c, void* dst, const void* src, int64_t bytes) {
+    TBK_REQUIRE(c && dst && src && bytes >= 0, TBK_EINVAL, "tbk_dev_upload: bad argument");
+    TBK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    TBK_HIP(hipStreamSynchronize(c->stream));
+    return TBK_OK;
+}
+extern "C" int tbk_dev_download(tbk_ctx* c, void* dst, const void* src, int64_t bytes) {
+    TBK_REQUIRE(c && dst && src && bytes >= 0, TBK_EINVAL, "tbk_dev_download: bad argument");
+    TBK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    TBK_HIP(hipStreamSynchronize(c->stream));
+    return TBK_OK;
+}
+
+// ------------------------------------------------------------------ timing
+extern "C" int tbk_timer_begin(tbk_ctx* c) {
+    TBK_REQUIRE(c, TBK_EINVAL, "tbk_timer_begin: null ctx");
+    TBK_HIP(hipEventRecord(c->timer0, c->stream));
+    return TBK_OK;
+}
+extern "C" int tbk_timer_end(tbk_ctx* c, double* ms) {
+    TBK_REQUIRE(c && ms, TBK_EINVAL, "tbk_timer_end: bad argument");
+    TBK_HIP(hipEventRecord(c->timer1, c->stream));
+    TBK_HIP(hipEventSynchronize(c->timer1));
+    float f = 0.f;
+    TBK_HIP(hipEventElapsedTime(&f, c->timer0, c->timer1));
+    *ms = f;
+    return TBK_OK;
+}
+
+static hipEvent_t prof_event(tbk_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(tbk_ctx* c, const char* n) : ctx(c), name(n) {
+    if (ctx->prof_on) {
+        t0 = prof_event(ctx);
+        t1 = prof_event(ctx);
+        hipEventRecord(t0, ctx->stream);
+    }
+}
+ProfScope::~ProfScope() {
+    if (t0) {
+        hipEventRecord(t1, ctx->stream);
+        ctx->prof_pending.push_back(ProfRec{name, t0, t1});
+    }
+}
+
+static int prof_collect(tbk_ctx* c) {
+    if (c->prof_pending.empty()) return TBK_OK;
+    TBK_HIP(hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof_pending) {
+        float f = 0.f;
+        TBK_HIP(hipEventElapsedTime(&f, r.t0, r.t1));
+        bool found = false;
+        for (auto& a : c->prof_agg)
+            if (a.name == r.name) {
+                a.launches++;
+                a.ms += f;
+                found = true;
+                break;
+            }
+        if (!found) c->prof_agg.push_back(ProfAgg{r.name, 1, (double)f});
+        c->event_pool.push_back(r.t0);
+        c->event_pool.push_back(r.t1);
+    }
+    c->prof_pending.clear();
+    return TBK_OK;
+}
+
+extern "C" int tbk_prof_enable(tbk_ctx* c, int on) {
+    TBK_REQUIRE(c, TBK_EINVAL, "tbk_prof_enable: null ctx");
+    c->prof_on = on != 0;
+    return TBK_OK;
+}
+extern "C" int tbk_prof_reset(tbk_ctx* c) {
+    TBK_REQUIRE(c, TBK_EINVAL, "tbk_prof_reset: null ctx");
+    int rc = prof_collect(c);
+    c->prof_agg.clear();
+    return rc;
+}
+extern "C" int tbk_prof_count(tbk_ctx* c, int* n) {
+    TBK_REQUIRE(c && n, TBK_EINVAL, "tbk_prof_count: bad argument");
+    int rc = prof_collect(c);
+    *n = (int)c->prof_agg.size();
+    return rc;
+}
+extern "C" int tbk_prof_get(tbk_ctx* c, int i, char* name, int cap, int64_t* launches, double* ms) {
+    TBK_REQUIRE(c && i >= 0 && i < (int)c->prof_agg.size(), TBK_EINVAL, "tbk_prof_get: index");
+    if (name && cap > 0) snprintf(name, cap, "%s", c->prof_agg[i].name.c_str());
+    if (launches) *launches = c->prof_agg[i].launches;
+    if (ms) *ms = c->prof_agg[i].ms;
+    return TBK_OK;
+}
+
+// ------------------------------------------------------------------ model
+// Flatten the reference's hopping list into upper-triangular "slots":
+//   S_ab(k) = sum_t amp_t * exp(2 pi i k.R_t)       (a <= b, state indices)
+//   H_ab(k) = conj(e_a) e_b S_ab(k),  e_a = exp(2 pi i k.tau_a)
+// which is _gen_ham's  amp*exp(2 pi i k.(R + tau_b - tau_a))  (pythtb.py:912-924)
+// with the orbital phases factored out (H = D^+ S D, D unitary diagonal).  The
+// conjugate entries H_ba are implied; a hop whose state pair is below the
+// diagonal is stored as (b,a,-R,conj amp); an i==j hop contributes both
+// (amp,R) and (conj amp,-R) to its diagonal slot (:919-924).
+namespace {
+struct TermKey {
+    int slot;
+    int R[4];
+    bool operator<(const TermKey& o) const {
+        if (slot != o.slot) return slot < o.slot;
+        for (int d = 0; d < 4; ++d)
+            if (R[d] != o.R[d]) return R[d] < o.R[d];
+        return false;
+    }
+};
+inline int slot_of(int n, int a, int b) { return a * n - a * (a - 1) / 2 + (b - a); }
+}  // namespace
+
+extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, const double* orb,
+                                const double* onsite, int64_t nhop, const int32_t* hop_i,
+                                const int32_t* hop_j, const int32_t* hop_R, const double* hop_amp,
+                                tbk_model** out) {
+    TBK_REQUIRE(ctx && out, TBK_EINVAL, "tbk_model_upload: null ctx/out");
+    TBK_REQUIRE(dim_k >= 0 && dim_k <= TBK_MAX_DIM, TBK_EINVAL, "tbk_model_upload: dim_k=%d", dim_k);
+    TBK_REQUIRE(nspin == 1 || nspin == 2, TBK_EINVAL, "tbk_model_upload: nspin=%d", nspin);
+    TBK_REQUIRE(norb >= 1, TBK_EINVAL, "tbk_model_upload: norb=%d", norb);
+    const int n = norb * nspin;
+    TBK_REQUIRE(n <= TBK_MAX_NSTA, TBK_EUNSUPPORTED,
+                "tbk_model_upload: %d states per k exceeds this build's limit of %d", n,
+                TBK_MAX_NSTA);
+    TBK_REQUIRE(onsite && (dim_k == 0 || orb), TBK_EINVAL, "tbk_model_upload: null table");
+    TBK_REQUIRE(nhop == 0 || (hop_i && hop_j && hop_amp && (dim_k == 0 || hop_R)), TBK_EINVAL,
+                "tbk_model_upload: null hopping table");
+    const int ns = nspin;
+    std::map<TermKey, cd> acc;
+    auto add = [&](int a, int b, const int* R, cd amp) {
+        TermKey key;
+        if (a <= b) {
+            key.slot = slot_of(n, a, b);
+            for (int d = 0; d < 4; ++d) key.R[d] = d < dim_k ? R[d] : 0;
+        } else {
+            key.slot = slot_of(n, b, a);
+            for (int d = 0; d < 4; ++d) key.R[d] = d < dim_k ? -R[d] : 0;
+            amp = cconj(amp);
+        }
+        auto it = acc.find(key);
+        if (it == acc.end())
+            acc[key] = amp;
+        else
+            it->second = cadd(it->second, amp);
+    };
+    const int zeroR[4] = {0, 0, 0, 0};
+    for (int o = 0; o < norb; ++o)
+        for (int s = 0; s < ns; ++s)
+            for (int t = s; t < ns; ++t) {  // upper part of the hermitian on-site block
+                const double* p = onsite + 2 * ((o * ns + s) * ns + t);
+                add(o * ns + s, o * ns + t, zeroR, cd{p[0], s == t ? 0.0 : p[1]});
+            }
+    for (int64_t h = 0; h < nhop; ++h) {
+        const int i = hop_i[h], j = hop_j[h];
+        TBK_REQUIRE(i >= 0 && i < norb && j >= 0 && j < norb, TBK_EINVAL,
+                    "tbk_model_upload: hop %lld has orbital index out of range", (long long)h);
+        int R[4] = {0, 0, 0, 0}, mR[4] = {0, 0, 0, 0};
+        for (int d = 0; d < dim_k; ++d) {
+            R[d] = hop_R[h * dim_k + d];
+            mR[d] = -R[d];
+        }
+        for (int s = 0; s < ns; ++s)
+            for (int t = 0; t < ns; ++t) {
+                const double* p = hop_amp + 2 * ((h * ns + s) * ns + t);
+                const cd amp{p[0], p[1]};
+                const int a = i * ns + s, b = j * ns + t;
+                // ham[i,s,j,t] += amp E_R ; ham[j,t,i,s] += conj(amp) E_-R   (:919-924).
+                // Off the diagonal the second is the hermitian mirror of the first and
+                // is implied by the slot storage; on it both land in the same slot.
+                if (a == b) {
+                    add(a, a, R, amp);
+                    add(a, a, mR, cconj(amp));
+                } else {
+                    add(a, b, R, amp);
+                }
+            }
+    }
+    // CSR over slots (std::map iterates in slot-major order)
+    const int nslot = n * (n + 1) / 2;
+    std::vector<int32_t> slot_ptr(nslot + 1, 0), slot_ab(nslot);
+    std::vector<cd> amp;
+    std::vector<int32_t> R4;
+    for (int a = 0; a < n; ++a)
+        for (int b = a; b < n; ++b) slot_ab[slot_of(n, a, b)] = a | (b << 16);
+    for (auto& kv : acc) {
+        if (kv.second.x == 0.0 && kv.second.y == 0.0) continue;
+        slot_ptr[kv.first.slot + 1]++;
+        amp.push_back(kv.second);
+        for (int d = 0; d < 4; ++d) R4.push_back(kv.first.R[d]);
+    }
+    for (int s = 0; s < nslot; ++s) slot_ptr[s + 1] += slot_ptr[s];
+    const int64_t nterm = (int64_t)amp.size();
+    std::vector<double> orb4((size_t)n * 4, 0.0);
+    for (int a = 0; a < n; ++a)
+        for (int d = 0; d < dim_k; ++d) orb4[a * 4 + d] = orb[(a / ns) * dim_k + d];
+
+    // one blob: [orb4 | amp | R4 | slot_ptr | slot_ab], 32-byte aligned pieces
+    auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
+    const size_t o_orb = 0;
+    const size_t o_amp = al(o_orb + orb4.size() * sizeof(double));
+    const size_t o_R = al(o_amp + std::max<size_t>(amp.size(), 1) * sizeof(cd));
+    const size_t o_ptr = al(o_R + std::max<size_t>(R4.size(), 4) * sizeof(int32_t));
+    const size_t o_ab = al(o_ptr + slot_ptr.size() * sizeof(int32_t));
+    const size_t total = al(o_ab + slot_ab.size() * sizeof(int32_t));
+    std::vector<unsigned char> host(total, 0);
+    memcpy(host.data() + o_orb, orb4.data(), orb4.size() * sizeof(double));
+    if (!amp.empty()) memcpy(host.data() + o_amp, amp.data(), amp.size() * sizeof(cd));
+    if (!R4.empty()) memcpy(host.data() + o_R, R4.data(), R4.size() * sizeof(int32_t));
+    memcpy(host.data() + o_ptr, slot_ptr.data(), slot_ptr.size() * sizeof(int32_t));
+    memcpy(host.data() + o_ab, slot_ab.data(), slot_ab.size() * sizeof(int32_t));
+
+    tbk_model* m = new (std::nothrow) tbk_model();
+    TBK_REQUIRE(m, TBK_ENOMEM, "tbk_model_upload: out of host memory");
+    m->ctx = ctx;
+    m->dim_k = dim_k;
+    m->norb = norb;
+    m->nspin = nspin;
+    m->nsta = n;
+    m->nslot = nslot;
+    m->nterm = nterm;
+    TBK_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(&m->blob, total);
+    if (e != hipSuccess) {
+        delete m;
+        tbk_set_error("tbk_model_upload: hipMalloc(%zu): %s", total, hipGetErrorString(e));
+        return TBK_ENOMEM;
+    }
+    TBK_HIP(hipMemcpyAsync(m->blob, host.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned char* base = (unsigned char*)m->blob;
+    m->view.dim_k = dim_k;
+    m->view.nsta = n;
+    m->view.nspin = nspin;
+    m->view.nslot = nslot;
+    m->view.orb = (const double4*)(base + o_orb);
+    m->view.term_amp = (const cd*)(base + o_amp);
+    m->view.term_R = (const int4*)(base + o_R);
+    m->view.slot_ptr = (const int32_t*)(base + o_ptr);
+    m->view.slot_ab = (const int32_t*)(base + o_ab);
+    *out = m;
+    return TBK_OK;
+}
+
+extern "C" int tbk_model_free(tbk_model* m) {
+    if (!m) return TBK_OK;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    if (m->blob) hipFree(m->blob);
+    delete m;
+    return TBK_OK;
+}
+
+extern "C" int tbk_model_info(tbk_model* m, int* dim_k, int* nsta, int64_t* nterm) {
+    TBK_REQUIRE(m, TBK_EINVAL, "tbk_model_info: null model");
+    if (dim_k) *dim_k = m->dim_k;
+    if (nsta) *nsta = m->nsta;
+    if (nterm) *nterm = m->nterm;
+    return TBK_OK;
+}
+
+// ------------------------------------------------------------------ wfs
+extern "C" int tbk_wfs_create(tbk_ctx* ctx, int dim_arr, const int32_t* mesh, int nsta_arr,
+                              int ncomp, tbk_wfs** out) {
+    TBK_REQUIRE(ctx && mesh && out, TBK_EINVAL, "tbk_wfs_create: null argument");
+    TBK_REQUIRE(dim_arr >= 1 && dim_arr <= TBK_MAX_DIM, TBK_EINVAL, "tbk_wfs_create: dim_arr=%d", dim_arr);
+    TBK_REQUIRE(nsta_arr >= 1 && ncomp >= 1, TBK_EINVAL, "tbk_wfs_create: nsta_arr=%d ncomp=%d",
+                nsta_arr, ncomp);
+    tbk_wfs* w = new (std::nothrow) tbk_wfs();
+    TBK_REQUIRE(w, TBK_ENOMEM, "tbk_wfs_create: out of host memory");
+    w->ctx = ctx;
+    w->view.dim_arr = dim_arr;
+    w->view.nsta = nsta_arr;
+    w->view.ncomp = ncomp;
+    int64_t npts = 1;
+    for (int d = 0; d < TBK_MAX_DIM; ++d) w->view.mesh[d] = 1;
+    for (int d = 0; d < dim_arr; ++d) {
+        if (mesh[d] < 2) {  // pythtb.py:2409
+            delete w;
+            tbk_set_error("tbk_wfs_create: mesh[%d]=%d, every mesh dimension must be >= 2", d, mesh[d]);
+            return TBK_EINVAL;
+        }
+        w->view.mesh[d] = mesh[d];
+        npts *= mesh[d];
+    }
+    int64_t st = 1;
+    for (int d = TBK_MAX_DIM - 1; d >= 0; --d) {
+        w->view.stride[d] = st;
+        st *= w->view.mesh[d];
+    }
+    // strides are for the dim_arr real axes stored first; shift so axis d of the
+    // array maps to stride[d] (trailing padded axes have size 1)
+    w->view.npts = npts;
+    w->bytes = npts * (int64_t)nsta_arr * ncomp * (int64_t)sizeof(cd);
+    TBK_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc((void**)&w->view.data, (size_t)w->bytes);
+    if (e != hipSuccess) {
+        tbk_set_error("tbk_wfs_create: hipMalloc(%lld bytes) failed: %s", (long long)w->bytes,
+                      hipGetErrorString(e));
+        delete w;
+        return TBK_ENOMEM;
+    }
+    TBK_HIP(hipMemsetAsync(w->view.data, 0, (size_t)w->bytes, ctx->stream));
+    TBK_HIP(hipMalloc((void**)&w->gaps_dev, TBK_MAX_NSTA * sizeof(unsigned long long)));
+    TBK_HIP(hipMalloc((void**)&w->pbc_dev, TBK_MAX_DIM * TBK_MAX_NSTA * sizeof(cd)));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    *out = w;
+    return TBK_OK;
+}
+
+extern "C" int tbk_wfs_free(tbk_wfs* w) {
+    if (!w) return TBK_OK;
+    hipSetDevice(w->ctx->device);
+    hipStreamSynchronize(w->ctx->stream);
+    if (w->view.data) hipFree(w->view.data);
+    if (w->gaps_dev) hipFree(w->gaps_dev);
+    if (w->pbc_dev) hipFree(w->pbc_dev);
+    if (w->flux_totals_dev) hipFree(w->flux_totals_dev);
+    if (w->flux_plaq_dev) hipFree(w->flux_plaq_dev);
+    if (w->flux_partial_dev) hipFree(w->flux_partial_dev);
+    delete w;
+    return TBK_OK;
+}
+
+extern "C" int tbk_wfs_upload(tbk_wfs* w, const double* host) {
+    TBK_REQUIRE(w && host, TBK_EINVAL, "tbk_wfs_upload: null argument");
+    TBK_HIP(hipMemcpyAsync(w->view.data, host, (size_t)w->bytes, hipMemcpyHostToDevice, w->ctx->stream));
+    TBK_HIP(hipStreamSynchronize(w->ctx->stream));
+    return TBK_OK;
+}
+extern "C" int tbk_wfs_download(tbk_wfs* w, double* host) {
+    TBK_REQUIRE(w && host, TBK_EINVAL, "tbk_wfs_download: null argument");
+    TBK_HIP(hipMemcpyAsync(host, w->view.data, (size_t)w->bytes, hipMemcpyDeviceToHost, w->ctx->stream));
+    TBK_HIP(hipStreamSynchronize(w->ctx->stream));
+    return TBK_OK;
+}
+extern "C" int tbk_wfs_device_ptr(tbk_wfs* w, void** p, int64_t* bytes) {
+    TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_device_ptr: null wfs");
+    if (p) *p = w->view.data;
+    if (bytes) *bytes = w->bytes;
+    return TBK_OK;
+}

@@ -1,0 +1,155 @@
+// tbk_internal.h -- shared host/device definitions for libtbk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/tbk.h"
+
+// ---------------------------------------------------------------- errors
+void tbk_set_error(const char* fmt, ...);
+
+#define TBK_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            tbk_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),        \
+                          __FILE__, __LINE__);                                          \
+            return TBK_EHIP;                                                            \
+        }                                                                               \
+    } while (0)
+
+#define TBK_REQUIRE(cond, code, ...)                                                    \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            tbk_set_error(__VA_ARGS__);                                                 \
+            return (code);                                                              \
+        }                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------- complex
+// c128 as a plain pair; every operation spelled out so the compiler emits
+// straight v_fma_f64 sequences (no library complex-multiply NaN fix-ups).
+struct cd {
+    double x, y;
+};
+__host__ __device__ inline cd cmake(double x, double y) { return cd{x, y}; }
+__host__ __device__ inline cd cconj(cd a) { return cd{a.x, -a.y}; }
+__host__ __device__ inline cd cadd(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+__host__ __device__ inline cd csub(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__host__ __device__ inline cd cmul(cd a, cd b) {
+    return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// conj(a) * b
+__host__ __device__ inline cd cmulc(cd a, cd b) {
+    return cd{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};
+}
+__host__ __device__ inline cd cscale(cd a, double s) { return cd{a.x * s, a.y * s}; }
+// acc += a*b
+__host__ __device__ inline void cfma(cd& acc, cd a, cd b) {
+    acc.x += a.x * b.x - a.y * b.y;
+    acc.y += a.x * b.y + a.y * b.x;
+}
+// acc += conj(a)*b
+__host__ __device__ inline void cfmac(cd& acc, cd a, cd b) {
+    acc.x += a.x * b.x + a.y * b.y;
+    acc.y += a.x * b.y - a.y * b.x;
+}
+__host__ __device__ inline double cabs2(cd a) { return a.x * a.x + a.y * a.y; }
+
+// ---------------------------------------------------------------- handles
+struct ProfRec {
+    const char* name;
+    hipEvent_t t0, t1;
+};
+struct ProfAgg {
+    std::string name;
+    int64_t launches;
+    double ms;
+};
+
+struct tbk_ctx {
+    int device = 0;
+    int cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t timer0 = nullptr, timer1 = nullptr;
+    bool prof_on = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+    std::vector<ProfAgg> prof_agg;
+    // scratch reused across calls (grown on demand, stream-ordered use only)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void* pinned = nullptr;  // small pinned staging buffer for results
+    size_t pinned_bytes = 0;
+    int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
+    // RCCL
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;
+};
+
+int tbk_ctx_scratch(tbk_ctx* ctx, size_t bytes, void** out);
+int tbk_ctx_pinned(tbk_ctx* ctx, size_t bytes, void** out);
+
+// RAII bracket recording HIP events around one kernel launch when profiling.
+struct ProfScope {
+    tbk_ctx* ctx;
+    const char* name;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    ProfScope(tbk_ctx* c, const char* n);
+    ~ProfScope();
+};
+
+// Device-side view of the model (passed to kernels by value).
+struct ModelView {
+    int dim_k;   // 0..4
+    int nsta;    // states per k  (norb*nspin)
+    int nspin;   // 1|2
+    int nslot;   // nsta*(nsta+1)/2 upper-triangular slots, row-major
+    const int32_t* slot_ptr;  // [nslot+1] term ranges
+    const int32_t* slot_ab;   // [nslot]  a | (b<<16)
+    const cd* term_amp;       // [nterm]
+    const int4* term_R;       // [nterm]  lattice vector (periodic comps, 0-padded)
+    const double4* orb;       // [nsta]   reduced position of each state's orbital
+};
+
+struct tbk_model {
+    tbk_ctx* ctx = nullptr;
+    int dim_k = 0, norb = 0, nspin = 1, nsta = 0, nslot = 0;
+    int64_t nterm = 0;
+    void* blob = nullptr;  // one device allocation holding all tables
+    ModelView view{};
+};
+
+struct WfsView {
+    int dim_arr;
+    int nsta;   // states stored per mesh point (nsta_arr)
+    int ncomp;  // components per state (norb*nspin)
+    int mesh[TBK_MAX_DIM];
+    int64_t stride[TBK_MAX_DIM];  // in mesh points
+    int64_t npts;
+    cd* data;
+};
+
+struct tbk_wfs {
+    tbk_ctx* ctx = nullptr;
+    WfsView view{};
+    int64_t bytes = 0;
+    // solve_grid results
+    unsigned long long* gaps_dev = nullptr;  // [TBK_MAX_NSTA] min gaps as ordered bits
+    int gaps_n = 0;
+    cd* pbc_dev = nullptr;                   // [TBK_MAX_DIM][TBK_MAX_NSTA]
+    std::vector<double> pbc_host;
+    // flux results
+    double* flux_totals_dev = nullptr;
+    int64_t flux_nslices = 0;
+    double* flux_plaq_dev = nullptr;
+    int64_t flux_plaq_cap = 0, flux_plaq_n = 0;
+    double* flux_partial_dev = nullptr;
+    int64_t flux_partial_cap = 0;
+};
+
+// kernels / launchers implemented in the .hip files
+int tbk_launch_gen_ham(tbk_model* m, const double* k_dev, int64_t nk, cd* ham_dev);
+int tbk_launch_solve_list(tbk_ctx* ctx, const ModelView* mv, int n, const double* k_dev,
+                          const cd* ham_dev, int64_t nk, double* eval_dev, cd* evec_dev);

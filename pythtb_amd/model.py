@@ -1,0 +1,436 @@
+"""tb_model: host-side mirror of PythTB's model class for the k-space hot path.
+
+Same constructor, setters, attribute names and call signatures as the reference
+(`pythtb.py:29-560`, `:862-1103`, `:1792-2026`), so scripts written for PythTB
+run unchanged; `_gen_ham`, `_sol_ham`, `solve_all` and `solve_one` execute on the
+MI355X through libtbk (no CPU path).  Model->model transforms, plotting and the
+Wannier90 reader are outside this package's scope.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["tb_model"]
+
+
+def _is_int(a):
+    return np.issubdtype(type(a), np.integer)        # pythtb.py:3950
+
+
+class tb_model(object):
+    """Tight-binding model in reduced coordinates (reference: pythtb.py:29-184)."""
+
+    def __init__(self, dim_k, dim_r, lat=None, orb=None, per=None, nspin=1):
+        if not _is_int(dim_k):
+            raise Exception("\n\nArgument dim_k not an integer")
+        if dim_k < 0 or dim_k > 4:
+            raise Exception("\n\nArgument dim_k out of range. Must be between 0 and 4.")
+        if not _is_int(dim_r):
+            raise Exception("\n\nArgument dim_r not an integer")
+        if dim_r < dim_k or dim_r > 4:
+            raise Exception("\n\nArgument dim_r out of range. Must be dim_r>=dim_k and dim_r<=4.")
+        self._dim_k = dim_k
+        self._dim_r = dim_r
+
+        if lat is None or (isinstance(lat, str) and lat == "unit"):
+            self._lat = np.identity(dim_r, float)
+            print(" Lattice vectors not specified! I will use identity matrix.")
+        else:
+            self._lat = np.array(lat, dtype=float)
+            if self._lat.shape != (dim_r, dim_r):
+                raise Exception("\n\nWrong lat array dimensions")
+        if dim_r > 0:
+            vol = np.linalg.det(self._lat)
+            if np.abs(vol) < 1.0E-6:
+                raise Exception("\n\nLattice vectors length/area/volume too close to zero, or zero.")
+            if vol < 0.0:
+                raise Exception("\n\nLattice vectors need to form right handed system.")
+
+        if orb is None or (isinstance(orb, str) and orb == "bravais"):
+            self._norb = 1
+            self._orb = np.zeros((1, dim_r))
+            print(" Orbital positions not specified. I will assume a single orbital at the origin.")
+        elif _is_int(orb):
+            self._norb = orb
+            self._orb = np.zeros((orb, dim_r))
+            print(" Orbital positions not specified. I will assume ", orb, " orbitals at the origin")
+        else:
+            self._orb = np.array(orb, dtype=float)
+            if self._orb.ndim != 2:
+                raise Exception("\n\nWrong orb array rank")
+            self._norb = self._orb.shape[0]
+            if self._orb.shape[1] != dim_r:
+                raise Exception("\n\nWrong orb array dimensions")
+
+        if per is None:
+            self._per = list(range(self._dim_k))
+        else:
+            if len(per) != self._dim_k:
+                raise Exception("\n\nWrong choice of periodic/infinite direction!")
+            self._per = per
+
+        if nspin not in [1, 2]:
+            raise Exception("\n\nWrong value of nspin, must be 1 or 2!")
+        self._nspin = nspin
+        self._assume_position_operator_diagonal = True
+        self._nsta = self._norb * self._nspin
+
+        if self._nspin == 1:
+            self._site_energies = np.zeros(self._norb, dtype=float)
+        else:
+            self._site_energies = np.zeros((self._norb, 2, 2), dtype=complex)
+        self._site_energies_specified = np.zeros(self._norb, dtype=bool)
+        self._hoppings = []
+        self._tbk_epoch = 0        # bumped whenever the tables change
+        self._tbk_cache = None     # (epoch, device handle)
+
+    # ------------------------------------------------------------------ tables
+    def _val_to_block(self, val):
+        """scalar / (I,sx,sy,sz) 4-vector / 2x2 -> 2x2 block for nspin=2 (pythtb.py:517-560)."""
+        if self._nspin == 1:
+            return val
+        v = np.array(val)
+        if v.shape == (2, 2):
+            return v
+        blk = np.zeros((2, 2), dtype=complex)
+        if v.shape == ():
+            blk[0, 0] = blk[1, 1] = v
+        elif v.shape == (4,):
+            blk[0, 0] = v[0] + v[3]
+            blk[1, 1] = v[0] - v[3]
+            blk[0, 1] = v[1] - 1.0j * v[2]
+            blk[1, 0] = v[1] + 1.0j * v[2]
+        else:
+            raise Exception(
+                "\n\nWrong format of the on-site or hopping term. Must be single number, or\n"
+                "in the case of a spinfull model can be array of four numbers or 2x2\nmatrix.")
+        return blk
+
+    def set_onsite(self, onsite_en, ind_i=None, mode="set"):
+        """On-site energies; modes set/reset/add (pythtb.py:186-306)."""
+        if ind_i is None:
+            if len(onsite_en) != self._norb:
+                raise Exception("\n\nWrong number of site energies")
+            values = list(onsite_en)
+            targets = list(range(self._norb))
+        else:
+            if ind_i < 0 or ind_i >= self._norb:
+                raise Exception("\n\nIndex ind_i out of scope.")
+            values = [onsite_en]
+            targets = [ind_i]
+        for ons in values:
+            a = np.array(ons)
+            if a.shape == ():
+                if np.abs(a - a.conjugate()) > 1.0E-8:
+                    raise Exception("\n\nOnsite energy should not have imaginary part!")
+            elif a.shape == (4,):
+                if np.max(np.abs(a - a.conjugate())) > 1.0E-8:
+                    raise Exception("\n\nOnsite energy or Zeeman field should not have imaginary part!")
+            elif a.shape == (2, 2):
+                if np.max(np.abs(a - a.T.conjugate())) > 1.0E-8:
+                    raise Exception("\n\nOnsite matrix should be Hermitian!")
+        how = mode.lower()
+        if how == "set":
+            if ind_i is not None:
+                if self._site_energies_specified[ind_i]:
+                    raise Exception("\n\nOnsite energy for this site was already specified! "
+                                    "Use mode=\"reset\" or mode=\"add\".")
+            elif np.any(self._site_energies_specified):
+                raise Exception("\n\nSome or all onsite energies were already specified! "
+                                "Use mode=\"reset\" or mode=\"add\".")
+        elif how not in ("reset", "add"):
+            raise Exception("\n\nWrong value of mode parameter")
+        for t, ons in zip(targets, values):
+            if how == "add":
+                self._site_energies[t] += self._val_to_block(ons)
+            else:
+                self._site_energies[t] = self._val_to_block(ons)
+            self._site_energies_specified[t] = True
+        self._tbk_epoch += 1
+
+    def set_hop(self, hop_amp, ind_i, ind_j, ind_R=None, mode="set", allow_conjugate_pair=False):
+        """Hopping <phi_0i|H|phi_Rj>; stored as [amp, i, j, R] (pythtb.py:308-515)."""
+        if self._dim_k != 0 and ind_R is None:
+            raise Exception("\n\nNeed to specify ind_R!")
+        if self._dim_k == 1 and _is_int(ind_R):
+            full = np.zeros(self._dim_r, dtype=int)
+            full[self._per] = ind_R
+            ind_R = full
+        if self._dim_k != 0 and len(ind_R) != self._dim_r:
+            raise Exception("\n\nLength of input ind_R vector must equal dim_r! Even if dim_k<dim_r.")
+        if ind_i < 0 or ind_i >= self._norb:
+            raise Exception("\n\nIndex ind_i out of scope.")
+        if ind_j < 0 or ind_j >= self._norb:
+            raise Exception("\n\nIndex ind_j out of scope.")
+        if ind_i == ind_j:
+            if self._dim_k == 0 or all(int(ind_R[k]) == 0 for k in self._per):
+                raise Exception("\n\nDo not use set_hop for onsite terms. Use set_onsite instead!")
+        r_per = None if self._dim_k == 0 else np.array(ind_R)[self._per]
+        if not allow_conjugate_pair:
+            for h in self._hoppings:
+                if ind_i == h[2] and ind_j == h[1]:
+                    if self._dim_k == 0:
+                        raise Exception(
+                            "\n\nFollowing matrix element was already implicitely specified:\n"
+                            "   i=" + str(ind_i) + " j=" + str(ind_j) + "\n"
+                            "Remember, specifying <i|H|j> automatically specifies <j|H|i>.  For\n"
+                            "consistency, specify all hoppings for a given bond in the same\n"
+                            "direction.  (Or, alternatively, see the documentation on the\n"
+                            "'allow_conjugate_pair' flag.)\n")
+                    if np.all(r_per == -np.array(h[3])[self._per]):
+                        raise Exception(
+                            "\n\nFollowing matrix element was already implicitely specified:\n"
+                            "   i=" + str(ind_i) + " j=" + str(ind_j) + " R=" + str(ind_R) + "\n"
+                            "Remember,specifying <i|H|j+R> automatically specifies <j|H|i-R>.  For\n"
+                            "consistency, specify all hoppings for a given bond in the same\n"
+                            "direction.  (Or, alternatively, see the documentation on the\n"
+                            "'allow_conjugate_pair' flag.)\n")
+        block = self._val_to_block(hop_amp)
+        entry = [block, int(ind_i), int(ind_j)]
+        if self._dim_k != 0:
+            entry.append(np.array(ind_R))
+        match = None                                   # last entry with the same (i,j,R)
+        for pos, h in enumerate(self._hoppings):
+            if ind_i == h[1] and ind_j == h[2]:
+                if self._dim_k == 0 or np.all(r_per == np.array(h[3])[self._per]):
+                    match = pos
+        how = mode.lower()
+        if how == "set":
+            if match is not None:
+                raise Exception("\n\nHopping energy for this site was already specified! "
+                                "Use mode=\"reset\" or mode=\"add\".")
+            self._hoppings.append(entry)
+        elif how == "reset":
+            if match is None:
+                self._hoppings.append(entry)
+            else:
+                self._hoppings[match] = entry
+        elif how == "add":
+            if match is None:
+                self._hoppings.append(entry)
+            else:
+                self._hoppings[match][0] += entry[0]
+        else:
+            raise Exception("\n\nWrong value of mode parameter")
+        self._tbk_epoch += 1
+
+    def get_num_orbitals(self):
+        return self._norb
+
+    def get_orb(self):
+        return self._orb.copy()
+
+    def get_lat(self):
+        return self._lat.copy()
+
+    def invalidate_device_cache(self):
+        """Call after editing `_hoppings` / `_site_energies` in place."""
+        self._tbk_epoch += 1
+
+    def __getstate__(self):                      # deepcopy / pickle: drop the device handle
+        st = dict(self.__dict__)
+        st["_tbk_cache"] = None
+        return st
+
+    def __del__(self):
+        cache = getattr(self, "_tbk_cache", None)
+        if cache is not None:
+            try:
+                _lib.lib.tbk_model_free(cache[2])
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ device
+    def _flat_tables(self):
+        """(orb_per, onsite, hop_i, hop_j, hop_R, hop_amp) in the layout of tbk_model_upload."""
+        ns, no, dk = self._nspin, self._norb, self._dim_k
+        nh = len(self._hoppings)
+        orb_per = np.ascontiguousarray(self._orb[:, self._per], dtype=float).reshape(no, dk)
+        onsite = np.zeros((no, ns, ns), dtype=complex)
+        if ns == 1:
+            onsite[:, 0, 0] = self._site_energies
+        else:
+            onsite[:] = self._site_energies
+        hop_i = np.zeros(nh, dtype=np.int32)
+        hop_j = np.zeros(nh, dtype=np.int32)
+        hop_R = np.zeros((nh, max(dk, 1)), dtype=np.int32)
+        hop_amp = np.zeros((nh, ns, ns), dtype=complex)
+        for h, hop in enumerate(self._hoppings):
+            hop_amp[h] = hop[0]
+            hop_i[h] = hop[1]
+            hop_j[h] = hop[2]
+            if dk > 0:
+                hop_R[h, :dk] = np.array(hop[3], dtype=int)[self._per]
+        return orb_per, onsite, hop_i, hop_j, np.ascontiguousarray(hop_R[:, :dk]), hop_amp
+
+    def _device_model(self):
+        ctx = _lib.default_context()
+        c = self._tbk_cache
+        if c is not None and c[0] == self._tbk_epoch and c[1] is ctx:
+            return c[2]
+        if c is not None:
+            _lib.lib.tbk_model_free(c[2])
+            self._tbk_cache = None
+        orb_per, onsite, hop_i, hop_j, hop_R, hop_amp = self._flat_tables()
+        h = C.c_void_p()
+        _lib.check(_lib.lib.tbk_model_upload(
+            ctx.handle, self._dim_k, self._norb, self._nspin, _lib.dptr(orb_per),
+            _lib.dptr(onsite.view(float)), len(hop_i), _lib.iptr(hop_i), _lib.iptr(hop_j),
+            _lib.iptr(hop_R.reshape(-1)) if hop_R.size else None,
+            _lib.dptr(hop_amp.view(float)) if hop_amp.size else None, C.byref(h)))
+        self._tbk_cache = (self._tbk_epoch, ctx, h)
+        return h
+
+    # ------------------------------------------------------------------ solve
+    def _k_array(self, k_list):
+        k = np.array(k_list, dtype=float)
+        if self._dim_k == 1 and k.ndim == 1:
+            k = k.reshape(-1, 1)
+        if k.ndim != 2 or k.shape[1] != self._dim_k:
+            raise Exception("\n\nk-vector of wrong shape!")
+        return np.ascontiguousarray(k)
+
+    def _gen_ham(self, k_input=None):
+        """H(k) for one k in reduced coordinates (pythtb.py:874-925), built on the device."""
+        if k_input is None:
+            if self._dim_k != 0:
+                raise Exception("\n\nHave to provide a k-vector!")
+            k = None
+        else:
+            kp = np.array(k_input, dtype=float)
+            if kp.ndim == 0:
+                kp = kp.reshape(1)
+            if kp.shape != (self._dim_k,):
+                raise Exception("\n\nk-vector of wrong shape!")
+            k = np.ascontiguousarray(kp.reshape(1, -1))
+        n = self._nsta
+        ham = np.zeros((1, n, n), dtype=complex)
+        _lib.check(_lib.lib.tbk_gen_ham(self._device_model(), _lib.dptr(k) if self._dim_k else None, 1,
+                                        _lib.dptr(ham.view(float))))
+        if self._nspin == 1:
+            return ham[0]
+        return ham[0].reshape(self._norb, 2, self._norb, 2)
+
+    def _sol_ham(self, ham, eig_vectors=False):
+        """Eigen-decomposition of one Hamiltonian (pythtb.py:927-953), on the device."""
+        n = self._nsta
+        hm = np.ascontiguousarray(np.array(ham, dtype=complex).reshape(1, n, n))
+        if np.max(hm[0] - hm[0].T.conj()) > 1.0E-9:
+            raise Exception("\n\nHamiltonian matrix is not hermitian?!")
+        ev = np.zeros((n, 1), dtype=float)
+        vec = np.zeros((n, 1, n), dtype=complex) if eig_vectors else None
+        _lib.check(_lib.lib.tbk_eigh_batch(_lib.default_context().handle, n, _lib.dptr(hm.view(float)), 1,
+                                           _lib.dptr(ev), _lib.dptr(vec.view(float)) if eig_vectors else None))
+        if not eig_vectors:
+            return ev[:, 0].copy()
+        out = vec[:, 0, :]
+        if self._nspin == 2:
+            out = out.reshape(n, self._norb, 2)
+        return ev[:, 0].copy(), out.copy()
+
+    def solve_all(self, k_list=None, eig_vectors=False):
+        """Eigenvalues eval[band,k] (and evec[band,k,orb(,spin)]) on a list of k
+        (pythtb.py:955-1079): one fused H(k)+eigh launch over the whole list."""
+        n = self._nsta
+        if k_list is None:
+            if self._dim_k != 0:
+                raise Exception("\n\nHave to provide a k-vector!")
+            nk, k = 1, None
+        else:
+            k = self._k_array(k_list) if self._dim_k > 0 else None
+            nk = len(k_list)
+        ev = np.zeros((n, nk), dtype=float)
+        vec = np.zeros((n, nk, n), dtype=complex) if eig_vectors else None
+        if nk > 0:
+            _lib.check(_lib.lib.tbk_solve_list(self._device_model(), _lib.dptr(k), nk, _lib.dptr(ev),
+                                               _lib.dptr(vec.view(float)) if eig_vectors else None))
+        if eig_vectors and self._nspin == 2:
+            vec = vec.reshape(n, nk, self._norb, 2)
+        if k_list is None:
+            return (ev[:, 0], vec[:, 0]) if eig_vectors else ev[:, 0]
+        return (ev, vec) if eig_vectors else ev
+
+    def solve_one(self, k_point=None, eig_vectors=False):
+        """solve_all for a single k (pythtb.py:1081-1103)."""
+        if k_point is None:
+            return self.solve_all(eig_vectors=eig_vectors)
+        if eig_vectors:
+            ev, vec = self.solve_all([k_point], eig_vectors=True)
+            return ev[:, 0], vec[:, 0]
+        return self.solve_all([k_point])[:, 0]
+
+    # ------------------------------------------------------------------ k generators (host)
+    def k_uniform_mesh(self, mesh_size):
+        """Gamma-containing uniform mesh, last index fastest (pythtb.py:1792-1861)."""
+        use = np.array(list(map(round, mesh_size)), dtype=int)
+        if use.shape != (self._dim_k,):
+            print(use.shape)
+            raise Exception("\n\nIncorrect size of the specified k-mesh!")
+        if np.min(use) <= 0:
+            raise Exception("\n\nMesh must have positive non-zero number of elements.")
+        if self._dim_k not in (1, 2, 3):
+            raise Exception("\n\nUnsupported dim_k!")
+        idx = np.indices(tuple(use)).reshape(self._dim_k, -1).T
+        return idx / use.astype(float)
+
+    def k_path(self, kpts, nk, report=True):
+        """Piecewise-linear path through `kpts` with `nk` points, spaced by the
+        Cartesian metric (pythtb.py:1863-2026).  Returns (k_vec, k_dist, k_node)."""
+        if isinstance(kpts, str):
+            named = {"full": [[0.0], [0.5], [1.0]], "fullc": [[-0.5], [0.0], [0.5]], "half": [[0.0], [0.5]]}
+            nodes = np.array(named[kpts]) if kpts in named else np.array(kpts)
+        else:
+            nodes = np.array(kpts)
+        if nodes.ndim == 1 and self._dim_k == 1:
+            nodes = nodes.reshape(-1, 1)
+        if nodes.shape[1] != self._dim_k:
+            print('input k-space dimension is', nodes.shape[1])
+            print('k-space dimension taken from model is', self._dim_k)
+            raise Exception("\n\nk-space dimensions do not match")
+        if nk < nodes.shape[0]:
+            raise Exception("\n\nMust have more points in the path than number of nodes.")
+        n_nodes = nodes.shape[0]
+        lat_per = np.copy(self._lat)[self._per]
+        k_metric = np.linalg.inv(np.dot(lat_per, lat_per.T))
+        k_node = np.zeros(n_nodes, dtype=float)
+        for s in range(1, n_nodes):
+            dk = nodes[s] - nodes[s - 1]
+            k_node[s] = k_node[s - 1] + np.sqrt(np.dot(dk, np.dot(k_metric, dk)))
+        node_index = [0]
+        for s in range(1, n_nodes - 1):
+            node_index.append(int(round(k_node[s] / k_node[-1] * (nk - 1))))
+        node_index.append(nk - 1)
+        k_dist = np.zeros(nk, dtype=float)
+        k_vec = np.zeros((nk, self._dim_k), dtype=float)
+        k_vec[0] = nodes[0]
+        for s in range(1, n_nodes):
+            lo, hi = node_index[s - 1], node_index[s]
+            frac = (np.arange(lo, hi + 1) - lo).astype(float) / float(hi - lo)
+            k_dist[lo:hi + 1] = k_node[s - 1] + frac * (k_node[s] - k_node[s - 1])
+            k_vec[lo:hi + 1] = nodes[s - 1] + frac[:, None] * (nodes[s] - nodes[s - 1])
+        if report:
+            if self._dim_k == 1:
+                print(' Path in 1D BZ defined by nodes at ' + str(nodes.flatten()))
+            else:
+                print('----- k_path report begin ----------')
+                keep = np.get_printoptions()
+                np.set_printoptions(precision=5)
+                print('real-space lattice vectors\n', lat_per)
+                print('k-space metric tensor\n', k_metric)
+                print('internal coordinates of nodes\n', nodes)
+                if lat_per.shape[0] == lat_per.shape[1]:
+                    rec = np.linalg.inv(lat_per).T
+                    print('reciprocal-space lattice vectors\n', rec)
+                    print('cartesian coordinates of nodes\n', np.tensordot(nodes, rec, axes=1))
+                print('list of segments:')
+                for s in range(1, n_nodes):
+                    seg = str(round(k_node[s] - k_node[s - 1], 5)).rjust(7)
+                    print('  length = ' + seg + '  from ', nodes[s - 1], ' to ', nodes[s])
+                print('node distance list:', k_node)
+                print('node index list:   ', np.array(node_index))
+                np.set_printoptions(precision=keep["precision"])
+                print('----- k_path report end ------------')
+            print()
+        return (k_vec, k_dist, k_node)

@@ -1,0 +1,359 @@
+"""wf_array: mesh of wavefunctions kept resident in MI355X HBM.
+
+Mirror of PythTB's `wf_array` (pythtb.py:2283-3205) for the hot path:
+`solve_on_grid`, `impose_pbc/impose_loop`, `berry_phase`, `berry_flux`, `[]`,
+`choose_states`, `empty_like`, `solve_on_one_point`.  The array lives on the
+device between `solve_on_grid` and the Berry calls; `_wfs` is a lazily
+materialised NumPy mirror (reading it, or using `wf[i,j]`, hands the host copy
+to the caller, after which the device copy is refreshed before its next use).
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .model import _is_int
+
+__all__ = ["wf_array"]
+
+_TWO_PI = 2.0 * np.pi
+
+
+def _no_2pi(x, clos):
+    """Bring x within pi of clos by 2 pi steps (pythtb.py:3867-3874)."""
+    return x - _TWO_PI * np.round((x - clos) / _TWO_PI) if abs(clos - x) > np.pi else x
+
+
+def _one_phase_cont(pha, clos):
+    """Sequential 2 pi unwrapping anchored at `clos` (pythtb.py:3876-3889)."""
+    out = np.array(pha, dtype=float, copy=True)
+    ref = clos
+    for i in range(len(out)):
+        v = out[i]
+        while abs(ref - v) > np.pi:
+            v += _TWO_PI if ref - v > np.pi else -_TWO_PI
+        out[i] = v
+        ref = v
+    return out
+
+
+def _array_phases_cont(arr_pha, clos):
+    """Greedy nearest matching of eigenphase sets on the unit circle along the
+    first index, then 2 pi unwrapping (pythtb.py:3891-3921)."""
+    out = np.zeros_like(arr_pha)
+    ref = np.array(clos, dtype=float)
+    for i in range(arr_pha.shape[0]):
+        free = list(range(arr_pha.shape[1]))
+        cur = np.exp(1.0j * arr_pha[i])
+        for j in range(ref.shape[0]):
+            dist = np.abs(np.exp(1.0j * ref[j]) - cur[free])
+            # the reference keeps the LAST index among equal minima (<= comparison)
+            best = free[len(dist) - 1 - int(np.argmin(dist[::-1]))]
+            free.remove(best)
+            v = arr_pha[i, best]
+            while abs(ref[j] - v) > np.pi:
+                v += _TWO_PI if ref[j] - v > np.pi else -_TWO_PI
+            out[i, j] = v
+        ref = out[i]
+    return out
+
+
+class wf_array(object):
+    """Array of wavefunctions on a (k or parameter) mesh: _wfs[k1..kD, state, orb(,spin)]."""
+
+    def __init__(self, model, mesh_arr, nsta_arr=None):
+        if nsta_arr is None:
+            self._nsta_arr = model._nsta
+        else:
+            if not _is_int(nsta_arr):
+                raise Exception("\n\nArgument nsta_arr not an integer")
+            self._nsta_arr = nsta_arr
+        self._nspin = model._nspin
+        self._norb = model._norb
+        self._orb = np.copy(model._orb)
+        self._model = copy.deepcopy(model)
+        self._mesh_arr = np.array(mesh_arr)
+        self._dim_arr = len(self._mesh_arr)
+        if True in (self._mesh_arr <= 1).tolist():
+            raise Exception("\n\nDimension of wf_array object in each direction must be 2 or larger.")
+        self._host = None          # NumPy mirror (allocated on first use)
+        self._host_valid = False
+        self._dev = None           # tbk_wfs handle
+        self._dev_shape = None
+        self._dev_valid = False
+
+    # ------------------------------------------------------------------ storage
+    def _shape(self, nsta=None):
+        shp = [int(x) for x in self._mesh_arr] + [int(self._nsta_arr if nsta is None else nsta), self._norb]
+        if self._nspin == 2:
+            shp.append(2)
+        return tuple(shp)
+
+    def _host_array(self):
+        """Host mirror, brought up to date, without giving up the device copy."""
+        if self._host is None:
+            self._host = np.zeros(self._shape(), dtype=complex)
+            if not self._dev_valid:
+                self._host_valid = True
+        if not self._host_valid:
+            if self._dev_valid:
+                _lib.check(_lib.lib.tbk_wfs_download(self._dev, _lib.dptr(self._host.view(float))))
+            self._host_valid = True
+        return self._host
+
+    @property
+    def _wfs(self):
+        arr = self._host_array()
+        self._dev_valid = False            # the caller may write through the returned array
+        return arr
+
+    @_wfs.setter
+    def _wfs(self, value):
+        self._host = np.ascontiguousarray(value, dtype=complex)
+        self._host_valid = True
+        self._dev_valid = False
+
+    def _free_dev(self):
+        if self._dev is not None:
+            _lib.lib.tbk_wfs_free(self._dev)
+        self._dev = None
+        self._dev_shape = None
+        self._dev_valid = False
+
+    def _dev_handle(self, shape):
+        """Device buffer of the given full shape (re-created when the shape changes)."""
+        if self._dev is not None and self._dev_shape == tuple(shape):
+            return self._dev
+        self._free_dev()
+        mesh = np.ascontiguousarray(shape[:self._dim_arr], dtype=np.int32)
+        nsta = int(shape[self._dim_arr])
+        ncomp = int(np.prod(shape[self._dim_arr + 1:]))
+        h = C.c_void_p()
+        _lib.check(_lib.lib.tbk_wfs_create(_lib.default_context().handle, self._dim_arr, _lib.iptr(mesh),
+                                           nsta, ncomp, C.byref(h)))
+        self._dev = h
+        self._dev_shape = tuple(shape)
+        return h
+
+    def _ensure_dev(self):
+        if self._dev_valid and self._dev is not None:
+            return self._dev
+        host = self._host_array()
+        if not host.flags["C_CONTIGUOUS"]:
+            host = self._host = np.ascontiguousarray(host)
+        h = self._dev_handle(host.shape)
+        _lib.check(_lib.lib.tbk_wfs_upload(h, _lib.dptr(host.view(float))))
+        self._dev_valid = True
+        return h
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_host"] = None if self._host is None and not self._dev_valid else np.copy(self._host_array())
+        st["_host_valid"] = st["_host"] is not None
+        st["_dev"] = None
+        st["_dev_shape"] = None
+        st["_dev_valid"] = False
+        return st
+
+    def __del__(self):
+        try:
+            self._free_dev()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ mesh solve
+    def solve_on_grid(self, start_k):
+        """Solve the model on the regular mesh anchored at start_k and impose
+        periodic boundary conditions (pythtb.py:2421-2532).  One kernel launch;
+        the eigenvectors stay on the device.  Returns the minimal direct gaps."""
+        if self._dim_arr != self._model._dim_k:
+            raise Exception("\n\nIf using solve_on_grid method, dimension of wf_array must equal"
+                            "\ndim_k of the tight-binding model!")
+        if self._nsta_arr != self._model._nsta:
+            raise Exception(
+                "\n\nWhen initializing this object, you specified nsta_arr to be " + str(self._nsta_arr) + ", but"
+                "\nthis does not match the total number of bands specified in the model,"
+                "\nwhich was " + str(self._model._nsta) + ".  If you wish to use the solve_on_grid method, do"
+                "\nnot specify the nsta_arr parameter when initializing this object.\n\n")
+        self._start_k = start_k
+        m = self._model
+        for d in range(self._dim_arr):                       # impose_pbc's guard (pythtb.py:2725)
+            if m._per[d] not in m._per:
+                raise Exception("Periodic boundary condition can be specified only along periodic directions!")
+        start = np.ascontiguousarray(np.array(start_k, dtype=float).reshape(-1))
+        if start.shape != (self._dim_arr,):
+            raise Exception("\n\nk-vector of wrong shape!")
+        n = m._nsta
+        pbc = np.zeros((self._dim_arr, n), dtype=complex)
+        for d in range(self._dim_arr):
+            fac = np.exp(-2.j * np.pi * self._orb[:, m._per[d]])     # pythtb.py:2729
+            pbc[d] = np.repeat(fac, self._nspin)
+        h = self._dev_handle(self._shape())
+        gaps = np.zeros(max(n - 1, 1), dtype=float)
+        n0 = int(self._mesh_arr[0])
+        _lib.check(_lib.lib.tbk_wfs_solve_grid(h, m._device_model(), _lib.dptr(start),
+                                               _lib.dptr(pbc.view(float)), 0, n0, _lib.dptr(gaps)))
+        self._dev_valid = True
+        self._host_valid = False
+        if n <= 1:
+            return None
+        return gaps[:n - 1]
+
+    def solve_on_one_point(self, kpt, mesh_indices):
+        """Solve at one k and store at mesh_indices (pythtb.py:2534-2566)."""
+        (eval, evec) = self._model.solve_one(kpt, eig_vectors=True)
+        if _is_int(mesh_indices):
+            self._wfs[(mesh_indices,)] = evec
+        else:
+            self._wfs[tuple(mesh_indices)] = evec
+
+    def choose_states(self, subset):
+        """New wf_array holding a subset of the states (pythtb.py:2568-2608)."""
+        subset = np.array(subset, dtype=int)
+        if subset.ndim != 1:
+            raise Exception("\n\nParameter subset must be a one-dimensional array.")
+        if self._dim_arr > 4:
+            raise Exception("\n\n_dim_array too large.")
+        new = copy.deepcopy(self)
+        new._nsta_arr = subset.shape[0]
+        new._wfs = np.take(self._host_array(), subset, axis=self._dim_arr)
+        return new
+
+    def empty_like(self, nsta_arr=None):
+        """Same-shaped uninitialised wf_array, optionally with another number of states
+        (pythtb.py:2610-2642)."""
+        new = copy.deepcopy(self)
+        if nsta_arr is not None:
+            new._nsta_arr = nsta_arr
+        new._wfs = np.empty(new._shape(), dtype=complex)
+        return new
+
+    def _check_key(self, key):
+        if self._dim_arr == 1:
+            if not _is_int(key):
+                raise TypeError("Key should be an integer!")
+            if key < -self._mesh_arr[0] or key >= self._mesh_arr[0]:
+                raise IndexError("Key outside the range!")
+        else:
+            if len(key) != self._dim_arr:
+                raise TypeError("Wrong dimensionality of key!")
+            for i, k in enumerate(key):
+                if not _is_int(k):
+                    raise TypeError("Key should be set of integers!")
+                if k < -self._mesh_arr[i] or k >= self._mesh_arr[i]:
+                    raise IndexError("Key outside the range!")
+
+    def __getitem__(self, key):
+        self._check_key(key)
+        return self._wfs[key]
+
+    def __setitem__(self, key, value):
+        self._check_key(key)
+        self._wfs[key] = np.array(value, dtype=complex)
+
+    # ------------------------------------------------------------------ boundary conditions
+    def impose_pbc(self, mesh_dir, k_dir):
+        """Last slice along mesh_dir = first slice * exp(-2 pi i orb[:,k_dir])
+        (pythtb.py:2674-2749); runs on the device copy."""
+        if k_dir not in self._model._per:
+            raise Exception("Periodic boundary condition can be specified only along periodic directions!")
+        if mesh_dir not in range(min(self._dim_arr, 4)):
+            raise Exception("\n\nWrong value of mesh_dir.")
+        fac = np.exp(-2.j * np.pi * self._orb[:, k_dir])
+        phase = np.ascontiguousarray(np.repeat(fac, self._nspin))
+        h = self._ensure_dev()
+        _lib.check(_lib.lib.tbk_wfs_impose(h, int(mesh_dir), _lib.dptr(phase.view(float))))
+        self._host_valid = False
+
+    def impose_loop(self, mesh_dir):
+        """Last slice along mesh_dir = first slice (pythtb.py:2751-2791)."""
+        if mesh_dir not in range(min(self._dim_arr, 4)):
+            raise Exception("\n\nWrong value of mesh_dir.")
+        h = self._ensure_dev()
+        _lib.check(_lib.lib.tbk_wfs_impose(h, int(mesh_dir), None))
+        self._host_valid = False
+
+    # ------------------------------------------------------------------ Berry quantities
+    def _occ(self, occ):
+        if (isinstance(occ, str) and occ == "All") or occ is None:
+            return np.arange(self._nsta_arr, dtype=np.int32)
+        return np.array(occ, dtype=int)
+
+    def berry_phase(self, occ="All", dir=None, contin=True, berry_evals=False):
+        """Berry phase (or Wilson-loop eigenphases) of every string along `dir`
+        (pythtb.py:2863-3066).  Link overlaps, polar factors, ordered products and
+        eigenphases are computed on the device; the 2 pi continuity pass is host work."""
+        occ = self._occ(occ)
+        if occ.ndim != 1:
+            raise Exception("\n\nParameter occ must be a one-dimensional array or string \"All\" or None.")
+        if self._model._assume_position_operator_diagonal == False:  # noqa: E712
+            raise Exception("\n\nBerry-like objects of Wannier90 models need "
+                            "my_model.ignore_position_operator_offdiagonal()")
+        if self._dim_arr == 1:
+            use_dir = 0
+        elif self._dim_arr in (2, 3):
+            if dir is None or dir not in range(self._dim_arr):
+                raise Exception("\n\nWrong direction for Berry phase calculation!")
+            use_dir = int(dir)
+        else:
+            raise Exception("\n\nWrong dimensionality!")
+        h = self._ensure_dev()
+        nocc = len(occ)
+        other = [int(self._mesh_arr[d]) for d in range(self._dim_arr) if d != use_dir]
+        nstr = int(np.prod(other)) if other else 1
+        out = np.zeros(nstr * (nocc if berry_evals else 1), dtype=float)
+        occ32 = np.ascontiguousarray(occ, dtype=np.int32)
+        _lib.check(_lib.lib.tbk_berry_phase(h, _lib.iptr(occ32), nocc, use_dir, 1 if berry_evals else 0,
+                                            _lib.dptr(out)))
+        if self._dim_arr == 1:
+            ret = out.copy() if berry_evals else np.float64(out[0])
+        else:
+            ret = out.reshape(other + ([nocc] if berry_evals else []))
+        if contin:
+            if not berry_evals:
+                if self._dim_arr == 2:
+                    ret = _one_phase_cont(ret, ret[0])
+                elif self._dim_arr == 3:
+                    for i in range(ret.shape[1]):
+                        clos = ret[0, 0] if i == 0 else ret[0, i - 1]
+                        ret[:, i] = _one_phase_cont(ret[:, i], clos)
+            else:
+                if self._dim_arr == 2:
+                    ret = _array_phases_cont(ret, ret[0, :])
+                elif self._dim_arr == 3:
+                    for i in range(ret.shape[1]):
+                        clos = ret[0, 0, :] if i == 0 else ret[0, i - 1, :]
+                        ret[:, i] = _array_phases_cont(ret[:, i], clos)
+        return ret
+
+    def berry_flux(self, occ="All", dirs=None, individual_phases=False):
+        """Berry flux through the (dirs[0],dirs[1]) planes (pythtb.py:3068-3205):
+        plaquette phases and their deterministic sum are computed on the device."""
+        occ = self._occ(occ)
+        if self._model._assume_position_operator_diagonal == False:  # noqa: E712
+            raise Exception("\n\nBerry-like objects of Wannier90 models need "
+                            "my_model.ignore_position_operator_offdiagonal()")
+        if dirs is None:
+            dirs = [0, 1]
+        if dirs[0] == dirs[1]:
+            raise Exception("Need to specify two different directions for Berry flux calculation.")
+        if dirs[0] >= self._dim_arr or dirs[1] >= self._dim_arr or dirs[0] < 0 or dirs[1] < 0:
+            raise Exception("Direction for Berry flux calculation out of bounds.")
+        if self._dim_arr not in (2, 3, 4):
+            raise Exception("\n\nWrong dimensionality!")
+        h = self._ensure_dev()
+        rest = [int(self._mesh_arr[d]) for d in range(self._dim_arr) if d not in (dirs[0], dirs[1])]
+        nsl = int(np.prod(rest)) if rest else 1
+        n0 = int(self._mesh_arr[dirs[0]]) - 1
+        n1 = int(self._mesh_arr[dirs[1]]) - 1
+        totals = np.zeros(nsl, dtype=float)
+        plaq = np.zeros((nsl, n0, n1), dtype=float) if individual_phases else None
+        occ32 = np.ascontiguousarray(occ, dtype=np.int32)
+        _lib.check(_lib.lib.tbk_berry_flux(h, _lib.iptr(occ32), len(occ32), int(dirs[0]), int(dirs[1]),
+                                           _lib.dptr(totals), _lib.dptr(plaq)))
+        if self._dim_arr == 2:
+            return plaq[0] if individual_phases else np.float64(totals[0])
+        if individual_phases:
+            return plaq.reshape(rest + [n0, n1])
+        return totals.reshape(rest)

@@ -1,0 +1,517 @@
+"""GPU parity: the HIP path (through the C ABI, via the tb_model / wf_array mirror)
+against golden vectors captured from the reference and against the CPU oracle.
+
+Tolerances (fp64; BASELINE.json asks for eigenvalues within 1e-10 of NumPy):
+  H(k) entries       1e-13      eigenvalues     1e-12
+  plaquette / string phases, fluxes, Wilson-loop eigenphases   1e-10
+Eigenvectors are gauge dependent and never compared raw: residual, orthonormality
+and gauge-invariant Berry quantities are checked instead.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_tables, load_golden
+import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+TOL_H = 1e-13
+TOL_E = 1e-12
+TOL_P = 1e-10
+
+POINT_CASES = ["graphene", "haldane0", "haldane02", "km_odd", "km_even", "chain3", "per02",
+               "molecule", "spin_chain", "cubic16"]
+
+
+@pytest.fixture(scope="module")
+def tb():
+    import pythtb_amd
+    pythtb_amd._lib.default_context()        # fail loudly here if no GPU / no library
+    return pythtb_amd
+
+
+def wrap(d):
+    return (np.asarray(d) + np.pi) % (2 * np.pi) - np.pi
+
+
+def assert_phase_sets_close(a, b, tol):
+    a = np.asarray(a).reshape(-1, np.asarray(a).shape[-1])
+    b = np.asarray(b).reshape(a.shape)
+    for ra, rb in zip(a, b):
+        free = list(range(len(rb)))
+        for x in ra:
+            d = [abs(wrap(x - rb[j])) for j in free]
+            j = int(np.argmin(d))
+            assert d[j] < tol, (ra, rb)
+            free.pop(j)
+
+
+# ------------------------------------------------------------------ kernels 1+2
+@pytest.mark.parametrize("name", POINT_CASES)
+def test_gen_ham_and_eigenvalues_match_reference(tb, name):
+    g = load_golden("point_" + name)
+    m = hp.model_from_tables(tb.tb_model, golden_tables(g))
+    n = m._nsta
+    if m._dim_k == 0:
+        ham = m._gen_ham().reshape(n, n)
+        assert np.max(np.abs(ham - g["ham"][0])) < TOL_H
+        ev = m.solve_all()
+        assert ev.shape == (n,)
+        assert np.max(np.abs(ev - g["evals"][:, 0])) < TOL_E
+        ev2, vec = m.solve_all(eig_vectors=True)
+        assert vec.shape == ((n, m._norb) if m._nspin == 1 else (n, m._norb, 2))
+        V = vec.reshape(n, n)
+        assert np.max(np.abs(g["ham"][0] @ V.T - V.T * ev2)) < 1e-12
+        return
+    k = g["k"]
+    for ik in range(0, len(k), 7):
+        ham = m._gen_ham(k[ik]).reshape(n, n)
+        assert np.max(np.abs(ham - g["ham"][ik])) < TOL_H
+    ev = m.solve_all(k)
+    assert ev.shape == (n, len(k)) and ev.flags["C_CONTIGUOUS"]
+    assert np.max(np.abs(ev - g["evals"])) < TOL_E
+    ev2, vec = m.solve_all(k, eig_vectors=True)
+    assert np.max(np.abs(ev2 - g["evals"])) < TOL_E
+    assert vec.shape == ((n, len(k), m._norb) if m._nspin == 1 else (n, len(k), m._norb, 2))
+    V = vec.reshape(n, len(k), n)
+    for ik in range(len(k)):
+        Vk = V[:, ik, :]                                   # rows are eigenvectors
+        assert np.max(np.abs(Vk.conj() @ Vk.T - np.identity(n))) < 1e-13
+        assert np.max(np.abs(g["ham"][ik] @ Vk.T - Vk.T * ev2[:, ik])) < 1e-12
+    # solve_one and _sol_ham on the same matrices
+    e1, v1 = m.solve_one(k[3], eig_vectors=True)
+    assert np.max(np.abs(e1 - g["evals"][:, 3])) < TOL_E and v1.shape == vec[:, 0].shape
+    hshape = (m._norb, m._norb) if m._nspin == 1 else (m._norb, 2, m._norb, 2)
+    e3 = m._sol_ham(g["ham"][5].reshape(hshape))
+    assert np.max(np.abs(e3 - g["evals"][:, 5])) < TOL_E
+    e4, v4 = m._sol_ham(g["ham"][5].reshape(hshape), eig_vectors=True)
+    V4 = v4.reshape(n, n)
+    assert np.max(np.abs(g["ham"][5] @ V4.T - V4.T * e4)) < 1e-12
+
+
+def test_sol_ham_rejects_non_hermitian(tb):
+    m = hp.haldane(tb.tb_model)
+    with pytest.raises(Exception, match="not hermitian"):
+        m._sol_ham(np.array([[0.0, 1.0], [0.5, 0.0]], dtype=complex))
+
+
+def test_eigh_batch_random_sizes_vs_numpy(tb):
+    """_sol_ham kernel on random Hermitian matrices, every size the build supports
+    up to 24 plus 33 and 64 (register path n<=4, wavefront path above)."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(7)
+    for n in list(range(1, 25)) + [33, 64]:
+        nk = 37 if n <= 24 else 5
+        a = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+        h = np.ascontiguousarray(a + np.transpose(a.conj(), (0, 2, 1)))
+        if n >= 4:                                          # exact degeneracies and a zero matrix
+            h[0] = np.diag([1.0] * (n // 2) + [2.0] * (n - n // 2))
+            h[1] = 0.0
+        ev = np.zeros((n, nk))
+        vec = np.zeros((n, nk, n), dtype=complex)
+        _lib.check(_lib.lib.tbk_eigh_batch(_lib.default_context().handle, n, _lib.dptr(h.view(float)), nk,
+                                           _lib.dptr(ev), _lib.dptr(vec.view(float))))
+        ref = np.linalg.eigvalsh(h).T
+        scale = max(1.0, np.abs(ref).max())
+        assert np.max(np.abs(ev - ref)) < 2e-13 * scale * n, n
+        for ik in range(nk):
+            V = vec[:, ik, :]
+            assert np.max(np.abs(V.conj() @ V.T - np.identity(n))) < 1e-12, n
+            assert np.max(np.abs(h[ik] @ V.T - V.T * ev[:, ik])) < 1e-11 * scale, n
+
+
+def test_solve_all_input_forms(tb):
+    """1-D models accept a flat list of scalars; lists of lists and arrays agree."""
+    m = hp.chain3(tb.tb_model, -1.0, 2.0, 0.3)
+    ks = [0.0, 0.1, 0.37, -0.2]
+    a = m.solve_all(ks)
+    b = m.solve_all([[x] for x in ks])
+    c = m.solve_all(np.array(ks).reshape(-1, 1))
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.array_equal(m.solve_one(0.37), a[:, 2])
+    with pytest.raises(Exception, match="wrong shape"):
+        hp.haldane(tb.tb_model).solve_all([[0.1, 0.2, 0.3]])
+
+
+def test_solve_all_deterministic(tb):
+    m = hp.kane_mele(tb.tb_model)
+    k = np.random.default_rng(1).random((300, 2))
+    e1, v1 = m.solve_all(k, eig_vectors=True)
+    e2, v2 = m.solve_all(k, eig_vectors=True)
+    assert np.array_equal(e1, e2) and np.array_equal(v1, v2)
+
+
+# ------------------------------------------------------------------ grids, flux, phases
+GRID_CASES = {
+    "haldane0_33": dict(occs=[0, 1, 2], dirs=[0, 1], flux=[(0, 1), (1, 0)]),
+    "haldane02_20x28": dict(occs=[0, 1], dirs=[0, 1], flux=[(0, 1)]),
+    "km_odd_65x33": dict(occs=[0], dirs=[0, 1], flux=[(0, 1)]),     # other occ sets split Kramers pairs
+    "km_even_41": dict(occs=[0], dirs=[1], flux=[(0, 1)]),
+    "chain3_41": dict(occs=[0, 1, 2], dirs=[0], flux=[]),
+    "per02_11": dict(occs=[0, 1], dirs=[0, 1], flux=[(0, 1)]),
+    "spin_chain_25": dict(occs=[0, 1], dirs=[0], flux=[]),
+    "cubic16_9": dict(occs=[0, 1], dirs=[0, 1, 2], flux=[(0, 1), (1, 2), (2, 0)]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GRID_CASES))
+def test_grid_flux_phase_match_reference(tb, name):
+    g = load_golden("grid_" + name)
+    spec = GRID_CASES[name]
+    m = hp.model_from_tables(tb.tb_model, golden_tables(g))
+    mesh = [int(x) for x in g["mesh"]]
+    w = tb.wf_array(m, mesh)
+    gaps = w.solve_on_grid(list(g["start_k"]))
+    if m._nsta > 1:
+        assert gaps.shape == (m._nsta - 1,)
+        assert np.max(np.abs(gaps - g["min_gaps"])) < TOL_E
+    else:
+        assert gaps is None
+    dim = len(mesh)
+    for io in spec["occs"]:
+        occ = [int(x) for x in g["occ%d" % io]]
+        for (d0, d1) in spec["flux"]:
+            tag = "occ%d_d%d%d" % (io, d0, d1)
+            plaq = w.berry_flux(occ, dirs=[d0, d1], individual_phases=True)
+            assert plaq.shape == g["flux_plaq_" + tag].shape
+            assert np.max(np.abs(wrap(plaq - g["flux_plaq_" + tag]))) < TOL_P
+            tot = w.berry_flux(occ, dirs=[d0, d1])
+            assert np.shape(tot) == g["flux_tot_" + tag].shape
+            assert np.max(np.abs(tot - g["flux_tot_" + tag])) < 1e-9
+        for d in spec["dirs"]:
+            for contin in (True, False):
+                ref = g["phase_occ%d_dir%d_c%d_e0" % (io, d, int(contin))]
+                got = w.berry_phase(occ, d if dim > 1 else None, contin=contin)
+                assert np.shape(got) == ref.shape
+                assert np.max(np.abs(wrap(got - ref))) < TOL_P, (name, io, d, contin)
+                ref = g["phase_occ%d_dir%d_c%d_e1" % (io, d, int(contin))]
+                got = w.berry_phase(occ, d if dim > 1 else None, contin=contin, berry_evals=True)
+                assert np.shape(got) == ref.shape
+                assert_phase_sets_close(got, ref, 1e-9)
+    # the device array and its host mirror agree with impose_pbc semantics
+    host = w._wfs
+    assert host.shape == tuple(mesh + [m._nsta, m._norb] + ([2] if m._nspin == 2 else []))
+    for d in range(dim):
+        fac = np.repeat(np.exp(-2j * np.pi * m._orb[:, m._per[d]]), m._nspin).reshape(host.shape[dim + 1:])
+        first = np.take(host, 0, axis=d)
+        last = np.take(host, -1, axis=d)
+        assert np.max(np.abs(last - first * fac)) < 1e-14
+
+
+def test_contin_matches_reference_exactly_when_no_branch_issue(tb):
+    g = load_golden("grid_haldane0_33")
+    m = hp.model_from_tables(tb.tb_model, golden_tables(g))
+    w = tb.wf_array(m, [33, 33])
+    w.solve_on_grid([-0.5, -0.5])
+    for d in (0, 1):
+        got = w.berry_phase([0], d, contin=True)
+        ref = g["phase_occ0_dir%d_c1_e0" % d]
+        assert np.max(np.abs(got - ref)) < TOL_P            # same 2 pi branch, not only mod 2 pi
+    assert abs(w.berry_flux([0]) / (2 * np.pi) + 1.0) < 1e-12   # Chern number -1
+
+
+def test_manual_fill_cone_and_3site(tb):
+    """wf_arrays filled through [] / solve_on_one_point (reference tests cone, 3site_cycle)."""
+    g = load_golden("manual_cone")
+    m = hp.model_from_tables(tb.tb_model, golden_tables(g))
+    n = 31
+    w = tb.wf_array(m, [n])
+    for i in range(n):
+        w.solve_on_one_point(g["circ_k"][i], i)
+    w[-1] = w[0]
+    got = np.array([w.berry_phase([0], 0), w.berry_phase([1], 0), w.berry_phase([0, 1], 0)])
+    assert np.max(np.abs(wrap(got - g["circ_phase"]))) < TOL_P
+    ws = tb.wf_array(m, [n, n])
+    for i in range(n):
+        for j in range(n):
+            ws[i, j] = m.solve_one(g["sq_k"][i, j], eig_vectors=True)[1]
+    got = np.array([ws.berry_flux([0]), ws.berry_flux([1]), ws.berry_flux([0, 1])])
+    assert np.max(np.abs(got - g["sq_flux"])) < 1e-9
+    assert np.max(np.abs(ws.berry_flux([0], individual_phases=True) - g["sq_plaq"])) < TOL_P
+
+    g = load_golden("manual_3site")
+    t, delta, lam, nkp = float(g["t"]), float(g["delta"]), g["lam"], int(g["nkp"])
+    w = tb.wf_array(hp.chain3(tb.tb_model, t, delta, 0.0), [nkp, len(lam)])
+    for il, lm in enumerate(lam):
+        mm = hp.chain3(tb.tb_model, t, delta, lm)
+        kv, _, _ = mm.k_path([[-0.5], [0.5]], nkp, report=False)
+        _, evec = mm.solve_all(kv, eig_vectors=True)
+        for ik in range(nkp):
+            w[ik, il] = evec[:, ik, :]
+    w.impose_pbc(0, 0)
+    assert np.max(np.abs(wrap(w.berry_phase([0], 0) - g["wann"] * 2 * np.pi))) < TOL_P
+    assert abs(w.berry_flux([0]) - g["flux"]) < 1e-9
+    got = np.array([w.berry_flux([0]), w.berry_flux([1]), w.berry_flux([2]),
+                    w.berry_flux([0, 1]), w.berry_flux([0, 1, 2])])
+    assert np.max(np.abs(got - g["flux_all"])) < 1e-9
+
+
+def test_wf_array_api_contract(tb):
+    m = hp.haldane(tb.tb_model)
+    w = tb.wf_array(m, [9, 7])
+    w.solve_on_grid([0.0, 0.0])
+    assert w[2, 3].shape == (2, 2) and w[-1, -1].shape == (2, 2)
+    with pytest.raises(IndexError):
+        w[9, 0]
+    with pytest.raises(TypeError):
+        w[1]
+    with pytest.raises(Exception, match="Wrong direction"):
+        w.berry_phase([0])
+    with pytest.raises(Exception, match="two different directions"):
+        w.berry_flux([0], dirs=[1, 1])
+    sub = w.choose_states([1])
+    assert sub._wfs.shape == (9, 7, 1, 2)
+    assert np.allclose(sub._wfs[:, :, 0], w._wfs[:, :, 1])
+    assert abs(sub.berry_flux([0]) - w.berry_flux([1])) < 1e-10
+    assert w.berry_flux("All") == w.berry_flux(None) == w.berry_flux(range(2))
+    e = w.empty_like(nsta_arr=5)
+    assert e._wfs.shape == (9, 7, 5, 2)
+    with pytest.raises(Exception, match="2 or larger"):
+        tb.wf_array(m, [1, 5])
+    with pytest.raises(Exception, match="nsta_arr"):
+        tb.wf_array(m, [5, 5], nsta_arr=1).solve_on_grid([0, 0])
+    # impose_loop copies without phases
+    w2 = tb.wf_array(m, [5, 5])
+    w2.solve_on_grid([0.0, 0.0])
+    w2.impose_loop(1)
+    assert np.array_equal(w2._wfs[:, -1], w2._wfs[:, 0])
+
+
+# ------------------------------------------------------------------ the reference's own golden files
+REF = os.path.join(GOLDEN, "reference_tests")
+
+
+def ref_npy(group, name):
+    return np.load(os.path.join(REF, group, name))
+
+
+def test_reference_goldens_band_structures(tb):
+    atol, rtol = 1e-12, 1e-8                               # reference tests: rtol=1e-8, atol=1e-14
+    g = hp.graphene(tb.tb_model, delta=0.0)
+    path = [[0., 0.], [2. / 3., 1. / 3.], [.5, .5], [0., 0.]]
+    kv, _, _ = g.k_path(path, 121, report=False)
+    np.testing.assert_allclose(g.solve_all(kv), ref_npy("graphene", "evals.npy"), rtol=rtol, atol=atol)
+
+    h = hp.haldane(tb.tb_model, delta=0.2)
+    path = [[0., 0.], [2. / 3., 1. / 3.], [.5, .5], [1. / 3., 2. / 3.], [0., 0.]]
+    kv, _, _ = h.k_path(path, 101, report=False)
+    np.testing.assert_allclose(h.solve_all(kv), ref_npy("haldane", "evals.npy"), rtol=rtol, atol=atol)
+    kp = [[i / 20.0, j / 20.0] for i in range(20) for j in range(20)]
+    np.testing.assert_allclose(h.solve_all(kp).flatten(), ref_npy("haldane", "evals_dos.npy"), rtol=rtol, atol=atol)
+
+    ev = np.array([hp.kane_mele(tb.tb_model, t).solve_all(kv) for t in ("even", "odd")])
+    np.testing.assert_allclose(ev, ref_npy("kane_mele", "kane_mele_evals.npy"), rtol=rtol, atol=atol)
+
+    cb = hp.quiet(tb.tb_model, 2, 2, [[1.0, 0.0], [0.0, 1.0]], [[0.0, 0.0], [0.5, 0.5]])
+    cb.set_onsite([-1.1, 1.1])
+    for R in ([0, 0], [1, 0], [0, 1], [1, 1]):
+        cb.set_hop(0.6, 1, 0, R)
+    kv2, _, _ = cb.k_path([[0.0, 0.0], [0.0, 0.5], [0.5, 0.5], [0.0, 0.0]], 301, report=False)
+    np.testing.assert_allclose(cb.solve_all(kv2), ref_npy("checkerboard", "evals.npy"), rtol=rtol, atol=atol)
+
+    tr = hp.quiet(tb.tb_model, 1, 2, [[2.0, 0.0], [0.0, 1.0]], [[0.0, 0.0], [0.5, 1.0]], per=[0])
+    tr.set_hop(2.0, 0, 0, [1, 0])
+    tr.set_hop(2.0, 1, 1, [1, 0])
+    tr.set_hop(0.8 + 0.6j, 0, 1, [0, 0])
+    tr.set_hop(0.8 + 0.6j, 1, 0, [1, 0])
+    kv3, _, _ = tr.k_path("fullc", 100, report=False)
+    np.testing.assert_allclose(tr.solve_all(kv3), ref_npy("trestle", "evals.npy"), rtol=rtol, atol=atol)
+
+    bl = hp.quiet(tb.tb_model, 2, 3, [[1.0, 0.0, 0.0], [0.0, 1.25, 0.0], [0.0, 0.0, 3.0]],
+                  [[0.0, 0.0, -0.15], [0.5, 0.5, 0.15]])
+    bl.set_onsite([-1.1, 1.1])
+    for R in ([0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]):
+        bl.set_hop(0.6, 1, 0, R)
+    kv4, _, _ = bl.k_path([[0.0, 0.0], [0.0, 0.5], [0.5, 0.5], [0.0, 0.0]], 81, report=False)
+    np.testing.assert_allclose(bl.solve_all(kv4), ref_npy("buckled_layer", "evals.npy"), rtol=rtol, atol=atol)
+
+    sq32 = np.sqrt(3.0) / 2.0
+    mol = hp.quiet(tb.tb_model, 0, 3, np.identity(3),
+                   [[(2.0 / 3.0) * sq32, 0.0, 0.0], [(-1.0 / 3.0) * sq32, 0.5, 0.0],
+                    [(-1.0 / 3.0) * sq32, -0.5, 0.0], [0.0, 0.0, 1.0]])
+    mol.set_onsite([-0.5, -0.5, -0.5, 0.5])
+    for i in range(4):
+        for j in range(i + 1, 4):
+            mol.set_hop(1.0, i, j)
+    np.testing.assert_allclose(mol.solve_all(), ref_npy("0dim", "evals.npy"), rtol=rtol, atol=atol)
+
+
+def test_reference_goldens_berry(tb):
+    # haldane_bp (tests/test_examples/haldane/haldane_bp/run.py): 31x31, start -0.5
+    m = hp.haldane(tb.tb_model, delta=0.0)
+    w = tb.wf_array(m, [31, 31])
+    w.solve_on_grid([-0.5, -0.5])
+    for name, occ in (("phi_a1", [0]), ("phi_b1", [1]), ("phi_c1", [0, 1])):
+        got = w.berry_phase(occ, 0, contin=True)
+        assert np.max(np.abs(got - ref_npy("haldane_bp", name + ".npy"))) < TOL_P
+    assert abs(w.berry_flux([0]) - ref_npy("haldane_bp", "flux_a1.npy")) < 1e-9
+    assert abs(ref_npy("haldane_bp", "flux_a2.npy") + 2 * np.pi) < 1e-9
+    # kane_mele wan_cent: berry_phase([0,1],dir=1,contin=False,berry_evals=True)/2pi on 41x41
+    cents = []
+    for top in ("even", "odd"):
+        wk = tb.wf_array(hp.kane_mele(tb.tb_model, top), [41, 41])
+        wk.solve_on_grid([-0.5, -0.5])
+        cents.append(wk.berry_phase([0, 1], dir=1, contin=False, berry_evals=True) / (2 * np.pi))
+    ref = ref_npy("kane_mele", "kane_mele_wan_cent.npy")
+    for a, b in zip(cents, ref):
+        assert_phase_sets_close(a * 2 * np.pi, b * 2 * np.pi, 1e-9)
+    # cone goldens
+    gc = load_golden("manual_cone")
+    mc = hp.graphene(tb.tb_model, delta=-0.1)
+    wc = tb.wf_array(mc, [31])
+    for i in range(31):
+        wc.solve_on_one_point(gc["circ_k"][i], i)
+    wc[-1] = wc[0]
+    for name, occ in (("bphase_circ0", [0]), ("bphase_circ1", [1]), ("bphase_circ01", [0, 1])):
+        assert abs(wrap(wc.berry_phase(occ, 0) - ref_npy("cone", name + ".npy"))) < TOL_P
+    # 3site_cycle_fin fluxes: (lambda, k) array, 5 occupations
+    t, delta = -1.3, 2.0
+    lam = np.linspace(0.0, 1.0, 21, endpoint=True)
+    kv, _, _ = hp.chain3(tb.tb_model, t, delta, 0.0).k_path([[-0.5], [0.5]], 31, report=False)
+    wl = tb.wf_array(hp.chain3(tb.tb_model, t, delta, 0.0), [21, 31])
+    for il, lm in enumerate(lam):
+        _, evec = hp.chain3(tb.tb_model, t, delta, lm).solve_all(kv, eig_vectors=True)
+        for ik in range(31):
+            wl[il, ik] = evec[:, ik, :]
+    got = np.array([wl.berry_flux([0]), wl.berry_flux([1]), wl.berry_flux([2]),
+                    wl.berry_flux([0, 1]), wl.berry_flux([0, 1, 2])])
+    assert np.max(np.abs(got - ref_npy("3site_cycle_fin", "3site_cycle_fluxes.npy"))) < 1e-9
+
+
+# ------------------------------------------------------------------ oracle at larger / random sizes
+@pytest.mark.parametrize("norb,dim_k,nspin,seed", [
+    (1, 1, 1, 0), (2, 2, 1, 1), (3, 3, 1, 2), (4, 2, 1, 3), (1, 2, 2, 4), (2, 3, 2, 5),
+    (5, 2, 1, 6), (3, 1, 2, 7), (7, 3, 1, 8), (4, 2, 2, 9), (11, 2, 1, 10), (16, 3, 1, 11),
+    (3, 4, 1, 12), (20, 1, 1, 13), (2, 0, 2, 14),
+])
+def test_random_models_vs_oracle(tb, norb, dim_k, nspin, seed):
+    from oracle import tb_oracle as orc
+    m = hp.random_model(tb.tb_model, norb, dim_k, nspin, seed)
+    n = m._nsta
+    if dim_k == 0:
+        assert np.max(np.abs(m.solve_all() - orc.solve_all(m))) < TOL_E * 10
+        assert np.max(np.abs(m._gen_ham() - orc.gen_ham(m))) < TOL_H * 10
+        return
+    k = np.random.default_rng(seed + 100).uniform(-1.5, 1.5, size=(200, dim_k))
+    ham = orc.ham_batch(m, k)
+    scale = max(1.0, np.abs(ham).max())
+    for ik in (0, 17, 199):
+        assert np.max(np.abs(m._gen_ham(k[ik]).reshape(n, n) - ham[ik])) < TOL_H * scale * 10
+    ev, vec = m.solve_all(k, eig_vectors=True)
+    ref = orc.solve_all_vec(m, k)
+    assert np.max(np.abs(ev - ref)) < TOL_E * scale * 10
+    assert np.array_equal(ev, m.solve_all(k))               # eigenvalue-only kernel variant agrees
+    V = vec.reshape(n, len(k), n)
+    for ik in range(0, len(k), 13):
+        assert np.max(np.abs(ham[ik] @ V[:, ik].T - V[:, ik].T * ev[:, ik])) < 1e-11 * scale
+
+
+@pytest.mark.parametrize("case", ["haldane", "km", "chain3x", "cubic16"])
+def test_mesh_berry_vs_oracle(tb, case):
+    """solve_on_grid + berry_* against the oracle run on the oracle's own eigenvectors."""
+    from oracle import tb_oracle as orc
+    if case == "haldane":
+        m, mesh, start, occs = hp.haldane(tb.tb_model, 0.3), [48, 37], [-0.37, 0.11], [[0], [1], [0, 1]]
+    elif case == "km":
+        m, mesh, start, occs = hp.kane_mele(tb.tb_model, "odd"), [40, 23], [0.013, -0.21], [[0, 1], [2, 3], [0, 1, 2, 3]]
+    elif case == "chain3x":
+        m, mesh, start, occs = hp.chain3(tb.tb_model, -1.0, 2.0, 0.1), [57], [0.05], [[0], [1, 2]]
+    else:
+        m, mesh, start, occs = hp.cubic16(tb.tb_model), [6, 5, 7], [0.1, 0.2, 0.3], [list(range(8)), list(range(16)), [2, 9, 4]]
+    w = tb.wf_array(m, mesh)
+    gaps = w.solve_on_grid(start)
+    owfs, ogaps = orc.solve_on_grid(m, mesh, start, vectorised=True)
+    assert np.max(np.abs(gaps - ogaps)) < 1e-11
+    D = len(mesh)
+    for occ in occs:
+        if D >= 2:
+            for dirs in ([0, 1], [1, 0]) + (([1, 2], [2, 0]) if D == 3 else ()):
+                got = w.berry_flux(occ, dirs=list(dirs), individual_phases=True)
+                ref = orc.berry_flux(owfs, D, occ, list(dirs), individual_phases=True, vectorised=True)
+                assert got.shape == ref.shape
+                assert np.max(np.abs(wrap(got - ref))) < TOL_P
+                tot = w.berry_flux(occ, dirs=list(dirs))
+                assert np.max(np.abs(tot - ref.sum(axis=(-2, -1)))) < 1e-9
+        for d in range(D):
+            for be in (False, True):
+                got = w.berry_phase(occ, d if D > 1 else None, contin=False, berry_evals=be)
+                ref = orc.berry_phase(owfs, D, occ, d if D > 1 else None, contin=False, berry_evals=be)
+                assert np.shape(got) == np.shape(ref)
+                if be:
+                    assert_phase_sets_close(got, ref, 1e-9)
+                else:
+                    assert np.max(np.abs(wrap(got - ref))) < TOL_P
+
+
+def test_upload_roundtrip_and_user_written_arrays(tb):
+    """A wf_array filled on the host (oracle eigenvectors, different gauge) gives the
+    same gauge-invariant numbers; download(upload(x)) is the identity."""
+    from oracle import tb_oracle as orc
+    m = hp.haldane(tb.tb_model, 0.1)
+    owfs, _ = orc.solve_on_grid(m, [21, 17], [-0.5, -0.5], vectorised=True)
+    w = tb.wf_array(m, [21, 17])
+    w._wfs = owfs
+    f = w.berry_flux([0], individual_phases=True)
+    assert np.array_equal(w._wfs, owfs)
+    assert np.max(np.abs(f - orc.berry_flux(owfs, 2, [0], individual_phases=True, vectorised=True))) < TOL_P
+    w[3, 4] = w[3, 4] * np.exp(0.7j)                          # a gauge change leaves fluxes alone
+    assert np.max(np.abs(w.berry_flux([0], individual_phases=True) - f)) < TOL_P
+
+
+# ------------------------------------------------------------------ BASELINE.json config sizes
+def test_config_B_haldane_1024_eigenvalues(tb):
+    """configs[1]: Haldane (delta=0.2) solve_all on k_uniform_mesh([1024,1024])."""
+    from oracle import tb_oracle as orc
+    m = hp.haldane(tb.tb_model, 0.2)
+    k = m.k_uniform_mesh([1024, 1024])
+    ev = m.solve_all(k)
+    assert ev.shape == (2, 1024 * 1024)
+    assert np.all(ev[0] <= ev[1])                             # sorted per k
+    assert abs(ev.sum()) < 1e-6                               # traceless up to 2*delta*0: sum E = tr H = 0
+    assert abs(ev.min() + ev.max()) < 1e-9                    # min -3.0x, max 3.0x symmetric
+    sel = np.random.default_rng(0).integers(0, len(k), 4096)
+    assert np.max(np.abs(ev[:, sel] - orc.solve_all_vec(m, k[sel]))) < TOL_E
+    ev2, vec = m.solve_all(k[:65536], eig_vectors=True)
+    assert np.max(np.abs(np.einsum("bko,bko->bk", vec.conj(), vec).real - 1.0)) < 1e-13
+
+
+def test_config_C_haldane_2048_chern(tb):
+    """configs[2]: Chern number of the lower Haldane band on the 2048x2048 mesh is exactly -1."""
+    m = hp.haldane(tb.tb_model, 0.0)
+    w = tb.wf_array(m, [2049, 2049])
+    gaps = w.solve_on_grid([-0.5, -0.5])
+    flux = w.berry_flux([0])
+    assert abs(flux / (2 * np.pi) + 1.0) < 1e-10
+    assert round(flux / (2 * np.pi)) == -1
+    assert abs(gaps[0] - 1.55884812) < 1e-6                   # BASELINE.md section 2 (reference run)
+    plaq = w.berry_flux([0], individual_phases=True)
+    assert plaq.shape == (2048, 2048)
+    assert abs(plaq.sum() - flux) < 1e-9                      # checksum of checksums
+    assert abs(w.berry_flux([0, 1])) < 1e-9                   # both bands together: zero flux
+    full = os.path.join(GOLDEN, "full_size.npz")
+    if os.path.exists(full):
+        g = load_golden("full_size")
+        assert abs(flux - float(g["C_flux"])) < 1e-9
+        assert np.max(np.abs(gaps - g["C_min_gaps"])) < 1e-12
+        assert np.max(np.abs(plaq.sum(axis=1) - g["C_flux_row_sums"])) < 1e-10
+
+
+def test_config_D_kane_mele_wilson_loop(tb):
+    """configs[3] on one GPU: Kane-Mele (odd) 4096x512 mesh, Wilson-loop eigenphases."""
+    m = hp.kane_mele(tb.tb_model, "odd")
+    w = tb.wf_array(m, [4097, 513])
+    gaps = w.solve_on_grid([-0.5, -0.5])
+    assert gaps[0] < 1e-10 and gaps[2] < 1e-10 and abs(gaps[1] - 0.86770552) < 1e-6   # Kramers pairs on the mesh
+    wc = w.berry_phase([0, 1], dir=0, contin=False, berry_evals=True)
+    assert wc.shape == (513, 2)
+    # time reversal: the centres at k_y and -k_y coincide as sets; Z2 odd: they wind
+    assert_phase_sets_close(wc[1:256], wc[-2:-257:-1], 1e-8)
+    tot = w.berry_phase([0, 1], dir=0, contin=False)
+    assert np.max(np.abs(wrap(wc.sum(axis=1) - tot))) < 1e-9   # sum of eigenphases = phase of det
+    full = os.path.join(GOLDEN, "full_size.npz")
+    if os.path.exists(full):
+        g = load_golden("full_size")
+        assert np.max(np.abs(gaps - g["D_min_gaps"])) < 1e-11
+        assert_phase_sets_close(wc, g["D_wan_cent"], 1e-8)
