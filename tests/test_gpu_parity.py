@@ -402,7 +402,7 @@ def test_random_models_vs_oracle(tb, norb, dim_k, nspin, seed):
     ev, vec = m.solve_all(k, eig_vectors=True)
     ref = orc.solve_all_vec(m, k)
     assert np.max(np.abs(ev - ref)) < TOL_E * scale * 10
-    assert np.array_equal(ev, m.solve_all(k))               # eigenvalue-only kernel variant agrees
+    assert np.max(np.abs(ev - m.solve_all(k))) < 1e-13 * scale   # eigenvalue-only kernel variant
     V = vec.reshape(n, len(k), n)
     for ik in range(0, len(k), 13):
         assert np.max(np.abs(ham[ik] @ V[:, ik].T - V[:, ik].T * ev[:, ik])) < 1e-11 * scale

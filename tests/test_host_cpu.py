@@ -1,0 +1,238 @@
+"""CPU-only checks: host logic of the tb_model / wf_array mirror (no kernels are
+launched), the C-ABI library loads and exports every symbol include/tbk.h
+declares, and the product fails loudly (never falls back) without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_tables, load_golden
+import helpers as hp
+from oracle import tb_oracle as orc
+
+import pythtb_amd as tb
+from pythtb_amd import _lib
+
+HAS_GPU = False
+try:
+    _n = ctypes.c_int(0)
+    HAS_GPU = _lib.lib.tbk_device_count(ctypes.byref(_n)) == 0 and _n.value > 0
+except Exception:
+    pass
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tbk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tbk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libtbk.so lacks %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.lib.tbk_version() >= 100
+
+
+def test_argument_errors_reported_without_gpu():
+    assert _lib.lib.tbk_ctx_sync(None) != 0
+    assert b"null ctx" in _lib.lib.tbk_last_error()
+    assert _lib.lib.tbk_model_info(None, None, None, None) != 0
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    m = hp.haldane(tb.tb_model)
+    with pytest.raises(_lib.TbkError, match="no CPU fallback|No CPU|needs an AMD GPU"):
+        m.solve_all([[0.0, 0.0]])
+    with pytest.raises(_lib.TbkError):
+        tb.wf_array(m, [5, 5]).solve_on_grid([0.0, 0.0])
+    src = ""
+    for f in ("model.py", "wfarray.py", "_lib.py", "__init__.py", "shard.py"):
+        src += open(os.path.join(ROOT, "pythtb_amd", f)).read()
+    assert "oracle" not in src.replace("no oracle", "")       # the product never imports the checker
+    assert "linalg.eigh" not in src and "linalg.eigvalsh" not in src and "linalg.svd" not in src
+
+
+@pytest.mark.parametrize("name", ["graphene", "haldane0", "km_odd", "chain3", "per02", "molecule", "spin_chain", "cubic16"])
+def test_model_tables_match_reference(name):
+    """set_onsite/set_hop/_val_to_block store exactly what the reference stores."""
+    t = golden_tables(load_golden("point_" + name))
+    if name == "graphene":
+        m = hp.graphene(tb.tb_model)
+    elif name == "haldane0":
+        m = hp.haldane(tb.tb_model, 0.0)
+    elif name == "km_odd":
+        m = hp.kane_mele(tb.tb_model, "odd")        # exercises mode="add" and 4-vector amplitudes
+    elif name == "chain3":
+        m = hp.chain3(tb.tb_model, -1.0, 2.0, 0.3)
+    elif name == "cubic16":
+        m = hp.cubic16(tb.tb_model)
+    else:
+        m = hp.model_from_tables(tb.tb_model, t)
+    mine = orc.model_tables(m)
+    for key in ("dim_k", "dim_r", "nspin", "orb", "lat", "hop_i", "hop_j", "hop_R", "per"):
+        assert np.array_equal(mine[key], t[key]), (name, key)
+    assert np.max(np.abs(mine["hop_amp"] - t["hop_amp"])) < 1e-16
+    assert np.max(np.abs(mine["site_energies"] - t["site_energies"])) < 1e-16
+    # flattened device tables: shapes and the periodic-component selection
+    orb_per, onsite, hi, hj, hR, amp = m._flat_tables()
+    assert orb_per.shape == (m._norb, m._dim_k) and onsite.shape == (m._norb, m._nspin, m._nspin)
+    assert hR.shape == (len(m._hoppings), m._dim_k) and amp.shape == (len(m._hoppings), m._nspin, m._nspin)
+    if m._dim_k:
+        assert np.array_equal(hR, t["hop_R"][:, list(t["per"])])
+        assert np.array_equal(orb_per, t["orb"][:, list(t["per"])])
+
+
+def test_flattened_tables_rebuild_hamiltonian():
+    """The (orb, onsite, hop_*) arrays handed to tbk_model_upload define the same H(k)."""
+    for m in (hp.kane_mele(tb.tb_model), hp.random_model(tb.tb_model, 3, 2, 2, 3), hp.random_model(tb.tb_model, 5, 3, 1, 4)):
+        orb_per, onsite, hi, hj, hR, amp = m._flat_tables()
+        ns, no = m._nspin, m._norb
+        k = np.random.default_rng(0).random((5, m._dim_k))
+        ref = orc.ham_batch(m, k)
+        for ik, kk in enumerate(k):
+            H = np.zeros((no, ns, no, ns), dtype=complex)
+            for o in range(no):
+                H[o, :, o, :] = onsite[o]
+            for h in range(len(hi)):
+                ph = np.exp(2j * np.pi * kk @ (hR[h] + orb_per[hj[h]] - orb_per[hi[h]]))
+                H[hi[h], :, hj[h], :] += amp[h] * ph
+                H[hj[h], :, hi[h], :] += (amp[h] * ph).conj().T
+            assert np.max(np.abs(H.reshape(no * ns, no * ns) - ref[ik])) < 1e-13
+
+
+def test_set_hop_and_onsite_rules():
+    m = hp.quiet(tb.tb_model, 2, 2, hp.LAT, hp.ORB)
+    m.set_hop(1.0, 0, 1, [0, 0])
+    with pytest.raises(Exception, match="already specified"):
+        m.set_hop(2.0, 0, 1, [0, 0])
+    with pytest.raises(Exception, match="implicitely specified"):
+        m.set_hop(2.0, 1, 0, [0, 0])
+    m.set_hop(2.0, 1, 0, [0, 0], allow_conjugate_pair=True)
+    m.set_hop(0.5, 0, 1, [0, 0], mode="add", allow_conjugate_pair=True)
+    m.set_hop(0.25, 0, 1, [1, 0], mode="reset")
+    assert [h[0] for h in m._hoppings] == [1.5, 2.0, 0.25]
+    with pytest.raises(Exception, match="set_onsite instead"):
+        m.set_hop(1.0, 0, 0, [0, 0])
+    with pytest.raises(Exception, match="out of scope"):
+        m.set_hop(1.0, 0, 2, [0, 0])
+    with pytest.raises(Exception, match="must equal dim_r"):
+        m.set_hop(1.0, 0, 1, [0])
+    with pytest.raises(Exception, match="Need to specify ind_R"):
+        m.set_hop(1.0, 0, 1)
+    with pytest.raises(Exception, match="mode parameter"):
+        m.set_hop(1.0, 0, 1, [3, 3], mode="bogus")
+    m.set_onsite([1.0, 2.0])
+    with pytest.raises(Exception, match="already specified"):
+        m.set_onsite([1.0, 2.0])
+    m.set_onsite(3.0, 1, mode="reset")
+    m.set_onsite(0.5, 1, mode="add")
+    assert np.array_equal(m._site_energies, [1.0, 3.5])
+    with pytest.raises(Exception, match="imaginary"):
+        m.set_onsite(1.0j, 0, mode="reset")
+    with pytest.raises(Exception, match="Wrong number"):
+        m.set_onsite([1.0])
+    s = hp.quiet(tb.tb_model, 1, 1, [[1.0]], [[0.0]], nspin=2)
+    s.set_onsite([[0.1, 0.2, 0.3, 0.4]])
+    assert np.allclose(s._site_energies[0], [[0.5, 0.2 - 0.3j], [0.2 + 0.3j, -0.3]])
+    with pytest.raises(Exception, match="Hermitian"):
+        s.set_onsite([[[0, 1], [2, 0]]], mode="reset")
+    s.set_hop(2, 0, 0, 1)                                     # 1-D: integer R accepted
+    assert np.array_equal(s._hoppings[0][3], [1]) and s._hoppings[0][0].shape == (2, 2)
+    with pytest.raises(Exception, match="Wrong format"):
+        s.set_hop([1, 2, 3], 0, 0, 2)
+
+
+def test_constructor_rules():
+    with pytest.raises(Exception, match="dim_k out of range"):
+        tb.tb_model(5, 5)
+    with pytest.raises(Exception, match="dim_r out of range"):
+        tb.tb_model(2, 1)
+    with pytest.raises(Exception, match="not an integer"):
+        tb.tb_model(1.0, 1)
+    with pytest.raises(Exception, match="right handed"):
+        tb.tb_model(2, 2, [[0, 1], [1, 0]], [[0, 0]])
+    with pytest.raises(Exception, match="close to zero"):
+        tb.tb_model(2, 2, [[1, 0], [1, 0]], [[0, 0]])
+    with pytest.raises(Exception, match="nspin"):
+        tb.tb_model(1, 1, [[1.0]], [[0.0]], nspin=3)
+    with pytest.raises(Exception, match="periodic"):
+        tb.tb_model(1, 2, [[1, 0], [0, 1]], [[0, 0]], per=[0, 1])
+    m = hp.quiet(tb.tb_model, 1, 2, None, 3)
+    assert m._norb == 3 and np.array_equal(m._lat, np.identity(2)) and m._per == [0]
+    assert m.get_num_orbitals() == 3 and m.get_orb().shape == (3, 2) and m.get_lat().shape == (2, 2)
+
+
+def test_k_generators_match_reference():
+    g = load_golden("kgen")
+    gr = hp.graphene(tb.tb_model)
+    kv, kd, kn = gr.k_path(g["g_path"], 121, report=False)
+    assert np.array_equal(kv, g["g_kvec"]) and np.array_equal(kd, g["g_kdist"]) and np.array_equal(kn, g["g_knode"])
+    kv, kd, kn = gr.k_path(g["km_path"], 101, report=False)
+    assert np.array_equal(kv, g["km_kvec"]) and np.array_equal(kd, g["km_kdist"]) and np.array_equal(kn, g["km_knode"])
+    c = hp.chain3(tb.tb_model, -1.0, 2.0, 0.0)
+    for key in ("full", "fullc", "half"):
+        kv, kd, kn = c.k_path(key, 17, report=False)
+        assert np.array_equal(kv, g["c_%s_kvec" % key]) and np.array_equal(kd, g["c_%s_kdist" % key])
+        assert np.array_equal(kn, g["c_%s_knode" % key])
+    kv, kd, kn = c.k_path([[-0.5], [0.5]], 31, report=False)
+    assert np.array_equal(kv, g["c_seg_kvec"]) and np.array_equal(kd, g["c_seg_kdist"])
+    p = hp.model_from_tables(tb.tb_model, golden_tables(load_golden("point_per02")))
+    kv, kd, kn = p.k_path([[0.0, 0.0], [0.5, 0.0], [0.5, 0.5]], 40, report=False)
+    assert np.array_equal(kv, g["p_kvec"]) and np.allclose(kd, g["p_kdist"], atol=1e-15, rtol=0)
+    assert np.array_equal(gr.k_uniform_mesh([4, 6]), g["mesh_4_6"])
+    assert np.array_equal(hp.cubic16(tb.tb_model).k_uniform_mesh([3, 4, 5]), g["mesh_3_4_5"])
+    assert np.array_equal(c.k_uniform_mesh([7]), g["mesh_7"])
+    with pytest.raises(Exception, match="more points"):
+        gr.k_path([[0, 0], [0.5, 0.5]], 1, report=False)
+    with pytest.raises(Exception, match="do not match"):
+        gr.k_path([[0.0], [0.5]], 5, report=False)
+    with pytest.raises(Exception, match="Incorrect size"):
+        gr.k_uniform_mesh([4])
+    hp.quiet(gr.k_path, [[0, 0], [0.5, 0.5]], 5)             # report path runs
+
+
+def test_wf_array_host_side():
+    m = hp.haldane(tb.tb_model)
+    w = tb.wf_array(m, [4, 5])
+    assert w._wfs.shape == (4, 5, 2, 2) and w._wfs.dtype == complex and not w._wfs.any()
+    w[1, 2] = [[1, 2], [3, 4j]]
+    assert w[1, 2][1, 1] == 4j and w[-3, -3][0, 1] == 2
+    with pytest.raises(IndexError):
+        w[4, 0]
+    with pytest.raises(IndexError):
+        w[0, -6]
+    with pytest.raises(TypeError):
+        w[0.5, 1]
+    with pytest.raises(TypeError):
+        w[0, 1, 2]
+    sub = w.choose_states([1])
+    assert sub._nsta_arr == 1 and sub._wfs.shape == (4, 5, 1, 2) and sub._wfs[1, 2, 0, 1] == 4j
+    assert w.empty_like()._wfs.shape == (4, 5, 2, 2) and w.empty_like(nsta_arr=3)._wfs.shape == (4, 5, 3, 2)
+    assert w._model is not m and w._model._hoppings is not m._hoppings
+    w1 = tb.wf_array(hp.chain3(tb.tb_model, -1, 2, 0), [6])
+    w1[5] = np.ones((3, 3))
+    with pytest.raises(TypeError):
+        w1[1, 2]
+    ks = tb.wf_array(hp.kane_mele(tb.tb_model), [3, 3])
+    assert ks._wfs.shape == (3, 3, 4, 2, 2)
+    with pytest.raises(Exception, match="2 or larger"):
+        tb.wf_array(m, [4, 1])
+    with pytest.raises(Exception, match="not an integer"):
+        tb.wf_array(m, [4, 4], nsta_arr=1.5)
+
+
+def test_phase_continuity_helpers_match_oracle():
+    from pythtb_amd.wfarray import _array_phases_cont, _one_phase_cont
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        pha = rng.uniform(-np.pi, np.pi, 40)
+        clos = rng.uniform(-10, 10)
+        assert np.allclose(_one_phase_cont(pha, clos), orc.one_phase_cont(pha, clos), atol=1e-14)
+        arr = rng.uniform(-np.pi, np.pi, (15, 4))
+        c0 = rng.uniform(-7, 7, 4)
+        assert np.allclose(_array_phases_cont(arr, c0), orc.array_phases_cont(arr, c0), atol=1e-14)
+    arr = np.array([[0.1, 0.1, 3.0], [0.1, 3.0, 0.1]])        # exact ties follow the reference's last-wins rule
+    assert np.allclose(_array_phases_cont(arr, arr[0]), orc.array_phases_cont(arr, arr[0]))
