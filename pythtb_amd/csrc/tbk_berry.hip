@@ -38,9 +38,11 @@ __device__ __forceinline__ int64_t axis_offset(const AxisSet& ax, int64_t s) {
 
 // ---------------------------------------------------------------- overlaps
 // M_ab = <u_a(P) | u_b(Q)> over the ncomp components (pythtb.py:3815-3817)
+// P, Q point at the components of band 0 at the two mesh points; band b of the
+// same point sits `plane` elements further (band-major device layout).
 template <int NOCC>
 __device__ __forceinline__ void link_matrix(const cd* __restrict__ P, const cd* __restrict__ Q,
-                                            const int* occ, int ncomp, cd (&M)[NOCC][NOCC]) {
+                                            const int* occ, int ncomp, int64_t plane, cd (&M)[NOCC][NOCC]) {
 #pragma unroll
     for (int a = 0; a < NOCC; ++a)
 #pragma unroll
@@ -49,8 +51,8 @@ __device__ __forceinline__ void link_matrix(const cd* __restrict__ P, const cd* 
         cd pa[NOCC], qb[NOCC];
 #pragma unroll
         for (int a = 0; a < NOCC; ++a) {
-            pa[a] = P[occ[a] * ncomp + o];
-            qb[a] = Q[occ[a] * ncomp + o];
+            pa[a] = P[occ[a] * plane + o];
+            qb[a] = Q[occ[a] * plane + o];
         }
 #pragma unroll
         for (int a = 0; a < NOCC; ++a)
@@ -88,12 +90,12 @@ __device__ __forceinline__ cd det_small(const cd (&M)[NOCC][NOCC]) {
 
 // dynamic sizes: matrices live in per-thread local memory, row-major, leading dim n
 __device__ inline void link_matrix_dyn(const cd* __restrict__ P, const cd* __restrict__ Q, const int* occ,
-                                       int nocc, int ncomp, cd* M) {
+                                       int nocc, int ncomp, int64_t plane, cd* M) {
     for (int a = 0; a < nocc; ++a)
         for (int b = 0; b < nocc; ++b) {
             cd acc{0.0, 0.0};
-            const cd* pa = P + occ[a] * ncomp;
-            const cd* qb = Q + occ[b] * ncomp;
+            const cd* pa = P + occ[a] * plane;
+            const cd* qb = Q + occ[b] * plane;
             for (int o = 0; o < ncomp; ++o) cfmac(acc, pa[o], qb[o]);
             M[a * nocc + b] = acc;
         }
@@ -346,22 +348,117 @@ struct FluxArgs {
     int n0, n1;        // plaquettes along dir0, dir1
     int64_t s0, s1;    // point strides of dir0, dir1
     AxisSet other;     // slice axes
-    int bps;           // blocks per slice
+    int bps;           // partial sums per slice (blocks, or wave tiles of the row kernel)
     double* plaq;      // nullable [nslices][n0][n1]
     double* partial;   // [nslices][bps]
+    // row-streaming kernel: canonical orientation a = slower-stride axis, b = faster
+    int na, nb;        // plaquettes along a, b
+    int64_t sa, sb;    // point strides
+    int swap;          // dirs[0] is the fast axis: phases negate, output transposes
+    int ti;            // plaquette rows per wave tile
+    int ncolw;         // wave tiles per row of tiles (63 plaquette columns each)
+    int64_t nwaves;    // nslices * bps
 };
 
 template <int NOCC, int MAXN>
-__device__ __forceinline__ cd one_link_det(const cd* P, const cd* Q, const int* occ, int nocc, int ncomp) {
+__device__ __forceinline__ cd one_link_det(const cd* P, const cd* Q, const int* occ, int nocc, int ncomp,
+                                           int64_t plane) {
     if constexpr (NOCC > 0) {
         cd M[NOCC][NOCC];
-        link_matrix<NOCC>(P, Q, occ, ncomp, M);
+        link_matrix<NOCC>(P, Q, occ, ncomp, plane, M);
         return det_small<NOCC>(M);
     } else {
         cd M[MAXN * MAXN];
-        link_matrix_dyn(P, Q, occ, nocc, ncomp, M);
+        link_matrix_dyn(P, Q, occ, nocc, ncomp, plane, M);
         return det_dyn(nocc, M);
     }
+}
+
+// ---- row-streaming flux kernel (ncomp <= 4): a wavefront owns 63 plaquette
+// columns x `ti` plaquette rows; lane = mesh column, rows are walked in order.
+// Each mesh point's occupied vectors are fetched once per tile (plus the right
+// neighbour, an L1 hit), each link determinant is computed once and shared:
+//   dV(ia,jb) = det<u(ia,jb)|u(ia+1,jb)>   own columns, neighbour's by shuffle
+//   dH(ia,jb) = det<u(ia,jb)|u(ia,jb+1)>   carried from the previous row
+//   F(ia,jb)  = -arg[ dV(ia,jb) dH(ia+1,jb) conj dV(ia,jb+1) conj dH(ia,jb) ]
+template <int NOCC, int NCOMP>
+__device__ __forceinline__ void load_vectors(const cd* __restrict__ p, const int* occ, int64_t plane,
+                                             cd (&u)[NOCC][NCOMP]) {
+#pragma unroll
+    for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+        for (int o = 0; o < NCOMP; ++o) u[a][o] = p[occ[a] * plane + o];
+}
+
+template <int NOCC, int NCOMP>
+__device__ __forceinline__ cd det_overlap(const cd (&p)[NOCC][NCOMP], const cd (&q)[NOCC][NCOMP]) {
+    cd M[NOCC][NOCC];
+#pragma unroll
+    for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+        for (int b = 0; b < NOCC; ++b) {
+            cd acc{0.0, 0.0};
+#pragma unroll
+            for (int o = 0; o < NCOMP; ++o) cfmac(acc, p[a][o], q[b][o]);
+            M[a][b] = acc;
+        }
+    return det_small<NOCC>(M);
+}
+
+template <int NOCC, int NCOMP>
+__global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= A.nwaves) return;
+    const int lane = threadIdx.x & 63;
+    const int slice = (int)(w / A.bps);
+    const int t = (int)(w - (int64_t)slice * A.bps);
+    const int trow = t / A.ncolw, colw = t - trow * A.ncolw;
+    const int ia0 = trow * A.ti;
+    const int ia1 = min(ia0 + A.ti, A.na);
+    const int jb = colw * 63 + lane;                 // mesh column held by this lane
+    const int jbc = min(jb, A.nb);                   // clamp: columns run 0..nb
+    const bool has_plaq = lane < 63 && jb < A.nb;
+    const bool has_right = jbc < A.nb;
+    const int64_t plane = A.v.npts * A.v.ncomp;
+    const int64_t rstep = A.sa * A.v.ncomp, cstep = A.sb * A.v.ncomp;
+    const cd* col = A.v.data + (axis_offset(A.other, slice) + (int64_t)jbc * A.sb) * A.v.ncomp + (int64_t)ia0 * rstep;
+    const int64_t per = (int64_t)A.na * A.nb;
+    cd cur[NOCC][NCOMP], nxt[NOCC][NCOMP], rgt[NOCC][NCOMP];
+    load_vectors<NOCC, NCOMP>(col, A.occ, plane, cur);
+    cd dHc{1.0, 0.0};
+    if (has_right) {
+        load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, rgt);
+        dHc = det_overlap<NOCC, NCOMP>(cur, rgt);
+    }
+    double sum = 0.0;
+    for (int ia = ia0; ia < ia1; ++ia) {
+        col += rstep;
+        load_vectors<NOCC, NCOMP>(col, A.occ, plane, nxt);
+        const cd dV = det_overlap<NOCC, NCOMP>(cur, nxt);
+        cd dHn{1.0, 0.0};
+        if (has_right) {
+            load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, rgt);
+            dHn = det_overlap<NOCC, NCOMP>(nxt, rgt);
+        }
+        const cd dVr{__shfl_down(dV.x, 1), __shfl_down(dV.y, 1)};
+        const cd z = cmul(cmul(dV, dHn), cconj(cmul(dVr, dHc)));
+        double pha = 0.0;
+        if (has_plaq) {
+            pha = -atan2(z.y, z.x);
+            if (A.swap) pha = -pha;
+            if (A.plaq)
+                A.plaq[slice * per + (A.swap ? (int64_t)jb * A.na + ia : (int64_t)ia * A.nb + jb)] = pha;
+        }
+        sum += pha;
+#pragma unroll
+        for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+            for (int o = 0; o < NCOMP; ++o) cur[a][o] = nxt[a][o];
+        dHc = dHn;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) A.partial[w] = sum;
 }
 
 // F(i,j) = -arg[ det<00|10> det<10|11> det<11|01> det<01|00> ]  (pythtb.py:3852-3863)
@@ -374,16 +471,17 @@ __global__ __launch_bounds__(256) void k_flux(const FluxArgs A) {
     double pha = 0.0;
     if (p < per) {
         const unsigned i = p / (unsigned)A.n1, j = p - i * (unsigned)A.n1;
-        const int per_pt = A.v.nsta * A.v.ncomp;
+        const int nc = A.v.ncomp;
+        const int64_t plane = A.v.npts * nc;
         const int64_t base = axis_offset(A.other, slice) + (int64_t)i * A.s0 + (int64_t)j * A.s1;
-        const cd* u00 = A.v.data + base * per_pt;
-        const cd* u10 = u00 + A.s0 * per_pt;
-        const cd* u01 = u00 + A.s1 * per_pt;
-        const cd* u11 = u10 + A.s1 * per_pt;
-        cd d = one_link_det<NOCC, MAXN>(u00, u10, A.occ, A.nocc, A.v.ncomp);
-        d = cmul(d, one_link_det<NOCC, MAXN>(u10, u11, A.occ, A.nocc, A.v.ncomp));
-        d = cmul(d, one_link_det<NOCC, MAXN>(u11, u01, A.occ, A.nocc, A.v.ncomp));
-        d = cmul(d, one_link_det<NOCC, MAXN>(u01, u00, A.occ, A.nocc, A.v.ncomp));
+        const cd* u00 = A.v.data + base * nc;
+        const cd* u10 = u00 + A.s0 * nc;
+        const cd* u01 = u00 + A.s1 * nc;
+        const cd* u11 = u10 + A.s1 * nc;
+        cd d = one_link_det<NOCC, MAXN>(u00, u10, A.occ, A.nocc, nc, plane);
+        d = cmul(d, one_link_det<NOCC, MAXN>(u10, u11, A.occ, A.nocc, nc, plane));
+        d = cmul(d, one_link_det<NOCC, MAXN>(u11, u01, A.occ, A.nocc, nc, plane));
+        d = cmul(d, one_link_det<NOCC, MAXN>(u01, u00, A.occ, A.nocc, nc, plane));
         pha = -atan2(d.y, d.x);
         if (A.plaq) A.plaq[(int64_t)slice * per + p] = pha;
     }
@@ -469,7 +567,23 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     other_axes(v, dir0, dir1, &A.other, &nslices);
     const int64_t per = (int64_t)A.n0 * A.n1;
     TBK_REQUIRE(per < (int64_t)0xffffffffu, TBK_EUNSUPPORTED, "plane of %lld plaquettes is too large", (long long)per);
-    A.bps = (int)((per + 255) / 256);
+    const bool rows = v.ncomp <= 4 && nocc <= v.ncomp;   // register-resident row-streaming kernel
+    if (rows) {
+        A.swap = A.s0 < A.s1;                            // lanes run along the smaller stride
+        A.na = A.swap ? A.n1 : A.n0;
+        A.nb = A.swap ? A.n0 : A.n1;
+        A.sa = A.swap ? A.s1 : A.s0;
+        A.sb = A.swap ? A.s0 : A.s1;
+        A.ncolw = (A.nb + 62) / 63;
+        // enough wave tiles to fill the chip (32 per CU), rows per tile in [4, 64]
+        const int64_t want = (int64_t)ctx->cus * 32;
+        int64_t ti = ((int64_t)A.na * A.ncolw * nslices + want - 1) / want;
+        A.ti = (int)std::max<int64_t>(4, std::min<int64_t>(64, ti));
+        A.bps = ((A.na + A.ti - 1) / A.ti) * A.ncolw;
+    } else {
+        A.bps = (int)((per + 255) / 256);
+    }
+    A.nwaves = nslices * A.bps;
     TBK_REQUIRE(nslices * A.bps < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many plaquette blocks");
     if (w->flux_nslices < nslices) {
         if (w->flux_totals_dev) TBK_HIP(hipFree(w->flux_totals_dev));
@@ -505,14 +619,32 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     A.partial = w->flux_partial_dev;
     {
         ProfScope ps(ctx, "berry_flux");
-        switch (nocc) {
-            case 1: launch_flux<1, 1>(ctx, A, nslices); break;
-            case 2: launch_flux<2, 1>(ctx, A, nslices); break;
-            case 3: launch_flux<3, 1>(ctx, A, nslices); break;
-            case 4: launch_flux<4, 1>(ctx, A, nslices); break;
-            default:
-                if (nocc <= 8) launch_flux<0, 8>(ctx, A, nslices);
-                else launch_flux<0, TBK_MAX_NOCC>(ctx, A, nslices);
+        if (rows) {
+            const dim3 grid((unsigned)((A.nwaves + 3) / 4)), blk(256);
+#define TBK_ROWS(NO, NC) hipLaunchKernelGGL((k_flux_rows<NO, NC>), grid, blk, 0, ctx->stream, A)
+            switch (v.ncomp * 8 + nocc) {
+                case 1 * 8 + 1: TBK_ROWS(1, 1); break;
+                case 2 * 8 + 1: TBK_ROWS(1, 2); break;
+                case 2 * 8 + 2: TBK_ROWS(2, 2); break;
+                case 3 * 8 + 1: TBK_ROWS(1, 3); break;
+                case 3 * 8 + 2: TBK_ROWS(2, 3); break;
+                case 3 * 8 + 3: TBK_ROWS(3, 3); break;
+                case 4 * 8 + 1: TBK_ROWS(1, 4); break;
+                case 4 * 8 + 2: TBK_ROWS(2, 4); break;
+                case 4 * 8 + 3: TBK_ROWS(3, 4); break;
+                default: TBK_ROWS(4, 4); break;
+            }
+#undef TBK_ROWS
+        } else {
+            switch (nocc) {
+                case 1: launch_flux<1, 1>(ctx, A, nslices); break;
+                case 2: launch_flux<2, 1>(ctx, A, nslices); break;
+                case 3: launch_flux<3, 1>(ctx, A, nslices); break;
+                case 4: launch_flux<4, 1>(ctx, A, nslices); break;
+                default:
+                    if (nocc <= 8) launch_flux<0, 8>(ctx, A, nslices);
+                    else launch_flux<0, TBK_MAX_NOCC>(ctx, A, nslices);
+            }
         }
         TBK_HIP(hipGetLastError());
     }
@@ -568,22 +700,22 @@ __global__ __launch_bounds__(256) void k_chain_partial(const ChainArgs A) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= A.nstrings * A.nseg) return;
     const int64_t seg = t / A.nstrings, s = t - seg * A.nstrings;
-    const int per_pt = A.v.nsta * A.v.ncomp;
+    const int nocc = A.nocc, ncomp = A.v.ncomp;
+    const int64_t plane = A.v.npts * ncomp;       // band-major: band b of a point is b*plane further
     const int i0 = (int)seg * A.seg_len;
     const int i1 = min(i0 + A.seg_len, A.nlinks);
-    const cd* P = A.v.data + (axis_offset(A.other, s) + (int64_t)i0 * A.sdir) * per_pt;
-    const int64_t step = A.sdir * per_pt;
-    const int nocc = A.nocc, ncomp = A.v.ncomp;
+    const cd* P = A.v.data + (axis_offset(A.other, s) + (int64_t)i0 * A.sdir) * ncomp;
+    const int64_t step = A.sdir * ncomp;
     if constexpr (!EVALS) {
         cd acc{1.0, 0.0};
         for (int i = i0; i < i1; ++i, P += step)
-            acc = cmul(acc, one_link_det<NOCC, MAXN>(P, P + step, A.occ, nocc, ncomp));
+            acc = cmul(acc, one_link_det<NOCC, MAXN>(P, P + step, A.occ, nocc, ncomp, plane));
         A.partial[seg * A.nstrings + s] = acc;
     } else if constexpr (NOCC == 1) {
         cd acc{1.0, 0.0};
         for (int i = i0; i < i1; ++i, P += step) {
             cd M[1][1];
-            link_matrix<1>(P, P + step, A.occ, ncomp, M);
+            link_matrix<1>(P, P + step, A.occ, ncomp, plane, M);
             const double r = sqrt(cabs2(M[0][0]));
             acc = cmul(acc, r > 0.0 ? cscale(M[0][0], 1.0 / r) : cd{1.0, 0.0});
         }
@@ -592,7 +724,7 @@ __global__ __launch_bounds__(256) void k_chain_partial(const ChainArgs A) {
         cd R[2][2] = {{cd{1.0, 0.0}, cd{0.0, 0.0}}, {cd{0.0, 0.0}, cd{1.0, 0.0}}};
         for (int i = i0; i < i1; ++i, P += step) {
             cd M[2][2];
-            link_matrix<2>(P, P + step, A.occ, ncomp, M);
+            link_matrix<2>(P, P + step, A.occ, ncomp, plane, M);
             polar2(M);
             cd T[2][2];
 #pragma unroll
@@ -611,7 +743,7 @@ __global__ __launch_bounds__(256) void k_chain_partial(const ChainArgs A) {
         for (int a = 0; a < nocc; ++a)
             for (int b = 0; b < nocc; ++b) R[a * nocc + b] = cd{a == b ? 1.0 : 0.0, 0.0};
         for (int i = i0; i < i1; ++i, P += step) {
-            link_matrix_dyn(P, P + step, A.occ, nocc, ncomp, M);
+            link_matrix_dyn(P, P + step, A.occ, nocc, ncomp, plane, M);
             polar_dyn(nocc, M, V, T);
             for (int a = 0; a < nocc; ++a)
                 for (int b = 0; b < nocc; ++b) {

@@ -406,6 +406,34 @@ extern "C" int tbk_model_info(tbk_model* m, int* dim_k, int* nsta, int64_t* nter
 }
 
 // ------------------------------------------------------------------ wfs
+// external (NumPy) layout [point][band][comp]  <->  device layout [band][point][comp]
+__global__ __launch_bounds__(256) void k_relayout(cd* __restrict__ dst, const cd* __restrict__ src,
+                                                  const int64_t npts, const int nsta, const int ncomp,
+                                                  const int to_device) {
+    const int64_t total = npts * nsta * ncomp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        // e enumerates the DESTINATION contiguously
+        if (to_device) {
+            const int o = (int)(e % ncomp);
+            const int64_t r = e / ncomp;
+            const int64_t p = r % npts;
+            const int b = (int)(r / npts);
+            dst[e] = src[(p * nsta + b) * ncomp + o];
+        } else {
+            const int o = (int)(e % ncomp);
+            const int64_t r = e / ncomp;
+            const int b = (int)(r % nsta);
+            const int64_t p = r / nsta;
+            dst[e] = src[((int64_t)b * npts + p) * ncomp + o];
+        }
+    }
+}
+
+__global__ void k_fill_u64(unsigned long long* p, int n, unsigned long long v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 extern "C" int tbk_wfs_create(tbk_ctx* ctx, int dim_arr, const int32_t* mesh, int nsta_arr,
                               int ncomp, tbk_wfs** out) {
     TBK_REQUIRE(ctx && mesh && out, TBK_EINVAL, "tbk_wfs_create: null argument");
@@ -430,12 +458,10 @@ extern "C" int tbk_wfs_create(tbk_ctx* ctx, int dim_arr, const int32_t* mesh, in
         npts *= mesh[d];
     }
     int64_t st = 1;
-    for (int d = TBK_MAX_DIM - 1; d >= 0; --d) {
+    for (int d = TBK_MAX_DIM - 1; d >= 0; --d) {  // trailing padded axes have size 1
         w->view.stride[d] = st;
         st *= w->view.mesh[d];
     }
-    // strides are for the dim_arr real axes stored first; shift so axis d of the
-    // array maps to stride[d] (trailing padded axes have size 1)
     w->view.npts = npts;
     w->bytes = npts * (int64_t)nsta_arr * ncomp * (int64_t)sizeof(cd);
     TBK_HIP(hipSetDevice(ctx->device));
@@ -447,7 +473,10 @@ extern "C" int tbk_wfs_create(tbk_ctx* ctx, int dim_arr, const int32_t* mesh, in
         return TBK_ENOMEM;
     }
     TBK_HIP(hipMemsetAsync(w->view.data, 0, (size_t)w->bytes, ctx->stream));
-    TBK_HIP(hipMalloc((void**)&w->gaps_dev, TBK_MAX_NSTA * sizeof(unsigned long long)));
+    const int ngap = 2 * TBK_GAP_SHARDS * TBK_MAX_NSTA;
+    TBK_HIP(hipMalloc((void**)&w->gaps_dev, ngap * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_fill_u64, dim3((ngap + 255) / 256), dim3(256), 0, ctx->stream, w->gaps_dev, ngap,
+                       0x7ff0000000000000ull);
     TBK_HIP(hipMalloc((void**)&w->pbc_dev, TBK_MAX_DIM * TBK_MAX_NSTA * sizeof(cd)));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
     *out = w;
@@ -461,6 +490,7 @@ extern "C" int tbk_wfs_free(tbk_wfs* w) {
     if (w->view.data) hipFree(w->view.data);
     if (w->gaps_dev) hipFree(w->gaps_dev);
     if (w->pbc_dev) hipFree(w->pbc_dev);
+    if (w->tab_dev) hipFree(w->tab_dev);
     if (w->flux_totals_dev) hipFree(w->flux_totals_dev);
     if (w->flux_plaq_dev) hipFree(w->flux_plaq_dev);
     if (w->flux_partial_dev) hipFree(w->flux_partial_dev);
@@ -468,18 +498,62 @@ extern "C" int tbk_wfs_free(tbk_wfs* w) {
     return TBK_OK;
 }
 
+static int relayout(tbk_wfs* w, cd* dst, const cd* src, int to_device) {
+    const WfsView& v = w->view;
+    const int64_t total = v.npts * v.nsta * v.ncomp;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)w->ctx->cus * 16);
+    ProfScope ps(w->ctx, "wfs_relayout");
+    hipLaunchKernelGGL(k_relayout, dim3(blocks), dim3(256), 0, w->ctx->stream, dst, src, v.npts, v.nsta, v.ncomp,
+                       to_device);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
+
 extern "C" int tbk_wfs_upload(tbk_wfs* w, const double* host) {
     TBK_REQUIRE(w && host, TBK_EINVAL, "tbk_wfs_upload: null argument");
-    TBK_HIP(hipMemcpyAsync(w->view.data, host, (size_t)w->bytes, hipMemcpyHostToDevice, w->ctx->stream));
-    TBK_HIP(hipStreamSynchronize(w->ctx->stream));
-    return TBK_OK;
+    tbk_ctx* ctx = w->ctx;
+    TBK_HIP(hipSetDevice(ctx->device));
+    if (w->view.nsta == 1) {  // the two layouts coincide
+        TBK_HIP(hipMemcpyAsync(w->view.data, host, (size_t)w->bytes, hipMemcpyHostToDevice, ctx->stream));
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        return TBK_OK;
+    }
+    cd* tmp = nullptr;
+    hipError_t e = hipMalloc((void**)&tmp, (size_t)w->bytes);
+    TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "tbk_wfs_upload: staging buffer of %lld bytes: %s", (long long)w->bytes,
+                hipGetErrorString(e));
+    int rc = TBK_OK;
+    if (hipMemcpyAsync(tmp, host, (size_t)w->bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = TBK_EHIP;
+    if (!rc) rc = relayout(w, w->view.data, tmp, 1);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(tmp);
+    if (rc == TBK_EHIP) tbk_set_error("tbk_wfs_upload: host to device copy failed");
+    return rc;
 }
+
 extern "C" int tbk_wfs_download(tbk_wfs* w, double* host) {
     TBK_REQUIRE(w && host, TBK_EINVAL, "tbk_wfs_download: null argument");
-    TBK_HIP(hipMemcpyAsync(host, w->view.data, (size_t)w->bytes, hipMemcpyDeviceToHost, w->ctx->stream));
-    TBK_HIP(hipStreamSynchronize(w->ctx->stream));
-    return TBK_OK;
+    tbk_ctx* ctx = w->ctx;
+    TBK_HIP(hipSetDevice(ctx->device));
+    if (w->view.nsta == 1) {
+        TBK_HIP(hipMemcpyAsync(host, w->view.data, (size_t)w->bytes, hipMemcpyDeviceToHost, ctx->stream));
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        return TBK_OK;
+    }
+    cd* tmp = nullptr;
+    hipError_t e = hipMalloc((void**)&tmp, (size_t)w->bytes);
+    TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "tbk_wfs_download: staging buffer of %lld bytes: %s", (long long)w->bytes,
+                hipGetErrorString(e));
+    int rc = relayout(w, tmp, w->view.data, 0);
+    if (!rc && hipMemcpyAsync(host, tmp, (size_t)w->bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+        rc = TBK_EHIP;
+        tbk_set_error("tbk_wfs_download: device to host copy failed");
+    }
+    hipStreamSynchronize(ctx->stream);
+    hipFree(tmp);
+    return rc;
 }
+
 extern "C" int tbk_wfs_device_ptr(tbk_wfs* w, void** p, int64_t* bytes) {
     TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_device_ptr: null wfs");
     if (p) *p = w->view.data;

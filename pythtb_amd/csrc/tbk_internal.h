@@ -121,6 +121,12 @@ struct tbk_model {
     ModelView view{};
 };
 
+// Device layout of a wf_array: BAND-MAJOR planes, data[band][point][comp] with
+// point = row-major mesh index.  (The reference / NumPy layout is
+// [point][band][comp]; tbk_wfs_upload/download convert.)  Band-major keeps the
+// bytes of an occupied subset contiguous, so berry_flux/berry_phase with
+// nocc < nsta read only the occupied planes, and the solve kernels' stores are
+// contiguous across lanes within each plane.
 struct WfsView {
     int dim_arr;
     int nsta;   // states stored per mesh point (nsta_arr)
@@ -130,16 +136,25 @@ struct WfsView {
     int64_t npts;
     cd* data;
 };
+__device__ __forceinline__ cd* wf_at(const WfsView& v, int band, int64_t point) {
+    return v.data + ((int64_t)band * v.npts + point) * v.ncomp;
+}
+
+#define TBK_GAP_SHARDS 64
 
 struct tbk_wfs {
     tbk_ctx* ctx = nullptr;
     WfsView view{};
     int64_t bytes = 0;
-    // solve_grid results
-    unsigned long long* gaps_dev = nullptr;  // [TBK_MAX_NSTA] min gaps as ordered bits
-    int gaps_n = 0;
+    // solve_grid: min gaps as ordered bit patterns, [2 parities][TBK_GAP_SHARDS][TBK_MAX_NSTA];
+    // each launch min-reduces into its parity and re-arms the other one for the next launch
+    unsigned long long* gaps_dev = nullptr;
+    int gaps_n = 0, gaps_parity = 0;
     cd* pbc_dev = nullptr;                   // [TBK_MAX_DIM][TBK_MAX_NSTA]
-    std::vector<double> pbc_host;
+    // per-axis phase tables of the regular mesh (rebuilt only when their inputs change)
+    cd* tab_dev = nullptr;                   // z[d][i] then f[d][i][n]
+    int64_t tab_cap = 0;
+    std::vector<double> tab_key;
     // flux results
     double* flux_totals_dev = nullptr;
     int64_t flux_nslices = 0;
@@ -148,8 +163,3 @@ struct tbk_wfs {
     double* flux_partial_dev = nullptr;
     int64_t flux_partial_cap = 0;
 };
-
-// kernels / launchers implemented in the .hip files
-int tbk_launch_gen_ham(tbk_model* m, const double* k_dev, int64_t nk, cd* ham_dev);
-int tbk_launch_solve_list(tbk_ctx* ctx, const ModelView* mv, int n, const double* k_dev,
-                          const cd* ham_dev, int64_t nk, double* eval_dev, cd* evec_dev);

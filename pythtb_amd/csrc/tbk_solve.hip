@@ -28,7 +28,15 @@ struct GridArgs {
     int gmesh[TBK_MAX_DIM];  // global mesh sizes (axis 0 may exceed the slab)
     int64_t row0;            // first global row of the slab (axis 0)
     const cd* pbc;           // [TBK_MAX_DIM][TBK_MAX_NSTA]
-    unsigned long long* gaps;
+    unsigned long long* gaps;       // [TBK_GAP_SHARDS][TBK_MAX_NSTA] min-reduced by this launch
+    unsigned long long* gaps_next;  // the other parity: re-armed (+inf) for the next launch
+    // per-axis tables of the regular mesh: z[d][i] = exp(2 pi i k_d(i)),
+    // f[d][i*n+o] = exp(-2 pi i k_d(i) tau_o,d) * (pbc phase if i is the periodic image)
+    const cd* tz[TBK_MAX_DIM];
+    const cd* tf[TBK_MAX_DIM];
+    int last;                // index of the last (fastest) mesh axis
+    int cpr;                 // 64-point chunks per mesh row (row = all leading axes)
+    int64_t nchunks;
 };
 
 struct ListArgs {
@@ -187,7 +195,34 @@ __device__ __forceinline__ void jacobi_small(SmallMat<N>& M) {
     if constexpr (N == 1) {
         return;
     } else if constexpr (N == 2) {
-        rotate<2, 0, 1, VEC>(M);  // exact for 2x2
+        // closed form, already ascending: lambda = m -+ r, one sqrt and one rsqrt.
+        //   delta >= 0: v- ~ (delta + r, -conj g)    delta < 0: v- ~ (g, delta - r)
+        // (the cancellation-free choice), |v-|^2 = 2 r (r + |delta|), v+ = (-conj v-_1, conj v-_0)
+        const double a = M.dg[0], d = M.dg[1];
+        const cd g = M.up[0][1];
+        const double delta = 0.5 * (d - a), mid = 0.5 * (a + d);
+        const double r = sqrt(delta * delta + cabs2(g));
+        M.dg[0] = mid - r;
+        M.dg[1] = mid + r;
+        if (VEC) {
+            const double ad = fabs(delta);
+            const double nrm2 = 2.0 * r * (r + ad);
+            cd v0{1.0, 0.0}, v1{0.0, 0.0};
+            if (nrm2 > 0.0) {
+                const double inv = rsqrt(nrm2);
+                if (delta >= 0.0) {
+                    v0 = cd{(ad + r) * inv, 0.0};
+                    v1 = cd{-g.x * inv, g.y * inv};
+                } else {
+                    v0 = cd{g.x * inv, g.y * inv};
+                    v1 = cd{-(ad + r) * inv, 0.0};
+                }
+            }
+            M.v[0][0] = v0;
+            M.v[1][0] = v1;
+            M.v[0][1] = cd{-v1.x, v1.y};
+            M.v[1][1] = cd{v0.x, -v0.y};
+        }
     } else {
         for (int sweep = 0; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
             double off = 0.0, dia = 0.0;
@@ -222,28 +257,53 @@ __device__ __forceinline__ void ranks_small(const double (&ev)[N], int (&rk)[N],
     }
 }
 
-// MODE 0: k list -> eval/evec (band-major).  MODE 1: wf mesh -> _wfs + min gaps.
-// MODE 2: supplied matrices -> eval/evec.
-template <int N, int MODE, bool VEC>
-__global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const int64_t nk,
-                                                     const ListArgs L, const GridArgs G) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool active = idx < nk;
-    const int64_t id = active ? idx : nk - 1;  // idle lanes redo the last point (no stores)
-
-    double kk[4] = {0.0, 0.0, 0.0, 0.0};
-    bool wrap[4] = {false, false, false, false};
-    if constexpr (MODE == 0) {
+// assemble S(k) into registers from the slot table
+template <int N>
+__device__ __forceinline__ void assemble_small(const ModelView& mv, const cd (&z)[4], SmallMat<N>& M) {
+    int slot = 0;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-            if (d < mv.dim_k) kk[d] = L.k[id * mv.dim_k + d];
-    } else if constexpr (MODE == 1) {
-        grid_point(G, id, kk, wrap);
+    for (int a = 0; a < N; ++a) {
+#pragma unroll
+        for (int b = a; b < N; ++b, ++slot) {
+            const cd s = slot_sum(mv, slot, z);
+            if (b == a) M.dg[a] = s.x; else M.up[a][b] = s;
+        }
     }
+}
 
+template <int N, bool VEC>
+__device__ __forceinline__ void init_vectors(SmallMat<N>& M) {
+    if (VEC) {
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = 0; b < N; ++b) M.v[a][b] = cd{a == b ? 1.0 : 0.0, 0.0};
+    }
+}
+
+// min over the mesh of E[b+1]-E[b] (all_gaps.min, pythtb.py:2495,2530): wave
+// reduction, then one conditional atomicMin per wave into a shard.  Gaps are
+// >= 0, so their bit patterns order like the values; the plain pre-read may be
+// stale but is never smaller than the truth, so skipping on it is safe.
+__device__ __forceinline__ void gap_min_wave(unsigned long long* shard_row, int b, double g) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) g = fmin(g, __shfl_xor(g, off));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(fmax(g, 0.0));
+        if (bits < __hip_atomic_load(shard_row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMin(shard_row + b, bits);
+    }
+}
+
+// ---- k list (MODE 0) or supplied matrices (MODE 2) -> eval[b][k], evec[b][k][o]
+template <int N, int MODE, bool VEC>
+__global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const int64_t nk, const ListArgs L) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nk) return;
+    double kk[4] = {0.0, 0.0, 0.0, 0.0};
     SmallMat<N> M;
     if constexpr (MODE == 2) {
-        const cd* h = L.ham + id * (int64_t)(N * N);
+        const cd* h = L.ham + idx * (int64_t)(N * N);
 #pragma unroll
         for (int a = 0; a < N; ++a) {
             M.dg[a] = h[a * N + a].x;
@@ -253,93 +313,125 @@ __global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const i
     } else {
         cd z[4];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
-        int slot = 0;
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-#pragma unroll
-            for (int b = a; b < N; ++b, ++slot) {
-                const cd s = slot_sum(mv, slot, z);
-                if (b == a) M.dg[a] = s.x; else M.up[a][b] = s;
-            }
+        for (int d = 0; d < 4; ++d) {
+            if (d < mv.dim_k) kk[d] = L.k[idx * mv.dim_k + d];
+            z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
         }
+        assemble_small<N>(mv, z, M);
     }
-    if (VEC) {
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-#pragma unroll
-            for (int b = 0; b < N; ++b) M.v[a][b] = cd{a == b ? 1.0 : 0.0, 0.0};
-    }
-
+    init_vectors<N, VEC>(M);
     jacobi_small<N, VEC>(M);
-
     int rk[N];
     double sorted[N];
     ranks_small<N>(M.dg, rk, sorted);
-
-    // eigenvector component o of S  ->  conj(e_o) * (pbc phases) * v   (D^+ v)
-    cd fo[N];
+#pragma unroll
+    for (int b = 0; b < N; ++b) L.eval[(int64_t)b * nk + idx] = sorted[b];
     if (VEC) {
+        // eigenvector of H = D^+ (eigenvector of S): component o times conj(e_o)
+        cd fo[N];
 #pragma unroll
         for (int o = 0; o < N; ++o) {
-            if constexpr (MODE == 2) {
-                fo[o] = cd{1.0, 0.0};
-            } else {
-                if (mv.nspin == 2 && (o & 1)) {
-                    fo[o] = fo[o - (o > 0)];
-                } else {
-                    fo[o] = cconj(expi2pi(kdot(kk, mv.orb[o])));
-                }
-            }
+            if constexpr (MODE == 2) fo[o] = cd{1.0, 0.0};
+            else if (mv.nspin == 2 && (o & 1)) fo[o] = fo[o - (o > 0)];
+            else fo[o] = cconj(expi2pi(kdot(kk, mv.orb[o])));
         }
-        if constexpr (MODE == 1) {
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-                if (wrap[d]) {
+        for (int b = 0; b < N; ++b) {
+            cd* out = L.evec + ((int64_t)rk[b] * nk + idx) * N;
 #pragma unroll
-                    for (int o = 0; o < N; ++o) fo[o] = cmul(fo[o], G.pbc[d * TBK_MAX_NSTA + o]);
-                }
+            for (int o = 0; o < N; ++o) out[o] = cmul(M.v[o][b], fo[o]);
         }
     }
+}
 
-    if constexpr (MODE == 1) {
-        // min direct gaps over the mesh (all_gaps.min, pythtb.py:2495,2530)
-        if constexpr (N > 1) {
-            __shared__ double red[4][N];
+// ---- per-axis tables of a regular mesh: one thread per (axis, index)
+__global__ __launch_bounds__(256) void k_grid_tables(const ModelView mv, const GridArgs G, cd* tz0, cd* tf0) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    int d = 0;
+    int64_t zoff = 0, foff = 0;
+    for (; d < G.wv.dim_arr; ++d) {
+        if (t < G.wv.mesh[d]) break;
+        t -= G.wv.mesh[d];
+        zoff += G.wv.mesh[d];
+        foff += (int64_t)G.wv.mesh[d] * mv.nsta;
+    }
+    if (d >= G.wv.dim_arr) return;
+    int64_t g = t + (d == 0 ? G.row0 : 0);
+    const int nd = G.gmesh[d];
+    const bool wrap = g == nd - 1;       // periodic image of index 0 (impose_pbc, pythtb.py:2729-2747)
+    if (wrap) g = 0;
+    const double kd = G.start_k[d] + (double)g / (double)(nd - 1);   // pythtb.py:2477,2490-2491
+    tz0[zoff + t] = expi2pi(kd);
+    for (int o = 0; o < mv.nsta; ++o) {
+        const double4 tau = mv.orb[o];
+        const double td = d == 0 ? tau.x : d == 1 ? tau.y : d == 2 ? tau.z : tau.w;
+        cd f = cconj(expi2pi(kd * td));
+        if (wrap) f = cmul(f, G.pbc[d * TBK_MAX_NSTA + o]);
+        tf0[foff + (int64_t)t * mv.nsta + o] = f;
+    }
+}
+
+// ---- regular mesh (solve_on_grid): one wavefront per 64-point chunk of a mesh
+// row, so every leading-axis quantity is wave-uniform (scalar loads) and the
+// per-lane phases come from coalesced reads of the last axis' table.
+template <int N>
+__global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const GridArgs G) {
+    const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (chunk >= G.nchunks) return;
+    if (blockIdx.x == 0 && threadIdx.x < (N > 1 ? N - 1 : 0)) {   // re-arm the other parity
+        for (int s = 0; s < TBK_GAP_SHARDS; ++s) G.gaps_next[s * TBK_MAX_NSTA + threadIdx.x] = 0x7ff0000000000000ull;
+    }
+    const int lane = threadIdx.x & 63;
+    const int last = G.last;
+    const int nlast = G.wv.mesh[last];
+    unsigned row = (unsigned)(chunk / G.cpr);
+    const int jc = (int)(chunk - (int64_t)row * G.cpr);
+    const int jl = jc * 64 + lane;
+    const bool active = jl < nlast;
+    const int jj = active ? jl : nlast - 1;           // idle lanes shadow the row's last point (no stores)
+    const int64_t point = (int64_t)row * nlast + jj;
+
+    cd z[4] = {cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}};
+    cd fo[N];
 #pragma unroll
-            for (int b = 0; b + 1 < N; ++b) {
-                double g = sorted[b + 1] - sorted[b];
+    for (int o = 0; o < N; ++o) fo[o] = G.tf[last][(int64_t)jj * N + o];
+    // leading axes: wave-uniform indices, last-to-first
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) g = fmin(g, __shfl_xor(g, off));
-                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][b] = g;
-            }
-            __syncthreads();
-            if (threadIdx.x < N - 1) {
-                const double g = fmin(fmin(red[0][threadIdx.x], red[1][threadIdx.x]),
-                                      fmin(red[2][threadIdx.x], red[3][threadIdx.x]));
-                // gaps are >= 0, so their bit patterns order like the values
-                atomicMin(G.gaps + threadIdx.x, (unsigned long long)__double_as_longlong(fmax(g, 0.0)));
-            }
+    for (int d = 2; d >= 0; --d) {
+        if (d < last) {
+            const unsigned md = (unsigned)G.wv.mesh[d];
+            const unsigned q = row / md;
+            const unsigned id = row - q * md;
+            row = q;
+            z[d] = G.tz[d][id];
+#pragma unroll
+            for (int o = 0; o < N; ++o) fo[o] = cmul(fo[o], G.tf[d][(int64_t)id * N + o]);
         }
-        if (active) {
-            cd* out = G.wv.data + id * (int64_t)(N * N);
+    }
+    // the last axis' unit phase sits at z[last]; keep the array statically indexed
+    const cd zl = G.tz[last][jj];
 #pragma unroll
-            for (int b = 0; b < N; ++b)
+    for (int d = 0; d < 4; ++d)
+        if (d == last) z[d] = zl;
+
+    SmallMat<N> M;
+    assemble_small<N>(mv, z, M);
+    init_vectors<N, true>(M);
+    jacobi_small<N, true>(M);
+    int rk[N];
+    double sorted[N];
+    ranks_small<N>(M.dg, rk, sorted);
+    if constexpr (N > 1) {
+        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * TBK_MAX_NSTA;
 #pragma unroll
-                for (int o = 0; o < N; ++o) out[rk[b] * N + o] = cmul(M.v[o][b], fo[o]);
-        }
-    } else {
-        if (active) {
+        for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, sorted[b + 1] - sorted[b]);
+    }
+    if (active) {
 #pragma unroll
-            for (int b = 0; b < N; ++b) L.eval[(int64_t)b * nk + id] = sorted[b];
-            if (VEC) {
+        for (int b = 0; b < N; ++b) {
+            cd* out = wf_at(G.wv, rk[b], point);
 #pragma unroll
-                for (int b = 0; b < N; ++b) {
-                    cd* out = L.evec + ((int64_t)rk[b] * nk + id) * N;
-#pragma unroll
-                    for (int o = 0; o < N; ++o) out[o] = cmul(M.v[o][b], fo[o]);
-                }
-            }
+            for (int o = 0; o < N; ++o) out[o] = cmul(M.v[o][b], fo[o]);
         }
     }
 }
@@ -555,12 +647,13 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
         if constexpr (MODE == 1) {
             if (lane + 1 < n) {
                 const double g = S.ev[S.perm[lane + 1]] - S.ev[S.perm[lane]];
-                atomicMin(G.gaps + lane, (unsigned long long)__double_as_longlong(fmax(g, 0.0)));
+                unsigned long long* slot = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * TBK_MAX_NSTA + lane;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(fmax(g, 0.0));
+                if (bits < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, bits);
             }
-            cd* out = G.wv.data + id * (int64_t)n * n;
             for (int e = lane; e < n * n; e += 64) {
                 const int rb = e / n, o = e - rb * n;
-                out[e] = cmul(S.Vt[S.perm[rb] * ld + o], S.eo[o]);
+                wf_at(G.wv, rb, id)[o] = cmul(S.Vt[S.perm[rb] * ld + o], S.eo[o]);
             }
         } else {
             if (lane < n) L.eval[(int64_t)lane * nk + id] = S.ev[S.perm[lane]];
@@ -618,23 +711,21 @@ __global__ __launch_bounds__(256) void k_gen_ham(const ModelView mv, const int64
     }
 }
 
-__global__ void k_fill_u64(unsigned long long* p, int n, unsigned long long v) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+__global__ void k_arm_gaps(unsigned long long* p) {
+    for (int i = threadIdx.x; i < TBK_GAP_SHARDS * TBK_MAX_NSTA; i += blockDim.x) p[i] = 0x7ff0000000000000ull;
 }
 
 // ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
 template <int MODE, bool VEC>
-static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L,
-                        const GridArgs& G) {
+static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L) {
     const unsigned blocks = (unsigned)((nk + 255) / 256);
     switch (n) {
-        case 1: hipLaunchKernelGGL((k_solve_small<1, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G); break;
-        case 2: hipLaunchKernelGGL((k_solve_small<2, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G); break;
-        case 3: hipLaunchKernelGGL((k_solve_small<3, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G); break;
-        case 4: hipLaunchKernelGGL((k_solve_small<4, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G); break;
+        case 1: hipLaunchKernelGGL((k_solve_small<1, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
+        case 2: hipLaunchKernelGGL((k_solve_small<2, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
+        case 3: hipLaunchKernelGGL((k_solve_small<3, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
+        case 4: hipLaunchKernelGGL((k_solve_small<4, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
         default: tbk_set_error("launch_small: n=%d", n); return TBK_EINVAL;
     }
     TBK_HIP(hipGetLastError());
@@ -662,15 +753,15 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     return TBK_OK;
 }
 
+// MODE 0 / 2: list kernels
 template <int MODE>
 static int launch_solve(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, bool vec,
-                        const ListArgs& L, const GridArgs& G, const char* name) {
+                        const ListArgs& L, const char* name) {
     if (nk <= 0) return TBK_OK;
     ProfScope ps(ctx, name);
-    if (n <= 4) return vec ? launch_small<MODE, true>(ctx, mv, n, nk, L, G)
-                           : launch_small<MODE, false>(ctx, mv, n, nk, L, G);
-    return vec ? launch_wave<MODE, true>(ctx, mv, n, nk, L, G)
-               : launch_wave<MODE, false>(ctx, mv, n, nk, L, G);
+    GridArgs G{};
+    if (n <= 4) return vec ? launch_small<MODE, true>(ctx, mv, n, nk, L) : launch_small<MODE, false>(ctx, mv, n, nk, L);
+    return vec ? launch_wave<MODE, true>(ctx, mv, n, nk, L, G) : launch_wave<MODE, false>(ctx, mv, n, nk, L, G);
 }
 
 static int check_noconv(tbk_ctx* ctx, int n) {
@@ -688,8 +779,7 @@ extern "C" int tbk_solve_list_dev(tbk_model* m, const double* k_dev, int64_t nk,
     TBK_REQUIRE(m && eval_dev && nk >= 0, TBK_EINVAL, "tbk_solve_list_dev: bad argument");
     TBK_REQUIRE(m->dim_k == 0 || k_dev || nk == 0, TBK_EINVAL, "tbk_solve_list_dev: null k");
     ListArgs L{k_dev, nullptr, eval_dev, (cd*)evec_dev};
-    GridArgs G{};
-    return launch_solve<0>(m->ctx, m->view, m->nsta, nk, evec_dev != nullptr, L, G,
+    return launch_solve<0>(m->ctx, m->view, m->nsta, nk, evec_dev != nullptr, L,
                            evec_dev ? "solve_list_vec" : "solve_list_val");
 }
 
@@ -745,8 +835,7 @@ extern "C" int tbk_eigh_batch(tbk_ctx* ctx, int n, const double* ham, int64_t nk
     mv.nspin = 1;
     mv.nslot = n * (n + 1) / 2;
     ListArgs L{nullptr, h_dev, e_dev, v_dev};
-    GridArgs G{};
-    rc = launch_solve<2>(ctx, mv, n, nk, evec != nullptr, L, G, "eigh_batch");
+    rc = launch_solve<2>(ctx, mv, n, nk, evec != nullptr, L, "eigh_batch");
     if (rc) return rc;
     TBK_HIP(hipMemcpyAsync(eval, e_dev, eb, hipMemcpyDeviceToHost, ctx->stream));
     if (evec) TBK_HIP(hipMemcpyAsync(evec, v_dev, vb, hipMemcpyDeviceToHost, ctx->stream));
@@ -804,47 +893,104 @@ extern "C" int tbk_wfs_solve_grid_async(tbk_wfs* w, tbk_model* m, const double* 
     tbk_ctx* ctx = w->ctx;
     TBK_HIP(hipSetDevice(ctx->device));
     const int n = m->nsta;
-    // pbc phases: re-upload only when they changed
-    const size_t np = (size_t)v.dim_arr * n * 2;
-    bool same = w->pbc_host.size() == np;
-    if (same) same = memcmp(w->pbc_host.data(), pbc_phase, np * sizeof(double)) == 0;
-    if (!same) {
-        w->pbc_host.assign(pbc_phase, pbc_phase + np);
-        std::vector<cd> st((size_t)TBK_MAX_DIM * TBK_MAX_NSTA, cd{0.0, 0.0});
-        for (int d = 0; d < v.dim_arr; ++d)
-            for (int o = 0; o < n; ++o)
-                st[d * TBK_MAX_NSTA + o] = cd{pbc_phase[2 * (d * n + o)], pbc_phase[2 * (d * n + o) + 1]};
-        TBK_HIP(hipMemcpyAsync(w->pbc_dev, st.data(), st.size() * sizeof(cd), hipMemcpyHostToDevice,
-                               ctx->stream));
-        TBK_HIP(hipStreamSynchronize(ctx->stream));  // st is a local: finish before it dies
-    }
+    const int D = v.dim_arr;
     GridArgs G{};
     G.wv = v;
     for (int d = 0; d < TBK_MAX_DIM; ++d) {
-        G.start_k[d] = d < v.dim_arr ? start_k[d] : 0.0;
+        G.start_k[d] = d < D ? start_k[d] : 0.0;
         G.gmesh[d] = v.mesh[d];
     }
     G.gmesh[0] = (int)global_n0;
     G.row0 = row0;
     G.pbc = w->pbc_dev;
-    G.gaps = w->gaps_dev;
+    // everything the per-axis tables depend on; rebuild them only when it changes
+    std::vector<double> key;
+    key.push_back((double)(uintptr_t)m->blob);
+    key.push_back((double)row0);
+    key.push_back((double)global_n0);
+    for (int d = 0; d < D; ++d) key.push_back(start_k[d]);
+    key.insert(key.end(), pbc_phase, pbc_phase + (size_t)D * n * 2);
+    int64_t ntab = 0;
+    for (int d = 0; d < D; ++d) ntab += v.mesh[d];
+    const int64_t need = ntab * (1 + n);
+    if (w->tab_cap < need) {
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (w->tab_dev) TBK_HIP(hipFree(w->tab_dev));
+        w->tab_dev = nullptr;
+        w->tab_cap = 0;
+        TBK_HIP(hipMalloc((void**)&w->tab_dev, need * sizeof(cd)));
+        w->tab_cap = need;
+        w->tab_key.clear();
+    }
+    {
+        int64_t zo = 0, fo = ntab;
+        for (int d = 0; d < D; ++d) {
+            G.tz[d] = w->tab_dev + zo;
+            G.tf[d] = w->tab_dev + fo;
+            zo += v.mesh[d];
+            fo += (int64_t)v.mesh[d] * n;
+        }
+    }
+    if (key != w->tab_key) {
+        std::vector<cd> st((size_t)TBK_MAX_DIM * TBK_MAX_NSTA, cd{0.0, 0.0});
+        for (int d = 0; d < D; ++d)
+            for (int o = 0; o < n; ++o)
+                st[d * TBK_MAX_NSTA + o] = cd{pbc_phase[2 * (d * n + o)], pbc_phase[2 * (d * n + o) + 1]};
+        TBK_HIP(hipMemcpyAsync(w->pbc_dev, st.data(), st.size() * sizeof(cd), hipMemcpyHostToDevice, ctx->stream));
+        TBK_HIP(hipStreamSynchronize(ctx->stream));  // st is a local: finish before it dies
+        ProfScope ps(ctx, "grid_tables");
+        hipLaunchKernelGGL(k_grid_tables, dim3((unsigned)((ntab + 255) / 256)), dim3(256), 0, ctx->stream, m->view, G,
+                           w->tab_dev, w->tab_dev + ntab);
+        TBK_HIP(hipGetLastError());
+        w->tab_key = key;
+    }
+    // min gaps: this launch reduces into one parity and re-arms the other
+    const size_t half = (size_t)TBK_GAP_SHARDS * TBK_MAX_NSTA;
+    G.gaps = w->gaps_dev + (size_t)w->gaps_parity * half;
+    G.gaps_next = w->gaps_dev + (size_t)(1 - w->gaps_parity) * half;
+    w->gaps_parity = 1 - w->gaps_parity;   // *_result reads 1 - gaps_parity
     w->gaps_n = n - 1;
-    hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(TBK_MAX_NSTA), 0, ctx->stream, w->gaps_dev, TBK_MAX_NSTA,
-                       0x7ff0000000000000ull);
+    G.last = D - 1;
+    G.cpr = (v.mesh[D - 1] + 63) / 64;
+    G.nchunks = (v.npts / v.mesh[D - 1]) * G.cpr;
+    ProfScope ps(ctx, "solve_grid");
+    if (n <= 4) {
+        TBK_REQUIRE(v.npts / v.mesh[D - 1] < (int64_t)0xffffffffu && G.nchunks < (int64_t)0x7fffffff * 4, TBK_EUNSUPPORTED,
+                    "tbk_wfs_solve_grid: mesh too large for 32-bit row indices");
+        const unsigned blocks = (unsigned)((G.nchunks + 3) / 4);
+        switch (n) {
+            case 1: hipLaunchKernelGGL((k_grid_small<1>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+            case 2: hipLaunchKernelGGL((k_grid_small<2>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+            case 3: hipLaunchKernelGGL((k_grid_small<3>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+            default: hipLaunchKernelGGL((k_grid_small<4>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+        }
+        TBK_HIP(hipGetLastError());
+        return TBK_OK;
+    }
+    {   // wavefront-per-matrix path re-arms the other parity with a tiny memset-like kernel
+        hipLaunchKernelGGL(k_arm_gaps, dim3(1), dim3(256), 0, ctx->stream, G.gaps_next);
+    }
     ListArgs L{};
-    return launch_solve<1>(ctx, m->view, n, v.npts, true, L, G, "solve_grid");
+    return launch_wave<1, true>(ctx, m->view, n, v.npts, L, G);
 }
 
 extern "C" int tbk_wfs_solve_grid_result(tbk_wfs* w, double* min_gaps) {
     TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_solve_grid_result: null wfs");
     tbk_ctx* ctx = w->ctx;
-    unsigned long long bits[TBK_MAX_NSTA];
+    const size_t half = (size_t)TBK_GAP_SHARDS * TBK_MAX_NSTA;
+    std::vector<unsigned long long> bits(half);
     if (w->gaps_n > 0 && min_gaps) {
-        TBK_HIP(hipMemcpyAsync(bits, w->gaps_dev, w->gaps_n * sizeof(unsigned long long),
-                               hipMemcpyDeviceToHost, ctx->stream));
+        TBK_HIP(hipMemcpyAsync(bits.data(), w->gaps_dev + (size_t)(1 - w->gaps_parity) * half,
+                               half * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     }
     TBK_HIP(hipStreamSynchronize(ctx->stream));
-    if (w->gaps_n > 0 && min_gaps) memcpy(min_gaps, bits, w->gaps_n * sizeof(double));
+    if (w->gaps_n > 0 && min_gaps) {
+        for (int b = 0; b < w->gaps_n; ++b) {
+            unsigned long long best = bits[b];
+            for (int s = 1; s < TBK_GAP_SHARDS; ++s) best = std::min(best, bits[(size_t)s * TBK_MAX_NSTA + b]);
+            memcpy(&min_gaps[b], &best, sizeof(double));
+        }
+    }
     return check_noconv(ctx, w->view.nsta);
 }
 
@@ -860,19 +1006,20 @@ extern "C" int tbk_wfs_solve_grid(tbk_wfs* w, tbk_model* m, const double* start_
 __global__ __launch_bounds__(256) void k_impose(const WfsView v, const int dir, const cd* __restrict__ phase,
                                                 const int64_t nface) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int per = v.nsta * v.ncomp;
-    if (idx >= nface * per) return;
-    const int64_t f = idx / per;
-    const int e = (int)(idx - f * per);
-    const int o = e % v.ncomp;
+    const int64_t per_band = nface * v.ncomp;
+    if (idx >= per_band * v.nsta) return;
+    const int band = (int)(idx / per_band);
+    const int64_t r = idx - band * per_band;
+    const int64_t f = r / v.ncomp;
+    const int o = (int)(r - f * v.ncomp);
     // face index f enumerates all mesh points with index 0 along dir
     const int64_t inner = v.stride[dir];           // points per unit step of dir
     const int64_t outer = f / inner, in = f - outer * inner;
     const int64_t p0 = outer * inner * v.mesh[dir] + in;
     const int64_t p1 = p0 + (int64_t)(v.mesh[dir] - 1) * inner;
-    cd val = v.data[p0 * per + e];
+    cd val = wf_at(v, band, p0)[o];
     if (phase) val = cmul(val, phase[o]);
-    v.data[p1 * per + e] = val;
+    wf_at(v, band, p1)[o] = val;
 }
 
 extern "C" int tbk_wfs_impose(tbk_wfs* w, int mesh_dir, const double* phase) {
