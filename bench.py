@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="diagnostics: skip the Chern-number assertion")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -216,7 +217,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        assert abs(chern + 1.0) < 1e-9, "Chern number %r != -1" % chern
+        assert args.no_check or abs(chern + 1.0) < 1e-9, "Chern number %r != -1" % chern
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

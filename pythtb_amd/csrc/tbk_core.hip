@@ -1,6 +1,7 @@
 // tbk_core.hip -- contexts, device memory, timing, model flattening, wf storage.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -246,9 +247,11 @@ extern "C" int tbk_prof_get(tbk_ctx* c, int i, char* name, int cap, int64_t* lau
 namespace {
 struct TermKey {
     int slot;
+    int last;  // index of the last periodic component (ordered first within a slot)
     int R[4];
     bool operator<(const TermKey& o) const {
         if (slot != o.slot) return slot < o.slot;
+        if (R[last] != o.R[last]) return R[last] < o.R[last];
         for (int d = 0; d < 4; ++d)
             if (R[d] != o.R[d]) return R[d] < o.R[d];
         return false;
@@ -274,8 +277,10 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
                 "tbk_model_upload: null hopping table");
     const int ns = nspin;
     std::map<TermKey, cd> acc;
+    const int last = dim_k > 0 ? dim_k - 1 : 0;
     auto add = [&](int a, int b, const int* R, cd amp) {
         TermKey key;
+        key.last = last;
         if (a <= b) {
             key.slot = slot_of(n, a, b);
             for (int d = 0; d < 4; ++d) key.R[d] = d < dim_k ? R[d] : 0;
@@ -337,6 +342,14 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     }
     for (int s = 0; s < nslot; ++s) slot_ptr[s + 1] += slot_ptr[s];
     const int64_t nterm = (int64_t)amp.size();
+    // the same ordered terms as cells (slot, p = R_last): a polynomial in z_last per slot
+    int pmax = 0;
+    for (int64_t t = 0; t < nterm; ++t) pmax = std::max(pmax, std::abs(R4[t * 4 + last]));
+    const int npow = 2 * pmax + 1;
+    std::vector<int32_t> cell_ptr((size_t)nslot * npow + 1, 0);
+    for (int s = 0; s < nslot; ++s)
+        for (int t = slot_ptr[s]; t < slot_ptr[s + 1]; ++t) cell_ptr[(size_t)s * npow + (R4[t * 4 + last] + pmax) + 1]++;
+    for (size_t c = 0; c + 1 < cell_ptr.size(); ++c) cell_ptr[c + 1] += cell_ptr[c];
     std::vector<double> orb4((size_t)n * 4, 0.0);
     for (int a = 0; a < n; ++a)
         for (int d = 0; d < dim_k; ++d) orb4[a * 4 + d] = orb[(a / ns) * dim_k + d];
@@ -348,8 +361,10 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     const size_t o_R = al(o_amp + std::max<size_t>(amp.size(), 1) * sizeof(cd));
     const size_t o_ptr = al(o_R + std::max<size_t>(R4.size(), 4) * sizeof(int32_t));
     const size_t o_ab = al(o_ptr + slot_ptr.size() * sizeof(int32_t));
-    const size_t total = al(o_ab + slot_ab.size() * sizeof(int32_t));
+    const size_t o_cell = al(o_ab + slot_ab.size() * sizeof(int32_t));
+    const size_t total = al(o_cell + cell_ptr.size() * sizeof(int32_t));
     std::vector<unsigned char> host(total, 0);
+    memcpy(host.data() + o_cell, cell_ptr.data(), cell_ptr.size() * sizeof(int32_t));
     memcpy(host.data() + o_orb, orb4.data(), orb4.size() * sizeof(double));
     if (!amp.empty()) memcpy(host.data() + o_amp, amp.data(), amp.size() * sizeof(cd));
     if (!R4.empty()) memcpy(host.data() + o_R, R4.data(), R4.size() * sizeof(int32_t));
@@ -384,6 +399,8 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     m->view.term_R = (const int4*)(base + o_R);
     m->view.slot_ptr = (const int32_t*)(base + o_ptr);
     m->view.slot_ab = (const int32_t*)(base + o_ab);
+    m->view.pmax = pmax;
+    m->view.cell_ptr = (const int32_t*)(base + o_cell);
     *out = m;
     return TBK_OK;
 }

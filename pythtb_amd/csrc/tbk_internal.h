@@ -111,6 +111,11 @@ struct ModelView {
     const cd* term_amp;       // [nterm]
     const int4* term_R;       // [nterm]  lattice vector (periodic comps, 0-padded)
     const double4* orb;       // [nsta]   reduced position of each state's orbital
+    // the same terms seen as a polynomial in z_last = exp(2 pi i k_last): cell
+    // (slot, p) holds the terms of `slot` whose last lattice component is p,
+    // p in [-pmax, pmax]; terms are ordered (slot, p, ...) so cells are ranges
+    int pmax;
+    const int32_t* cell_ptr;  // [nslot*(2*pmax+1) + 1]
 };
 
 struct tbk_model {

@@ -16,6 +16,7 @@
 //   nsta  > 4 : one 64-lane wavefront per k, S and V in LDS, parallel-ordered
 //               (round-robin) Jacobi, nsta/2 disjoint rotations per round.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include "tbk_internal.h"
@@ -37,6 +38,10 @@ struct GridArgs {
     int last;                // index of the last (fastest) mesh axis
     int cpr;                 // 64-point chunks per mesh row (row = all leading axes)
     int64_t nchunks;
+    int seg;                 // chunks per wave tile (k_grid_rows)
+    int tpr;                 // wave tiles per row
+    int64_t ntiles;
+    int ablate;              // diagnostics only (TBK_ABLATE_GRID): 1 = no stores, 2 = no eigen-solve
 };
 
 struct ListArgs {
@@ -415,9 +420,14 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
         if (d == last) z[d] = zl;
 
     SmallMat<N> M;
-    assemble_small<N>(mv, z, M);
     init_vectors<N, true>(M);
-    jacobi_small<N, true>(M);
+    if (G.ablate != 2) {
+        assemble_small<N>(mv, z, M);
+        jacobi_small<N, true>(M);
+    } else {
+#pragma unroll
+        for (int a = 0; a < N; ++a) M.dg[a] = zl.x + a;
+    }
     int rk[N];
     double sorted[N];
     ranks_small<N>(M.dg, rk, sorted);
@@ -426,13 +436,151 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
 #pragma unroll
         for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, sorted[b + 1] - sorted[b]);
     }
-    if (active) {
+    if (active && (G.ablate != 1 || sorted[0] == 1.2345e300)) {
 #pragma unroll
         for (int b = 0; b < N; ++b) {
             cd* out = wf_at(G.wv, rk[b], point);
 #pragma unroll
             for (int o = 0; o < N; ++o) out[o] = cmul(M.v[o][b], fo[o]);
         }
+    }
+}
+
+// ---- regular mesh, polynomial form.  On a mesh row the leading-axis phases are
+// fixed, so S_ab(k) = sum_p C_ab,p z_last^p with row coefficients
+//   C_ab,p = sum_{t in cell(ab,p)} amp_t prod_{d<last} z_d^{R_d}
+// A wavefront owns `seg` consecutive 64-point chunks of one row: its lanes build
+// the row's coefficient cells once (in parallel, one cell per lane) into LDS and
+// every point then costs (2 pmax + 1) complex FMAs per slot read as LDS broadcasts
+// -- no per-point table walk, no scalar-load latency chain, no sincospi.
+template <int N>
+__global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const GridArgs G) {
+    extern __shared__ __align__(16) unsigned char lds_rows[];
+    constexpr int NSLOT = N * (N + 1) / 2;
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int npow = 2 * mv.pmax + 1;
+    const int ncell = NSLOT * npow;
+    cd* C = reinterpret_cast<cd*>(lds_rows) + wib * ncell;
+    cd* stage = reinterpret_cast<cd*>(lds_rows) + 4 * ncell + wib * (64 * N);
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wib;
+    const bool live = tile < G.ntiles;
+    const int last = G.last;
+    const int nlast = G.wv.mesh[last];
+    unsigned row = 0;
+    int jc0 = 0, jc1 = 0;
+    cd frow[N];
+#pragma unroll
+    for (int o = 0; o < N; ++o) frow[o] = cd{1.0, 0.0};
+    if (blockIdx.x == 0 && threadIdx.x < (N > 1 ? N - 1 : 0)) {   // re-arm the other parity
+        for (int s = 0; s < TBK_GAP_SHARDS; ++s) G.gaps_next[s * TBK_MAX_NSTA + threadIdx.x] = 0x7ff0000000000000ull;
+    }
+    if (live) {
+        row = (unsigned)(tile / G.tpr);
+        const int ts = (int)(tile - (int64_t)row * G.tpr);
+        jc0 = ts * G.seg;
+        jc1 = min(jc0 + G.seg, G.cpr);
+        cd z[4] = {cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}};
+        unsigned rem = row;
+#pragma unroll
+        for (int d = 2; d >= 0; --d) {
+            if (d < last) {
+                const unsigned md = (unsigned)G.wv.mesh[d];
+                const unsigned q = rem / md;
+                const unsigned id = rem - q * md;
+                rem = q;
+                z[d] = G.tz[d][id];
+#pragma unroll
+                for (int o = 0; o < N; ++o) frow[o] = cmul(frow[o], G.tf[d][(int64_t)id * N + o]);
+            }
+        }
+        for (int cell = lane; cell < ncell; cell += 64) {
+            const int t0 = mv.cell_ptr[cell], t1 = mv.cell_ptr[cell + 1];
+            cd acc{0.0, 0.0};
+            for (int t = t0; t < t1; ++t) {
+                int4 R = mv.term_R[t];
+                if (last == 0) R.x = 0; else if (last == 1) R.y = 0; else if (last == 2) R.z = 0; else R.w = 0;
+                cfma(acc, mv.term_amp[t], phase_of_R(z, R));
+            }
+            C[cell] = acc;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    double gmin[N > 1 ? N - 1 : 1];
+#pragma unroll
+    for (int b = 0; b + 1 < N; ++b) gmin[b] = __longlong_as_double(0x7ff0000000000000ll);
+    const int pmax = mv.pmax;
+    for (int jc = jc0; jc < jc1; ++jc) {
+        const int jl = jc * 64 + lane;
+        const bool active = jl < nlast;
+        const int jj = active ? jl : nlast - 1;       // idle lanes shadow the row's last point (no stores)
+        const int64_t point = (int64_t)row * nlast + jj;
+        const cd zl = G.tz[last][jj];
+        SmallMat<N> M;
+        {
+            int slot = 0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+#pragma unroll
+                for (int b = a; b < N; ++b, ++slot) {
+                    const cd* Cs = C + slot * npow + pmax;
+                    cd acc = Cs[0];
+                    cd zp = zl;
+                    for (int p = 1; p <= pmax; ++p) {
+                        cfma(acc, Cs[p], zp);
+                        cfma(acc, Cs[-p], cconj(zp));
+                        if (p < pmax) zp = cmul(zp, zl);
+                    }
+                    if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
+                }
+            }
+        }
+        init_vectors<N, true>(M);
+        jacobi_small<N, true>(M);
+        int rk[N];
+        double sorted[N];
+        ranks_small<N>(M.dg, rk, sorted);
+#pragma unroll
+        for (int b = 0; b + 1 < N; ++b) gmin[b] = fmin(gmin[b], sorted[b + 1] - sorted[b]);
+        // eigenvectors of H: D^+ v, periodic-image phases folded into fo
+        cd fo[N];
+#pragma unroll
+        for (int o = 0; o < N; ++o) fo[o] = cmul(frow[o], G.tf[last][(int64_t)jj * N + o]);
+        // LDS-staged store: per band plane the wave owns one contiguous run of
+        // 64*N elements, so lanes trade elements through LDS and every store
+        // instruction writes 1 KiB of consecutive bytes.
+        const int nvalid = min(64, nlast - jc * 64) * N;
+        const int64_t point0 = (int64_t)row * nlast + (int64_t)jc * 64;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int o = 0; o < N; ++o) {
+                cd val{0.0, 0.0};
+#pragma unroll
+                for (int b = 0; b < N; ++b) {      // band with rank r (static register select)
+                    const cd cand = cmul(M.v[o][b], fo[o]);
+                    val.x = rk[b] == r ? cand.x : val.x;
+                    val.y = rk[b] == r ? cand.y : val.y;
+                }
+                stage[lane * N + o] = val;
+            }
+            asm volatile("" ::: "memory");
+            cd* dst = G.wv.data + ((int64_t)r * G.wv.npts + point0) * N;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int e = i * 64 + lane;
+                if (e < nvalid) dst[e] = stage[e];
+            }
+        }
+        (void)point;
+        (void)active;
+    }
+    if constexpr (N > 1) {
+        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * TBK_MAX_NSTA;
+#pragma unroll
+        for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, gmin[b]);
     }
 }
 
@@ -953,16 +1101,37 @@ extern "C" int tbk_wfs_solve_grid_async(tbk_wfs* w, tbk_model* m, const double* 
     G.last = D - 1;
     G.cpr = (v.mesh[D - 1] + 63) / 64;
     G.nchunks = (v.npts / v.mesh[D - 1]) * G.cpr;
+    {
+        const char* ab = getenv("TBK_ABLATE_GRID");
+        G.ablate = ab ? atoi(ab) : 0;
+    }
     ProfScope ps(ctx, "solve_grid");
     if (n <= 4) {
         TBK_REQUIRE(v.npts / v.mesh[D - 1] < (int64_t)0xffffffffu && G.nchunks < (int64_t)0x7fffffff * 4, TBK_EUNSUPPORTED,
                     "tbk_wfs_solve_grid: mesh too large for 32-bit row indices");
-        const unsigned blocks = (unsigned)((G.nchunks + 3) / 4);
-        switch (n) {
-            case 1: hipLaunchKernelGGL((k_grid_small<1>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
-            case 2: hipLaunchKernelGGL((k_grid_small<2>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
-            case 3: hipLaunchKernelGGL((k_grid_small<3>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
-            default: hipLaunchKernelGGL((k_grid_small<4>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+        const int64_t nrows = v.npts / v.mesh[D - 1];
+        const int64_t want = (int64_t)ctx->cus * 32;     // wave tiles that fill the chip
+        G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, G.cpr), G.nchunks / want));
+        G.tpr = (G.cpr + G.seg - 1) / G.seg;
+        G.ntiles = nrows * G.tpr;
+        const size_t lds = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
+        const char* old = getenv("TBK_GRID_KERNEL");
+        if (lds <= 48 * 1024 && !(old && atoi(old) == 1)) {
+            const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
+            switch (n) {
+                case 1: hipLaunchKernelGGL((k_grid_rows<1>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G); break;
+                case 2: hipLaunchKernelGGL((k_grid_rows<2>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G); break;
+                case 3: hipLaunchKernelGGL((k_grid_rows<3>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G); break;
+                default: hipLaunchKernelGGL((k_grid_rows<4>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G); break;
+            }
+        } else {   // very long-ranged models: walk the term table per point
+            const unsigned blocks = (unsigned)((G.nchunks + 3) / 4);
+            switch (n) {
+                case 1: hipLaunchKernelGGL((k_grid_small<1>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+                case 2: hipLaunchKernelGGL((k_grid_small<2>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+                case 3: hipLaunchKernelGGL((k_grid_small<3>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+                default: hipLaunchKernelGGL((k_grid_small<4>), dim3(blocks), dim3(256), 0, ctx->stream, m->view, G); break;
+            }
         }
         TBK_HIP(hipGetLastError());
         return TBK_OK;
