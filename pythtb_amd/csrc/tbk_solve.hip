@@ -453,12 +453,13 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
 // the row's coefficient cells once (in parallel, one cell per lane) into LDS and
 // every point then costs (2 pmax + 1) complex FMAs per slot read as LDS broadcasts
 // -- no per-point table walk, no scalar-load latency chain, no sincospi.
-template <int N>
+template <int N, int PM>
 __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const GridArgs G) {
     extern __shared__ __align__(16) unsigned char lds_rows[];
     constexpr int NSLOT = N * (N + 1) / 2;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int npow = 2 * mv.pmax + 1;
+    const int pmax = PM >= 0 ? PM : mv.pmax;      // PM: compile-time range of the last lattice component
+    const int npow = 2 * pmax + 1;
     const int ncell = NSLOT * npow;
     cd* C = reinterpret_cast<cd*>(lds_rows) + wib * ncell;
     cd* stage = reinterpret_cast<cd*>(lds_rows) + 4 * ncell + wib * (64 * N);
@@ -510,7 +511,6 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     double gmin[N > 1 ? N - 1 : 1];
 #pragma unroll
     for (int b = 0; b + 1 < N; ++b) gmin[b] = __longlong_as_double(0x7ff0000000000000ll);
-    const int pmax = mv.pmax;
     for (int jc = jc0; jc < jc1; ++jc) {
         const int jl = jc * 64 + lane;
         const bool active = jl < nlast;
@@ -527,10 +527,19 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
                     const cd* Cs = C + slot * npow + pmax;
                     cd acc = Cs[0];
                     cd zp = zl;
-                    for (int p = 1; p <= pmax; ++p) {
-                        cfma(acc, Cs[p], zp);
-                        cfma(acc, Cs[-p], cconj(zp));
-                        if (p < pmax) zp = cmul(zp, zl);
+                    if constexpr (PM >= 0) {
+#pragma unroll
+                        for (int p = 1; p <= PM; ++p) {
+                            cfma(acc, Cs[p], zp);
+                            cfma(acc, Cs[-p], cconj(zp));
+                            if (p < PM) zp = cmul(zp, zl);
+                        }
+                    } else {
+                        for (int p = 1; p <= pmax; ++p) {
+                            cfma(acc, Cs[p], zp);
+                            cfma(acc, Cs[-p], cconj(zp));
+                            zp = cmul(zp, zl);
+                        }
                     }
                     if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
                 }
@@ -540,7 +549,15 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
         jacobi_small<N, true>(M);
         int rk[N];
         double sorted[N];
-        ranks_small<N>(M.dg, rk, sorted);
+        if constexpr (N <= 2) {                   // the closed forms come out ascending
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+                rk[b] = b;
+                sorted[b] = M.dg[b];
+            }
+        } else {
+            ranks_small<N>(M.dg, rk, sorted);
+        }
 #pragma unroll
         for (int b = 0; b + 1 < N; ++b) gmin[b] = fmin(gmin[b], sorted[b + 1] - sorted[b]);
         // eigenvectors of H: D^+ v, periodic-image phases folded into fo
@@ -558,11 +575,15 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
 #pragma unroll
             for (int o = 0; o < N; ++o) {
                 cd val{0.0, 0.0};
+                if constexpr (N <= 2) {
+                    val = cmul(M.v[o][r], fo[o]);
+                } else {
 #pragma unroll
-                for (int b = 0; b < N; ++b) {      // band with rank r (static register select)
-                    const cd cand = cmul(M.v[o][b], fo[o]);
-                    val.x = rk[b] == r ? cand.x : val.x;
-                    val.y = rk[b] == r ? cand.y : val.y;
+                    for (int b = 0; b < N; ++b) {  // band with rank r (static register select)
+                        const cd cand = cmul(M.v[o][b], fo[o]);
+                        val.x = rk[b] == r ? cand.x : val.x;
+                        val.y = rk[b] == r ? cand.y : val.y;
+                    }
                 }
                 stage[lane * N + o] = val;
             }
@@ -1118,12 +1139,27 @@ extern "C" int tbk_wfs_solve_grid_async(tbk_wfs* w, tbk_model* m, const double* 
         const char* old = getenv("TBK_GRID_KERNEL");
         if (lds <= 48 * 1024 && !(old && atoi(old) == 1)) {
             const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
-            switch (n) {
-                case 1: hipLaunchKernelGGL((k_grid_rows<1>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G); break;
-                case 2: hipLaunchKernelGGL((k_grid_rows<2>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G); break;
-                case 3: hipLaunchKernelGGL((k_grid_rows<3>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G); break;
-                default: hipLaunchKernelGGL((k_grid_rows<4>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G); break;
+#define TBK_ROWS(NN, PP) hipLaunchKernelGGL((k_grid_rows<NN, PP>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G)
+            const int pm = m->view.pmax;
+            switch (n * 4 + (pm <= 2 ? pm : 3)) {
+                case 4 + 0: TBK_ROWS(1, 0); break;
+                case 4 + 1: TBK_ROWS(1, 1); break;
+                case 4 + 2: TBK_ROWS(1, 2); break;
+                case 4 + 3: TBK_ROWS(1, -1); break;
+                case 8 + 0: TBK_ROWS(2, 0); break;
+                case 8 + 1: TBK_ROWS(2, 1); break;
+                case 8 + 2: TBK_ROWS(2, 2); break;
+                case 8 + 3: TBK_ROWS(2, -1); break;
+                case 12 + 0: TBK_ROWS(3, 0); break;
+                case 12 + 1: TBK_ROWS(3, 1); break;
+                case 12 + 2: TBK_ROWS(3, 2); break;
+                case 12 + 3: TBK_ROWS(3, -1); break;
+                case 16 + 0: TBK_ROWS(4, 0); break;
+                case 16 + 1: TBK_ROWS(4, 1); break;
+                case 16 + 2: TBK_ROWS(4, 2); break;
+                default: TBK_ROWS(4, -1); break;
             }
+#undef TBK_ROWS
         } else {   // very long-ranged models: walk the term table per point
             const unsigned blocks = (unsigned)((G.nchunks + 3) / 4);
             switch (n) {
