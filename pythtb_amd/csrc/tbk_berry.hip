@@ -13,6 +13,7 @@
 // Ordered nocc x nocc products are split into per-thread segments and combined
 // in order (matrix products are associative, not commutative).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include "tbk_internal.h"
@@ -358,6 +359,7 @@ struct FluxArgs {
     int ti;            // plaquette rows per wave tile
     int ncolw;         // wave tiles per row of tiles (63 plaquette columns each)
     int64_t nwaves;    // nslices * bps
+    int ablate;        // diagnostics only (TBK_ABLATE_FLUX): 1 = no atan2, 2 = no prefetch loads
 };
 
 template <int NOCC, int MAXN>
@@ -372,6 +374,24 @@ __device__ __forceinline__ cd one_link_det(const cd* P, const cd* Q, const int* 
         link_matrix_dyn(P, Q, occ, nocc, ncomp, plane, M);
         return det_dyn(nocc, M);
     }
+}
+
+// arg(z) = atan2(y, x).  Plaquette and link phases on a fine mesh are tiny, so the
+// common case |y| <= 2^-6 x (x > 0) takes the odd Taylor series of atan through
+// t^13 (truncation < 2^-90 |t|, i.e. below half an ulp of the result); anything
+// else -- large phases, x <= 0, zeros, non-finite -- goes to the library atan2.
+__device__ __forceinline__ double arg_small_first(double y, double x) {
+    if (x > 0.0 && fabs(y) <= 0.015625 * x) {
+        const double t = y / x, t2 = t * t;
+        double p = -1.0 / 13.0;
+        p = fma(p, t2, 1.0 / 11.0);
+        p = fma(p, t2, -1.0 / 9.0);
+        p = fma(p, t2, 1.0 / 7.0);
+        p = fma(p, t2, -1.0 / 5.0);
+        p = fma(p, t2, 1.0 / 3.0);
+        return fma(-(t * t2), p, t);
+    }
+    return atan2(y, x);
 }
 
 // ---- row-streaming flux kernel (ncomp <= 4): a wavefront owns 63 plaquette
@@ -418,33 +438,32 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
     const int jb = colw * 63 + lane;                 // mesh column held by this lane
     const int jbc = min(jb, A.nb);                   // clamp: columns run 0..nb
     const bool has_plaq = lane < 63 && jb < A.nb;
-    const bool has_right = jbc < A.nb;
     const int64_t plane = A.v.npts * A.v.ncomp;
-    const int64_t rstep = A.sa * A.v.ncomp, cstep = A.sb * A.v.ncomp;
+    const int64_t rstep = A.sa * A.v.ncomp;
+    // right neighbour; the last mesh column pairs with itself (det<u|u> = 1, value unused)
+    const int64_t cstep = jbc < A.nb ? A.sb * A.v.ncomp : 0;
     const cd* col = A.v.data + (axis_offset(A.other, slice) + (int64_t)jbc * A.sb) * A.v.ncomp + (int64_t)ia0 * rstep;
     const int64_t per = (int64_t)A.na * A.nb;
-    cd cur[NOCC][NCOMP], nxt[NOCC][NCOMP], rgt[NOCC][NCOMP];
+    cd cur[NOCC][NCOMP], nxt[NOCC][NCOMP], rgt[NOCC][NCOMP], pn[NOCC][NCOMP], pr[NOCC][NCOMP];
     load_vectors<NOCC, NCOMP>(col, A.occ, plane, cur);
-    cd dHc{1.0, 0.0};
-    if (has_right) {
-        load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, rgt);
-        dHc = det_overlap<NOCC, NCOMP>(cur, rgt);
-    }
+    load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, rgt);
+    cd dHc = det_overlap<NOCC, NCOMP>(cur, rgt);
+    col += rstep;
+    load_vectors<NOCC, NCOMP>(col, A.occ, plane, nxt);
+    load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, rgt);
     double sum = 0.0;
     for (int ia = ia0; ia < ia1; ++ia) {
-        col += rstep;
-        load_vectors<NOCC, NCOMP>(col, A.occ, plane, nxt);
+        // prefetch mesh row ia+2 while row ia+1 is consumed (the tile's last row re-reads itself)
+        if (ia + 1 < ia1 && A.ablate != 2) col += rstep;
+        load_vectors<NOCC, NCOMP>(col, A.occ, plane, pn);
+        load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, pr);
         const cd dV = det_overlap<NOCC, NCOMP>(cur, nxt);
-        cd dHn{1.0, 0.0};
-        if (has_right) {
-            load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, rgt);
-            dHn = det_overlap<NOCC, NCOMP>(nxt, rgt);
-        }
+        const cd dHn = det_overlap<NOCC, NCOMP>(nxt, rgt);
         const cd dVr{__shfl_down(dV.x, 1), __shfl_down(dV.y, 1)};
         const cd z = cmul(cmul(dV, dHn), cconj(cmul(dVr, dHc)));
         double pha = 0.0;
         if (has_plaq) {
-            pha = -atan2(z.y, z.x);
+            pha = A.ablate == 1 ? -z.y : -arg_small_first(z.y, z.x);
             if (A.swap) pha = -pha;
             if (A.plaq)
                 A.plaq[slice * per + (A.swap ? (int64_t)jb * A.na + ia : (int64_t)ia * A.nb + jb)] = pha;
@@ -453,7 +472,11 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
 #pragma unroll
         for (int a = 0; a < NOCC; ++a)
 #pragma unroll
-            for (int o = 0; o < NCOMP; ++o) cur[a][o] = nxt[a][o];
+            for (int o = 0; o < NCOMP; ++o) {
+                cur[a][o] = nxt[a][o];
+                nxt[a][o] = pn[a][o];
+                rgt[a][o] = pr[a][o];
+            }
         dHc = dHn;
     }
 #pragma unroll
@@ -495,17 +518,25 @@ __global__ __launch_bounds__(256) void k_flux(const FluxArgs A) {
     if (threadIdx.x == 0) A.partial[(int64_t)slice * A.bps + blk] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// one block per slice: ordered strided sums, then a fixed tree
-__global__ __launch_bounds__(256) void k_flux_reduce(const double* __restrict__ partial, int bps,
-                                                     double* __restrict__ totals) {
+// one block per slice: fixed-shape sum (4 interleaved accumulators per thread so the
+// loads overlap, then an LDS tree) -- the same order every run, no atomics
+__global__ __launch_bounds__(1024) void k_flux_reduce(const double* __restrict__ partial, int bps,
+                                                      double* __restrict__ totals) {
     const double* p = partial + (int64_t)blockIdx.x * bps;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < bps; i += 256) s += p[i];
-    __shared__ double red[256];
-    red[threadIdx.x] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < bps; i += 4 * 1024) {
+        s0 += p[i];
+        s1 += p[i + 1024];
+        s2 += p[i + 2048];
+        s3 += p[i + 3072];
+    }
+    for (; i < bps; i += 1024) s0 += p[i];
+    __shared__ double red[1024];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
 #pragma unroll
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
         if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
@@ -584,6 +615,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         A.bps = (int)((per + 255) / 256);
     }
     A.nwaves = nslices * A.bps;
+    { const char* ab = getenv("TBK_ABLATE_FLUX"); A.ablate = ab ? atoi(ab) : 0; }
     TBK_REQUIRE(nslices * A.bps < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many plaquette blocks");
     if (w->flux_nslices < nslices) {
         if (w->flux_totals_dev) TBK_HIP(hipFree(w->flux_totals_dev));
@@ -650,7 +682,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     }
     {
         ProfScope ps(ctx, "flux_reduce");
-        hipLaunchKernelGGL(k_flux_reduce, dim3((unsigned)nslices), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(k_flux_reduce, dim3((unsigned)nslices), dim3(1024), 0, ctx->stream,
                            (const double*)w->flux_partial_dev, A.bps, w->flux_totals_dev);
         TBK_HIP(hipGetLastError());
     }
