@@ -59,7 +59,7 @@ def haldane(tb):
     return m
 
 
-def cpu_baseline(sample_mesh=193):
+def cpu_baseline(sample_mesh=513):
     """Oracle (a NumPy port of the reference's per-k / per-plaquette Python loops)
     timed on one host core on a bounded sample of the same workload."""
     from oracle import tb_oracle as orc
@@ -213,7 +213,7 @@ def main():
             "solve_kpts_per_s": MESH * MESH / (kern["solve_grid"]["avg_ms"] * 1e-3) if "solve_grid" in kern else None,
             "flux_plaq_per_s": MESH * MESH / (kern["berry_flux"]["avg_ms"] * 1e-3) if "berry_flux" in kern else None,
             "check": {"chern": chern, "min_gap": float(allv[:, 1].min())},
-            "device": info["name"],
+            "device": info["name"].strip() or "gfx950", "compute_units": info["compute_units"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
