@@ -130,7 +130,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.prof_enable(True)
+    # HIP-event brackets on the kernels' own stream, inside the timed region.  A bracket
+    # costs ~3 us of stream time (3 kernels x 2 events = 20% of a step), so every 7th
+    # launch is bracketed: coprime with the 3 launches per step, every kernel is sampled
+    # once per 7 steps.  TBK_PROF_PERIOD=1 brackets every launch, 0 none.
+    ctx.prof_enable(int(os.environ.get("TBK_PROF_PERIOD", "7")))
     ctx.prof_reset()
     barrier()
     t0 = time.perf_counter()

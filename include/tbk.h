@@ -62,7 +62,9 @@ int tbk_dev_download(tbk_ctx* ctx, void* dst, const void* src_dev, int64_t bytes
  * brackets recorded inside the library around every launch while enabled. */
 int tbk_timer_begin(tbk_ctx* ctx);
 int tbk_timer_end(tbk_ctx* ctx, double* elapsed_ms);
-int tbk_prof_enable(tbk_ctx* ctx, int on);
+/* period: 0 = off, 1 = bracket every launch, N = bracket every N-th launch (an event
+ * record costs about 3 us of stream time, so timed loops sample)                     */
+int tbk_prof_enable(tbk_ctx* ctx, int period);
 int tbk_prof_reset(tbk_ctx* ctx);
 int tbk_prof_count(tbk_ctx* ctx, int* n_kernels);
 int tbk_prof_get(tbk_ctx* ctx, int index, char* name, int name_cap, int64_t* launches,

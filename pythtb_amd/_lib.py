@@ -145,8 +145,9 @@ class Context(object):
         check(lib.tbk_timer_end(self.handle, C.byref(ms)))
         return ms.value
 
-    def prof_enable(self, on=True):
-        check(lib.tbk_prof_enable(self.handle, 1 if on else 0))
+    def prof_enable(self, period=1):
+        """0/False: off; 1/True: HIP-event bracket around every kernel launch; N: every N-th."""
+        check(lib.tbk_prof_enable(self.handle, int(period)))
 
     def prof_reset(self):
         check(lib.tbk_prof_reset(self.handle))

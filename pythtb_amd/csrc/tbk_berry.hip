@@ -359,6 +359,10 @@ struct FluxArgs {
     int ti;            // plaquette rows per wave tile
     int ncolw;         // wave tiles per row of tiles (63 plaquette columns each)
     int64_t nwaves;    // nslices * bps
+    int bpb;           // blocks per slice of the row kernel (4 wave tiles each)
+    int fused;         // row kernel: last-arriving block finishes the sum (else k_flux_reduce does)
+    unsigned* counters;  // [nslices][16] arrival tickets (8 shards + top), zero between launches
+    double* totals;    // [nslices]
     int ablate;        // diagnostics only (TBK_ABLATE_FLUX): 1 = no atan2, 2 = no prefetch loads
 };
 
@@ -427,17 +431,17 @@ __device__ __forceinline__ cd det_overlap(const cd (&p)[NOCC][NCOMP], const cd (
 
 template <int NOCC, int NCOMP>
 __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
-    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= A.nwaves) return;
-    const int lane = threadIdx.x & 63;
-    const int slice = (int)(w / A.bps);
-    const int t = (int)(w - (int64_t)slice * A.bps);
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slice = blockIdx.x / A.bpb;            // blocks never straddle slices
+    const int blk = blockIdx.x - slice * A.bpb;
+    const bool live = blk * 4 + wib < A.bps;         // idle waves shadow the last tile, contribute 0
+    const int t = live ? blk * 4 + wib : A.bps - 1;
     const int trow = t / A.ncolw, colw = t - trow * A.ncolw;
     const int ia0 = trow * A.ti;
     const int ia1 = min(ia0 + A.ti, A.na);
     const int jb = colw * 63 + lane;                 // mesh column held by this lane
     const int jbc = min(jb, A.nb);                   // clamp: columns run 0..nb
-    const bool has_plaq = lane < 63 && jb < A.nb;
+    const bool has_plaq = live && lane < 63 && jb < A.nb;
     const int64_t plane = A.v.npts * A.v.ncomp;
     const int64_t rstep = A.sa * A.v.ncomp;
     // right neighbour; the last mesh column pairs with itself (det<u|u> = 1, value unused)
@@ -481,7 +485,62 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-    if (lane == 0) A.partial[w] = sum;
+    // ---- deterministic total without a second launch: every block publishes one
+    // partial (fixed shape), the block that arrives last (two-level ticket: 8 shard
+    // counters, one top counter) sums the slice's partials in a fixed order.
+    __shared__ double wsum[4];
+    __shared__ double red[256];
+    __shared__ int last_flag;
+    if (lane == 0) wsum[wib] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // hand-off without cache-wide fences (a release fence per block costs microseconds):
+        // the partial is one 8-byte agent-scope (write-through) store, drained before the
+        // ticket; the last block reads the partials with agent-scope loads (L1 bypass).
+        const double mine = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (!A.fused) {   // a separate k_flux_reduce launch finishes the sum
+            A.partial[(int64_t)slice * A.bpb + blk] = mine;
+            last_flag = 0;
+        } else {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(A.partial) + (int64_t)slice * A.bpb + blk,
+                           (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* cnt = A.counters + (int64_t)slice * 16;
+        const int shard = blk & 7;
+        const unsigned shard_size = (unsigned)(A.bpb - shard + 7) / 8u;
+        int last = 0;
+        if (atomicAdd(cnt + shard, 1u) == shard_size - 1u) {
+            const unsigned nshards = (unsigned)min(A.bpb, 8);
+            if (atomicAdd(cnt + 8, 1u) == nshards - 1u) last = 1;
+        }
+        last_flag = last;
+        }
+    }
+    __syncthreads();
+    if (last_flag) {
+        const unsigned long long* pb = reinterpret_cast<const unsigned long long*>(A.partial) + (int64_t)slice * A.bpb;
+        auto ld = [&](int idx) {
+            return __longlong_as_double((long long)__hip_atomic_load(pb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        };
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int i = threadIdx.x;
+        for (; i + 3 * 256 < A.bpb; i += 4 * 256) {
+            s0 += ld(i);
+            s1 += ld(i + 256);
+            s2 += ld(i + 512);
+            s3 += ld(i + 768);
+        }
+        for (; i < A.bpb; i += 256) s0 += ld(i);
+        red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+#pragma unroll
+        for (int w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) A.totals[slice] = red[0];
+        if (threadIdx.x < 9) A.counters[(int64_t)slice * 16 + threadIdx.x] = 0u;   // re-arm for the next launch
+    }
 }
 
 // F(i,j) = -arg[ det<00|10> det<10|11> det<11|01> det<01|00> ]  (pythtb.py:3852-3863)
@@ -615,14 +674,25 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         A.bps = (int)((per + 255) / 256);
     }
     A.nwaves = nslices * A.bps;
+    A.bpb = (A.bps + 3) / 4;
+    { const char* fu = getenv("TBK_FLUX_FUSED"); A.fused = fu ? atoi(fu) : 0; }
     { const char* ab = getenv("TBK_ABLATE_FLUX"); A.ablate = ab ? atoi(ab) : 0; }
     TBK_REQUIRE(nslices * A.bps < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many plaquette blocks");
-    if (w->flux_nslices < nslices) {
+    if (w->flux_nslices_cap < nslices) {
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
         if (w->flux_totals_dev) TBK_HIP(hipFree(w->flux_totals_dev));
+        if (w->flux_cnt_dev) TBK_HIP(hipFree(w->flux_cnt_dev));
         w->flux_totals_dev = nullptr;
+        w->flux_cnt_dev = nullptr;
+        w->flux_nslices_cap = 0;
         TBK_HIP(hipMalloc((void**)&w->flux_totals_dev, nslices * sizeof(double)));
+        TBK_HIP(hipMalloc((void**)&w->flux_cnt_dev, nslices * 16 * sizeof(unsigned)));
+        TBK_HIP(hipMemsetAsync(w->flux_cnt_dev, 0, nslices * 16 * sizeof(unsigned), ctx->stream));
+        w->flux_nslices_cap = nslices;
     }
     w->flux_nslices = nslices;
+    A.counters = w->flux_cnt_dev;
+    A.totals = w->flux_totals_dev;
     if (w->flux_partial_cap < nslices * A.bps) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
         if (w->flux_partial_dev) TBK_HIP(hipFree(w->flux_partial_dev));
@@ -652,7 +722,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     {
         ProfScope ps(ctx, "berry_flux");
         if (rows) {
-            const dim3 grid((unsigned)((A.nwaves + 3) / 4)), blk(256);
+            const dim3 grid((unsigned)(nslices * A.bpb)), blk(256);
 #define TBK_ROWS(NO, NC) hipLaunchKernelGGL((k_flux_rows<NO, NC>), grid, blk, 0, ctx->stream, A)
             switch (v.ncomp * 8 + nocc) {
                 case 1 * 8 + 1: TBK_ROWS(1, 1); break;
@@ -680,10 +750,10 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         }
         TBK_HIP(hipGetLastError());
     }
-    {
+    if (!rows || !A.fused) {
         ProfScope ps(ctx, "flux_reduce");
         hipLaunchKernelGGL(k_flux_reduce, dim3((unsigned)nslices), dim3(1024), 0, ctx->stream,
-                           (const double*)w->flux_partial_dev, A.bps, w->flux_totals_dev);
+                           (const double*)w->flux_partial_dev, rows ? A.bpb : A.bps, w->flux_totals_dev);
         TBK_HIP(hipGetLastError());
     }
     return TBK_OK;

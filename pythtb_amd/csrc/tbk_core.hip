@@ -175,7 +175,7 @@ static hipEvent_t prof_event(tbk_ctx* c) {
 }
 
 ProfScope::ProfScope(tbk_ctx* c, const char* n) : ctx(c), name(n) {
-    if (ctx->prof_on) {
+    if (ctx->prof_period > 0 && (ctx->prof_tick++ % (unsigned)ctx->prof_period) == 0) {
         t0 = prof_event(ctx);
         t1 = prof_event(ctx);
         hipEventRecord(t0, ctx->stream);
@@ -212,7 +212,8 @@ static int prof_collect(tbk_ctx* c) {
 
 extern "C" int tbk_prof_enable(tbk_ctx* c, int on) {
     TBK_REQUIRE(c, TBK_EINVAL, "tbk_prof_enable: null ctx");
-    c->prof_on = on != 0;
+    c->prof_period = on < 0 ? 0 : on;
+    c->prof_tick = 0;
     return TBK_OK;
 }
 extern "C" int tbk_prof_reset(tbk_ctx* c) {
@@ -509,6 +510,7 @@ extern "C" int tbk_wfs_free(tbk_wfs* w) {
     if (w->pbc_dev) hipFree(w->pbc_dev);
     if (w->tab_dev) hipFree(w->tab_dev);
     if (w->flux_totals_dev) hipFree(w->flux_totals_dev);
+    if (w->flux_cnt_dev) hipFree(w->flux_cnt_dev);
     if (w->flux_plaq_dev) hipFree(w->flux_plaq_dev);
     if (w->flux_partial_dev) hipFree(w->flux_partial_dev);
     delete w;

@@ -73,7 +73,8 @@ struct tbk_ctx {
     int cus = 0;
     hipStream_t stream = nullptr;
     hipEvent_t timer0 = nullptr, timer1 = nullptr;
-    bool prof_on = false;
+    int prof_period = 0;   // 0 off, 1 bracket every launch, N bracket every Nth launch
+    unsigned prof_tick = 0;
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> event_pool;
     std::vector<ProfAgg> prof_agg;
@@ -162,7 +163,8 @@ struct tbk_wfs {
     std::vector<double> tab_key;
     // flux results
     double* flux_totals_dev = nullptr;
-    int64_t flux_nslices = 0;
+    unsigned* flux_cnt_dev = nullptr;        // [slices][16] arrival tickets of the row kernel
+    int64_t flux_nslices = 0, flux_nslices_cap = 0;
     double* flux_plaq_dev = nullptr;
     int64_t flux_plaq_cap = 0, flux_plaq_n = 0;
     double* flux_partial_dev = nullptr;
