@@ -791,7 +791,8 @@ struct ChainArgs {
     AxisSet other;     // string axes (original order)
     int64_t nstrings;
     int seg_len, nseg;
-    cd* partial;       // det: [nseg][nstrings]; evals: [nseg][nstrings][nocc*nocc]
+    int final_lanes;   // k_chain_final_wave: lanes taking part in the ordered tree
+    cd* partial;      // det: [nseg][nstrings]; evals: [nseg][nstrings][nocc*nocc]
     double* out;       // det: [nstrings]; evals: [nstrings][nocc]
     int* flags;
 };
@@ -905,6 +906,85 @@ __global__ __launch_bounds__(64) void k_chain_final(const ChainArgs A) {
     }
 }
 
+// Same finish for long strings (many segments): one wavefront per string.  Lane l
+// multiplies its contiguous run of segments in order, then an ordered pairwise
+// tree over the lanes through LDS (associativity keeps the order), lane 0 finishes.
+template <int MAXN, bool EVALS>
+__global__ __launch_bounds__(64) void k_chain_final_wave(const ChainArgs A) {
+    extern __shared__ __align__(16) unsigned char lds_chain[];
+    cd* ex = reinterpret_cast<cd*>(lds_chain);
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int nocc = A.nocc;
+    const int nn = EVALS ? nocc * nocc : 1;
+    const int P = A.final_lanes;                           // participating lanes (power of two <= 64)
+    const int run = (A.nseg + P - 1) / P;
+    const int g0 = lane * run, g1 = min(g0 + run, A.nseg);
+    cd R[EVALS ? MAXN * MAXN : 1], T[EVALS ? MAXN * MAXN : 1];
+    auto load_seg = [&](int g, cd* dst) {
+        const cd* M = A.partial + ((int64_t)g * A.nstrings + s) * nn;
+        for (int e = 0; e < nn; ++e) dst[e] = M[e];
+    };
+    auto mul_into_R = [&](const cd* M) {                    // R <- R * M
+        if constexpr (!EVALS) {
+            R[0] = cmul(R[0], M[0]);
+        } else {
+            for (int a = 0; a < nocc; ++a)
+                for (int b = 0; b < nocc; ++b) {
+                    cd acc{0.0, 0.0};
+                    for (int j = 0; j < nocc; ++j) cfma(acc, R[a * nocc + j], M[j * nocc + b]);
+                    T[a * nocc + b] = acc;
+                }
+            for (int e = 0; e < nn; ++e) R[e] = T[e];
+        }
+    };
+    const bool has = lane < P && g0 < g1;
+    if (has) {
+        load_seg(g0, R);
+        for (int g = g0 + 1; g < g1; ++g) {
+            cd M[EVALS ? MAXN * MAXN : 1];
+            load_seg(g, M);
+            mul_into_R(M);
+        }
+    } else {                                               // identity: neutral in the ordered product
+        for (int e = 0; e < nn; ++e) R[e] = cd{0.0, 0.0};
+        if constexpr (!EVALS) R[0] = cd{1.0, 0.0};
+        else for (int a = 0; a < nocc; ++a) R[a * nocc + a] = cd{1.0, 0.0};
+    }
+    if (lane < P)
+        for (int e = 0; e < nn; ++e) ex[lane * nn + e] = R[e];
+    __syncthreads();
+    for (int off = 1; off < P; off <<= 1) {
+        const bool act = lane < P && (lane % (2 * off)) == 0 && lane + off < P;
+        if (act) mul_into_R(ex + (lane + off) * nn);
+        __syncthreads();
+        if (act)
+            for (int e = 0; e < nn; ++e) ex[lane * nn + e] = R[e];
+        __syncthreads();
+    }
+    if (lane != 0) return;
+    if constexpr (!EVALS) {
+        A.out[s] = -atan2(R[0].y, R[0].x);
+    } else {
+        if (nocc == 1) {
+            A.out[s] = -atan2(R[0].y, R[0].x);
+            return;
+        }
+        cd ev[MAXN], rc[MAXN], rs[MAXN];
+        if (!eigvals_dyn(nocc, R, ev, rc, rs)) atomicExch(A.flags + 1, 1);
+        double* o = A.out + s * nocc;
+        for (int j = 0; j < nocc; ++j) {
+            const double ph = -atan2(ev[j].y, ev[j].x);
+            int pos = j;
+            while (pos > 0 && o[pos - 1] > ph) {
+                o[pos] = o[pos - 1];
+                --pos;
+            }
+            o[pos] = ph;
+        }
+    }
+}
+
 extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir, int berry_evals, double* out) {
     TBK_REQUIRE(w && out, TBK_EINVAL, "tbk_berry_phase: null argument");
     const WfsView& v = w->view;
@@ -961,11 +1041,24 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     }
     {
         ProfScope ps(ctx, "chain_final");
-        const dim3 g2((unsigned)((A.nstrings + 63) / 64)), b2(64);
-        if (!ev) hipLaunchKernelGGL((k_chain_final<1, false>), g2, b2, 0, ctx->stream, A);
-        else if (nocc <= 4) hipLaunchKernelGGL((k_chain_final<4, true>), g2, b2, 0, ctx->stream, A);
-        else if (nocc <= 8) hipLaunchKernelGGL((k_chain_final<8, true>), g2, b2, 0, ctx->stream, A);
-        else hipLaunchKernelGGL((k_chain_final<TBK_MAX_NOCC, true>), g2, b2, 0, ctx->stream, A);
+        if (A.nseg > 4 && A.nstrings < (int64_t)0x7fffffff) {   // long strings: a wavefront per string
+            const int nn = ev ? nocc * nocc : 1;
+            int P = 64;
+            while (P > 1 && (P / 2 >= A.nseg || (size_t)P * nn * sizeof(cd) > 64 * 1024)) P /= 2;
+            A.final_lanes = P;
+            const size_t lds = (size_t)P * nn * sizeof(cd);
+            const dim3 g2((unsigned)A.nstrings), b2(64);
+            if (!ev) hipLaunchKernelGGL((k_chain_final_wave<1, false>), g2, b2, lds, ctx->stream, A);
+            else if (nocc <= 4) hipLaunchKernelGGL((k_chain_final_wave<4, true>), g2, b2, lds, ctx->stream, A);
+            else if (nocc <= 8) hipLaunchKernelGGL((k_chain_final_wave<8, true>), g2, b2, lds, ctx->stream, A);
+            else hipLaunchKernelGGL((k_chain_final_wave<TBK_MAX_NOCC, true>), g2, b2, lds, ctx->stream, A);
+        } else {
+            const dim3 g2((unsigned)((A.nstrings + 63) / 64)), b2(64);
+            if (!ev) hipLaunchKernelGGL((k_chain_final<1, false>), g2, b2, 0, ctx->stream, A);
+            else if (nocc <= 4) hipLaunchKernelGGL((k_chain_final<4, true>), g2, b2, 0, ctx->stream, A);
+            else if (nocc <= 8) hipLaunchKernelGGL((k_chain_final<8, true>), g2, b2, 0, ctx->stream, A);
+            else hipLaunchKernelGGL((k_chain_final<TBK_MAX_NOCC, true>), g2, b2, 0, ctx->stream, A);
+        }
         TBK_HIP(hipGetLastError());
     }
     int flag = 0;

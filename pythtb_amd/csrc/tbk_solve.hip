@@ -150,16 +150,18 @@ __device__ __forceinline__ void rotate(SmallMat<N>& M) {
     const cd g = M.up[P][Q];
     const double g2 = cabs2(g);
     if (g2 > 0.0) {
-        const double ga = sqrt(g2);
-        const double inv = 1.0 / ga;
-        const cd w{g.x * inv, g.y * inv};
-        const double tau = (M.dg[Q] - M.dg[P]) * (0.5 * inv);
-        const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
-        const double c = 1.0 / sqrt(1.0 + t * t);
-        const double s = t * c;
-        const cd sw{s * w.x, s * w.y};
-        M.dg[P] -= t * ga;
-        M.dg[Q] += t * ga;
+        // division-free parameters (one sqrt, one rsqrt): with a = (d_Q - d_P)/2,
+        // r = sqrt(a^2 + |g|^2):  c = (|a|+r) / sqrt(2r(r+|a|)),
+        // s w = sgn(a) g / sqrt(2r(r+|a|)),  new diagonal = mid -+ sgn(a) r
+        const double a = 0.5 * (M.dg[Q] - M.dg[P]), aa = fabs(a);
+        const double r = sqrt(a * a + g2);
+        const double inv = rsqrt(2.0 * r * (r + aa));
+        const double c = (aa + r) * inv;
+        const double sg = copysign(1.0, a);
+        const cd sw{sg * g.x * inv, sg * g.y * inv};
+        const double mid = 0.5 * (M.dg[P] + M.dg[Q]);
+        M.dg[P] = mid - sg * r;
+        M.dg[Q] = mid + sg * r;
         M.up[P][Q] = cd{0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < N; ++r) {
@@ -736,13 +738,13 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
                     if (q < n) {  // not the bye
                         const cd g = S.A[p * ld + q];
                         const double g2 = cabs2(g);
-                        if (g2 > 0.0) {
-                            const double ga = sqrt(g2), inv = 1.0 / ga;
-                            const double tau = (S.A[q * ld + q].x - S.A[p * ld + p].x) * (0.5 * inv);
-                            const double t = copysign(1.0, tau) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                            c = 1.0 / sqrt(1.0 + t * t);
-                            const double s = t * c;
-                            sw = cd{s * g.x * inv, s * g.y * inv};
+                        if (g2 > 0.0) {   // same division-free parameters as rotate<>
+                            const double a = 0.5 * (S.A[q * ld + q].x - S.A[p * ld + p].x), aa = fabs(a);
+                            const double r = sqrt(a * a + g2);
+                            const double inv = rsqrt(2.0 * r * (r + aa));
+                            const double sg = copysign(1.0, a);
+                            c = (aa + r) * inv;
+                            sw = cd{sg * g.x * inv, sg * g.y * inv};
                             code = p | (q << 16);
                         }
                     }
