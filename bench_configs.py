@@ -12,12 +12,17 @@ import json
 import sys
 import time
 
+import os
+
 import numpy as np
 
-import pythtb_amd as tb
-from pythtb_amd import _lib
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
 
-sys.path.insert(0, "tests")
+import pythtb_amd as tb  # noqa: E402
+from pythtb_amd import _lib  # noqa: E402
+
 import helpers as hp  # noqa: E402  (model builders written against the public API)
 
 lib = _lib.lib

@@ -1041,7 +1041,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     }
     {
         ProfScope ps(ctx, "chain_final");
-        if (A.nseg > 4 && A.nstrings < (int64_t)0x7fffffff) {   // long strings: a wavefront per string
+        if (A.nseg >= 16 && A.nstrings < (int64_t)0x7fffffff) {   // long strings: a wavefront per string
             const int nn = ev ? nocc * nocc : 1;
             int P = 64;
             while (P > 1 && (P / 2 >= A.nseg || (size_t)P * nn * sizeof(cd) > 64 * 1024)) P /= 2;

@@ -632,6 +632,10 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
     const int lane = threadIdx.x;
     const int m = (n + 1) & ~1;  // players in the round-robin (bye if n odd)
     const int half = m >> 1;
+    // fixed lane -> (fast index c0, slow start i0) map for the n x (n or n/2) element
+    // walks of the sweeps: no divisions inside the rounds
+    const int c0 = lane % n, i0 = lane / n, istep = 64 / n > 0 ? 64 / n : 1;
+    const bool walker = lane < n * istep;
     WaveLds S;
     S.A = (cd*)lds_raw;
     S.Vt = S.A + n * ld;
@@ -702,11 +706,11 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
         bool converged = false;
         for (int sweep = 0; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
             double off = 0.0, dia = 0.0;
-            for (int e = lane; e < n * n; e += 64) {
-                const int a = e / n, b = e - a * n;
-                const double v2 = cabs2(S.A[a * ld + b]);
-                if (a == b) dia += v2; else off += v2;
-            }
+            if (walker)
+                for (int a = i0; a < n; a += istep) {
+                    const double v2 = cabs2(S.A[a * ld + c0]);
+                    if (a == c0) dia += v2; else off += v2;
+                }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 off += __shfl_xor(off, o);
@@ -754,8 +758,8 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
                 }
                 __syncthreads();
                 // columns: A <- A J   (rows r fastest across lanes)
-                for (int e = lane; e < half * n; e += 64) {
-                    const int i = e / n, r = e - i * n;
+                for (int i = walker ? i0 : half; i < half; i += istep) {
+                    const int r = c0;
                     const int code = S.pq[i];
                     if (code < 0) continue;
                     const int p = code & 0xffff, q = code >> 16;
@@ -767,8 +771,8 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
                 }
                 __syncthreads();
                 // rows: A <- J^+ A, and V^T rows p,q (V <- V J)
-                for (int e = lane; e < half * n; e += 64) {
-                    const int i = e / n, cidx = e - i * n;
+                for (int i = walker ? i0 : half; i < half; i += istep) {
+                    const int cidx = c0;
                     const int code = S.pq[i];
                     if (code < 0) continue;
                     const int p = code & 0xffff, q = code >> 16;
