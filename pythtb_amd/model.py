@@ -286,6 +286,8 @@ class tb_model(object):
     # ------------------------------------------------------------------ solve
     def _k_array(self, k_list):
         k = np.array(k_list, dtype=float)
+        if k.size == 0:                               # empty list: the reference's loop runs zero times
+            return np.zeros((0, self._dim_k), dtype=float)
         if self._dim_k == 1 and k.ndim == 1:
             k = k.reshape(-1, 1)
         if k.ndim != 2 or k.shape[1] != self._dim_k:

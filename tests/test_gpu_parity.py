@@ -515,3 +515,90 @@ def test_config_D_kane_mele_wilson_loop(tb):
         g = load_golden("full_size")
         assert np.max(np.abs(gaps - g["D_min_gaps"])) < 1e-11
         assert_phase_sets_close(wc, g["D_wan_cent"], 1e-8)
+
+
+# ------------------------------------------------------------------ edge cases and plumbing
+def test_edge_cases(tb):
+    m = hp.haldane(tb.tb_model, 0.1)
+    ev = m.solve_all([])                                       # empty list
+    assert ev.shape == (2, 0)
+    ev, vec = m.solve_all(np.zeros((0, 2)), eig_vectors=True)
+    assert ev.shape == (2, 0) and vec.shape == (2, 0, 2)
+    one = m.solve_all([[0.25, 0.75]])                          # single k, ragged python list of lists
+    assert one.shape == (2, 1)
+    big = m.solve_all(np.tile([[0.25, 0.75]], (1000, 1)))      # identical k -> identical columns
+    assert np.all(big == one)
+    # smallest legal meshes, 1-state models (solve_on_grid returns None: no gaps)
+    w = tb.wf_array(m, [2, 2])
+    w.solve_on_grid([0.0, 0.0])
+    assert w.berry_flux([0], individual_phases=True).shape == (1, 1)
+    s = hp.quiet(tb.tb_model, 1, 1, [[1.0]], [[0.3]])
+    s.set_onsite([0.7])
+    s.set_hop(0.5 + 0.2j, 0, 0, [1])
+    ws = tb.wf_array(s, [17])
+    assert ws.solve_on_grid([0.0]) is None
+    assert abs(abs(ws[3][0, 0]) - 1.0) < 1e-14
+    ph = ws.berry_phase([0])
+    assert abs(((ph - 2 * np.pi * 0.3 + np.pi) % (2 * np.pi)) - np.pi) < 1e-12    # single band: 2 pi tau
+    ev = s.solve_all([0.0, 0.25, 0.5])
+    assert np.allclose(ev[0], 0.7 + 2 * np.real((0.5 + 0.2j) * np.exp(2j * np.pi * np.array([0.0, 0.25, 0.5]))), atol=1e-14)
+    # long-range hoppings (|R| up to 5) take the dynamic-pmax kernels
+    lr = hp.random_model(tb.tb_model, 2, 2, 1, 21, nhop=12, rmax=5)
+    from oracle import tb_oracle as orc
+    wl = tb.wf_array(lr, [19, 23])
+    gaps = wl.solve_on_grid([0.1, -0.3])
+    owfs, ogaps = orc.solve_on_grid(lr, [19, 23], [0.1, -0.3], vectorised=True)
+    assert np.max(np.abs(gaps - ogaps)) < 1e-11
+    ref = orc.berry_flux(owfs, 2, [0], individual_phases=True, vectorised=True)
+    assert np.max(np.abs(wrap(wl.berry_flux([0], individual_phases=True) - ref))) < TOL_P
+    # non-contiguous, repeated-order occupation lists; transposed planes negate the flux
+    w4 = tb.wf_array(hp.kane_mele(tb.tb_model, "even"), [12, 9])
+    w4.solve_on_grid([0.05, 0.07])
+    a = w4.berry_flux([3, 0], individual_phases=True)
+    b = w4.berry_flux([0, 3], individual_phases=True)
+    assert np.max(np.abs(a - b)) < 1e-12
+    assert np.max(np.abs(w4.berry_flux([0, 1], dirs=[1, 0], individual_phases=True)
+                         + w4.berry_flux([0, 1], dirs=[0, 1], individual_phases=True).T)) < 1e-12
+
+
+def test_large_nocc_and_unsupported_sizes(tb):
+    from pythtb_amd import _lib
+    m = hp.random_model(tb.tb_model, 20, 2, 1, 33)
+    w = tb.wf_array(m, [6, 5])
+    w.solve_on_grid([0.0, 0.0])
+    from oracle import tb_oracle as orc
+    owfs, _ = orc.solve_on_grid(m, [6, 5], [0.0, 0.0], vectorised=True)
+    occ = list(range(12))
+    assert np.max(np.abs(wrap(w.berry_flux(occ, individual_phases=True)
+                              - orc.berry_flux(owfs, 2, occ, individual_phases=True, vectorised=True)))) < TOL_P
+    got = w.berry_phase(occ, 0, contin=False, berry_evals=True)
+    assert_phase_sets_close(got, orc.berry_phase(owfs, 2, occ, 0, contin=False, berry_evals=True), 1e-9)
+    with pytest.raises(_lib.TbkError, match="limit"):
+        w.berry_flux(list(range(17)))                         # nocc > TBK_MAX_NOCC fails loudly
+    big = hp.quiet(tb.tb_model, 1, 1, [[1.0]], 70)
+    with pytest.raises(_lib.TbkError, match="limit"):
+        big.solve_all([0.1])                                   # nsta > TBK_MAX_NSTA fails loudly
+
+
+def test_rccl_single_rank_allgather(tb):
+    """tbk_comm_* with a 1-rank communicator (the N>1 path's collective, as far as one GPU goes)."""
+    import ctypes as C
+    from pythtb_amd import _lib
+    lib, ctx = _lib.lib, _lib.default_context()
+    uid = (C.c_ubyte * 128)()
+    _lib.check(lib.tbk_comm_unique_id(uid))
+    _lib.check(lib.tbk_comm_init(ctx.handle, uid, 1, 0))
+    try:
+        src = np.array([1.5, -2.0, 3.25])
+        send, recv = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, 24, C.byref(send)))
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, 24, C.byref(recv)))
+        _lib.check(lib.tbk_dev_upload(ctx.handle, send, src.ctypes.data_as(C.c_void_p), 24))
+        _lib.check(lib.tbk_comm_allgather_f64(ctx.handle, send, recv, 3))
+        out = np.zeros(3)
+        _lib.check(lib.tbk_dev_download(ctx.handle, out.ctypes.data_as(C.c_void_p), recv, 24))
+        assert np.array_equal(out, src)
+        _lib.check(lib.tbk_dev_free(ctx.handle, send))
+        _lib.check(lib.tbk_dev_free(ctx.handle, recv))
+    finally:
+        _lib.check(lib.tbk_comm_destroy(ctx.handle))
