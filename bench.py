@@ -156,26 +156,54 @@ def main():
     gather = "none"
     allv = np.array([[tot[0], gaps[0], elapsed]])
     if world > 1:
+        import torch
         mine = np.array([tot[0], gaps[0], elapsed])
-        try:                                        # the one collective: RCCL all-gather over xGMI
-            uid = (C.c_ubyte * 128)()
-            if rank == 0:
+
+        def all_ok(ok):
+            """Every rank takes the same branch: true only if the step succeeded everywhere."""
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        # the one collective of the path: RCCL all-gather over xGMI (tbk_comm_*).  Each stage is
+        # agreed on by all ranks, so a failure anywhere sends everybody to the gloo gather together.
+        err = ""
+        uid_bytes = None
+        if rank == 0:
+            try:
+                uid = (C.c_ubyte * 128)()
                 _lib.check(lib.tbk_comm_unique_id(uid))
-            box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0)
-            uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
-            _lib.check(lib.tbk_comm_init(ctx.handle, uid, world, rank))
-            send, recv = C.c_void_p(), C.c_void_p()
-            _lib.check(lib.tbk_dev_alloc(ctx.handle, 24, C.byref(send)))
-            _lib.check(lib.tbk_dev_alloc(ctx.handle, 24 * world, C.byref(recv)))
-            _lib.check(lib.tbk_dev_upload(ctx.handle, send, mine.ctypes.data_as(C.c_void_p), 24))
-            _lib.check(lib.tbk_comm_allgather_f64(ctx.handle, send, recv, 3))
-            allv = np.zeros((world, 3))
-            _lib.check(lib.tbk_dev_download(ctx.handle, allv.ctypes.data_as(C.c_void_p), recv, 24 * world))
-            gather = "rccl_allgather"
-        except Exception as e:                      # keep the measurement; say what happened
-            import torch
-            sys.stderr.write("[bench] RCCL gather failed on rank %d (%s); using the gloo gather\n" % (rank, e))
+                uid_bytes = bytes(uid)
+            except Exception as e:
+                err = "unique_id: %s" % e
+        box = [uid_bytes]
+        dist.broadcast_object_list(box, src=0)
+        ok = box[0] is not None
+        if ok:
+            try:
+                uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+                _lib.check(lib.tbk_comm_init(ctx.handle, uid, world, rank))
+            except Exception as e:
+                ok, err = False, "init: %s" % e
+        ok = all_ok(ok)
+        if ok:
+            try:
+                send, recv = C.c_void_p(), C.c_void_p()
+                _lib.check(lib.tbk_dev_alloc(ctx.handle, 24, C.byref(send)))
+                _lib.check(lib.tbk_dev_alloc(ctx.handle, 24 * world, C.byref(recv)))
+                _lib.check(lib.tbk_dev_upload(ctx.handle, send, mine.ctypes.data_as(C.c_void_p), 24))
+                _lib.check(lib.tbk_comm_allgather_f64(ctx.handle, send, recv, 3))
+                got = np.zeros((world, 3))
+                _lib.check(lib.tbk_dev_download(ctx.handle, got.ctypes.data_as(C.c_void_p), recv, 24 * world))
+            except Exception as e:
+                ok, err = False, "allgather: %s" % e
+            ok = all_ok(ok)
+        if ok:
+            allv, gather = got, "rccl_allgather"
+        else:                                       # keep the measurement; say what happened
+            if err:
+                sys.stderr.write("[bench] rank %d: RCCL gather unavailable (%s); using the gloo gather\n"
+                                 % (rank, " ".join(str(err).split())))
             buf = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
             dist.all_gather(buf, torch.from_numpy(mine))
             allv = np.stack([b.numpy() for b in buf])

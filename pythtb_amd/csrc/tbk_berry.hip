@@ -669,6 +669,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         const int64_t want = (int64_t)ctx->cus * 32;
         int64_t ti = ((int64_t)A.na * A.ncolw * nslices + want - 1) / want;
         A.ti = (int)std::max<int64_t>(4, std::min<int64_t>(64, ti));
+        if (const char* tk = getenv("TBK_FLUX_TI")) A.ti = std::max(1, atoi(tk));   // tuning knob
         A.bps = ((A.na + A.ti - 1) / A.ti) * A.ncolw;
     } else {
         A.bps = (int)((per + 255) / 256);

@@ -1139,7 +1139,9 @@ extern "C" int tbk_wfs_solve_grid_async(tbk_wfs* w, tbk_model* m, const double* 
         const int64_t nrows = v.npts / v.mesh[D - 1];
         const int64_t want = (int64_t)ctx->cus * 32;     // wave tiles that fill the chip
         G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, G.cpr), G.nchunks / want));
+        if (const char* sg = getenv("TBK_GRID_SEG")) G.seg = std::max(1, std::min(atoi(sg), G.cpr));   // tuning knob
         G.tpr = (G.cpr + G.seg - 1) / G.seg;
+        G.seg = (G.cpr + G.tpr - 1) / G.tpr;             // balance the tiles of a row (33 chunks -> 7,7,7,7,5)
         G.ntiles = nrows * G.tpr;
         const size_t lds = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
         const char* old = getenv("TBK_GRID_KERNEL");
