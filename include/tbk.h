@@ -126,6 +126,12 @@ int tbk_wfs_solve_grid(tbk_wfs* wfs, tbk_model* model, const double* start_k,
 int tbk_wfs_solve_grid_async(tbk_wfs* wfs, tbk_model* model, const double* start_k,
                              const double* pbc_phase, int64_t row0, int64_t global_n0);
 int tbk_wfs_solve_grid_result(tbk_wfs* wfs, double* min_gaps);
+/* General sharding window: the handle holds the points [offset[d], offset[d]+mesh[d]) of a
+ * global mesh of global_mesh[d] points along every axis d (k-sharding of Berry strings
+ * cuts an axis other than 0).  Results through tbk_wfs_solve_grid_result.              */
+int tbk_wfs_solve_window_async(tbk_wfs* wfs, tbk_model* model, const double* start_k,
+                               const double* pbc_phase, const int64_t* offset,
+                               const int64_t* global_mesh);
 /* impose_pbc (:2674-2749) / impose_loop (:2751-2791) on a filled array:
  * last slice along mesh_dir = first slice * phase[comp] (phase NULL: copy) */
 int tbk_wfs_impose(tbk_wfs* wfs, int mesh_dir, const double* phase_c128);

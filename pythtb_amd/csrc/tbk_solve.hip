@@ -27,7 +27,7 @@ struct GridArgs {
     WfsView wv;
     double start_k[TBK_MAX_DIM];
     int gmesh[TBK_MAX_DIM];  // global mesh sizes (axis 0 may exceed the slab)
-    int64_t row0;            // first global row of the slab (axis 0)
+    int64_t off[TBK_MAX_DIM];  // global index of the window's first point along each axis
     const cd* pbc;           // [TBK_MAX_DIM][TBK_MAX_NSTA]
     unsigned long long* gaps;       // [TBK_GAP_SHARDS][TBK_MAX_NSTA] min-reduced by this launch
     unsigned long long* gaps_next;  // the other parity: re-armed (+inf) for the next launch
@@ -121,7 +121,7 @@ __device__ __forceinline__ void grid_point(const GridArgs& G, int64_t id, double
         kk[d] = 0.0;
         wrap[d] = false;
         if (d < G.wv.dim_arr) {
-            int64_t g = ii[d] + (d == 0 ? G.row0 : 0);
+            int64_t g = ii[d] + G.off[d];
             const int nd = G.gmesh[d];
             if (g == nd - 1) {
                 g = 0;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_grid_tables(const ModelView mv, const G
         foff += (int64_t)G.wv.mesh[d] * mv.nsta;
     }
     if (d >= G.wv.dim_arr) return;
-    int64_t g = t + (d == 0 ? G.row0 : 0);
+    int64_t g = t + G.off[d];
     const int nd = G.gmesh[d];
     const bool wrap = g == nd - 1;       // periodic image of index 0 (impose_pbc, pythtb.py:2729-2747)
     if (wrap) g = 0;
@@ -1054,7 +1054,17 @@ extern "C" int tbk_gen_ham(tbk_model* m, const double* k, int64_t nk, double* ha
 // ---------------------------------------------------------------------------
 extern "C" int tbk_wfs_solve_grid_async(tbk_wfs* w, tbk_model* m, const double* start_k,
                                         const double* pbc_phase, int64_t row0, int64_t global_n0) {
-    TBK_REQUIRE(w && m && start_k && pbc_phase, TBK_EINVAL, "tbk_wfs_solve_grid: null argument");
+    TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_solve_grid: null argument");
+    int64_t off[TBK_MAX_DIM] = {row0, 0, 0, 0}, gm[TBK_MAX_DIM];
+    for (int d = 0; d < TBK_MAX_DIM; ++d) gm[d] = w->view.mesh[d];
+    gm[0] = global_n0;
+    return tbk_wfs_solve_window_async(w, m, start_k, pbc_phase, off, gm);
+}
+
+extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double* start_k,
+                                          const double* pbc_phase, const int64_t* offset,
+                                          const int64_t* global_mesh) {
+    TBK_REQUIRE(w && m && start_k && pbc_phase && offset && global_mesh, TBK_EINVAL, "tbk_wfs_solve_grid: null argument");
     TBK_REQUIRE(w->ctx == m->ctx, TBK_EINVAL, "tbk_wfs_solve_grid: model and wfs live on different contexts");
     const WfsView& v = w->view;
     // pythtb.py:2448-2459
@@ -1062,9 +1072,11 @@ extern "C" int tbk_wfs_solve_grid_async(tbk_wfs* w, tbk_model* m, const double* 
                 "tbk_wfs_solve_grid: dimension of wf_array (%d) must equal dim_k (%d)", v.dim_arr, m->dim_k);
     TBK_REQUIRE(v.nsta == m->nsta && v.ncomp == m->nsta, TBK_EINVAL,
                 "tbk_wfs_solve_grid: array holds %d states of %d components, model has %d", v.nsta, v.ncomp, m->nsta);
-    TBK_REQUIRE(global_n0 >= v.mesh[0] && row0 >= 0 && row0 + v.mesh[0] <= global_n0, TBK_EINVAL,
-                "tbk_wfs_solve_grid: slab rows [%lld,%lld) outside global axis of %lld", (long long)row0,
-                (long long)(row0 + v.mesh[0]), (long long)global_n0);
+    for (int d = 0; d < v.dim_arr; ++d)
+        TBK_REQUIRE(global_mesh[d] >= v.mesh[d] && global_mesh[d] < (int64_t)0x7fffffff && offset[d] >= 0 &&
+                        offset[d] + v.mesh[d] <= global_mesh[d],
+                    TBK_EINVAL, "tbk_wfs_solve_grid: window [%lld,%lld) outside global axis %d of %lld",
+                    (long long)offset[d], (long long)(offset[d] + v.mesh[d]), d, (long long)global_mesh[d]);
     tbk_ctx* ctx = w->ctx;
     TBK_HIP(hipSetDevice(ctx->device));
     const int n = m->nsta;
@@ -1073,17 +1085,18 @@ extern "C" int tbk_wfs_solve_grid_async(tbk_wfs* w, tbk_model* m, const double* 
     G.wv = v;
     for (int d = 0; d < TBK_MAX_DIM; ++d) {
         G.start_k[d] = d < D ? start_k[d] : 0.0;
-        G.gmesh[d] = v.mesh[d];
+        G.gmesh[d] = d < D ? (int)global_mesh[d] : 1;
+        G.off[d] = d < D ? offset[d] : 0;
     }
-    G.gmesh[0] = (int)global_n0;
-    G.row0 = row0;
     G.pbc = w->pbc_dev;
     // everything the per-axis tables depend on; rebuild them only when it changes
     std::vector<double> key;
     key.push_back((double)(uintptr_t)m->blob);
-    key.push_back((double)row0);
-    key.push_back((double)global_n0);
-    for (int d = 0; d < D; ++d) key.push_back(start_k[d]);
+    for (int d = 0; d < D; ++d) {
+        key.push_back(start_k[d]);
+        key.push_back((double)offset[d]);
+        key.push_back((double)global_mesh[d]);
+    }
     key.insert(key.end(), pbc_phase, pbc_phase + (size_t)D * n * 2);
     int64_t ntab = 0;
     for (int d = 0; d < D; ++d) ntab += v.mesh[d];

@@ -200,6 +200,34 @@ class wf_array(object):
             return None
         return gaps[:n - 1]
 
+    def solve_on_grid_window(self, start_k, offset, global_mesh):
+        """Extension for k-sharded runs (not in the reference): this array holds the points
+        [offset[d], offset[d]+mesh[d]) of a global solve_on_grid mesh of global_mesh[d] points per
+        axis; every point is computed locally (periodic images and halo rows are recomputed, so
+        no rank talks to another).  Returns the minimal gaps over this window."""
+        m = self._model
+        if self._dim_arr != m._dim_k or self._nsta_arr != m._nsta:
+            raise Exception("\n\nsolve_on_grid_window needs a full-band wf_array with dim_arr == dim_k")
+        start = np.ascontiguousarray(np.array(start_k, dtype=float).reshape(-1))
+        off = np.ascontiguousarray(offset, dtype=np.int64)
+        gm = np.ascontiguousarray(global_mesh, dtype=np.int64)
+        if start.shape != (self._dim_arr,) or off.shape != (self._dim_arr,) or gm.shape != (self._dim_arr,):
+            raise Exception("\n\nk-vector of wrong shape!")
+        n = m._nsta
+        pbc = np.zeros((self._dim_arr, n), dtype=complex)
+        for d in range(self._dim_arr):
+            pbc[d] = np.repeat(np.exp(-2.j * np.pi * self._orb[:, m._per[d]]), self._nspin)
+        h = self._dev_handle(self._shape())
+        i64p = C.POINTER(C.c_int64)
+        _lib.check(_lib.lib.tbk_wfs_solve_window_async(h, m._device_model(), _lib.dptr(start), _lib.dptr(pbc.view(float)),
+                                                      off.ctypes.data_as(i64p), gm.ctypes.data_as(i64p)))
+        gaps = np.zeros(max(n - 1, 1), dtype=float)
+        _lib.check(_lib.lib.tbk_wfs_solve_grid_result(h, _lib.dptr(gaps)))
+        self._start_k = start_k
+        self._dev_valid = True
+        self._host_valid = False
+        return None if n <= 1 else gaps[:n - 1]
+
     def solve_on_one_point(self, kpt, mesh_indices):
         """Solve at one k and store at mesh_indices (pythtb.py:2534-2566)."""
         (eval, evec) = self._model.solve_one(kpt, eig_vectors=True)

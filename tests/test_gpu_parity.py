@@ -602,3 +602,44 @@ def test_rccl_single_rank_allgather(tb):
         _lib.check(lib.tbk_dev_free(ctx.handle, recv))
     finally:
         _lib.check(lib.tbk_comm_destroy(ctx.handle))
+
+
+def test_sharded_windows_equal_unsharded(tb):
+    """SURVEY 8e on one GPU: run every rank's window in turn (flux: slabs along axis 0 with a halo
+    row; Berry strings along dir 0: windows along axis 1) and compare with the unsharded arrays."""
+    from pythtb_amd import shard
+    m = hp.kane_mele(tb.tb_model, "odd")
+    mesh, start = [49, 37], [-0.5, -0.5]
+    full = tb.wf_array(m, mesh)
+    gaps = full.solve_on_grid(start)
+    ref_flux = full.berry_flux([0, 1], individual_phases=True)
+    ref_wl = full.berry_phase([0, 1], 0, contin=False, berry_evals=True)
+    ref_bp = full.berry_phase([2, 3], 0, contin=False)
+    host = full._wfs.copy()
+    for world in (2, 3, 8):
+        parts, gmins = [], []
+        for r in range(world):                               # flux: slabs of plaquette rows
+            row0, nrows = shard.split_rows(mesh[0], world, r)
+            w = tb.wf_array(m, [nrows, mesh[1]])
+            gmins.append(w.solve_on_grid_window(start, [row0, 0], mesh))
+            assert np.array_equal(w._wfs, host[row0:row0 + nrows])          # bit-identical, halo row included
+            p = w.berry_flux([0, 1], individual_phases=True)
+            assert np.array_equal(p, ref_flux[row0:row0 + nrows - 1])
+            parts.append(w.berry_flux([0, 1]))
+        assert abs(sum(parts) - ref_flux.sum()) < 1e-11
+        assert np.max(np.abs(np.min(gmins, axis=0) - gaps)) == 0.0
+        wl, bp = [], []
+        for r in range(world):                               # strings along dir 0: cut axis 1
+            axis, b, e = shard.split_strings(mesh, 0, world, r)
+            assert axis == 1
+            if e - b < 2:                                    # a wf_array axis needs >= 2 points: widen by one
+                b = max(0, min(b, mesh[1] - 2))
+                e2 = b + 2
+            else:
+                e2 = e
+            w = tb.wf_array(m, [mesh[0], e2 - b])
+            w.solve_on_grid_window(start, [0, b], mesh)
+            wl.append(w.berry_phase([0, 1], 0, contin=False, berry_evals=True)[:e - b])
+            bp.append(w.berry_phase([2, 3], 0, contin=False)[:e - b])
+        assert np.array_equal(np.concatenate(wl), ref_wl)
+        assert np.array_equal(np.concatenate(bp), ref_bp)
