@@ -66,6 +66,8 @@ int tbk_timer_end(tbk_ctx* ctx, double* elapsed_ms);
  * record costs about 3 us of stream time, so timed loops sample)                     */
 int tbk_prof_enable(tbk_ctx* ctx, int period);
 int tbk_prof_reset(tbk_ctx* ctx);
+/* median duration of an EMPTY bracket (two event records, nothing between them)        */
+int tbk_prof_calibrate(tbk_ctx* ctx, int reps, double* median_ms);
 int tbk_prof_count(tbk_ctx* ctx, int* n_kernels);
 int tbk_prof_get(tbk_ctx* ctx, int index, char* name, int name_cap, int64_t* launches,
                  double* total_ms);

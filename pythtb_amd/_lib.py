@@ -47,6 +47,7 @@ SIGNATURES = {
     "tbk_timer_end": (_i, [_p, _dp]),
     "tbk_prof_enable": (_i, [_p, _i]),
     "tbk_prof_reset": (_i, [_p]),
+    "tbk_prof_calibrate": (_i, [_p, _i, _dp]),
     "tbk_prof_count": (_i, [_p, C.POINTER(C.c_int)]),
     "tbk_prof_get": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(C.c_int64), _dp]),
     "tbk_model_upload": (_i, [_p, _i, _i, _i, _dp, _dp, _i64, _ip, _ip, _ip, _dp, _pp]),
@@ -149,6 +150,12 @@ class Context(object):
     def prof_enable(self, period=1):
         """0/False: off; 1/True: HIP-event bracket around every kernel launch; N: every N-th."""
         check(lib.tbk_prof_enable(self.handle, int(period)))
+
+    def prof_calibrate(self, reps=50):
+        """Median duration (ms) of an empty HIP-event bracket on this stream."""
+        ms = C.c_double(0.0)
+        check(lib.tbk_prof_calibrate(self.handle, int(reps), C.byref(ms)))
+        return ms.value
 
     def prof_reset(self):
         check(lib.tbk_prof_reset(self.handle))

@@ -216,6 +216,28 @@ extern "C" int tbk_prof_enable(tbk_ctx* c, int on) {
     c->prof_tick = 0;
     return TBK_OK;
 }
+// cost of an empty bracket (two event records back to back, nothing between): what every
+// bracketed duration contains on top of the kernel itself
+extern "C" int tbk_prof_calibrate(tbk_ctx* c, int reps, double* median_ms) {
+    TBK_REQUIRE(c && median_ms && reps > 0, TBK_EINVAL, "tbk_prof_calibrate: bad argument");
+    std::vector<float> v;
+    hipEvent_t a, b;
+    TBK_HIP(hipEventCreate(&a));
+    TBK_HIP(hipEventCreate(&b));
+    for (int i = 0; i < reps; ++i) {
+        TBK_HIP(hipEventRecord(a, c->stream));
+        TBK_HIP(hipEventRecord(b, c->stream));
+        TBK_HIP(hipEventSynchronize(b));
+        float f = 0.f;
+        TBK_HIP(hipEventElapsedTime(&f, a, b));
+        v.push_back(f);
+    }
+    TBK_HIP(hipEventDestroy(a));
+    TBK_HIP(hipEventDestroy(b));
+    std::sort(v.begin(), v.end());
+    *median_ms = v[v.size() / 2];
+    return TBK_OK;
+}
 extern "C" int tbk_prof_reset(tbk_ctx* c) {
     TBK_REQUIRE(c, TBK_EINVAL, "tbk_prof_reset: null ctx");
     int rc = prof_collect(c);
