@@ -615,7 +615,8 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
 struct WaveLds {
     cd* A;      // [n][ld]
     cd* Vt;     // [n][ld]  Vt[b][o] = component o of eigenvector b
-    cd* rot;    // [n/2+1]  (c, -) and sw packed: rot[2i] = {c, 0}, rot[2i+1] = sw
+    cd* T;      // [n][ld]  scratch of the warm-start similarity transform
+    cd* rot;   // [n/2+1]  (c, -) and sw packed: rot[2i] = {c, 0}, rot[2i+1] = sw
     int* pq;    // [n/2+1]  p | q<<16 (p<q), -1 for the bye
     double* ev; // [n]
     int* perm;  // [n]  perm[rank] = column
@@ -625,7 +626,7 @@ struct WaveLds {
 template <int MODE, bool VEC>
 __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int64_t nk,
                                                    const ListArgs L, const GridArgs G,
-                                                   int* noconv_flag) {
+                                                   int* noconv_flag, const int run) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int n = mv.nsta;
     const int ld = n + 1;
@@ -639,13 +640,22 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
     WaveLds S;
     S.A = (cd*)lds_raw;
     S.Vt = S.A + n * ld;
-    S.rot = S.Vt + n * ld;
+    S.T = S.Vt + n * ld;                 // present only when runs are longer than one point
+    S.rot = run > 1 ? S.T + n * ld : S.T;
     S.eo = S.rot + 2 * half;
     S.ev = (double*)(S.eo + n);
     S.pq = (int*)(S.ev + n);
     S.perm = S.pq + half;
 
-    for (int64_t id = blockIdx.x; id < nk; id += gridDim.x) {
+    // A wavefront walks a contiguous run of points.  After the first one, Jacobi is WARM
+    // STARTED: the new matrix is first rotated into the previous point's eigenbasis
+    // (A <- V^+ A V, two n^3 products through LDS), where it is already nearly diagonal for
+    // neighbouring k -- 2-3 sweeps instead of 7-9.  V keeps accumulating the rotations; runs
+    // are short (<= 64 points) so its orthonormality drift stays at the 1e-15 level.
+    const int64_t id_begin = (int64_t)blockIdx.x * run;
+    const int64_t id_end = id_begin + run < nk ? id_begin + run : nk;
+    for (int64_t id = id_begin; id < id_end; ++id) {
+        const bool cold = id == id_begin;
         double kk[4] = {0.0, 0.0, 0.0, 0.0};
         bool wrap[4] = {false, false, false, false};
         if constexpr (MODE == 0) {
@@ -684,11 +694,29 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
                 }
             }
         }
+        if (cold) {
+            if (walker)
+                for (int a = i0; a < n; a += istep) S.Vt[a * ld + c0] = cd{a == c0 ? 1.0 : 0.0, 0.0};
+        } else {
+            __syncthreads();
+            // T[o][c] = sum_p A[o][p] V[p][c]       (Vt[c][p] = V[p][c])
+            if (walker)
+                for (int o = i0; o < n; o += istep) {
+                    cd acc{0.0, 0.0};
+                    for (int p = 0; p < n; ++p) cfma(acc, S.A[o * ld + p], S.Vt[c0 * ld + p]);
+                    S.T[o * ld + c0] = acc;
+                }
+            __syncthreads();
+            // A'[b][c] = sum_o conj(V[o][b]) T[o][c]
+            if (walker)
+                for (int b = i0; b < n; b += istep) {
+                    cd acc{0.0, 0.0};
+                    for (int o = 0; o < n; ++o) cfmac(acc, S.Vt[b * ld + o], S.T[o * ld + c0]);
+                    if (b == c0) acc.y = 0.0;
+                    S.A[b * ld + c0] = acc;
+                }
+        }
         if (VEC) {
-            for (int e = lane; e < n * n; e += 64) {
-                const int a = e / n, b = e - a * n;
-                S.Vt[a * ld + b] = cd{a == b ? 1.0 : 0.0, 0.0};
-            }
             if (lane < n) {
                 cd f{1.0, 0.0};
                 if constexpr (MODE != 2) f = cconj(expi2pi(kdot(kk, mv.orb[lane])));
@@ -783,7 +811,8 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
                         S.A[p * ld + cidx] = cd{c * x.x - (sw.x * y.x - sw.y * y.y), c * x.y - (sw.x * y.y + sw.y * y.x)};
                         S.A[q * ld + cidx] = cd{(sw.x * x.x + sw.y * x.y) + c * y.x, (sw.x * x.y - sw.y * x.x) + c * y.y};
                     }
-                    if (VEC) {  // v'_rp = c v_rp - conj(sw) v_rq ; v'_rq = sw v_rp + c v_rq
+                    {   // V is kept in every mode (it is the next point's starting basis):
+                        // v'_rp = c v_rp - conj(sw) v_rq ; v'_rq = sw v_rp + c v_rq
                         const cd x = S.Vt[p * ld + cidx], y = S.Vt[q * ld + cidx];
                         S.Vt[p * ld + cidx] = cd{c * x.x - (sw.x * y.x + sw.y * y.y), c * x.y - (sw.x * y.y - sw.y * y.x)};
                         S.Vt[q * ld + cidx] = cd{(sw.x * x.x - sw.y * x.y) + c * y.x, (sw.x * x.y + sw.y * x.x) + c * y.y};
@@ -842,9 +871,9 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
     }
 }
 
-static size_t wave_lds_bytes(int n) {
+static size_t wave_lds_bytes(int n, bool with_t) {
     const int ld = n + 1, half = (n + 1) / 2;
-    size_t b = (size_t)2 * n * ld * sizeof(cd);  // A, Vt
+    size_t b = (size_t)(with_t ? 3 : 2) * n * ld * sizeof(cd);  // A, Vt (, T)
     b += (size_t)2 * half * sizeof(cd);          // rot
     b += (size_t)n * sizeof(cd);                 // eo
     b += (size_t)n * sizeof(double);             // ev
@@ -910,7 +939,8 @@ static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
 template <int MODE, bool VEC>
 static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L,
                        const GridArgs& G) {
-    const size_t lds = wave_lds_bytes(n);
+    const bool with_t = wave_lds_bytes(n, true) <= 160 * 1024;   // else every point starts cold
+    const size_t lds = wave_lds_bytes(n, with_t);
     TBK_REQUIRE(lds <= 160 * 1024, TBK_EUNSUPPORTED, "nsta=%d needs %zu bytes of LDS per wavefront", n, lds);
     static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
     if (lds > 64 * 1024 && !attr_set[VEC][MODE]) {
@@ -922,8 +952,14 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // enough resident wavefronts to fill the chip; each strides over the k list
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds));
     const int64_t want = (int64_t)ctx->cus * per_cu * 2;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nk, want));
-    hipLaunchKernelGGL((k_solve_wave<MODE, VEC>), dim3(blocks), dim3(64), lds, ctx->stream, mv, nk, L, G, flag);
+    // contiguous runs of points per wavefront (warm-started Jacobi), at most 64 long
+    int64_t run = std::max<int64_t>(1, std::min<int64_t>(64, (nk + want - 1) / want));
+    if (const char* rk = getenv("TBK_WAVE_RUN")) run = std::max(1, atoi(rk));   // tuning knob (1 = always cold)
+    if (!with_t) run = 1;
+    const int64_t nblocks = (nk + run - 1) / run;
+    TBK_REQUIRE(nblocks < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many k-points for one launch");
+    const unsigned blocks = (unsigned)nblocks;
+    hipLaunchKernelGGL((k_solve_wave<MODE, VEC>), dim3(blocks), dim3(64), lds, ctx->stream, mv, nk, L, G, flag, (int)run);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
