@@ -75,7 +75,7 @@ __device__ __forceinline__ cd det_small(const cd (&M)[NOCC][NOCC]) {
         d = csub(d, cmul(M[0][1], det2(M[1][0], M[1][2], M[2][0], M[2][2])));
         d = cadd(d, cmul(M[0][2], det2(M[1][0], M[1][1], M[2][0], M[2][1])));
         return d;
-    } else {
+    } else if constexpr (NOCC == 4) {
         // 4x4 through complementary 2x2 minors of rows (0,1) and (2,3)
         auto top = [&](int i, int j) { return det2(M[0][i], M[0][j], M[1][i], M[1][j]); };
         auto bot = [&](int i, int j) { return det2(M[2][i], M[2][j], M[3][i], M[3][j]); };
@@ -86,6 +86,49 @@ __device__ __forceinline__ cd det_small(const cd (&M)[NOCC][NOCC]) {
         d = csub(d, cmul(top(1, 3), bot(0, 2)));
         d = cadd(d, cmul(top(2, 3), bot(0, 1)));
         return d;
+    } else {
+        // 5..8: LU with partial pivoting, fully unrolled so the matrix stays in registers;
+        // the data-dependent row swap is a chain of register selects
+        cd A[NOCC][NOCC];
+#pragma unroll
+        for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+            for (int b = 0; b < NOCC; ++b) A[a][b] = M[a][b];
+        cd det{1.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < NOCC; ++c) {
+            int piv = c;
+            double best = cabs2(A[c][c]);
+#pragma unroll
+            for (int r = c + 1; r < NOCC; ++r) {
+                const double v = cabs2(A[r][c]);
+                const bool g = v > best;
+                best = g ? v : best;
+                piv = g ? r : piv;
+            }
+#pragma unroll
+            for (int r = c + 1; r < NOCC; ++r) {
+                const bool sw = piv == r;
+#pragma unroll
+                for (int j = c; j < NOCC; ++j) {
+                    const cd x = A[c][j], y = A[r][j];
+                    A[c][j] = cd{sw ? y.x : x.x, sw ? y.y : x.y};
+                    A[r][j] = cd{sw ? x.x : y.x, sw ? x.y : y.y};
+                }
+            }
+            if (piv != c) det = cd{-det.x, -det.y};
+            const cd p = A[c][c];
+            det = cmul(det, p);
+            const double ip = best > 0.0 ? 1.0 / best : 0.0;     // singular overlap: det becomes 0
+            const cd pinv{p.x * ip, -p.y * ip};
+#pragma unroll
+            for (int r = c + 1; r < NOCC; ++r) {
+                const cd f = cmul(A[r][c], pinv);
+#pragma unroll
+                for (int j = c + 1; j < NOCC; ++j) A[r][j] = csub(A[r][j], cmul(f, A[c][j]));
+            }
+        }
+        return det;
     }
 }
 
@@ -744,9 +787,11 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
                 case 2: launch_flux<2, 1>(ctx, A, nslices); break;
                 case 3: launch_flux<3, 1>(ctx, A, nslices); break;
                 case 4: launch_flux<4, 1>(ctx, A, nslices); break;
-                default:
-                    if (nocc <= 8) launch_flux<0, 8>(ctx, A, nslices);
-                    else launch_flux<0, TBK_MAX_NOCC>(ctx, A, nslices);
+                case 5: launch_flux<5, 1>(ctx, A, nslices); break;
+                case 6: launch_flux<6, 1>(ctx, A, nslices); break;
+                case 7: launch_flux<7, 1>(ctx, A, nslices); break;
+                case 8: launch_flux<8, 1>(ctx, A, nslices); break;
+                default: launch_flux<0, TBK_MAX_NOCC>(ctx, A, nslices);
             }
         }
         TBK_HIP(hipGetLastError());
@@ -1027,9 +1072,11 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 case 2: hipLaunchKernelGGL((k_chain_partial<2, 1, false>), grid, blk, 0, ctx->stream, A); break;
                 case 3: hipLaunchKernelGGL((k_chain_partial<3, 1, false>), grid, blk, 0, ctx->stream, A); break;
                 case 4: hipLaunchKernelGGL((k_chain_partial<4, 1, false>), grid, blk, 0, ctx->stream, A); break;
-                default:
-                    if (nocc <= 8) hipLaunchKernelGGL((k_chain_partial<0, 8, false>), grid, blk, 0, ctx->stream, A);
-                    else hipLaunchKernelGGL((k_chain_partial<0, TBK_MAX_NOCC, false>), grid, blk, 0, ctx->stream, A);
+                case 5: hipLaunchKernelGGL((k_chain_partial<5, 1, false>), grid, blk, 0, ctx->stream, A); break;
+                case 6: hipLaunchKernelGGL((k_chain_partial<6, 1, false>), grid, blk, 0, ctx->stream, A); break;
+                case 7: hipLaunchKernelGGL((k_chain_partial<7, 1, false>), grid, blk, 0, ctx->stream, A); break;
+                case 8: hipLaunchKernelGGL((k_chain_partial<8, 1, false>), grid, blk, 0, ctx->stream, A); break;
+                default: hipLaunchKernelGGL((k_chain_partial<0, TBK_MAX_NOCC, false>), grid, blk, 0, ctx->stream, A);
             }
         } else {
             if (nocc == 1) hipLaunchKernelGGL((k_chain_partial<1, 1, true>), grid, blk, 0, ctx->stream, A);

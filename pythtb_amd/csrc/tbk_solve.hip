@@ -38,6 +38,8 @@ struct GridArgs {
     int last;                // index of the last (fastest) mesh axis
     int cpr;                 // 64-point chunks per mesh row (row = all leading axes)
     int64_t nchunks;
+    int wnchunk;             // k_solve_wave: aligned chains per mesh row that touch the window
+    int64_t wcfirst;         // ... and the global number of the first of them
     int seg;                 // chunks per wave tile (k_grid_rows)
     int tpr;                 // wave tiles per row
     int64_t ntiles;
@@ -128,6 +130,37 @@ __device__ __forceinline__ void grid_point(const GridArgs& G, int64_t id, double
                 wrap[d] = true;
             }
             // kpt = start_k + float(i)/float(N-1)      (pythtb.py:2477,2490-2491)
+            kk[d] = G.start_k[d] + (double)g / (double)(nd - 1);
+        }
+    }
+}
+
+// Same, from the local row (all leading axes, row-major) and the GLOBAL index along the
+// last axis (which may lie before the window: chain predecessors that are not stored).
+__device__ __forceinline__ void grid_point_rowcol(const GridArgs& G, int64_t row, int64_t g_last,
+                                                  double (&kk)[4], bool (&wrap)[4]) {
+    int64_t gi[4] = {0, 0, 0, 0};
+    int64_t rem = row;
+#pragma unroll
+    for (int d = 2; d >= 0; --d) {
+        if (d < G.last) {
+            const int64_t md = G.wv.mesh[d];
+            const int64_t q = rem / md;
+            gi[d] = rem - q * md + G.off[d];
+            rem = q;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        kk[d] = 0.0;
+        wrap[d] = false;
+        if (d <= G.last) {
+            int64_t g = d == G.last ? g_last : gi[d];
+            const int nd = G.gmesh[d];
+            if (g == nd - 1) {
+                g = 0;
+                wrap[d] = true;
+            }
             kk[d] = G.start_k[d] + (double)g / (double)(nd - 1);
         }
     }
@@ -647,15 +680,36 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
     S.pq = (int*)(S.ev + n);
     S.perm = S.pq + half;
 
-    // A wavefront walks a contiguous run of points.  After the first one, Jacobi is WARM
-    // STARTED: the new matrix is first rotated into the previous point's eigenbasis
+    // A wavefront walks a short chain of consecutive points.  After the first one, Jacobi is
+    // WARM STARTED: the new matrix is first rotated into the previous point's eigenbasis
     // (A <- V^+ A V, two n^3 products through LDS), where it is already nearly diagonal for
-    // neighbouring k -- 2-3 sweeps instead of 7-9.  V keeps accumulating the rotations; runs
-    // are short (<= 64 points) so its orthonormality drift stays at the 1e-15 level.
-    const int64_t id_begin = (int64_t)blockIdx.x * run;
-    const int64_t id_end = id_begin + run < nk ? id_begin + run : nk;
-    for (int64_t id = id_begin; id < id_end; ++id) {
-        const bool cold = id == id_begin;
+    // neighbouring k -- 2-3 sweeps instead of 7-9.  V keeps accumulating the rotations; chains
+    // are short so its orthonormality drift stays at the 1e-15 level.
+    //
+    // The eigenvector gauge depends on the chain, so for a mesh the chain of a point must be
+    // a function of the point alone: chains are the aligned blocks [c*run, (c+1)*run) of the
+    // GLOBAL index along the last axis, the periodic image (global index N-1) always starts
+    // cold (exactly like index 0, whose k it shares), and a window that begins inside a block
+    // recomputes the block's earlier points without storing them.  Periodic images, halo rows
+    // and shard windows therefore reproduce the unsharded array bit for bit.
+    int64_t it_begin = 0, it_end = 0, grow = 0;
+    const int nlast = MODE == 1 ? G.wv.mesh[G.last] : 1;
+    const int64_t off_last = MODE == 1 ? G.off[G.last] : 0;
+    const int gnl = MODE == 1 ? G.gmesh[G.last] : 1;
+    if constexpr (MODE == 1) {
+        grow = blockIdx.x / G.wnchunk;
+        const int64_t c = G.wcfirst + (blockIdx.x - grow * G.wnchunk);
+        it_begin = c * run;                                  // global last-axis indices
+        it_end = it_begin + run < gnl ? it_begin + run : gnl;
+        if (it_end > off_last + nlast) it_end = off_last + nlast;
+    } else {
+        it_begin = (int64_t)blockIdx.x * run;                // positions in the k list
+        it_end = it_begin + run < nk ? it_begin + run : nk;
+    }
+    for (int64_t it = it_begin; it < it_end; ++it) {
+        bool cold = it == it_begin;
+        bool store = true;
+        int64_t id = it;
         double kk[4] = {0.0, 0.0, 0.0, 0.0};
         bool wrap[4] = {false, false, false, false};
         if constexpr (MODE == 0) {
@@ -663,7 +717,10 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
             for (int d = 0; d < 4; ++d)
                 if (d < mv.dim_k) kk[d] = L.k[id * mv.dim_k + d];
         } else if constexpr (MODE == 1) {
-            grid_point(G, id, kk, wrap);
+            cold = cold || it == gnl - 1;
+            store = it >= off_last;
+            id = grow * nlast + (it - off_last);             // local row-major point (valid when store)
+            grid_point_rowcol(G, grow, it, kk, wrap);
         }
         __syncthreads();  // previous matrix fully written out before LDS is reused
         // ---- assemble S(k) (or load the supplied matrix) into A, V^T = I
@@ -848,6 +905,7 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
             S.perm[r] = lane;
         }
         __syncthreads();
+        if (!store) continue;   // a chain predecessor outside the window: only its basis was needed
         if constexpr (MODE == 1) {
             if (lane + 1 < n) {
                 const double g = S.ev[S.perm[lane + 1]] - S.ev[S.perm[lane]];
@@ -952,14 +1010,29 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // enough resident wavefronts to fill the chip; each strides over the k list
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds));
     const int64_t want = (int64_t)ctx->cus * per_cu * 2;
-    // contiguous runs of points per wavefront (warm-started Jacobi), at most 64 long
-    int64_t run = std::max<int64_t>(1, std::min<int64_t>(64, (nk + want - 1) / want));
-    if (const char* rk = getenv("TBK_WAVE_RUN")) run = std::max(1, atoi(rk));   // tuning knob (1 = always cold)
-    if (!with_t) run = 1;
-    const int64_t nblocks = (nk + run - 1) / run;
+    // chains of consecutive points per wavefront (warm-started Jacobi)
+    int64_t run, nblocks;
+    GridArgs G2 = G;
+    if (MODE == 1) {
+        // mesh: fixed chain length, aligned to the global last-axis index (see the kernel)
+        run = 16;
+        if (const char* rk = getenv("TBK_WAVE_RUN")) run = std::max(1, atoi(rk));   // tuning knob (1 = always cold)
+        if (!with_t) run = 1;
+        const int last = G.last;
+        const int64_t off = G.off[last], nl = G.wv.mesh[last];
+        G2.wcfirst = off / run;
+        G2.wnchunk = (int)((off + nl - 1) / run - G2.wcfirst + 1);
+        nblocks = (G.wv.npts / nl) * G2.wnchunk;
+    } else {
+        // k list: contiguous runs by list position, at most 64 long
+        run = std::max<int64_t>(1, std::min<int64_t>(64, (nk + want - 1) / want));
+        if (const char* rk = getenv("TBK_WAVE_RUN")) run = std::max(1, atoi(rk));
+        if (!with_t) run = 1;
+        nblocks = (nk + run - 1) / run;
+    }
     TBK_REQUIRE(nblocks < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many k-points for one launch");
     const unsigned blocks = (unsigned)nblocks;
-    hipLaunchKernelGGL((k_solve_wave<MODE, VEC>), dim3(blocks), dim3(64), lds, ctx->stream, mv, nk, L, G, flag, (int)run);
+    hipLaunchKernelGGL((k_solve_wave<MODE, VEC>), dim3(blocks), dim3(64), lds, ctx->stream, mv, nk, L, G2, flag, (int)run);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
