@@ -159,6 +159,18 @@ int tbk_berry_flux_result(tbk_wfs* wfs, double* totals, double* plaq);
 int tbk_berry_phase(tbk_wfs* wfs, const int32_t* occ, int nocc, int dir, int berry_evals,
                     double* out);
 
+/* ---- position operator / hybrid Wannier functions (first "next" row) ----
+ * tb_model.position_matrix (pythtb.py:2034-2098), position_expectation (:2100-2141) and
+ * position_hwf (:2143-2279), batched over nk points.
+ * evec[nk][nsub][ncomp] c128: the states at each point; pos[ncomp]: reduced coordinate of
+ * each component's orbital along the chosen non-periodic direction (repeated per spin).
+ * xmat (nullable)  [nk][nsub][nsub] c128      X_mn = <u_m| r |u_n>
+ * hwfc (nullable)  [nk][nsub]                 eigenvalues of X, ascending
+ * hwf  (nullable)  [nk][nsub][nsub]  rows = eigenvectors of X on the input states, or with
+ *                  orbital_basis != 0 [nk][nsub][ncomp] expanded on the orbitals (:2262-2277) */
+int tbk_position_hwf(tbk_ctx* ctx, const double* evec, int64_t nk, int nsub, int ncomp,
+                     const double* pos, double* xmat, double* hwfc, double* hwf, int orbital_basis);
+
 /* ---- multi-GPU: one process per GPU, k-points sharded, one gather ------
  * Thin RCCL wrappers (librccl is dlopen'ed on first use).  The 128-byte id is
  * created on rank 0 and distributed by the launcher (any out-of-band channel). */

@@ -498,6 +498,55 @@ def berry_flux(wfs, dim_arr, occ="All", dirs=None, individual_phases=False, vect
 
 
 # --------------------------------------------------------------------------
+# Position operator / hybrid Wannier functions
+# --------------------------------------------------------------------------
+
+def position_matrix(m, evec, dir):
+    """X_mn = <u_m| r_dir |u_n> for the states evec[band,orb(,spin)].  pythtb.py:2034-2098."""
+    if dir in m._per:
+        raise Exception("Can not compute position matrix elements along periodic direction!")
+    if dir < 0 or dir >= m._dim_r:
+        raise Exception("Direction out of range!")
+    pos = np.repeat(m._orb[:, dir], m._nspin)
+    ev = np.asarray(evec).reshape(np.asarray(evec).shape[0], -1)
+    nb = ev.shape[0]
+    out = np.zeros((nb, nb), dtype=complex)
+    for a in range(nb):
+        for b in range(nb):
+            out[a, b] = np.dot(ev[a].conj(), pos * ev[b])
+    if np.max(out - out.T.conj()) > 1.0e-9:
+        raise Exception("\n\n Position matrix is not hermitian?!")
+    return out
+
+
+def position_expectation(m, evec, dir):
+    """pythtb.py:2100-2141."""
+    return np.array(np.real(position_matrix(m, evec, dir).diagonal()), dtype=float)
+
+
+def position_hwf(m, evec, dir, hwf_evec=False, basis="orbital"):
+    """Eigen-decomposition of the position matrix.  pythtb.py:2143-2279."""
+    x = position_matrix(m, evec, dir)
+    if not hwf_evec:
+        return np.sort(np.array(np.linalg.eigvalsh(x).real, dtype=float))
+    w, v = np.linalg.eigh(x)
+    order = np.argsort(np.array(w.real, dtype=float))
+    w = np.array(w.real, dtype=float)[order]
+    rows = v.T[order]
+    which = basis.lower().strip()
+    if which in ("wavefunction", "bloch"):
+        return w, rows
+    if which != "orbital":
+        raise Exception("\n\nBasis must be either 'wavefunction', 'bloch', or 'orbital'")
+    ev = np.asarray(evec)
+    flat = ev.reshape(ev.shape[0], -1)
+    orb = rows @ flat
+    if m._nspin == 2:
+        orb = orb.reshape(rows.shape[0], m._norb, 2)
+    return w, orb
+
+
+# --------------------------------------------------------------------------
 # Synthetic model builders used by tests / bench (definitions: SURVEY.md 8d)
 # --------------------------------------------------------------------------
 

@@ -71,6 +71,7 @@ SIGNATURES = {
     "tbk_berry_flux_async": (_i, [_p, _ip, _i, _i, _i, _i]),
     "tbk_berry_flux_result": (_i, [_p, _dp, _dp]),
     "tbk_berry_phase": (_i, [_p, _ip, _i, _i, _i, _dp]),
+    "tbk_position_hwf": (_i, [_p, _dp, _i64, _i, _i, _dp, _dp, _dp, _dp, _i]),
     "tbk_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
     "tbk_comm_init": (_i, [_p, C.POINTER(C.c_ubyte), _i, _i]),
     "tbk_comm_destroy": (_i, [_p]),

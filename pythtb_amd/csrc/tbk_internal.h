@@ -170,3 +170,9 @@ struct tbk_wfs {
     double* flux_partial_dev = nullptr;
     int64_t flux_partial_cap = 0;
 };
+
+// implemented in tbk_solve.hip: batched Hermitian eigen-solve, all pointers on the device
+// (eval[n][nk], evec[n][nk][n]); tbk_eigh_check reports Jacobi non-convergence
+int tbk_eigh_dev(tbk_ctx* ctx, int n, const cd* ham_dev, int64_t nk, double* eval_dev, cd* evec_dev,
+                 const char* name);
+int tbk_eigh_check(tbk_ctx* ctx, int n);

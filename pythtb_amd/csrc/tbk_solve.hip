@@ -1127,6 +1127,19 @@ extern "C" int tbk_eigh_batch(tbk_ctx* ctx, int n, const double* ham, int64_t nk
     return check_noconv(ctx, n);
 }
 
+// device-to-device form used by other translation units (position operator path)
+int tbk_eigh_dev(tbk_ctx* ctx, int n, const cd* ham_dev, int64_t nk, double* eval_dev, cd* evec_dev,
+                 const char* name) {
+    ModelView mv{};
+    mv.nsta = n;
+    mv.nspin = 1;
+    mv.nslot = n * (n + 1) / 2;
+    ListArgs L{nullptr, ham_dev, eval_dev, evec_dev};
+    return launch_solve<2>(ctx, mv, n, nk, evec_dev != nullptr, L, name);
+}
+
+int tbk_eigh_check(tbk_ctx* ctx, int n) { return check_noconv(ctx, n); }
+
 extern "C" int tbk_gen_ham(tbk_model* m, const double* k, int64_t nk, double* ham_out) {
     TBK_REQUIRE(m && ham_out && nk >= 0, TBK_EINVAL, "tbk_gen_ham: bad argument");
     if (nk == 0) return TBK_OK;

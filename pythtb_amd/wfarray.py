@@ -302,6 +302,42 @@ class wf_array(object):
         _lib.check(_lib.lib.tbk_wfs_impose(h, int(mesh_dir), None))
         self._host_valid = False
 
+    # ------------------------------------------------------------------ position operator
+    def _occ_states(self, key, occ):
+        if isinstance(occ, str) and occ == "All":
+            occ = np.arange(self._nsta_arr, dtype=int)
+        else:
+            occ = np.array(occ, dtype=int)
+        if occ.ndim != 1:
+            raise Exception("\n\nParameter occ must be a one-dimensional array or string \"All\".")
+        return self._host_array()[tuple(key)][occ]
+
+    def position_matrix(self, key, occ, dir):
+        """tb_model.position_matrix for the states `occ` stored at mesh point `key` (pythtb.py:2793-2810)."""
+        return self._model.position_matrix(self._occ_states(key, occ), dir)
+
+    def position_expectation(self, key, occ, dir):
+        """pythtb.py:2812-2829."""
+        return self._model.position_expectation(self._occ_states(key, occ), dir)
+
+    def position_hwf(self, key, occ, dir, hwf_evec=False, basis="wavefunction"):
+        """pythtb.py:2831-2861 (note the default basis differs from tb_model.position_hwf)."""
+        return self._model.position_hwf(self._occ_states(key, occ), dir, hwf_evec, basis)
+
+    def position_hwf_mesh(self, occ, dir, hwf_evec=False, basis="wavefunction"):
+        """Extension: position_hwf for every mesh point in one batched device call.  Returns
+        hwfc[mesh..., nocc] (and hwf[mesh..., nocc, x]) -- the loop the reference's examples
+        write around position_hwf (e.g. examples/cubic_slab_hwf.py)."""
+        occ = np.arange(self._nsta_arr, dtype=int) if isinstance(occ, str) and occ == "All" else np.array(occ, dtype=int)
+        host = self._host_array()
+        mesh = tuple(int(x) for x in self._mesh_arr)
+        ev = np.take(host.reshape((-1,) + host.shape[self._dim_arr:]), occ, axis=1)
+        res = self._model.position_hwf(ev, dir, hwf_evec, basis)
+        if not hwf_evec:
+            return res.reshape(mesh + res.shape[1:])
+        hwfc, hwf = res
+        return hwfc.reshape(mesh + hwfc.shape[1:]), hwf.reshape(mesh + hwf.shape[1:])
+
     # ------------------------------------------------------------------ Berry quantities
     def _occ(self, occ):
         if (isinstance(occ, str) and occ == "All") or occ is None:

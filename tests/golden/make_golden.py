@@ -259,6 +259,80 @@ def manual_cases():
                             w.berry_flux([0, 1]), w.berry_flux([0, 1, 2])]))
 
 
+def hwf_cases():
+    """Position-operator / hybrid-Wannier path.  The finite models come from the
+    reference's cut_piece/remove_orb (out of scope for the product), so their tables are part of
+    the fixture; outputs follow tests/test_examples/slab/cubic_slab_hwf/run.py and
+    tests/test_examples/haldane/haldane_hwf/run.py and are cross-checked here against the
+    reference's own golden files."""
+    tdir = "/root/reference/tests/test_examples"
+    # --- cubic slab (17 orbitals, dim_k=2, dim_r=3)
+    lat = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
+    bulk = quiet(ref.tb_model, 3, 3, lat, [[0.0, 0.0, 0.0], [0.5, 0.5, 0.5]])
+    bulk.set_onsite([-1.0, 1.0])
+    for lvec in ([-1, 0, 0], [0, 0, -1], [-1, -1, 0], [0, -1, -1]):
+        bulk.set_hop(0.4, 0, 1, lvec)
+    for lvec in ([0, 0, 0], [0, -1, 0], [-1, -1, -1], [-1, 0, -1]):
+        bulk.set_hop(0.7, 0, 1, lvec)
+    nl = 9
+    slab = bulk.cut_piece(nl, 2, glue_edgs=False).remove_orb(2 * nl - 1)
+    k1 = np.linspace(0.0, 1.0, 10, endpoint=False)
+    kpts = np.array([[kx, ky] for kx in k1 for ky in k1])
+    evals = slab.solve_all(kpts)
+    nk = 9
+    arr = ref.wf_array(slab, [nk, nk])
+    arr.solve_on_grid([0.0, 0.0])
+    hwf_arr = arr.empty_like(nsta_arr=nl)
+    hwfc = np.zeros([nk, nk, nl])
+    pexp = np.zeros([nk, nk, nl])
+    for ix in range(nk):
+        for iy in range(nk):
+            val, vec = arr.position_hwf([ix, iy], occ=list(range(nl)), dir=2, hwf_evec=True, basis="orbital")
+            hwfc[ix, iy] = val
+            hwf_arr[ix, iy] = vec
+            pexp[ix, iy] = arr.position_expectation([ix, iy], list(range(nl)), 2)
+    hwf_arr.impose_pbc(0, 0)
+    hwf_arr.impose_pbc(1, 1)
+    px = np.array([hwf_arr.berry_phase(dir=0, occ=[n]) / (2.0 * np.pi) for n in range(nl)])
+    xm = arr.position_matrix([2, 5], [0, 3, 4], 2)
+    vw, ww = arr.position_hwf([2, 5], [0, 3, 4], 2, hwf_evec=True)           # default basis: wavefunction
+    g = os.path.join(tdir, "slab/cubic_slab_hwf/golden_outputs")
+    assert np.allclose(evals, np.load(os.path.join(g, "evals.npy")), rtol=1e-8, atol=1e-13)
+    assert np.allclose(hwfc, np.load(os.path.join(g, "hwfc.npy")), rtol=1e-8, atol=1e-13)
+    assert np.allclose(px, np.load(os.path.join(g, "px.npy")), rtol=1e-8, atol=1e-12)
+    out = tables(slab)
+    out.update(kpts=kpts, evals=evals, hwfc=hwfc, px=px, pexp=pexp, xmat_2_5=xm, hwfc_2_5=vw,
+               hwfproj_2_5=np.abs(ww) ** 2)
+    save("hwf_cubic_slab", **out)
+    # --- Haldane ribbon (20 orbitals, dim_k=1, dim_r=2)
+    hal = quiet(ref.tb_model, 2, 2, LAT, ORB)
+    t, t2 = -1.0, 0.05 - 0.15j
+    hal.set_onsite([0.2, -0.2])
+    hal.set_hop(t, 0, 1, [0, 0])
+    hal.set_hop(t, 1, 0, [1, 0])
+    hal.set_hop(t, 1, 0, [0, 1])
+    hal.set_hop(t2, 0, 0, [1, 0])
+    hal.set_hop(t2, 1, 1, [1, -1])
+    hal.set_hop(t2, 1, 1, [0, 1])
+    hal.set_hop(t2.conjugate(), 1, 1, [1, 0])
+    hal.set_hop(t2.conjugate(), 0, 0, [1, -1])
+    hal.set_hop(t2.conjugate(), 0, 0, [0, 1])
+    rib = hal.cut_piece(10, fin_dir=1, glue_edgs=False)
+    kv, _, _ = rib.k_path([0.0, 0.5, 1.0], 100, report=False)
+    rev, rvec = rib.solve_all(kv, eig_vectors=True)
+    rev = rev - 0.25
+    pos_exps = np.array([rib.position_expectation(rvec[:, i], dir=1) for i in range(rvec.shape[1])])
+    nocc = np.array([int(np.sum(rev[:, i] < 0.0)) for i in range(rev.shape[1])])
+    hw = [rib.position_hwf(rvec[rev[:, i] < 0.0, i], 1) for i in range(rvec.shape[1])]
+    g = os.path.join(tdir, "haldane/haldane_hwf/golden_outputs")
+    gold = np.load(os.path.join(g, "hwfcs.npy"), allow_pickle=True)
+    assert all(np.allclose(a, b, rtol=1e-8, atol=1e-12) for a, b in zip(hw, gold))
+    assert np.allclose(rev, np.load(os.path.join(g, "rib_eval.npy"), allow_pickle=True).astype(float), rtol=1e-8, atol=1e-12)
+    out = tables(rib)
+    out.update(k_vec=kv, rib_eval=rev, pos_exps=pos_exps, nocc=nocc, hwfcs_flat=np.concatenate(hw))
+    save("hwf_haldane_ribbon", **out)
+
+
 def full_size():
     out = {}
     t0 = time.time()
@@ -288,6 +362,9 @@ def full_size():
 if __name__ == "__main__":
     if "--full" in sys.argv:
         full_size()
+        sys.exit(0)
+    if "--hwf" in sys.argv:
+        hwf_cases()
         sys.exit(0)
     pointwise("graphene", graphene())
     pointwise("haldane0", haldane(0.0))

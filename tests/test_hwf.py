@@ -1,0 +1,146 @@
+"""Position-operator / hybrid-Wannier path (the first "next" row of SURVEY.md 8f): the oracle
+against the fixtures on CPU, the HIP path against the same fixtures on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_tables, load_golden
+import helpers as hp
+from oracle import tb_oracle as orc
+
+
+def wrap(d):
+    return (np.asarray(d) + np.pi) % (2 * np.pi) - np.pi
+
+
+def slab_check(model, solve_all, wf_factory, px_tol):
+    """Runs tests/test_examples/slab/cubic_slab_hwf/run.py through the given implementation."""
+    g = load_golden("hwf_cubic_slab")
+    ref_dir = os.path.join(GOLDEN, "reference_tests", "cubic_slab_hwf")
+    evals = solve_all(model, g["kpts"])
+    assert np.max(np.abs(evals - g["evals"])) < 1e-11
+    np.testing.assert_allclose(evals, np.load(os.path.join(ref_dir, "evals.npy")), rtol=1e-8, atol=1e-11)
+    hwfc, px, pexp, extra = wf_factory(model)
+    assert np.max(np.abs(hwfc - g["hwfc"])) < 1e-10
+    np.testing.assert_allclose(hwfc, np.load(os.path.join(ref_dir, "hwfc.npy")), rtol=1e-8, atol=1e-10)
+    # per-band expectations depend on the basis inside degenerate groups (the slab has symmetry-
+    # degenerate bands on this mesh); their sum over the occupied group = tr X is invariant
+    assert np.max(np.abs(pexp.sum(axis=-1) - g["pexp"].sum(axis=-1))) < 1e-10
+    assert np.max(np.abs(pexp.sum(axis=-1) - hwfc.sum(axis=-1))) < 1e-10
+    assert np.max(np.abs(wrap(2 * np.pi * (px - g["px"])))) < px_tol
+    xm, c25, proj = extra
+    assert np.max(np.abs(c25 - g["hwfc_2_5"])) < 1e-10
+    assert np.max(np.abs(np.linalg.eigvalsh(xm) - g["hwfc_2_5"])) < 1e-10      # gauge-free view of X
+    assert np.max(np.abs(np.abs(xm) - np.abs(g["xmat_2_5"]))) < 1e-10
+    assert np.max(np.abs(proj - g["hwfproj_2_5"])) < 1e-9
+
+
+def test_oracle_hwf_cubic_slab():
+    g = load_golden("hwf_cubic_slab")
+    m = orc.Model.from_tables(golden_tables(g))
+    nl, nk = 9, 9
+
+    def wf(model):
+        wfs, _ = orc.solve_on_grid(model, [nk, nk], [0.0, 0.0])
+        hw = np.zeros((nk, nk, nl, model._norb), dtype=complex)
+        hwfc = np.zeros((nk, nk, nl))
+        pexp = np.zeros((nk, nk, nl))
+        for ix in range(nk):
+            for iy in range(nk):
+                hwfc[ix, iy], hw[ix, iy] = orc.position_hwf(model, wfs[ix, iy][:nl], 2, True, "orbital")
+                pexp[ix, iy] = orc.position_expectation(model, wfs[ix, iy][:nl], 2)
+        orc.impose_pbc(model, hw, 0, 0)
+        orc.impose_pbc(model, hw, 1, 1)
+        px = np.array([orc.berry_phase(hw, 2, [n], 0) / (2 * np.pi) for n in range(nl)])
+        ev = wfs[2, 5][[0, 3, 4]]
+        c25, w25 = orc.position_hwf(model, ev, 2, True, "wavefunction")
+        return hwfc, px, pexp, (orc.position_matrix(model, ev, 2), c25, np.abs(w25) ** 2)
+
+    slab_check(m, lambda mm, k: orc.solve_all_vec(mm, k), wf, 1e-9)
+
+
+def test_oracle_hwf_haldane_ribbon():
+    g = load_golden("hwf_haldane_ribbon")
+    m = orc.Model.from_tables(golden_tables(g))
+    ev, vec = orc.solve_all_vec(m, g["k_vec"], True)
+    ev = ev - 0.25
+    assert np.max(np.abs(ev - g["rib_eval"])) < 1e-11
+    flat, pos = [], []
+    for i in range(ev.shape[1]):
+        pos.append(orc.position_expectation(m, vec[:, i], 1))
+        flat.append(orc.position_hwf(m, vec[ev[:, i] < 0.0, i], 1))
+    assert np.array_equal([len(f) for f in flat], g["nocc"])
+    assert np.max(np.abs(np.concatenate(flat) - g["hwfcs_flat"])) < 1e-10
+    # per-state expectations are gauge free only for non-degenerate states
+    gaps = np.minimum(np.diff(ev, axis=0, prepend=-np.inf), np.diff(ev, axis=0, append=np.inf))
+    ok = (gaps > 1e-6).T
+    assert np.max(np.abs((np.array(pos) - g["pos_exps"])[ok])) < 1e-8
+
+
+@pytest.mark.gpu
+def test_gpu_hwf_cubic_slab():
+    import pythtb_amd as tb
+    g = load_golden("hwf_cubic_slab")
+    m = hp.model_from_tables(tb.tb_model, golden_tables(g))
+    nl, nk = 9, 9
+
+    def wf(model):
+        arr = tb.wf_array(model, [nk, nk])
+        arr.solve_on_grid([0.0, 0.0])
+        hwf_arr = arr.empty_like(nsta_arr=nl)
+        hwfc = np.zeros((nk, nk, nl))
+        pexp = np.zeros((nk, nk, nl))
+        for ix in range(nk):
+            for iy in range(nk):
+                val, vec = arr.position_hwf([ix, iy], occ=list(range(nl)), dir=2, hwf_evec=True, basis="orbital")
+                hwfc[ix, iy] = val
+                hwf_arr[ix, iy] = vec
+                pexp[ix, iy] = arr.position_expectation([ix, iy], list(range(nl)), 2)
+        hwf_arr.impose_pbc(0, 0)
+        hwf_arr.impose_pbc(1, 1)
+        px = np.array([hwf_arr.berry_phase(dir=0, occ=[n]) / (2.0 * np.pi) for n in range(nl)])
+        # batched extension == the per-point loop
+        c_all, w_all = arr.position_hwf_mesh(list(range(nl)), 2, hwf_evec=True, basis="orbital")
+        assert np.max(np.abs(c_all - hwfc)) < 1e-12 and w_all.shape == (nk, nk, nl, model._norb)
+        assert np.max(np.abs(arr.position_hwf_mesh(list(range(nl)), 2) - hwfc)) < 1e-12
+        xm = arr.position_matrix([2, 5], [0, 3, 4], 2)
+        c25, w25 = arr.position_hwf([2, 5], [0, 3, 4], 2, hwf_evec=True)
+        assert np.max(np.abs(xm @ w25.T - w25.T * c25)) < 1e-12              # rows are eigenvectors of X
+        return hwfc, px, pexp, (xm, c25, np.abs(w25) ** 2)
+
+    slab_check(m, lambda mm, k: mm.solve_all(k), wf, 1e-9)
+    with pytest.raises(Exception, match="periodic direction"):
+        m.position_matrix(m.solve_one([0.1, 0.2], eig_vectors=True)[1], 0)
+    with pytest.raises(Exception, match="out of range"):
+        m.position_matrix(m.solve_one([0.1, 0.2], eig_vectors=True)[1], 3)
+    with pytest.raises(Exception, match="Basis must be"):
+        m.position_hwf(m.solve_one([0.1, 0.2], eig_vectors=True)[1], 2, hwf_evec=True, basis="nope")
+
+
+@pytest.mark.gpu
+def test_gpu_hwf_haldane_ribbon_and_spin():
+    import pythtb_amd as tb
+    g = load_golden("hwf_haldane_ribbon")
+    m = hp.model_from_tables(tb.tb_model, golden_tables(g))
+    ev, vec = m.solve_all(g["k_vec"], eig_vectors=True)
+    ev = ev - 0.25
+    assert np.max(np.abs(ev - g["rib_eval"])) < 1e-11
+    flat = [m.position_hwf(vec[ev[:, i] < 0.0, i], 1) for i in range(ev.shape[1])]
+    assert np.array_equal([len(f) for f in flat], g["nocc"])
+    assert np.max(np.abs(np.concatenate(flat) - g["hwfcs_flat"])) < 1e-10
+    pos = np.array([m.position_expectation(vec[:, i], dir=1) for i in range(ev.shape[1])])
+    gaps = np.minimum(np.diff(ev, axis=0, prepend=-np.inf), np.diff(ev, axis=0, append=np.inf))
+    assert np.max(np.abs((pos - g["pos_exps"])[(gaps > 1e-6).T])) < 1e-8
+    # spinor model with a non-periodic direction, against the oracle on the same eigenvectors
+    s = hp.model_from_tables(tb.tb_model, golden_tables(load_golden("point_spin_chain")))
+    e, v = s.solve_one([0.17], eig_vectors=True)
+    for occ in ([0, 1, 2], [1, 4], list(range(6))):
+        x = s.position_matrix(v[occ], 1)
+        assert np.max(np.abs(x - orc.position_matrix(s, v[occ], 1))) < 1e-13
+        c, w = s.position_hwf(v[occ], 1, hwf_evec=True, basis="orbital")
+        assert w.shape == (len(occ), 3, 2)
+        assert np.max(np.abs(c - orc.position_hwf(s, v[occ], 1))) < 1e-12
+        pos = np.repeat(s._orb[:, 1], 2)
+        wf = w.reshape(len(occ), -1)
+        assert np.max(np.abs(np.einsum("ij,j,ij->i", wf.conj(), pos, wf).real - c)) < 1e-12   # <hwf|r|hwf> = centre
