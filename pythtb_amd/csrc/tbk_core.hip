@@ -62,6 +62,7 @@ extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
     if (c->scratch) hipFree(c->scratch);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->flags_dev) hipFree(c->flags_dev);
+    if (c->work) hipFree(c->work);
     hipEventDestroy(c->timer0);
     hipEventDestroy(c->timer1);
     hipStreamDestroy(c->stream);

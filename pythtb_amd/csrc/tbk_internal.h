@@ -84,6 +84,8 @@ struct tbk_ctx {
     void* pinned = nullptr;  // small pinned staging buffer for results
     size_t pinned_bytes = 0;
     int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
+    void* work = nullptr;      // workspace of the workgroup-per-matrix eigen-solver (n > 64)
+    size_t work_bytes = 0;
     // RCCL
     void* rccl_lib = nullptr;
     void* comm = nullptr;

@@ -654,12 +654,15 @@ struct WaveLds {
     double* ev; // [n]
     int* perm;  // [n]  perm[rank] = column
     cd* eo;     // [n]  conj(e_o) * pbc phases
+    double* red; // [8]  cross-wavefront reduction scratch (workgroup-per-matrix form)
 };
 
-template <int MODE, bool VEC>
-__global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int64_t nk,
+// NT = 64: one wavefront per matrix, matrices in LDS.  NT = 256 (n = 65..256): one
+// workgroup per matrix, matrices in a global workspace (L2-resident), always cold-started.
+template <int MODE, bool VEC, int NT>
+__global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int64_t nk,
                                                    const ListArgs L, const GridArgs G,
-                                                   int* noconv_flag, const int run) {
+                                                   int* noconv_flag, const int run, cd* work) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int n = mv.nsta;
     const int ld = n + 1;
@@ -668,16 +671,24 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
     const int half = m >> 1;
     // fixed lane -> (fast index c0, slow start i0) map for the n x (n or n/2) element
     // walks of the sweeps: no divisions inside the rounds
-    const int c0 = lane % n, i0 = lane / n, istep = 64 / n > 0 ? 64 / n : 1;
+    const int c0 = lane % n, i0 = lane / n, istep = NT / n > 0 ? NT / n : 1;
     const bool walker = lane < n * istep;
     WaveLds S;
-    S.A = (cd*)lds_raw;
-    S.Vt = S.A + n * ld;
-    S.T = S.Vt + n * ld;                 // present only when runs are longer than one point
-    S.rot = run > 1 ? S.T + n * ld : S.T;
+    if constexpr (NT == 64) {
+        S.A = (cd*)lds_raw;
+        S.Vt = S.A + n * ld;
+        S.T = S.Vt + n * ld;                 // present only when runs are longer than one point
+        S.rot = run > 1 ? S.T + n * ld : S.T;
+    } else {
+        S.A = work + (size_t)blockIdx.x * 2 * n * ld;
+        S.Vt = S.A + n * ld;
+        S.T = S.Vt;                          // unused: workgroup-per-matrix solves start cold
+        S.rot = (cd*)lds_raw;
+    }
     S.eo = S.rot + 2 * half;
     S.ev = (double*)(S.eo + n);
-    S.pq = (int*)(S.ev + n);
+    S.red = S.ev + n;
+    S.pq = (int*)(S.red + 8);
     S.perm = S.pq + half;
 
     // A wavefront walks a short chain of consecutive points.  After the first one, Jacobi is
@@ -707,7 +718,7 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
         it_end = it_begin + run < nk ? it_begin + run : nk;
     }
     for (int64_t it = it_begin; it < it_end; ++it) {
-        bool cold = it == it_begin;
+        bool cold = it == it_begin || NT > 64;
         bool store = true;
         int64_t id = it;
         double kk[4] = {0.0, 0.0, 0.0, 0.0};
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
         // ---- assemble S(k) (or load the supplied matrix) into A, V^T = I
         if constexpr (MODE == 2) {
             const cd* h = L.ham + id * (int64_t)n * n;
-            for (int e = lane; e < n * n; e += 64) {
+            for (int e = lane; e < n * n; e += NT) {
                 const int a = e / n, b = e - a * n;
                 // use the upper triangle, mirror it (the reference's eigh reads one triangle)
                 cd v = a <= b ? h[a * n + b] : cconj(h[b * n + a]);
@@ -737,7 +748,7 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
             cd z[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
-            for (int slot = lane; slot < mv.nslot; slot += 64) {
+            for (int slot = lane; slot < mv.nslot; slot += NT) {
                 const int ab = mv.slot_ab[slot];
                 const int a = ab & 0xffff, b = ab >> 16;
                 const int t0 = mv.slot_ptr[slot], t1 = mv.slot_ptr[slot + 1];
@@ -800,6 +811,20 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
             for (int o = 32; o > 0; o >>= 1) {
                 off += __shfl_xor(off, o);
                 dia += __shfl_xor(dia, o);
+            }
+            if constexpr (NT > 64) {   // combine the wavefronts of the workgroup (fixed order)
+                __syncthreads();
+                if ((lane & 63) == 0) {
+                    S.red[2 * (lane >> 6)] = off;
+                    S.red[2 * (lane >> 6) + 1] = dia;
+                }
+                __syncthreads();
+                off = 0.0;
+                dia = 0.0;
+                for (int wv = 0; wv < NT / 64; ++wv) {
+                    off += S.red[2 * wv];
+                    dia += S.red[2 * wv + 1];
+                }
             }
             if (off <= 2.0e-32 * (dia + off)) {
                 converged = true;
@@ -913,14 +938,14 @@ __global__ __launch_bounds__(64) void k_solve_wave(const ModelView mv, const int
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(fmax(g, 0.0));
                 if (bits < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, bits);
             }
-            for (int e = lane; e < n * n; e += 64) {
+            for (int e = lane; e < n * n; e += NT) {
                 const int rb = e / n, o = e - rb * n;
                 wf_at(G.wv, rb, id)[o] = cmul(S.Vt[S.perm[rb] * ld + o], S.eo[o]);
             }
         } else {
             if (lane < n) L.eval[(int64_t)lane * nk + id] = S.ev[S.perm[lane]];
             if (VEC) {
-                for (int e = lane; e < n * n; e += 64) {
+                for (int e = lane; e < n * n; e += NT) {
                     const int rb = e / n, o = e - rb * n;
                     L.evec[((int64_t)rb * nk + id) * n + o] = cmul(S.Vt[S.perm[rb] * ld + o], S.eo[o]);
                 }
@@ -934,7 +959,7 @@ static size_t wave_lds_bytes(int n, bool with_t) {
     size_t b = (size_t)(with_t ? 3 : 2) * n * ld * sizeof(cd);  // A, Vt (, T)
     b += (size_t)2 * half * sizeof(cd);          // rot
     b += (size_t)n * sizeof(cd);                 // eo
-    b += (size_t)n * sizeof(double);             // ev
+    b += (size_t)(n + 8) * sizeof(double);       // ev, red
     b += (size_t)(half + n) * sizeof(int);       // pq, perm
     return (b + 15) & ~(size_t)15;
 }
@@ -997,22 +1022,55 @@ static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
 template <int MODE, bool VEC>
 static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L,
                        const GridArgs& G) {
+    int* flag = ctx->flags_dev;  // sticky until read by check_noconv
+    GridArgs G2 = G;
+    if (n > 64) {
+        // ---- workgroup per matrix (n = 65..TBK_MAX_NSTA): 256 threads, A and V^T in a global
+        // workspace, cold start.  Ribbon / slab models: few, large matrices.
+        const size_t lds = wave_lds_bytes(n, false) - (size_t)2 * n * (n + 1) * sizeof(cd);   // small arrays only
+        const int64_t cap = std::max<int64_t>(64, (int64_t)ctx->cus * 4);
+        int64_t run, nblocks;
+        if (MODE == 1) {
+            const int last = G.last;
+            const int64_t off = G.off[last], nl = G.wv.mesh[last];
+            run = std::max<int64_t>(1, (G.wv.npts + cap - 1) / cap);
+            G2.wcfirst = off / run;
+            G2.wnchunk = (int)((off + nl - 1) / run - G2.wcfirst + 1);
+            nblocks = (G.wv.npts / nl) * G2.wnchunk;
+        } else {
+            run = std::max<int64_t>(1, (nk + cap - 1) / cap);
+            nblocks = (nk + run - 1) / run;
+        }
+        TBK_REQUIRE(nblocks < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many k-points for one launch");
+        const size_t wbytes = (size_t)nblocks * 2 * n * (n + 1) * sizeof(cd);
+        if (wbytes > ctx->work_bytes) {
+            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->work) TBK_HIP(hipFree(ctx->work));
+            ctx->work = nullptr;
+            ctx->work_bytes = 0;
+            hipError_t e = hipMalloc(&ctx->work, wbytes);
+            TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "eigen-solver workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
+            ctx->work_bytes = wbytes;
+        }
+        hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 256>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, mv, nk, L,
+                           G2, flag, (int)run, (cd*)ctx->work);
+        TBK_HIP(hipGetLastError());
+        return TBK_OK;
+    }
     const bool with_t = wave_lds_bytes(n, true) <= 160 * 1024;   // else every point starts cold
     const size_t lds = wave_lds_bytes(n, with_t);
     TBK_REQUIRE(lds <= 160 * 1024, TBK_EUNSUPPORTED, "nsta=%d needs %zu bytes of LDS per wavefront", n, lds);
     static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
     if (lds > 64 * 1024 && !attr_set[VEC][MODE]) {
-        TBK_HIP(hipFuncSetAttribute((const void*)k_solve_wave<MODE, VEC>,
+        TBK_HIP(hipFuncSetAttribute((const void*)k_solve_wave<MODE, VEC, 64>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set[VEC][MODE] = true;
     }
-    int* flag = ctx->flags_dev;  // sticky until read by check_noconv
-    // enough resident wavefronts to fill the chip; each strides over the k list
+    // enough resident wavefronts to fill the chip
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds));
     const int64_t want = (int64_t)ctx->cus * per_cu * 2;
     // chains of consecutive points per wavefront (warm-started Jacobi)
     int64_t run, nblocks;
-    GridArgs G2 = G;
     if (MODE == 1) {
         // mesh: fixed chain length, aligned to the global last-axis index (see the kernel)
         run = 16;
@@ -1032,7 +1090,8 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     }
     TBK_REQUIRE(nblocks < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many k-points for one launch");
     const unsigned blocks = (unsigned)nblocks;
-    hipLaunchKernelGGL((k_solve_wave<MODE, VEC>), dim3(blocks), dim3(64), lds, ctx->stream, mv, nk, L, G2, flag, (int)run);
+    hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 64>), dim3(blocks), dim3(64), lds, ctx->stream, mv, nk, L, G2, flag, (int)run,
+                       (cd*)nullptr);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

@@ -102,7 +102,7 @@ def test_eigh_batch_random_sizes_vs_numpy(tb):
     up to 24 plus 33 and 64 (register path n<=4, wavefront path above)."""
     from pythtb_amd import _lib
     rng = np.random.default_rng(7)
-    for n in list(range(1, 25)) + [33, 64]:
+    for n in list(range(1, 25)) + [33, 64, 65, 100, 137, 256]:   # > 64: workgroup-per-matrix kernel
         nk = 37 if n <= 24 else 5
         a = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
         h = np.ascontiguousarray(a + np.transpose(a.conj(), (0, 2, 1)))
@@ -575,9 +575,41 @@ def test_large_nocc_and_unsupported_sizes(tb):
     assert_phase_sets_close(got, orc.berry_phase(owfs, 2, occ, 0, contin=False, berry_evals=True), 1e-9)
     with pytest.raises(_lib.TbkError, match="limit"):
         w.berry_flux(list(range(17)))                         # nocc > TBK_MAX_NOCC fails loudly
-    big = hp.quiet(tb.tb_model, 1, 1, [[1.0]], 70)
+    big = hp.quiet(tb.tb_model, 1, 1, [[1.0]], 300)
     with pytest.raises(_lib.TbkError, match="limit"):
         big.solve_all([0.1])                                   # nsta > TBK_MAX_NSTA fails loudly
+
+
+def test_wide_models_workgroup_kernel(tb):
+    """65 <= nsta <= 256 (ribbons, slabs): one workgroup per matrix, matrices in global memory."""
+    from oracle import tb_oracle as orc
+    m = hp.random_model(tb.tb_model, 45, 1, 2, 5, nhop=150, rmax=2)        # 90 states, spinor, 1-D
+    k = np.linspace(-0.5, 0.5, 23)
+    ev, vec = m.solve_all(k, eig_vectors=True)
+    ref = orc.solve_all_vec(m, k.reshape(-1, 1))
+    scale = np.abs(ref).max()
+    assert np.max(np.abs(ev - ref)) < 1e-12 * scale
+    ham = orc.ham_batch(m, k.reshape(-1, 1))
+    V = vec.reshape(90, len(k), 90)
+    for ik in range(len(k)):
+        assert np.max(np.abs(V[:, ik].conj() @ V[:, ik].T - np.identity(90))) < 1e-12
+        assert np.max(np.abs(ham[ik] @ V[:, ik].T - V[:, ik].T * ev[:, ik])) < 1e-11 * scale
+    assert np.max(np.abs(m.solve_all(k) - ref)) < 1e-12 * scale              # eigenvalue-only variant
+    w = tb.wf_array(m, [14])
+    gaps = w.solve_on_grid([0.0])
+    owfs, ogaps = orc.solve_on_grid(m, [14], [0.0], vectorised=True)
+    assert np.max(np.abs(gaps - ogaps)) < 1e-10 * scale
+    for occ in (list(range(8)), [3], list(range(20, 36))):
+        got = w.berry_phase(occ)
+        assert abs(wrap(got - orc.berry_phase(owfs, 1, occ))) < 1e-8         # random model: small gaps
+    assert np.max(np.abs(w._wfs[-1] - w._wfs[0] * np.repeat(np.exp(-2j * np.pi * m._orb[:, 0]), 2).reshape(45, 2))) < 1e-13
+    m2 = hp.random_model(tb.tb_model, 130, 2, 1, 8, nhop=500, rmax=1)        # 130 states, 2-D mesh
+    w2 = tb.wf_array(m2, [4, 5])
+    g2 = w2.solve_on_grid([0.1, 0.2])
+    _, og2 = orc.solve_on_grid(m2, [4, 5], [0.1, 0.2], vectorised=True)
+    assert np.max(np.abs(g2 - og2)) < 1e-10 * np.abs(og2).max() + 1e-11
+    e0 = m2.solve_one([0.1, 0.2])
+    assert np.max(np.abs(e0 - orc.solve_all_vec(m2, [[0.1, 0.2]])[:, 0])) < 1e-11 * np.abs(e0).max()
 
 
 def test_rccl_single_rank_allgather(tb):
