@@ -502,3 +502,8 @@ class tb_model(object):
                 print('----- k_path report end ------------')
             print()
         return (k_vec, k_dist, k_node)
+
+
+from . import transforms as _transforms  # noqa: E402
+
+_transforms.install(tb_model)
