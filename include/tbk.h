@@ -33,7 +33,7 @@ extern "C" {
 #define TBK_ENOCONV 6  /* an iterative kernel hit its sweep limit      */
 
 #define TBK_MAX_DIM 4      /* dim_k, dim_arr <= 4      (pythtb.py:99)   */
-#define TBK_MAX_NSTA 256   /* states per k in this build                */
+#define TBK_MAX_NSTA 2048  /* states per k in this build                */
 #define TBK_MAX_NOCC 16    /* bands in one Berry overlap matrix         */
 
 typedef struct tbk_ctx tbk_ctx;     /* device + stream + workspaces          */

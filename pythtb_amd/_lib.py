@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtbk.so")
 
 MAX_DIM = 4
-MAX_NSTA = 256
+MAX_NSTA = 2048
 MAX_NOCC = 16
 
 if not os.path.exists(LIB_PATH):

@@ -514,11 +514,11 @@ extern "C" int tbk_wfs_create(tbk_ctx* ctx, int dim_arr, const int32_t* mesh, in
         return TBK_ENOMEM;
     }
     TBK_HIP(hipMemsetAsync(w->view.data, 0, (size_t)w->bytes, ctx->stream));
-    const int ngap = 2 * TBK_GAP_SHARDS * TBK_MAX_NSTA;
+    const int ngap = 2 * TBK_GAP_SHARDS * ncomp;   // [parity][shard][ncomp]
     TBK_HIP(hipMalloc((void**)&w->gaps_dev, ngap * sizeof(unsigned long long)));
     hipLaunchKernelGGL(k_fill_u64, dim3((ngap + 255) / 256), dim3(256), 0, ctx->stream, w->gaps_dev, ngap,
                        0x7ff0000000000000ull);
-    TBK_HIP(hipMalloc((void**)&w->pbc_dev, TBK_MAX_DIM * TBK_MAX_NSTA * sizeof(cd)));
+    TBK_HIP(hipMalloc((void**)&w->pbc_dev, TBK_MAX_DIM * (size_t)ncomp * sizeof(cd)));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
     *out = w;
     return TBK_OK;

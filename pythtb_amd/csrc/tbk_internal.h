@@ -154,11 +154,11 @@ struct tbk_wfs {
     tbk_ctx* ctx = nullptr;
     WfsView view{};
     int64_t bytes = 0;
-    // solve_grid: min gaps as ordered bit patterns, [2 parities][TBK_GAP_SHARDS][TBK_MAX_NSTA];
+    // solve_grid: min gaps as ordered bit patterns, [2 parities][TBK_GAP_SHARDS][ncomp];
     // each launch min-reduces into its parity and re-arms the other one for the next launch
     unsigned long long* gaps_dev = nullptr;
     int gaps_n = 0, gaps_parity = 0;
-    cd* pbc_dev = nullptr;                   // [TBK_MAX_DIM][TBK_MAX_NSTA]
+    cd* pbc_dev = nullptr;                   // [TBK_MAX_DIM][nsta]
     // per-axis phase tables of the regular mesh (rebuilt only when their inputs change)
     cd* tab_dev = nullptr;                   // z[d][i] then f[d][i][n]
     int64_t tab_cap = 0;

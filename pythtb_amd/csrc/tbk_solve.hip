@@ -28,8 +28,8 @@ struct GridArgs {
     double start_k[TBK_MAX_DIM];
     int gmesh[TBK_MAX_DIM];  // global mesh sizes (axis 0 may exceed the slab)
     int64_t off[TBK_MAX_DIM];  // global index of the window's first point along each axis
-    const cd* pbc;           // [TBK_MAX_DIM][TBK_MAX_NSTA]
-    unsigned long long* gaps;       // [TBK_GAP_SHARDS][TBK_MAX_NSTA] min-reduced by this launch
+    const cd* pbc;           // [TBK_MAX_DIM][nsta]
+    unsigned long long* gaps;       // [TBK_GAP_SHARDS][nsta] min-reduced by this launch
     unsigned long long* gaps_next;  // the other parity: re-armed (+inf) for the next launch
     // per-axis tables of the regular mesh: z[d][i] = exp(2 pi i k_d(i)),
     // f[d][i*n+o] = exp(-2 pi i k_d(i) tau_o,d) * (pbc phase if i is the periodic image)
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_grid_tables(const ModelView mv, const G
         const double4 tau = mv.orb[o];
         const double td = d == 0 ? tau.x : d == 1 ? tau.y : d == 2 ? tau.z : tau.w;
         cd f = cconj(expi2pi(kd * td));
-        if (wrap) f = cmul(f, G.pbc[d * TBK_MAX_NSTA + o]);
+        if (wrap) f = cmul(f, G.pbc[d * mv.nsta + o]);
         tf0[foff + (int64_t)t * mv.nsta + o] = f;
     }
 }
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
     const int64_t chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (chunk >= G.nchunks) return;
     if (blockIdx.x == 0 && threadIdx.x < (N > 1 ? N - 1 : 0)) {   // re-arm the other parity
-        for (int s = 0; s < TBK_GAP_SHARDS; ++s) G.gaps_next[s * TBK_MAX_NSTA + threadIdx.x] = 0x7ff0000000000000ull;
+        for (int s = 0; s < TBK_GAP_SHARDS; ++s) G.gaps_next[s * N + threadIdx.x] = 0x7ff0000000000000ull;
     }
     const int lane = threadIdx.x & 63;
     const int last = G.last;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
     double sorted[N];
     ranks_small<N>(M.dg, rk, sorted);
     if constexpr (N > 1) {
-        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * TBK_MAX_NSTA;
+        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * N;
 #pragma unroll
         for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, sorted[b + 1] - sorted[b]);
     }
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
 #pragma unroll
     for (int o = 0; o < N; ++o) frow[o] = cd{1.0, 0.0};
     if (blockIdx.x == 0 && threadIdx.x < (N > 1 ? N - 1 : 0)) {   // re-arm the other parity
-        for (int s = 0; s < TBK_GAP_SHARDS; ++s) G.gaps_next[s * TBK_MAX_NSTA + threadIdx.x] = 0x7ff0000000000000ull;
+        for (int s = 0; s < TBK_GAP_SHARDS; ++s) G.gaps_next[s * N + threadIdx.x] = 0x7ff0000000000000ull;
     }
     if (live) {
         row = (unsigned)(tile / G.tpr);
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
         (void)active;
     }
     if constexpr (N > 1) {
-        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * TBK_MAX_NSTA;
+        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * N;
 #pragma unroll
         for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, gmin[b]);
     }
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
                 if constexpr (MODE == 1) {
 #pragma unroll
                     for (int d = 0; d < 4; ++d)
-                        if (wrap[d]) f = cmul(f, G.pbc[d * TBK_MAX_NSTA + lane]);
+                        if (wrap[d]) f = cmul(f, G.pbc[d * n + lane]);
                 }
                 S.eo[lane] = f;
             }
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
         if constexpr (MODE == 1) {
             if (lane + 1 < n) {
                 const double g = S.ev[S.perm[lane + 1]] - S.ev[S.perm[lane]];
-                unsigned long long* slot = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * TBK_MAX_NSTA + lane;
+                unsigned long long* slot = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * n + lane;
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(fmax(g, 0.0));
                 if (bits < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, bits);
             }
@@ -998,9 +998,11 @@ __global__ __launch_bounds__(256) void k_gen_ham(const ModelView mv, const int64
     }
 }
 
-__global__ void k_arm_gaps(unsigned long long* p) {
-    for (int i = threadIdx.x; i < TBK_GAP_SHARDS * TBK_MAX_NSTA; i += blockDim.x) p[i] = 0x7ff0000000000000ull;
+__global__ void k_arm_gaps(unsigned long long* p, const int n) {
+    for (int i = threadIdx.x; i < TBK_GAP_SHARDS * n; i += blockDim.x) p[i] = 0x7ff0000000000000ull;
 }
+
+#include "tbk_solve_big.inl"   // n > 256: one kernel launch per Jacobi round, whole chip per batch
 
 // ---------------------------------------------------------------------------
 // host-side launchers
@@ -1024,8 +1026,9 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
                        const GridArgs& G) {
     int* flag = ctx->flags_dev;  // sticky until read by check_noconv
     GridArgs G2 = G;
+    if (n > 256) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
     if (n > 64) {
-        // ---- workgroup per matrix (n = 65..TBK_MAX_NSTA): 256 threads, A and V^T in a global
+        // ---- workgroup per matrix (n = 65..256): 256 threads, A and V^T in a global
         // workspace, cold start.  Ribbon / slab models: few, large matrices.
         const size_t lds = wave_lds_bytes(n, false) - (size_t)2 * n * (n + 1) * sizeof(cd);   // small arrays only
         const int64_t cap = std::max<int64_t>(64, (int64_t)ctx->cus * 4);
@@ -1301,10 +1304,10 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
         }
     }
     if (key != w->tab_key) {
-        std::vector<cd> st((size_t)TBK_MAX_DIM * TBK_MAX_NSTA, cd{0.0, 0.0});
+        std::vector<cd> st((size_t)TBK_MAX_DIM * n, cd{0.0, 0.0});
         for (int d = 0; d < D; ++d)
             for (int o = 0; o < n; ++o)
-                st[d * TBK_MAX_NSTA + o] = cd{pbc_phase[2 * (d * n + o)], pbc_phase[2 * (d * n + o) + 1]};
+                st[d * n + o] = cd{pbc_phase[2 * (d * n + o)], pbc_phase[2 * (d * n + o) + 1]};
         TBK_HIP(hipMemcpyAsync(w->pbc_dev, st.data(), st.size() * sizeof(cd), hipMemcpyHostToDevice, ctx->stream));
         TBK_HIP(hipStreamSynchronize(ctx->stream));  // st is a local: finish before it dies
         ProfScope ps(ctx, "grid_tables");
@@ -1314,7 +1317,7 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
         w->tab_key = key;
     }
     // min gaps: this launch reduces into one parity and re-arms the other
-    const size_t half = (size_t)TBK_GAP_SHARDS * TBK_MAX_NSTA;
+    const size_t half = (size_t)TBK_GAP_SHARDS * w->view.ncomp;
     G.gaps = w->gaps_dev + (size_t)w->gaps_parity * half;
     G.gaps_next = w->gaps_dev + (size_t)(1 - w->gaps_parity) * half;
     w->gaps_parity = 1 - w->gaps_parity;   // *_result reads 1 - gaps_parity
@@ -1375,7 +1378,7 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
         return TBK_OK;
     }
     {   // wavefront-per-matrix path re-arms the other parity with a tiny memset-like kernel
-        hipLaunchKernelGGL(k_arm_gaps, dim3(1), dim3(256), 0, ctx->stream, G.gaps_next);
+        hipLaunchKernelGGL(k_arm_gaps, dim3(1), dim3(256), 0, ctx->stream, G.gaps_next, n);
     }
     ListArgs L{};
     return launch_wave<1, true>(ctx, m->view, n, v.npts, L, G);
@@ -1384,7 +1387,7 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
 extern "C" int tbk_wfs_solve_grid_result(tbk_wfs* w, double* min_gaps) {
     TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_solve_grid_result: null wfs");
     tbk_ctx* ctx = w->ctx;
-    const size_t half = (size_t)TBK_GAP_SHARDS * TBK_MAX_NSTA;
+    const size_t half = (size_t)TBK_GAP_SHARDS * w->view.ncomp;
     std::vector<unsigned long long> bits(half);
     if (w->gaps_n > 0 && min_gaps) {
         TBK_HIP(hipMemcpyAsync(bits.data(), w->gaps_dev + (size_t)(1 - w->gaps_parity) * half,
@@ -1394,7 +1397,7 @@ extern "C" int tbk_wfs_solve_grid_result(tbk_wfs* w, double* min_gaps) {
     if (w->gaps_n > 0 && min_gaps) {
         for (int b = 0; b < w->gaps_n; ++b) {
             unsigned long long best = bits[b];
-            for (int s = 1; s < TBK_GAP_SHARDS; ++s) best = std::min(best, bits[(size_t)s * TBK_MAX_NSTA + b]);
+            for (int s = 1; s < TBK_GAP_SHARDS; ++s) best = std::min(best, bits[(size_t)s * w->view.ncomp + b]);
             memcpy(&min_gaps[b], &best, sizeof(double));
         }
     }

@@ -575,7 +575,7 @@ def test_large_nocc_and_unsupported_sizes(tb):
     assert_phase_sets_close(got, orc.berry_phase(owfs, 2, occ, 0, contin=False, berry_evals=True), 1e-9)
     with pytest.raises(_lib.TbkError, match="limit"):
         w.berry_flux(list(range(17)))                         # nocc > TBK_MAX_NOCC fails loudly
-    big = hp.quiet(tb.tb_model, 1, 1, [[1.0]], 300)
+    big = hp.quiet(tb.tb_model, 1, 1, [[1.0]], 2100)
     with pytest.raises(_lib.TbkError, match="limit"):
         big.solve_all([0.1])                                   # nsta > TBK_MAX_NSTA fails loudly
 
@@ -610,6 +610,44 @@ def test_wide_models_workgroup_kernel(tb):
     assert np.max(np.abs(g2 - og2)) < 1e-10 * np.abs(og2).max() + 1e-11
     e0 = m2.solve_one([0.1, 0.2])
     assert np.max(np.abs(e0 - orc.solve_all_vec(m2, [[0.1, 0.2]])[:, 0])) < 1e-11 * np.abs(e0).max()
+
+
+def test_very_wide_models_whole_chip_jacobi(tb):
+    """nsta > 256 (flakes, thick slabs): one kernel launch per Jacobi round over all 2x2 blocks."""
+    from oracle import tb_oracle as orc
+    from pythtb_amd import _lib
+    import ctypes as C
+    m = hp.random_model(tb.tb_model, 301, 1, 1, 11, nhop=1200, rmax=1)      # odd n: the bye player
+    k = np.array([-0.37, 0.0, 0.21])
+    ev, vec = m.solve_all(k, eig_vectors=True)
+    ref = orc.solve_all_vec(m, k.reshape(-1, 1))
+    scale = np.abs(ref).max()
+    assert np.max(np.abs(ev - ref)) < 1e-12 * scale
+    ham = orc.ham_batch(m, k.reshape(-1, 1))
+    for ik in range(len(k)):
+        V = vec[:, ik, :]
+        assert np.max(np.abs(V.conj() @ V.T - np.identity(301))) < 1e-12
+        assert np.max(np.abs(ham[ik] @ V.T - V.T * ev[:, ik])) < 1e-11 * scale
+    assert np.max(np.abs(m.solve_all(k) - ref)) < 1e-12 * scale
+    # mesh mode: periodic image, gaps, Berry phase of a band group
+    m2 = hp.random_model(tb.tb_model, 140, 1, 2, 3, nhop=500, rmax=1)       # 280 spinor states
+    w = tb.wf_array(m2, [5])
+    gaps = w.solve_on_grid([0.0])
+    owfs, ogaps = orc.solve_on_grid(m2, [5], [0.0], vectorised=True)
+    assert np.max(np.abs(gaps - ogaps)) < 1e-10 * np.abs(ogaps).max() + 1e-11
+    assert np.max(np.abs(w._wfs[-1] - w._wfs[0] * np.repeat(np.exp(-2j * np.pi * m2._orb[:, 0]), 2).reshape(140, 2))) < 1e-13
+    # supplied matrices, even n, through the C ABI
+    rng = np.random.default_rng(5)
+    n = 512
+    a = rng.normal(size=(2, n, n)) + 1j * rng.normal(size=(2, n, n))
+    hmat = np.ascontiguousarray(a + a.conj().transpose(0, 2, 1))
+    e = np.zeros((n, 2))
+    v = np.zeros((n, 2, n), dtype=complex)
+    _lib.check(_lib.lib.tbk_eigh_batch(_lib.default_context().handle, n, _lib.dptr(hmat), 2, _lib.dptr(e), _lib.dptr(v)))
+    for i in range(2):
+        want = np.linalg.eigvalsh(hmat[i])
+        assert np.max(np.abs(e[:, i] - want)) < 1e-12 * np.abs(want).max()
+        assert np.max(np.abs(hmat[i] @ v[:, i].T - v[:, i].T * e[:, i])) < 1e-10 * np.abs(want).max()
 
 
 def test_rccl_single_rank_allgather(tb):
