@@ -171,6 +171,26 @@ int tbk_berry_phase(tbk_wfs* wfs, const int32_t* occ, int nocc, int dir, int ber
 int tbk_position_hwf(tbk_ctx* ctx, const double* evec, int64_t nk, int nsub, int ncomp,
                      const double* pos, double* xmat, double* hwfc, double* hwf, int orbital_basis);
 
+/* ---- k generators on the device, eigenvalue reductions (third "next" row) ----
+ * tb_model.k_uniform_mesh (pythtb.py:1792-1861): k_dev[prod(mesh)][dim_k], point
+ * (i_0,..) row-major = (i_0/N_0, ...); dim_k 1..3 like the reference.                  */
+int tbk_k_uniform_mesh_dev(tbk_ctx* ctx, int dim_k, const int32_t* mesh, double* k_dev);
+/* interpolation step of tb_model.k_path (pythtb.py:1978-1996): nodes[n_nodes][dim_k] and
+ * node_index[n_nodes] (0 .. nk-1, increasing; both computed on the host, :1926-1976)
+ * -> k_dev[nk][dim_k], bit-equal to the reference's k_vec.                             */
+int tbk_k_path_dev(tbk_ctx* ctx, int dim_k, int n_nodes, const double* nodes,
+                   const int32_t* node_index, int64_t nk, double* k_dev);
+/* solve_all(k_uniform_mesh(mesh)) with the k list generated on the device (no upload):
+ * eval[n][nk], evec[n][nk][n] or NULL.                                                  */
+int tbk_solve_mesh(tbk_model* model, const int32_t* mesh, double* eval, double* evec);
+/* The reduction of the reference's DOS example (examples/haldane.py:96-121: histogram of
+ * solve_all over a uniform mesh) without downloading the eigenvalues: counts[n][nbins] per
+ * band with np.histogram's bin rule for the given edges[nbins+1] (equal-width bins, last
+ * bin closed), and/or the band extrema band_min[n], band_max[n] (each nullable;
+ * nbins = 0 with edges = counts = NULL computes the extrema alone).                     */
+int tbk_dos_mesh(tbk_model* model, const int32_t* mesh, int nbins, const double* edges,
+                 int64_t* counts, double* band_min, double* band_max);
+
 /* ---- multi-GPU: one process per GPU, k-points sharded, one gather ------
  * Thin RCCL wrappers (librccl is dlopen'ed on first use).  The 128-byte id is
  * created on rank 0 and distributed by the launcher (any out-of-band channel). */

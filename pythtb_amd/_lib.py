@@ -72,6 +72,10 @@ SIGNATURES = {
     "tbk_berry_flux_result": (_i, [_p, _dp, _dp]),
     "tbk_berry_phase": (_i, [_p, _ip, _i, _i, _i, _dp]),
     "tbk_position_hwf": (_i, [_p, _dp, _i64, _i, _i, _dp, _dp, _dp, _dp, _i]),
+    "tbk_k_uniform_mesh_dev": (_i, [_p, _i, _ip, _p]),
+    "tbk_k_path_dev": (_i, [_p, _i, _i, _dp, _ip, _i64, _p]),
+    "tbk_solve_mesh": (_i, [_p, _ip, _dp, _dp]),
+    "tbk_dos_mesh": (_i, [_p, _ip, _i, _dp, C.POINTER(C.c_int64), _dp, _dp]),
     "tbk_comm_unique_id": (_i, [C.POINTER(C.c_ubyte)]),
     "tbk_comm_init": (_i, [_p, C.POINTER(C.c_ubyte), _i, _i]),
     "tbk_comm_destroy": (_i, [_p]),

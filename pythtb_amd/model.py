@@ -3,8 +3,8 @@
 Same constructor, setters, attribute names and call signatures as the reference
 (`pythtb.py:29-560`, `:862-1103`, `:1792-2026`), so scripts written for PythTB
 run unchanged; `_gen_ham`, `_sol_ham`, `solve_all` and `solve_one` execute on the
-MI355X through libtbk (no CPU path).  Model->model transforms, plotting and the
-Wannier90 reader are outside this package's scope.
+MI355X through libtbk (no CPU path).  The model->model transforms live in
+transforms.py; plotting is outside this package's scope.
 """
 import ctypes as C
 
@@ -362,6 +362,53 @@ class tb_model(object):
             ev, vec = self.solve_all([k_point], eig_vectors=True)
             return ev[:, 0], vec[:, 0]
         return self.solve_all([k_point])[:, 0]
+
+    # ------------------------------------------------------------------ mesh shortcuts (extensions)
+    def _mesh_arg(self, mesh_size):
+        mesh = np.array(list(map(round, mesh_size)), dtype=np.int32)     # same checks as k_uniform_mesh
+        if mesh.shape != (self._dim_k,):
+            print(mesh.shape)
+            raise Exception("\n\nIncorrect size of the specified k-mesh!")
+        if np.min(mesh) <= 0:
+            raise Exception("\n\nMesh must have positive non-zero number of elements.")
+        if self._dim_k not in (1, 2, 3):
+            raise Exception("\n\nUnsupported dim_k!")
+        return np.ascontiguousarray(mesh), int(np.prod(mesh, dtype=np.int64))
+
+    def solve_all_mesh(self, mesh_size, eig_vectors=False):
+        """Extension: `solve_all(k_uniform_mesh(mesh_size), eig_vectors)` with the k list generated
+        on the device -- the same arrays, minus the 8*dim_k bytes per k-point of upload."""
+        mesh, nk = self._mesh_arg(mesh_size)
+        n = self._nsta
+        ev = np.zeros((n, nk), dtype=float)
+        vec = np.zeros((n, nk, n), dtype=complex) if eig_vectors else None
+        _lib.check(_lib.lib.tbk_solve_mesh(self._device_model(), _lib.iptr(mesh), _lib.dptr(ev),
+                                           _lib.dptr(vec.view(float)) if eig_vectors else None))
+        if eig_vectors and self._nspin == 2:
+            vec = vec.reshape(n, nk, self._norb, 2)
+        return (ev, vec) if eig_vectors else ev
+
+    def dos_mesh(self, mesh_size, bins=50, range=None, per_band=False):
+        """Extension: `np.histogram(solve_all(k_uniform_mesh(mesh_size)).flatten(), bins, range)` -- the
+        density-of-states reduction of the reference's examples/haldane.py:96-121 -- with the
+        eigenvalues kept on the device: (counts, bin_edges), counts int64 `(bins,)`, or
+        `(nsta, bins)` with per_band=True.  `bins` is a number of equal-width bins."""
+        mesh, nk = self._mesh_arg(mesh_size)
+        if not _is_int(bins) or bins < 1:
+            raise Exception("\n\ndos_mesh: bins must be a positive integer (equal-width bins)")
+        n = self._nsta
+        h = self._device_model()
+        if range is None:
+            lo = np.zeros(n)
+            hi = np.zeros(n)
+            _lib.check(_lib.lib.tbk_dos_mesh(h, _lib.iptr(mesh), 0, None, None, _lib.dptr(lo), _lib.dptr(hi)))
+            range = (lo.min(), hi.max())
+        # the edges np.histogram itself would use for this range (incl. its widening of an empty range)
+        edges = np.ascontiguousarray(np.histogram_bin_edges(np.zeros(0), bins=int(bins), range=range), dtype=float)
+        counts = np.zeros((n, int(bins)), dtype=np.int64)
+        _lib.check(_lib.lib.tbk_dos_mesh(h, _lib.iptr(mesh), int(bins), _lib.dptr(edges),
+                                         counts.ctypes.data_as(_lib.C.POINTER(_lib.C.c_int64)), None, None))
+        return (counts if per_band else counts.sum(axis=0)), edges
 
     # ------------------------------------------------------------------ position operator
     def ignore_position_operator_offdiagonal(self):
