@@ -9,7 +9,8 @@ There is no CPU fallback.
 """
 from .model import tb_model
 from .wfarray import wf_array
+from .w90 import w90
 from . import shard
 
 __version__ = "0.1.0"
-__all__ = ["tb_model", "wf_array", "shard", "__version__"]
+__all__ = ["tb_model", "wf_array", "w90", "shard", "__version__"]

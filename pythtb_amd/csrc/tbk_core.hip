@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <array>
 #include <map>
 #include <new>
 #include "tbk_internal.h"
@@ -378,7 +379,33 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     for (int a = 0; a < n; ++a)
         for (int d = 0; d < dim_k; ++d) orb4[a * 4 + d] = orb[(a / ns) * dim_k + d];
 
-    // one blob: [orb4 | amp | R4 | slot_ptr | slot_ab], 32-byte aligned pieces
+    // the same terms grouped by lattice vector: S(k) = sum_R e^{2 pi i k.R} U_R with U_R dense over the
+    // slots -- one phase per R instead of one per term.  Built for the register-resident solvers
+    // (n = 5..8) when the blocks are reasonably full (Wannier-type long-ranged tables).
+    std::vector<int32_t> rvec;
+    std::vector<cd> rblock;
+    int nR = 0;
+    if (n >= 5 && n <= 8 && nterm > 0) {
+        std::map<std::array<int, 4>, int> rid;
+        for (int64_t t = 0; t < nterm; ++t) {
+            std::array<int, 4> key{R4[t * 4], R4[t * 4 + 1], R4[t * 4 + 2], R4[t * 4 + 3]};
+            if (rid.emplace(key, (int)rid.size()).second)
+                for (int d = 0; d < 4; ++d) rvec.push_back(key[d]);
+        }
+        if ((int64_t)rid.size() * nslot <= 4 * nterm + 64) {
+            nR = (int)rid.size();
+            rblock.assign((size_t)nR * nslot, cd{0.0, 0.0});
+            for (int s = 0; s < nslot; ++s)
+                for (int t = slot_ptr[s]; t < slot_ptr[s + 1]; ++t) {
+                    std::array<int, 4> key{R4[t * 4], R4[t * 4 + 1], R4[t * 4 + 2], R4[t * 4 + 3]};
+                    rblock[(size_t)rid[key] * nslot + s] = amp[t];
+                }
+        } else {
+            rvec.clear();
+        }
+    }
+
+    // one blob: [orb4 | amp | R4 | slot_ptr | slot_ab | cell_ptr | rvec | rblock], 32-byte aligned pieces
     auto al = [](size_t x) { return (x + 31) & ~(size_t)31; };
     const size_t o_orb = 0;
     const size_t o_amp = al(o_orb + orb4.size() * sizeof(double));
@@ -386,8 +413,14 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     const size_t o_ptr = al(o_R + std::max<size_t>(R4.size(), 4) * sizeof(int32_t));
     const size_t o_ab = al(o_ptr + slot_ptr.size() * sizeof(int32_t));
     const size_t o_cell = al(o_ab + slot_ab.size() * sizeof(int32_t));
-    const size_t total = al(o_cell + cell_ptr.size() * sizeof(int32_t));
+    const size_t o_rvec = al(o_cell + cell_ptr.size() * sizeof(int32_t));
+    const size_t o_rblk = al(o_rvec + std::max<size_t>(rvec.size(), 4) * sizeof(int32_t));
+    const size_t total = al(o_rblk + std::max<size_t>(rblock.size(), 1) * sizeof(cd));
     std::vector<unsigned char> host(total, 0);
+    if (nR > 0) {
+        memcpy(host.data() + o_rvec, rvec.data(), rvec.size() * sizeof(int32_t));
+        memcpy(host.data() + o_rblk, rblock.data(), rblock.size() * sizeof(cd));
+    }
     memcpy(host.data() + o_cell, cell_ptr.data(), cell_ptr.size() * sizeof(int32_t));
     memcpy(host.data() + o_orb, orb4.data(), orb4.size() * sizeof(double));
     if (!amp.empty()) memcpy(host.data() + o_amp, amp.data(), amp.size() * sizeof(cd));
@@ -425,6 +458,9 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     m->view.slot_ab = (const int32_t*)(base + o_ab);
     m->view.pmax = pmax;
     m->view.cell_ptr = (const int32_t*)(base + o_cell);
+    m->view.nR = nR;
+    m->view.rvec = (const int4*)(base + o_rvec);
+    m->view.rblock = (const cd*)(base + o_rblk);
     *out = m;
     return TBK_OK;
 }

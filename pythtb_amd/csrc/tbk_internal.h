@@ -119,6 +119,11 @@ struct ModelView {
     // p in [-pmax, pmax]; terms are ordered (slot, p, ...) so cells are ranges
     int pmax;
     const int32_t* cell_ptr;  // [nslot*(2*pmax+1) + 1]
+    // the same terms grouped by lattice vector (n = 5..8 only, 0 when not built):
+    // S_slot(k) = sum_r rblock[r][slot] * exp(2 pi i k.rvec[r])
+    int nR;
+    const int4* rvec;         // [nR]
+    const cd* rblock;         // [nR][nslot]
 };
 
 struct tbk_model {

@@ -1003,6 +1003,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 }
 
 #include "tbk_solve_big.inl"   // n > 256: one kernel launch per Jacobi round, whole chip per batch
+#include "tbk_solve_reg.inl"   // n = 5..8: register-resident cyclic Jacobi, 1/2/4 lanes per matrix
 
 // ---------------------------------------------------------------------------
 // host-side launchers
@@ -1027,6 +1028,11 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     int* flag = ctx->flags_dev;  // sticky until read by check_noconv
     GridArgs G2 = G;
     if (n > 256) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
+    static const bool use_reg = [] {   // TBK_REG=0: fall back to the wavefront-per-matrix kernel (A/B runs)
+        const char* e = getenv("TBK_REG");
+        return !(e && atoi(e) == 0);
+    }();
+    if (n <= 8 && use_reg) return launch_reg<MODE, VEC>(ctx, mv, n, nk, L, G);
     if (n > 64) {
         // ---- workgroup per matrix (n = 65..256): 256 threads, A and V^T in a global
         // workspace, cold start.  Ribbon / slab models: few, large matrices.

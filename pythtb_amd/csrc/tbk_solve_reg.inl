@@ -1,0 +1,255 @@
+// tbk_solve_reg.inl -- included by tbk_solve.hip.
+//
+// n = 5..8 states per k: cyclic Jacobi with the matrix in REGISTERS, like the n <= 4 kernels,
+// instead of one wavefront per matrix through LDS (which costs ~1000 cycles of barrier and LDS
+// latency per Jacobi round no matter how small the matrix is).
+//
+// One thread per matrix (L = 1).  Eigenvalues only: n = 8 needs 162 VGPRs, no spills.  With
+// eigenvectors V does not fit next to A in 256 VGPRs (n = 8: 128 more doubles); the compiler
+// parks the overflow in AGPRs (no scratch), one wavefront per SIMD -- measured on silicon
+// (8 Wannier functions, 65^3 mesh): 1.83 ms, against 7.77 ms for the wavefront-per-matrix kernel.
+//
+// The kernel is also written for L = 2 or 4 neighbouring lanes sharing a matrix: every lane
+// of the group keeps the whole A and performs the same rotations on it (identical arithmetic
+// -> identical parameters, no communication) but owns only the rows o = sub, sub+L, ... of V
+// (V <- V J touches each row on its own), and H(k) assembly is split over the group.  That
+// trades the AGPR traffic for redundant A updates; it measured slower for n <= 8 (1.97 / 2.46
+// ms), so those instantiations are only built with -DTBK_REG_MULTILANE (TBK_REG_LANES=2|4
+// then selects them); the scheme is what would carry the register approach to n = 9, 10.
+//
+// H(k) assembly: when the model carries the R-grouped table (ModelView::nR > 0) one phase is
+// formed per lattice vector and every slot gets one complex FMA with a wave-uniform
+// coefficient; otherwise the slot-major term table is walked like in the other kernels.
+
+template <int N, int NR>
+struct RegMat {
+    double dg[N];       // diagonal (real)
+    cd up[N][N];        // strict upper triangle (p < q) used
+    cd v[NR][N];        // v[i][b]: component o = sub + L*i of eigenvector b
+};
+
+template <int N, int NR, int P, int Q, bool VEC>
+__device__ __forceinline__ void rotate_reg(RegMat<N, NR>& M) {
+    const cd g = M.up[P][Q];
+    const double g2 = cabs2(g);
+    if (g2 > 0.0) {   // same division-free parameters as rotate<>
+        const double a = 0.5 * (M.dg[Q] - M.dg[P]), aa = fabs(a);
+        const double r = sqrt(a * a + g2);
+        const double inv = rsqrt(2.0 * r * (r + aa));
+        const double c = (aa + r) * inv;
+        const double sg = copysign(1.0, a);
+        const cd sw{sg * g.x * inv, sg * g.y * inv};
+        const double mid = 0.5 * (M.dg[P] + M.dg[Q]);
+        M.dg[P] = mid - sg * r;
+        M.dg[Q] = mid + sg * r;
+        M.up[P][Q] = cd{0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            if (r == P || r == Q) continue;
+            cd x = r < P ? M.up[r][P] : cconj(M.up[P][r]);
+            cd y = r < Q ? M.up[r][Q] : cconj(M.up[Q][r]);
+            cd xn{c * x.x - (sw.x * y.x + sw.y * y.y), c * x.y - (sw.x * y.y - sw.y * y.x)};
+            cd yn{(sw.x * x.x - sw.y * x.y) + c * y.x, (sw.x * x.y + sw.y * x.x) + c * y.y};
+            if (r < P) M.up[r][P] = xn; else M.up[P][r] = cconj(xn);
+            if (r < Q) M.up[r][Q] = yn; else M.up[Q][r] = cconj(yn);
+        }
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const cd x = M.v[i][P], y = M.v[i][Q];
+                M.v[i][P] = cd{c * x.x - (sw.x * y.x + sw.y * y.y), c * x.y - (sw.x * y.y - sw.y * y.x)};
+                M.v[i][Q] = cd{(sw.x * x.x - sw.y * x.y) + c * y.x, (sw.x * x.y + sw.y * x.x) + c * y.y};
+            }
+        }
+    }
+}
+
+template <int N, int NR, int P, int Q, bool VEC>
+struct SweepReg {
+    __device__ static __forceinline__ void run(RegMat<N, NR>& M) {
+        rotate_reg<N, NR, P, Q, VEC>(M);
+        if constexpr (Q + 1 < N)
+            SweepReg<N, NR, P, Q + 1, VEC>::run(M);
+        else if constexpr (P + 2 < N)
+            SweepReg<N, NR, P + 1, P + 2, VEC>::run(M);
+    }
+};
+
+// MODE 0: k list, 1: regular mesh into a wf_array (+ min gaps), 2: supplied matrices
+template <int N, int L, int MODE, bool VEC>
+__global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G) {
+    constexpr int NR = VEC ? (N + L - 1) / L : 1;
+    constexpr int NS = N * (N + 1) / 2;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int sub = (int)(tid & (L - 1));
+    const int64_t id_raw = tid / L;
+    const bool live = id_raw < nk;
+    const int64_t id = live ? id_raw : nk - 1;   // idle tail lanes shadow the last point (shuffles stay defined)
+    double kk[4] = {0.0, 0.0, 0.0, 0.0};
+    bool wrap[4] = {false, false, false, false};
+    RegMat<N, NR> M;
+    if constexpr (MODE == 2) {
+        const cd* h = Lst.ham + id * (int64_t)(N * N);
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            M.dg[a] = h[a * N + a].x;
+#pragma unroll
+            for (int b = a + 1; b < N; ++b) M.up[a][b] = h[a * N + b];
+        }
+    } else {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d < mv.dim_k) kk[d] = Lst.k[id * mv.dim_k + d];
+        } else {
+            grid_point(G, id, kk, wrap);
+        }
+        cd z[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
+        if (mv.nR > 0) {
+            // terms grouped by lattice vector: one phase per R, then NS complex FMAs whose
+            // coefficients are wave-uniform (scalar loads) when L == 1
+            cd acc[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = cd{0.0, 0.0};
+            for (int r = sub; r < mv.nR; r += L) {
+                const cd ph = phase_of_R(z, mv.rvec[r]);
+                const cd* u = mv.rblock + (size_t)r * NS;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) cfma(acc[s], u[s], ph);
+            }
+            int slot = 0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+#pragma unroll
+                for (int b = a; b < N; ++b, ++slot) {
+                    cd v = acc[slot];
+                    if constexpr (L >= 2) {
+                        v.x += __shfl_xor(v.x, 1);
+                        v.y += __shfl_xor(v.y, 1);
+                    }
+                    if constexpr (L >= 4) {
+                        v.x += __shfl_xor(v.x, 2);
+                        v.y += __shfl_xor(v.y, 2);
+                    }
+                    if (b == a) M.dg[a] = v.x; else M.up[a][b] = v;
+                }
+            }
+        } else {
+            int slot = 0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+#pragma unroll
+                for (int b = a; b < N; ++b, ++slot) {
+                    const int t0 = mv.slot_ptr[slot], t1 = mv.slot_ptr[slot + 1];
+                    cd acc{0.0, 0.0};
+                    for (int t = t0 + sub; t < t1; t += L) cfma(acc, mv.term_amp[t], phase_of_R(z, mv.term_R[t]));
+                    if constexpr (L >= 2) {
+                        acc.x += __shfl_xor(acc.x, 1);
+                        acc.y += __shfl_xor(acc.y, 1);
+                    }
+                    if constexpr (L >= 4) {
+                        acc.x += __shfl_xor(acc.x, 2);
+                        acc.y += __shfl_xor(acc.y, 2);
+                    }
+                    if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
+                }
+            }
+        }
+    }
+    if (VEC) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int b = 0; b < N; ++b) M.v[i][b] = cd{sub + L * i == b ? 1.0 : 0.0, 0.0};
+    }
+    for (int sweep = 0; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
+        double off = 0.0, dia = 0.0;
+#pragma unroll
+        for (int p = 0; p < N; ++p) {
+            dia += M.dg[p] * M.dg[p];
+#pragma unroll
+            for (int q = p + 1; q < N; ++q) off += cabs2(M.up[p][q]);
+        }
+        if (off <= 1.0e-32 * (dia + off)) break;
+        SweepReg<N, NR, 0, 1, VEC>::run(M);
+    }
+    int rk[N];
+    double sorted[N];
+    ranks_small<N>(M.dg, rk, sorted);
+    if constexpr (MODE == 1) {
+        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * N;
+#pragma unroll
+        for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, live && sub == 0 ? sorted[b + 1] - sorted[b] : INFINITY);
+    } else {
+        if (live && sub == 0) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) Lst.eval[(int64_t)b * nk + id] = sorted[b];
+        }
+    }
+    if (VEC && live) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int o = sub + L * i;
+            if (o >= N) continue;
+            cd f{1.0, 0.0};
+            if constexpr (MODE != 2) f = cconj(expi2pi(kdot(kk, mv.orb[o])));
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (wrap[d]) f = cmul(f, G.pbc[d * N + o]);
+            }
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+                const cd val = cmul(M.v[i][b], f);
+                if constexpr (MODE == 1) wf_at(G.wv, rk[b], id)[o] = val;
+                else Lst.evec[((int64_t)rk[b] * nk + id) * N + o] = val;
+            }
+        }
+    }
+}
+
+// lanes per matrix when eigenvectors are wanted
+static int reg_lanes(int) {
+#ifdef TBK_REG_MULTILANE
+    static const int forced = [] {
+        const char* e = getenv("TBK_REG_LANES");
+        const int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4) ? v : 0;
+    }();
+    if (forced) return forced;
+#endif
+    return 1;
+}
+
+template <int N, int MODE, bool VEC>
+static int launch_reg_n(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G) {
+    const int lanes = VEC ? reg_lanes(N) : 1;
+    const unsigned blocks = (unsigned)((nk * lanes + 255) / 256);
+    if constexpr (VEC) {
+        switch (lanes) {
+#ifdef TBK_REG_MULTILANE
+            case 2: hipLaunchKernelGGL((k_solve_reg<N, 2, MODE, true>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G); break;
+            case 4: hipLaunchKernelGGL((k_solve_reg<N, 4, MODE, true>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G); break;
+#endif
+            default: hipLaunchKernelGGL((k_solve_reg<N, 1, MODE, true>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G); break;
+        }
+    } else {
+        hipLaunchKernelGGL((k_solve_reg<N, 1, MODE, false>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G);
+    }
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
+
+template <int MODE, bool VEC>
+static int launch_reg(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L, const GridArgs& G) {
+    TBK_REQUIRE(nk * 4 < (int64_t)0x7fffffff * 256, TBK_EUNSUPPORTED, "too many k-points for one launch");
+    switch (n) {
+        case 5: return launch_reg_n<5, MODE, VEC>(ctx, mv, nk, L, G);
+        case 6: return launch_reg_n<6, MODE, VEC>(ctx, mv, nk, L, G);
+        case 7: return launch_reg_n<7, MODE, VEC>(ctx, mv, nk, L, G);
+        case 8: return launch_reg_n<8, MODE, VEC>(ctx, mv, nk, L, G);
+        default: tbk_set_error("launch_reg: n=%d", n); return TBK_EINVAL;
+    }
+}
