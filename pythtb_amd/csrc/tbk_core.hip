@@ -380,19 +380,30 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
         for (int d = 0; d < dim_k; ++d) orb4[a * 4 + d] = orb[(a / ns) * dim_k + d];
 
     // the same terms grouped by lattice vector: S(k) = sum_R e^{2 pi i k.R} U_R with U_R dense over the
-    // slots -- one phase per R instead of one per term.  Built for the register-resident solvers
-    // (n = 5..8) when the blocks are reasonably full (Wannier-type long-ranged tables).
+    // slots -- one phase per R instead of one per term, and coalesced coefficient loads.  Built for
+    // the register (n = 5..8) and wavefront (n <= 64) solvers when the blocks are reasonably full
+    // (Wannier-type long-ranged tables, dense synthetic models).
     std::vector<int32_t> rvec;
     std::vector<cd> rblock;
     int nR = 0;
-    if (n >= 5 && n <= 8 && nterm > 0) {
+    // the non-empty slots {a | b<<16, t0, t1, 0}: sparse models (ribbons, slabs) have ~3n of n^2/2
+    std::vector<int32_t> nz;
+    for (int s = 0; s < nslot; ++s)
+        if (slot_ptr[s + 1] > slot_ptr[s]) {
+            nz.push_back(slot_ab[s]);
+            nz.push_back(slot_ptr[s]);
+            nz.push_back(slot_ptr[s + 1]);
+            nz.push_back(0);
+        }
+    const int nnz = (int)(nz.size() / 4);
+    if (n >= 5 && n <= 64 && nterm > 0) {
         std::map<std::array<int, 4>, int> rid;
         for (int64_t t = 0; t < nterm; ++t) {
             std::array<int, 4> key{R4[t * 4], R4[t * 4 + 1], R4[t * 4 + 2], R4[t * 4 + 3]};
             if (rid.emplace(key, (int)rid.size()).second)
                 for (int d = 0; d < 4; ++d) rvec.push_back(key[d]);
         }
-        if ((int64_t)rid.size() * nslot <= 4 * nterm + 64) {
+        if ((int64_t)rid.size() * nslot <= 4 * nterm + 64 && rid.size() <= 256) {
             nR = (int)rid.size();
             rblock.assign((size_t)nR * nslot, cd{0.0, 0.0});
             for (int s = 0; s < nslot; ++s)
@@ -415,8 +426,10 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     const size_t o_cell = al(o_ab + slot_ab.size() * sizeof(int32_t));
     const size_t o_rvec = al(o_cell + cell_ptr.size() * sizeof(int32_t));
     const size_t o_rblk = al(o_rvec + std::max<size_t>(rvec.size(), 4) * sizeof(int32_t));
-    const size_t total = al(o_rblk + std::max<size_t>(rblock.size(), 1) * sizeof(cd));
+    const size_t o_nz = al(o_rblk + std::max<size_t>(rblock.size(), 1) * sizeof(cd));
+    const size_t total = al(o_nz + std::max<size_t>(nz.size(), 4) * sizeof(int32_t));
     std::vector<unsigned char> host(total, 0);
+    if (nnz > 0) memcpy(host.data() + o_nz, nz.data(), nz.size() * sizeof(int32_t));
     if (nR > 0) {
         memcpy(host.data() + o_rvec, rvec.data(), rvec.size() * sizeof(int32_t));
         memcpy(host.data() + o_rblk, rblock.data(), rblock.size() * sizeof(cd));
@@ -461,6 +474,8 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     m->view.nR = nR;
     m->view.rvec = (const int4*)(base + o_rvec);
     m->view.rblock = (const cd*)(base + o_rblk);
+    m->view.nnz = nnz;
+    m->view.nz = (const int4*)(base + o_nz);
     *out = m;
     return TBK_OK;
 }

@@ -124,6 +124,9 @@ struct ModelView {
     int nR;
     const int4* rvec;         // [nR]
     const cd* rblock;         // [nR][nslot]
+    // the non-empty slots only: {a | b<<16, t0, t1, 0}
+    int nnz;
+    const int4* nz;           // [nnz]
 };
 
 struct tbk_model {

@@ -685,8 +685,8 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
         S.T = S.Vt;                          // unused: workgroup-per-matrix solves start cold
         S.rot = (cd*)lds_raw;
     }
-    S.eo = S.rot + 2 * half;
-    S.ev = (double*)(S.eo + n);
+    S.eo = S.rot + 2 * half;                 // doubles as the per-R phase table during assembly
+    S.ev = (double*)(S.eo + (n > mv.nR ? n : mv.nR));
     S.red = S.ev + n;
     S.pq = (int*)(S.red + 8);
     S.perm = S.pq + half;
@@ -748,17 +748,41 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
             cd z[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
-            for (int slot = lane; slot < mv.nslot; slot += NT) {
-                const int ab = mv.slot_ab[slot];
-                const int a = ab & 0xffff, b = ab >> 16;
-                const int t0 = mv.slot_ptr[slot], t1 = mv.slot_ptr[slot + 1];
-                cd acc{0.0, 0.0};
-                for (int t = t0; t < t1; ++t) cfma(acc, mv.term_amp[t], phase_of_R(z, mv.term_R[t]));
-                if (a == b) {
-                    S.A[a * ld + a] = cd{acc.x, 0.0};
-                } else {
-                    S.A[a * ld + b] = acc;
-                    S.A[b * ld + a] = cconj(acc);
+            if (mv.nR > 0) {
+                // dense model: S_slot = sum_R U_R[slot] e^{2 pi i k.R}.  One lane per phase, then every
+                // slot is nR independent, coalesced coefficient loads (the table stays in L2)
+                for (int r = lane; r < mv.nR; r += NT) S.eo[r] = phase_of_R(z, mv.rvec[r]);
+                __syncthreads();
+                for (int slot = lane; slot < mv.nslot; slot += NT) {
+                    const int ab = mv.slot_ab[slot];
+                    const int a = ab & 0xffff, b = ab >> 16;
+                    const cd* u = mv.rblock + slot;
+                    cd acc{0.0, 0.0};
+#pragma unroll 4
+                    for (int r = 0; r < mv.nR; ++r) cfma(acc, u[(size_t)r * mv.nslot], S.eo[r]);
+                    if (a == b) {
+                        S.A[a * ld + a] = cd{acc.x, 0.0};
+                    } else {
+                        S.A[a * ld + b] = acc;
+                        S.A[b * ld + a] = cconj(acc);
+                    }
+                }
+                __syncthreads();   // phases consumed before eo is rewritten below
+            } else {
+                // sparse model (ribbons, slabs): clear A, then walk the non-empty slots only
+                for (int e = lane; e < n * ld; e += NT) S.A[e] = cd{0.0, 0.0};
+                __syncthreads();
+                for (int i = lane; i < mv.nnz; i += NT) {
+                    const int4 s = mv.nz[i];
+                    const int a = s.x & 0xffff, b = s.x >> 16;
+                    cd acc{0.0, 0.0};
+                    for (int t = s.y; t < s.z; ++t) cfma(acc, mv.term_amp[t], phase_of_R(z, mv.term_R[t]));
+                    if (a == b) {
+                        S.A[a * ld + a] = cd{acc.x, 0.0};
+                    } else {
+                        S.A[a * ld + b] = acc;
+                        S.A[b * ld + a] = cconj(acc);
+                    }
                 }
             }
         }
@@ -800,7 +824,8 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
 
         // ---- parallel-ordered Jacobi sweeps
         bool converged = false;
-        for (int sweep = 0; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
+        const int sweep_cap = G.ablate >= 10 ? G.ablate - 10 : TBK_JACOBI_MAX_SWEEPS;   // diagnostics: TBK_ABLATE_GRID=10+k caps the sweeps at k
+        for (int sweep = 0; sweep < sweep_cap; ++sweep) {
             double off = 0.0, dia = 0.0;
             if (walker)
                 for (int a = i0; a < n; a += istep) {
@@ -915,7 +940,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
                 __syncthreads();
             }
         }
-        if (!converged && lane == 0) atomicExch(noconv_flag, 1);
+        if (!converged && lane == 0 && G.ablate < 10) atomicExch(noconv_flag, 1);
 
         // ---- order eigenvalues (stable ascending), write out
         if (lane < n) S.ev[lane] = S.A[lane * ld + lane].x;
@@ -954,11 +979,11 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
     }
 }
 
-static size_t wave_lds_bytes(int n, bool with_t) {
+static size_t wave_lds_bytes(int n, bool with_t, int nR = 0) {
     const int ld = n + 1, half = (n + 1) / 2;
     size_t b = (size_t)(with_t ? 3 : 2) * n * ld * sizeof(cd);  // A, Vt (, T)
     b += (size_t)2 * half * sizeof(cd);          // rot
-    b += (size_t)n * sizeof(cd);                 // eo
+    b += (size_t)std::max(n, nR) * sizeof(cd);   // eo (also the per-R phases during assembly)
     b += (size_t)(n + 8) * sizeof(double);       // ev, red
     b += (size_t)(half + n) * sizeof(int);       // pq, perm
     return (b + 15) & ~(size_t)15;
@@ -1066,8 +1091,8 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }
-    const bool with_t = wave_lds_bytes(n, true) <= 160 * 1024;   // else every point starts cold
-    const size_t lds = wave_lds_bytes(n, with_t);
+    const bool with_t = wave_lds_bytes(n, true, mv.nR) <= 160 * 1024;   // else every point starts cold
+    const size_t lds = wave_lds_bytes(n, with_t, mv.nR);
     TBK_REQUIRE(lds <= 160 * 1024, TBK_EUNSUPPORTED, "nsta=%d needs %zu bytes of LDS per wavefront", n, lds);
     static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
     if (lds > 64 * 1024 && !attr_set[VEC][MODE]) {
