@@ -856,7 +856,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
                 break;
             }
             for (int round = 0; round < m - 1; ++round) {
-                // pairing of round `round`: player m-1 fixed, the others rotate
+                // pairing of round `round`: player m-1 fixed (the bye when n is odd), the others rotate
                 if (lane < half) {
                     int p, q;
                     if (lane == 0) {
@@ -866,15 +866,9 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
                         p = (round + lane) % (m - 1);
                         q = (round - lane + (m - 1)) % (m - 1);
                     }
-                    if (p > q) {
-                        const int t = p;
-                        p = q;
-                        q = t;
-                    }
                     double c = 1.0;
                     cd sw{0.0, 0.0};
-                    int code = -1;
-                    if (q < n) {  // not the bye
+                    if (p < n) {  // not the bye
                         const cd g = S.A[p * ld + q];
                         const double g2 = cabs2(g);
                         if (g2 > 0.0) {   // same division-free parameters as rotate<>
@@ -884,58 +878,69 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
                             const double sg = copysign(1.0, a);
                             c = (aa + r) * inv;
                             sw = cd{sg * g.x * inv, sg * g.y * inv};
-                            code = p | (q << 16);
                         }
                     }
-                    S.pq[lane] = code;
+                    S.pq[lane] = p | (q << 16);
                     S.rot[2 * lane] = cd{c, 0.0};
                     S.rot[2 * lane + 1] = sw;
                 }
                 __syncthreads();
-                // columns: A <- A J   (rows r fastest across lanes)
-                for (int i = walker ? i0 : half; i < half; i += istep) {
-                    const int r = c0;
-                    const int code = S.pq[i];
-                    if (code < 0) continue;
-                    const int p = code & 0xffff, q = code >> 16;
-                    const double c = S.rot[2 * i].x;
-                    const cd sw = S.rot[2 * i + 1];
-                    const cd x = S.A[r * ld + p], y = S.A[r * ld + q];
-                    S.A[r * ld + p] = cd{c * x.x - (sw.x * y.x + sw.y * y.y), c * x.y - (sw.x * y.y - sw.y * y.x)};
-                    S.A[r * ld + q] = cd{(sw.x * x.x - sw.y * x.y) + c * y.x, (sw.x * x.y + sw.y * x.x) + c * y.y};
+                // A <- J^+ A J, one 2x2 block {p_i,q_i} x {p_j,q_j} at a time: the blocks of a round are
+                // disjoint, so every element is read and written once, in place
+                for (int blk = lane; blk < half * half; blk += NT) {
+                    const int i = blk / half, j = blk - i * half;
+                    const int ci_ = S.pq[i], cj_ = S.pq[j];
+                    const int pi = ci_ & 0xffff, qi = ci_ >> 16, pj = cj_ & 0xffff, qj = cj_ >> 16;
+                    const bool vi = pi < n, vj = pj < n;   // false: the bye "player"
+                    const double ci = S.rot[2 * i].x, cj = S.rot[2 * j].x;
+                    const cd si = S.rot[2 * i + 1], sj = S.rot[2 * j + 1];
+                    const cd zero{0.0, 0.0};
+                    cd x00 = vi && vj ? S.A[pi * ld + pj] : zero;
+                    cd x01 = vi ? S.A[pi * ld + qj] : zero;
+                    cd x10 = vj ? S.A[qi * ld + pj] : zero;
+                    cd x11 = S.A[qi * ld + qj];
+                    {   // columns:  a'_rp = c a_rp - conj(s) a_rq ;  a'_rq = s a_rp + c a_rq
+                        const cd a = x00, b = x01;
+                        x00 = cd{cj * a.x - (sj.x * b.x + sj.y * b.y), cj * a.y - (sj.x * b.y - sj.y * b.x)};
+                        x01 = cd{(sj.x * a.x - sj.y * a.y) + cj * b.x, (sj.x * a.y + sj.y * a.x) + cj * b.y};
+                    }
+                    {
+                        const cd a = x10, b = x11;
+                        x10 = cd{cj * a.x - (sj.x * b.x + sj.y * b.y), cj * a.y - (sj.x * b.y - sj.y * b.x)};
+                        x11 = cd{(sj.x * a.x - sj.y * a.y) + cj * b.x, (sj.x * a.y + sj.y * a.x) + cj * b.y};
+                    }
+                    {   // rows:  a'_pc = c a_pc - s a_qc ;  a'_qc = conj(s) a_pc + c a_qc
+                        const cd a = x00, b = x10;
+                        x00 = cd{ci * a.x - (si.x * b.x - si.y * b.y), ci * a.y - (si.x * b.y + si.y * b.x)};
+                        x10 = cd{(si.x * a.x + si.y * a.y) + ci * b.x, (si.x * a.y - si.y * a.x) + ci * b.y};
+                    }
+                    {
+                        const cd a = x01, b = x11;
+                        x01 = cd{ci * a.x - (si.x * b.x - si.y * b.y), ci * a.y - (si.x * b.y + si.y * b.x)};
+                        x11 = cd{(si.x * a.x + si.y * a.y) + ci * b.x, (si.x * a.y - si.y * a.x) + ci * b.y};
+                    }
+                    if (i == j) {   // the rotated pair itself: exactly diagonal, real
+                        x01 = zero;
+                        x10 = zero;
+                        x00.y = 0.0;
+                        x11.y = 0.0;
+                    }
+                    if (vi && vj) S.A[pi * ld + pj] = x00;
+                    if (vi) S.A[pi * ld + qj] = x01;
+                    if (vj) S.A[qi * ld + pj] = x10;
+                    S.A[qi * ld + qj] = x11;
                 }
-                __syncthreads();
-                // rows: A <- J^+ A, and V^T rows p,q (V <- V J)
+                // V <- V J (rows p, q of V^T); V is kept in every mode (it is the next point's basis)
                 for (int i = walker ? i0 : half; i < half; i += istep) {
                     const int cidx = c0;
                     const int code = S.pq[i];
-                    if (code < 0) continue;
                     const int p = code & 0xffff, q = code >> 16;
+                    if (p >= n) continue;
                     const double c = S.rot[2 * i].x;
                     const cd sw = S.rot[2 * i + 1];
-                    {   // a'_pc = c a_pc - sw a_qc ; a'_qc = conj(sw) a_pc + c a_qc
-                        const cd x = S.A[p * ld + cidx], y = S.A[q * ld + cidx];
-                        S.A[p * ld + cidx] = cd{c * x.x - (sw.x * y.x - sw.y * y.y), c * x.y - (sw.x * y.y + sw.y * y.x)};
-                        S.A[q * ld + cidx] = cd{(sw.x * x.x + sw.y * x.y) + c * y.x, (sw.x * x.y - sw.y * x.x) + c * y.y};
-                    }
-                    {   // V is kept in every mode (it is the next point's starting basis):
-                        // v'_rp = c v_rp - conj(sw) v_rq ; v'_rq = sw v_rp + c v_rq
-                        const cd x = S.Vt[p * ld + cidx], y = S.Vt[q * ld + cidx];
-                        S.Vt[p * ld + cidx] = cd{c * x.x - (sw.x * y.x + sw.y * y.y), c * x.y - (sw.x * y.y - sw.y * y.x)};
-                        S.Vt[q * ld + cidx] = cd{(sw.x * x.x - sw.y * x.y) + c * y.x, (sw.x * x.y + sw.y * x.x) + c * y.y};
-                    }
-                }
-                __syncthreads();
-                // pin the rotated pair exactly: zero off-diagonal, real diagonal
-                if (lane < half) {
-                    const int code = S.pq[lane];
-                    if (code >= 0) {
-                        const int p = code & 0xffff, q = code >> 16;
-                        S.A[p * ld + q] = cd{0.0, 0.0};
-                        S.A[q * ld + p] = cd{0.0, 0.0};
-                        S.A[p * ld + p].y = 0.0;
-                        S.A[q * ld + q].y = 0.0;
-                    }
+                    const cd x = S.Vt[p * ld + cidx], y = S.Vt[q * ld + cidx];
+                    S.Vt[p * ld + cidx] = cd{c * x.x - (sw.x * y.x + sw.y * y.y), c * x.y - (sw.x * y.y - sw.y * y.x)};
+                    S.Vt[q * ld + cidx] = cd{(sw.x * x.x - sw.y * x.y) + c * y.x, (sw.x * x.y + sw.y * x.x) + c * y.y};
                 }
                 __syncthreads();
             }
