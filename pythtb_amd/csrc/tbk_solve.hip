@@ -1057,7 +1057,19 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
                        const GridArgs& G) {
     int* flag = ctx->flags_dev;  // sticky until read by check_noconv
     GridArgs G2 = G;
-    if (n > 256) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
+    static const int big_from = [] {   // tuning knob: smallest n sent to the whole-chip solver regardless of batch size
+        const char* e = getenv("TBK_BIG_FROM");
+        return e ? std::max(65, atoi(e)) : 257;
+    }();
+    // Few matrices (fewer than ~CUs/2) cannot fill the chip one workgroup each: give them the whole-chip
+    // solver too (n = 128: 32 k-points 21.6 -> 10.5 ms; 128: equal; 512: 108 vs 134 ms).  A mesh window
+    // decides on the size of the GLOBAL mesh, so every shard of an array takes the same route.
+    int64_t nk_eff = nk;
+    if (MODE == 1) {
+        nk_eff = 1;
+        for (int d = 0; d < G.wv.dim_arr; ++d) nk_eff *= G.gmesh[d];
+    }
+    if (n >= big_from || (n > 64 && nk_eff <= 160)) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
     static const bool use_reg = [] {   // TBK_REG=0: fall back to the wavefront-per-matrix kernel (A/B runs)
         const char* e = getenv("TBK_REG");
         return !(e && atoi(e) == 0);
