@@ -403,7 +403,8 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
             if (rid.emplace(key, (int)rid.size()).second)
                 for (int d = 0; d < 4; ++d) rvec.push_back(key[d]);
         }
-        if ((int64_t)rid.size() * nslot <= 4 * nterm + 64 && rid.size() <= 256) {
+        // n <= 16: always (the register kernels assemble from this table only), else when dense enough
+        if (rid.size() <= 256 && ((n <= 16 && rid.size() <= 64) || (int64_t)rid.size() * nslot <= 4 * nterm + 64)) {
             nR = (int)rid.size();
             rblock.assign((size_t)nR * nslot, cd{0.0, 0.0});
             for (int s = 0; s < nslot; ++s)

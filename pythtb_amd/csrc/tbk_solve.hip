@@ -1034,6 +1034,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 
 #include "tbk_solve_big.inl"   // n > 256: one kernel launch per Jacobi round, whole chip per batch
 #include "tbk_solve_reg.inl"   // n = 5..8: register-resident cyclic Jacobi, 1/2/4 lanes per matrix
+#include "tbk_solve_row16.inl" // n = 15, 16 on lists: one DPP row of 16 lanes per matrix, rows of A in registers
 
 // ---------------------------------------------------------------------------
 // host-side launchers
@@ -1075,6 +1076,18 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         return !(e && atoi(e) == 0);
     }();
     if (n <= 8 && use_reg) return launch_reg<MODE, VEC>(ctx, mv, n, nk, L, G);
+    static const bool use_row16 = [] {   // TBK_ROW16=0: wavefront-per-matrix LDS kernel instead (A/B runs)
+        const char* e = getenv("TBK_ROW16");
+        return !(e && atoi(e) == 0);
+    }();
+    // One DPP row per matrix pays off where its fixed 16x16 cost is not wasted on padding and where the
+    // LDS kernel cannot warm-start profitably: n = 15, 16 on k lists and supplied matrices (262144 k, n = 16:
+    // 6.8-7.1 ms eigenvalues against 13.1 (mesh order) / 19.0 (random order) ms, 12.1 against 12.5 / 17.5 ms
+    // with vectors; at n = 12 and below the LDS kernel wins).  Mesh solves keep the warm-started LDS kernel
+    // (a fine mesh needs ~3 sweeps there).  Needs the R-grouped table unless the matrices are supplied.
+    if constexpr (MODE != 1) {
+        if (n >= 15 && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0)) return launch_row16<MODE, VEC>(ctx, mv, nk, L, G);
+    }
     if (n > 64) {
         // ---- workgroup per matrix (n = 65..256): 256 threads, A and V^T in a global
         // workspace, cold start.  Ribbon / slab models: few, large matrices.

@@ -650,6 +650,42 @@ def test_very_wide_models_whole_chip_jacobi(tb):
         assert np.max(np.abs(hmat[i] @ v[:, i].T - v[:, i].T * e[:, i])) < 1e-10 * np.abs(want).max()
 
 
+def test_row16_register_solver(tb):
+    """n = 15, 16 on k lists / supplied matrices: one DPP row of 16 lanes per matrix (15 exercises the padding row)."""
+    from oracle import tb_oracle as orc
+    from pythtb_amd import _lib
+    for norb, nspin, seed in ((16, 1, 3), (15, 1, 4), (8, 2, 5)):
+        m = hp.random_model(tb.tb_model, norb, 2, nspin, seed, nhop=90, rmax=1)
+        n = norb * nspin
+        k = np.random.default_rng(seed).uniform(-0.5, 0.5, size=(37, 2))
+        ev, vec = m.solve_all(k, eig_vectors=True)
+        ref = orc.solve_all_vec(m, k)
+        scale = np.abs(ref).max()
+        assert np.max(np.abs(ev - ref)) < 1e-12 * scale
+        assert np.max(np.abs(m.solve_all(k) - ref)) < 1e-12 * scale
+        ham = orc.ham_batch(m, k)
+        V = vec.reshape(n, len(k), n)
+        for ik in range(len(k)):
+            assert np.max(np.abs(V[:, ik].conj() @ V[:, ik].T - np.identity(n))) < 1e-12
+            assert np.max(np.abs(ham[ik] @ V[:, ik].T - V[:, ik].T * ev[:, ik])) < 1e-11 * scale
+    rng = np.random.default_rng(9)
+    for n in (15, 16):
+        a = rng.normal(size=(70, n, n)) + 1j * rng.normal(size=(70, n, n))
+        hmat = np.ascontiguousarray(a + a.conj().transpose(0, 2, 1))
+        hmat[3] = np.diag(np.arange(n, dtype=float))                 # already diagonal
+        hmat[4] = np.ones((n, n))                                     # rank one: n-1 degenerate eigenvalues
+        hmat[5] = 0.0
+        e = np.zeros((n, 70))
+        v = np.zeros((n, 70, n), dtype=complex)
+        _lib.check(_lib.lib.tbk_eigh_batch(_lib.default_context().handle, n, _lib.dptr(hmat), 70, _lib.dptr(e), _lib.dptr(v)))
+        for i in range(70):
+            want = np.linalg.eigvalsh(hmat[i])
+            sc = max(1.0, np.abs(want).max())
+            assert np.max(np.abs(e[:, i] - want)) < 1e-12 * sc
+            assert np.max(np.abs(hmat[i] @ v[:, i].T - v[:, i].T * e[:, i])) < 1e-11 * sc
+            assert np.max(np.abs(v[:, i].conj() @ v[:, i].T - np.identity(n))) < 1e-12
+
+
 def test_rccl_single_rank_allgather(tb):
     """tbk_comm_* with a 1-rank communicator (the N>1 path's collective, as far as one GPU goes)."""
     import ctypes as C
