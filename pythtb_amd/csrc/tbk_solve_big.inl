@@ -389,7 +389,7 @@ static int launch_big(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
             TBK_HIP(hipStreamSynchronize(ctx->stream));
             if (pending == 0) break;
             for (int round = 0; round < m - 1; ++round) {
-                hipLaunchKernelGGL(k_big_rotate, dim3(tiles_x, 2 * tiles_a, nb), dim3(256), 0, ctx->stream, W, round, par, tiles_a);
+                hipLaunchKernelGGL(k_big_rotate, dim3(tiles_x, (VEC ? 2 : 1) * tiles_a, nb), dim3(256), 0, ctx->stream, W, round, par, tiles_a);
                 par ^= 1;
             }
             TBK_HIP(hipGetLastError());
