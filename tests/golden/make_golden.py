@@ -145,6 +145,18 @@ def cubic16(seed=0):                          # SURVEY.md section 8d recipe
     return m
 
 
+def quad4():                                   # 4-D k-space (dim_k = dim_r = 4), 3 orbitals: the 4-D slicing paths
+    rng = np.random.default_rng(3)
+    m = quiet(ref.tb_model, 4, 4, np.identity(4), rng.random((3, 4)))
+    m.set_onsite([-1.0, 0.2, 1.3])
+    r = np.random.default_rng(5)
+    for (i, j, R) in [(0, 1, [0, 0, 0, 0]), (1, 2, [0, 0, 0, 0]), (0, 2, [1, 0, 0, 0]), (0, 0, [0, 1, 0, 0]),
+                      (1, 1, [0, 0, 1, 0]), (2, 2, [0, 0, 0, 1]), (0, 1, [0, 1, -1, 0]), (1, 2, [1, 0, 0, -1]),
+                      (2, 0, [0, 0, 1, 1])]:
+        m.set_hop(0.3 * (r.standard_normal() + 1j * r.standard_normal()), i, j, R)
+    return m
+
+
 def save(name, **arrs):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrs)
@@ -360,6 +372,10 @@ def full_size():
 
 
 if __name__ == "__main__":
+    if "--quad4" in sys.argv:
+        grid_case("quad4_4354", quad4(), [4, 3, 5, 4], [0.1, -0.2, 0.3, 0.05], [[0], [0, 1]], [],
+                  flux_dirs=[[0, 1], [2, 3], [3, 1]])
+        sys.exit(0)
     if "--full" in sys.argv:
         full_size()
         sys.exit(0)

@@ -153,6 +153,7 @@ GRID_CASES = {
     "per02_11": dict(occs=[0, 1], dirs=[0, 1], flux=[(0, 1)]),
     "spin_chain_25": dict(occs=[0, 1], dirs=[0], flux=[]),
     "cubic16_9": dict(occs=[0, 1], dirs=[0, 1, 2], flux=[(0, 1), (1, 2), (2, 0)]),
+    "quad4_4354": dict(occs=[0, 1], dirs=[], flux=[(0, 1), (2, 3), (3, 1)]),     # 4-D: flux only (pythtb.py:3028-3029)
 }
 
 
@@ -190,6 +191,9 @@ def test_grid_flux_phase_match_reference(tb, name):
                 got = w.berry_phase(occ, d if dim > 1 else None, contin=contin, berry_evals=True)
                 assert np.shape(got) == ref.shape
                 assert_phase_sets_close(got, ref, 1e-9)
+    if dim == 4:
+        with pytest.raises(Exception, match="Wrong dimensionality"):
+            w.berry_phase([0], 1)
     # the device array and its host mirror agree with impose_pbc semantics
     host = w._wfs
     assert host.shape == tuple(mesh + [m._nsta, m._norb] + ([2] if m._nspin == 2 else []))
