@@ -118,3 +118,22 @@ def test_spinor_model_equals_its_doubled_scalar_model(tb):    # test_spin.py:8-6
     m1.set_hop(-0.12, 1, 2, [2, 3])
     m1.set_hop([-0.34, 0.21, -0.14, 0.29], 2, 0, [-1, 2])       # a0 I + a1 sx + a2 sy + a3 sz
     equivalent(tb, [m0, m1], [2, 1], [[0, 1], [0, 1]])
+
+
+def test_smallest_models(tb):                               # tests/test_pythtb.py:19-62
+    assert isinstance(tb.__version__, str) and tb.__version__
+    one = quiet(tb.tb_model, 0, 1, [[1.0]], [[0.0]])
+    one.set_onsite([2.5])
+    ev = one.solve_all()
+    assert ev.shape == (1,) and np.allclose(ev, [2.5])
+    assert np.array_equal(one.solve_all(), one.solve_all())
+    two = quiet(tb.tb_model, 0, 1, [[1.0]], [[0.0], [0.5]])
+    two.set_onsite([0.0, 0.0])
+    two.set_hop(3.0, 0, 1)
+    ev = np.sort(two.solve_all())
+    assert ev.shape == (2,) and np.allclose(ev, [-3.0, 3.0])
+    chain = quiet(tb.tb_model, 1, 1, [[1.0]], [[0.0]])
+    chain.set_onsite([0.0])
+    k_vec, k_dist, k_node = chain.k_path([[0.0], [0.5]], 5, report=False)
+    assert k_vec.shape == (5, 1) and k_dist.shape == (5,) and len(k_node) == 2
+    assert k_dist[0] == pytest.approx(0.0) and k_dist[-1] > 0.0
