@@ -61,7 +61,6 @@ extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
     }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->scratch) hipFree(c->scratch);
-    if (c->pinned) hipHostFree(c->pinned);
     if (c->flags_dev) hipFree(c->flags_dev);
     if (c->work) hipFree(c->work);
     hipEventDestroy(c->timer0);
@@ -102,19 +101,6 @@ int tbk_ctx_scratch(tbk_ctx* c, size_t bytes, void** out) {
         c->scratch_bytes = want;
     }
     *out = c->scratch;
-    return TBK_OK;
-}
-
-int tbk_ctx_pinned(tbk_ctx* c, size_t bytes, void** out) {
-    if (bytes > c->pinned_bytes) {
-        TBK_HIP(hipStreamSynchronize(c->stream));
-        if (c->pinned) TBK_HIP(hipHostFree(c->pinned));
-        c->pinned = nullptr;
-        size_t want = std::max(bytes, (size_t)1 << 16);
-        TBK_HIP(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
-        c->pinned_bytes = want;
-    }
-    *out = c->pinned;
     return TBK_OK;
 }
 

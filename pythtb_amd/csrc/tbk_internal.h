@@ -81,8 +81,6 @@ struct tbk_ctx {
     // scratch reused across calls (grown on demand, stream-ordered use only)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
-    void* pinned = nullptr;  // small pinned staging buffer for results
-    size_t pinned_bytes = 0;
     int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
     void* work = nullptr;      // workspace of the workgroup-per-matrix eigen-solver (n > 64)
     size_t work_bytes = 0;
@@ -92,7 +90,6 @@ struct tbk_ctx {
 };
 
 int tbk_ctx_scratch(tbk_ctx* ctx, size_t bytes, void** out);
-int tbk_ctx_pinned(tbk_ctx* ctx, size_t bytes, void** out);
 
 // RAII bracket recording HIP events around one kernel launch when profiling.
 struct ProfScope {
@@ -119,7 +116,8 @@ struct ModelView {
     // p in [-pmax, pmax]; terms are ordered (slot, p, ...) so cells are ranges
     int pmax;
     const int32_t* cell_ptr;  // [nslot*(2*pmax+1) + 1]
-    // the same terms grouped by lattice vector (n = 5..8 only, 0 when not built):
+    // the same terms grouped by lattice vector (built for n = 5..16 always, up to 64 when the blocks
+    // are dense; nR = 0 when not built):
     // S_slot(k) = sum_r rblock[r][slot] * exp(2 pi i k.rvec[r])
     int nR;
     const int4* rvec;         // [nR]
