@@ -553,7 +553,14 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
         const int64_t point = (int64_t)row * nlast + jj;
         const cd zl = G.tz[last][jj];
         SmallMat<N> M;
-        {
+        if (G.ablate == 2) {   // diagnostics: no assembly, no eigen-solve (the store stream alone)
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+                M.dg[a] = a + zl.x;
+#pragma unroll
+                for (int b = 0; b < N; ++b) M.v[a][b] = cd{zl.x + a, zl.y + b};
+            }
+        } else {
             int slot = 0;
 #pragma unroll
             for (int a = 0; a < N; ++a) {
@@ -579,9 +586,9 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
                     if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
                 }
             }
+            init_vectors<N, true>(M);
+            jacobi_small<N, true>(M);
         }
-        init_vectors<N, true>(M);
-        jacobi_small<N, true>(M);
         int rk[N];
         double sorted[N];
         if constexpr (N <= 2) {                   // the closed forms come out ascending
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const int e = i * 64 + lane;
-                if (e < nvalid) dst[e] = stage[e];
+                if (e < nvalid && (G.ablate != 1 || sorted[0] == 1.2345e300)) dst[e] = stage[e];   // ablate 1: no stores
             }
         }
         (void)point;
