@@ -568,6 +568,7 @@ extern "C" int tbk_wfs_free(tbk_wfs* w) {
     hipStreamSynchronize(w->ctx->stream);
     if (w->view.data) hipFree(w->view.data);
     if (w->gaps_dev) hipFree(w->gaps_dev);
+    if (w->gap_part_dev) hipFree(w->gap_part_dev);
     if (w->pbc_dev) hipFree(w->pbc_dev);
     if (w->tab_dev) hipFree(w->tab_dev);
     if (w->flux_totals_dev) hipFree(w->flux_totals_dev);

@@ -164,6 +164,8 @@ struct tbk_wfs {
     // each launch min-reduces into its parity and re-arms the other one for the next launch
     unsigned long long* gaps_dev = nullptr;
     int gaps_n = 0, gaps_parity = 0;
+    double* gap_part_dev = nullptr;          // per-tile minima of the row kernel (n <= 4), [ntiles][n-1]
+    int64_t gap_part_cap = 0, gap_part_n = 0; // gap_part_n > 0: the last solve wrote partials, not shards
     cd* pbc_dev = nullptr;                   // [TBK_MAX_DIM][nsta]
     // per-axis phase tables of the regular mesh (rebuilt only when their inputs change)
     cd* tab_dev = nullptr;                   // z[d][i] then f[d][i][n]

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include "tbk_internal.h"
 
 #define TBK_JACOBI_MAX_SWEEPS 30
@@ -31,6 +32,7 @@ struct GridArgs {
     const cd* pbc;           // [TBK_MAX_DIM][nsta]
     unsigned long long* gaps;       // [TBK_GAP_SHARDS][nsta] min-reduced by this launch
     unsigned long long* gaps_next;  // the other parity: re-armed (+inf) for the next launch
+    double* gap_part;               // k_grid_rows: [ntiles][n-1] per-tile minima (no atomics)
     // per-axis tables of the regular mesh: z[d][i] = exp(2 pi i k_d(i)),
     // f[d][i*n+o] = exp(-2 pi i k_d(i) tau_o,d) * (pbc phase if i is the periodic image)
     const cd* tz[TBK_MAX_DIM];
@@ -507,9 +509,6 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     cd frow[N];
 #pragma unroll
     for (int o = 0; o < N; ++o) frow[o] = cd{1.0, 0.0};
-    if (blockIdx.x == 0 && threadIdx.x < (N > 1 ? N - 1 : 0)) {   // re-arm the other parity
-        for (int s = 0; s < TBK_GAP_SHARDS; ++s) G.gaps_next[s * N + threadIdx.x] = 0x7ff0000000000000ull;
-    }
     if (live) {
         row = (unsigned)(tile / G.tpr);
         const int ts = (int)(tile - (int64_t)row * G.tpr);
@@ -542,16 +541,44 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     }
     __syncthreads();
     if (!live) return;
+    if (G.ablate == 4) {   // diagnostics: tile set-up only
+        if (C[0].x == 1.2345e300) G.wv.data[0] = C[1];
+        return;
+    }
 
     double gmin[N > 1 ? N - 1 : 1];
 #pragma unroll
     for (int b = 0; b + 1 < N; ++b) gmin[b] = __longlong_as_double(0x7ff0000000000000ll);
-    for (int jc = jc0; jc < jc1; ++jc) {
-        const int jl = jc * 64 + lane;
-        const bool active = jl < nlast;
-        const int jj = active ? jl : nlast - 1;       // idle lanes shadow the row's last point (no stores)
-        const int64_t point = (int64_t)row * nlast + jj;
-        const cd zl = G.tz[last][jj];
+    // The per-point table entries of chunk jc+1 are fetched while chunk jc is being solved: vmcnt counts
+    // loads and stores in issue order, so a load issued AFTER a chunk's stores could only be waited for
+    // together with them -- every wavefront would sit out the full write latency once per chunk.
+    cd zl_next{1.0, 0.0}, tf_next[N];
+    {
+        const int j0 = min(jc0 * 64 + lane, nlast - 1);
+        zl_next = G.tz[last][j0];
+#pragma unroll
+        for (int o = 0; o < N; ++o) tf_next[o] = G.tf[last][(int64_t)j0 * N + o];
+        // consume them here: loads still pending at the loop entry would be merged into the loop-head
+        // state of the waitcnt pass and cost a vmcnt(0) on every iteration
+        asm volatile("" ::"v"(zl_next.x), "v"(zl_next.y));
+#pragma unroll
+        for (int o = 0; o < N; ++o) asm volatile("" ::"v"(tf_next[o].x), "v"(tf_next[o].y));
+    }
+    // FULL chunks (64 valid points) store unconditionally: with a fixed number of stores per iteration the
+    // compiler can wait for the prefetched loads with vmcnt(2N) and leave the stores in flight; any
+    // store under a lane condition makes that count unknown and forces vmcnt(0) at the loop head.
+    auto chunk = [&](const int jc, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const cd zl = zl_next;
+        cd tfl[N];
+#pragma unroll
+        for (int o = 0; o < N; ++o) tfl[o] = tf_next[o];
+        if (jc + 1 < jc1 && G.ablate != 5) {   // (ablate 5: diagnostics, no per-chunk table loads)
+            const int jn = min((jc + 1) * 64 + lane, nlast - 1);
+            zl_next = G.tz[last][jn];
+#pragma unroll
+            for (int o = 0; o < N; ++o) tf_next[o] = G.tf[last][(int64_t)jn * N + o];
+        }
         SmallMat<N> M;
         if (G.ablate == 2) {   // diagnostics: no assembly, no eigen-solve (the store stream alone)
 #pragma unroll
@@ -605,11 +632,11 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
         // eigenvectors of H: D^+ v, periodic-image phases folded into fo
         cd fo[N];
 #pragma unroll
-        for (int o = 0; o < N; ++o) fo[o] = cmul(frow[o], G.tf[last][(int64_t)jj * N + o]);
+        for (int o = 0; o < N; ++o) fo[o] = cmul(frow[o], tfl[o]);
         // LDS-staged store: per band plane the wave owns one contiguous run of
         // 64*N elements, so lanes trade elements through LDS and every store
         // instruction writes 1 KiB of consecutive bytes.
-        const int nvalid = min(64, nlast - jc * 64) * N;
+        const int nvalid = G.ablate == 1 ? 0 : min(64, nlast - jc * 64) * N;   // (ablate 1: no stores, diagnostics)
         const int64_t point0 = (int64_t)row * nlast + (int64_t)jc * 64;
 #pragma unroll
         for (int r = 0; r < N; ++r) {
@@ -634,16 +661,26 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const int e = i * 64 + lane;
-                if (e < nvalid && (G.ablate != 1 || sorted[0] == 1.2345e300)) dst[e] = stage[e];   // ablate 1: no stores
+                if constexpr (FULL) dst[e] = stage[e];
+                else if (e < nvalid) dst[e] = stage[e];
             }
         }
-        (void)point;
-        (void)active;
-    }
+    };
+    const int jfull = G.ablate == 1 ? jc0 : max(jc0, min(jc1, nlast / 64));   // chunks [jc0, jfull) are complete
+    for (int jc = jc0; jc < jfull; ++jc) chunk(jc, std::true_type{});
+    for (int jc = jfull; jc < jc1; ++jc) chunk(jc, std::false_type{});
     if constexpr (N > 1) {
-        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * N;
+        // min gaps: one plain store per tile and band pair, reduced when the result is asked for.  (A guarded
+        // atomicMin here needs the guard's value: loaded at the end it keeps the wavefront from retiring for
+        // a memory latency -- 3.8 us of the 2048^2 solve; loaded at set-up it is still +inf for every early
+        // wavefront and 10^4 atomics pile up on 64 addresses -- 71 us.)
 #pragma unroll
-        for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, gmin[b]);
+        for (int b = 0; b + 1 < N; ++b) {
+            double g = gmin[b];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) g = fmin(g, __shfl_xor(g, off));
+            if (lane == 0) G.gap_part[tile * (N - 1) + b] = g;
+        }
     }
 }
 
@@ -1035,6 +1072,20 @@ __global__ __launch_bounds__(256) void k_gen_ham(const ModelView mv, const int64
     }
 }
 
+// min over the per-tile partial gaps of k_grid_rows: one workgroup per band pair
+__global__ __launch_bounds__(256) void k_gap_part_reduce(const double* __restrict__ part, const int64_t ntiles, const int ng,
+                                                         double* __restrict__ out) {
+    const int b = blockIdx.x;
+    double g = INFINITY;
+    for (int64_t t = threadIdx.x; t < ntiles; t += 256) g = fmin(g, part[t * ng + b]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) g = fmin(g, __shfl_xor(g, off));
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) out[b] = fmax(fmin(fmin(red[0], red[1]), fmin(red[2], red[3])), 0.0);
+}
+
 __global__ void k_arm_gaps(unsigned long long* p, const int n) {
     for (int i = threadIdx.x; i < TBK_GAP_SHARDS * n; i += blockDim.x) p[i] = 0x7ff0000000000000ull;
 }
@@ -1390,6 +1441,7 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
     G.gaps_next = w->gaps_dev + (size_t)(1 - w->gaps_parity) * half;
     w->gaps_parity = 1 - w->gaps_parity;   // *_result reads 1 - gaps_parity
     w->gaps_n = n - 1;
+    w->gap_part_n = 0;
     G.last = D - 1;
     G.cpr = (v.mesh[D - 1] + 63) / 64;
     G.nchunks = (v.npts / v.mesh[D - 1]) * G.cpr;
@@ -1412,6 +1464,17 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
         const char* old = getenv("TBK_GRID_KERNEL");
         if (lds <= 48 * 1024 && !(old && atoi(old) == 1)) {
             const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
+            const int64_t npart = G.ntiles * std::max(n - 1, 1);
+            if (w->gap_part_cap < npart) {
+                TBK_HIP(hipStreamSynchronize(ctx->stream));
+                if (w->gap_part_dev) TBK_HIP(hipFree(w->gap_part_dev));
+                w->gap_part_dev = nullptr;
+                w->gap_part_cap = 0;
+                TBK_HIP(hipMalloc((void**)&w->gap_part_dev, (size_t)npart * sizeof(double)));
+                w->gap_part_cap = npart;
+            }
+            G.gap_part = w->gap_part_dev;
+            w->gap_part_n = G.ntiles;       // tbk_wfs_solve_grid_result reduces these instead of the shards
 #define TBK_ROWS(NN, PP) hipLaunchKernelGGL((k_grid_rows<NN, PP>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G)
             const int pm = m->view.pmax;
             switch (n * 4 + (pm <= 2 ? pm : 3)) {
@@ -1455,9 +1518,21 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
 extern "C" int tbk_wfs_solve_grid_result(tbk_wfs* w, double* min_gaps) {
     TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_solve_grid_result: null wfs");
     tbk_ctx* ctx = w->ctx;
+    if (w->gap_part_n > 0 && w->gaps_n > 0 && min_gaps) {   // the row kernel left per-tile minima
+        void* base = nullptr;
+        int rc = tbk_ctx_scratch(ctx, 256 + (size_t)w->gaps_n * sizeof(double), &base);
+        if (rc) return rc;
+        double* out_dev = (double*)((unsigned char*)base + 256);
+        hipLaunchKernelGGL(k_gap_part_reduce, dim3(w->gaps_n), dim3(256), 0, ctx->stream, w->gap_part_dev, w->gap_part_n,
+                           w->gaps_n, out_dev);
+        TBK_HIP(hipGetLastError());
+        TBK_HIP(hipMemcpyAsync(min_gaps, out_dev, (size_t)w->gaps_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        return check_noconv(ctx, w->view.nsta);
+    }
     const size_t half = (size_t)TBK_GAP_SHARDS * w->view.ncomp;
     std::vector<unsigned long long> bits(half);
-    if (w->gaps_n > 0 && min_gaps) {
+    if (w->gap_part_n == 0 && w->gaps_n > 0 && min_gaps) {
         TBK_HIP(hipMemcpyAsync(bits.data(), w->gaps_dev + (size_t)(1 - w->gaps_parity) * half,
                                half * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     }
