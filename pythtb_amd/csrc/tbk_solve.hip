@@ -1144,7 +1144,9 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // with vectors; at n = 12 and below the LDS kernel wins).  Mesh solves keep the warm-started LDS kernel
     // (a fine mesh needs ~3 sweeps there).  Needs the R-grouped table unless the matrices are supplied.
     if constexpr (MODE != 1) {
-        if (n >= 15 && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0)) return launch_row16<MODE, VEC>(ctx, mv, nk, L, G);
+        // (eigenvalues only: already from n = 13, where the LDS kernel takes ~9-10 ms for the same 262144 k)
+        if ((n >= 15 || (!VEC && n >= 13)) && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0))
+            return launch_row16<MODE, VEC>(ctx, mv, nk, L, G);
     }
     if (n > 64) {
         // ---- workgroup per matrix (n = 65..256): 256 threads, A and V^T in a global
