@@ -645,14 +645,44 @@ __global__ __launch_bounds__(1024) void k_flux_reduce(const double* __restrict__
     if (threadIdx.x == 0) totals[blockIdx.x] = red[0];
 }
 
-static int fill_occ(const tbk_wfs* w, const int32_t* occ, int nocc, int* dst) {
+static int check_occ(const tbk_wfs* w, const int32_t* occ, int nocc) {
     TBK_REQUIRE(occ && nocc >= 1, TBK_EINVAL, "occ must list at least one state");
-    TBK_REQUIRE(nocc <= TBK_MAX_NOCC, TBK_EUNSUPPORTED, "nocc=%d exceeds this build's limit of %d", nocc, TBK_MAX_NOCC);
-    for (int i = 0; i < nocc; ++i) {
+    for (int i = 0; i < nocc; ++i)
         TBK_REQUIRE(occ[i] >= 0 && occ[i] < w->view.nsta, TBK_EINVAL, "occ[%d]=%d outside 0..%d", i, occ[i],
                     w->view.nsta - 1);
-        dst[i] = occ[i];
-    }
+    return TBK_OK;
+}
+
+static int fill_occ(const tbk_wfs* w, const int32_t* occ, int nocc, int* dst) {
+    int rc = check_occ(w, occ, nocc);
+    if (rc) return rc;
+    TBK_REQUIRE(nocc <= TBK_MAX_NOCC, TBK_EUNSUPPORTED, "nocc=%d exceeds this build's limit of %d", nocc, TBK_MAX_NOCC);
+    for (int i = 0; i < nocc; ++i) dst[i] = occ[i];
+    return TBK_OK;
+}
+
+#include "tbk_berry_big.inl"   // nocc > TBK_MAX_NOCC: link determinants by LU, one workgroup per link
+
+// scratch of the large-nocc paths: [occ | dets of ndirs directions | LU workspace]
+static int big_scratch(tbk_wfs* w, const int32_t* occ, int nocc, int ndirs, size_t extra, int** occ_dev, cd** dets,
+                       void** work, size_t* work_bytes, void** extra_dev) {
+    tbk_ctx* ctx = w->ctx;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t ob = al((size_t)nocc * sizeof(int));
+    const size_t db = al((size_t)w->view.npts * sizeof(cd));
+    const size_t per = (size_t)nocc * nocc * sizeof(cd);
+    const bool in_lds = (size_t)nocc * (nocc + 1) * sizeof(cd) <= 96 * 1024;
+    const size_t wb = in_lds ? 0 : al(per * (size_t)std::min<int64_t>(w->view.npts, (int64_t)ctx->cus * 4));
+    void* base = nullptr;
+    int rc = tbk_ctx_scratch(ctx, 256 + ob + ndirs * db + wb + al(extra), &base);
+    if (rc) return rc;
+    unsigned char* p = (unsigned char*)base + 256;
+    *occ_dev = (int*)p;
+    *dets = (cd*)(p + ob);
+    *work = wb ? (void*)(p + ob + ndirs * db) : nullptr;
+    *work_bytes = wb;
+    if (extra_dev) *extra_dev = p + ob + ndirs * db + wb;
+    TBK_HIP(hipMemcpyAsync(*occ_dev, occ, (size_t)nocc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     return TBK_OK;
 }
 
@@ -686,7 +716,8 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     TBK_REQUIRE(dir0 >= 0 && dir1 >= 0 && dir0 < v.dim_arr && dir1 < v.dim_arr, TBK_EINVAL,
                 "Direction for Berry flux calculation out of bounds.");
     FluxArgs A{};
-    int rc = fill_occ(w, occ, nocc, A.occ);
+    const bool big = nocc > TBK_MAX_NOCC;     // link determinants by LU (tbk_berry_big.inl)
+    int rc = big ? check_occ(w, occ, nocc) : fill_occ(w, occ, nocc, A.occ);
     if (rc) return rc;
     tbk_ctx* ctx = w->ctx;
     TBK_HIP(hipSetDevice(ctx->device));
@@ -700,7 +731,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     other_axes(v, dir0, dir1, &A.other, &nslices);
     const int64_t per = (int64_t)A.n0 * A.n1;
     TBK_REQUIRE(per < (int64_t)0xffffffffu, TBK_EUNSUPPORTED, "plane of %lld plaquettes is too large", (long long)per);
-    const bool rows = v.ncomp <= 4 && nocc <= v.ncomp;   // register-resident row-streaming kernel
+    const bool rows = !big && v.ncomp <= 4 && nocc <= v.ncomp;   // register-resident row-streaming kernel
     if (rows) {
         A.swap = A.s0 < A.s1;                            // lanes run along the smaller stride
         A.na = A.swap ? A.n1 : A.n0;
@@ -763,7 +794,32 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         A.plaq = w->flux_plaq_dev;
     }
     A.partial = w->flux_partial_dev;
-    {
+    if (big) {
+        int* occ_dev = nullptr;
+        cd* dets = nullptr;
+        void* work = nullptr;
+        size_t work_bytes = 0;
+        rc = big_scratch(w, occ, nocc, 2, 0, &occ_dev, &dets, &work, &work_bytes, nullptr);
+        if (rc) return rc;
+        rc = launch_link_dets(w, occ_dev, nocc, dir0, dets, work, work_bytes);
+        if (rc) return rc;
+        rc = launch_link_dets(w, occ_dev, nocc, dir1, dets + v.npts, work, work_bytes);
+        if (rc) return rc;
+        PlaqDetArgs P{};
+        P.d0 = dets;
+        P.d1 = dets + v.npts;
+        P.n0 = A.n0;
+        P.n1 = A.n1;
+        P.s0 = A.s0;
+        P.s1 = A.s1;
+        P.other = A.other;
+        P.bps = A.bps;
+        P.plaq = A.plaq;
+        P.partial = A.partial;
+        ProfScope ps(ctx, "berry_flux");
+        hipLaunchKernelGGL(k_flux_from_dets, dim3((unsigned)(nslices * A.bps)), dim3(256), 0, ctx->stream, P);
+        TBK_HIP(hipGetLastError());
+    } else {
         ProfScope ps(ctx, "berry_flux");
         if (rows) {
             const dim3 grid((unsigned)(nslices * A.bpb)), blk(256);
@@ -1036,7 +1092,8 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     const WfsView& v = w->view;
     TBK_REQUIRE(dir >= 0 && dir < v.dim_arr, TBK_EINVAL, "Wrong direction for Berry phase calculation!");
     ChainArgs A{};
-    int rc = fill_occ(w, occ, nocc, A.occ);
+    const bool big = nocc > TBK_MAX_NOCC && !berry_evals;   // det of the string = product of link dets (LU per link)
+    int rc = big ? check_occ(w, occ, nocc) : fill_occ(w, occ, nocc, A.occ);
     if (rc) return rc;
     tbk_ctx* ctx = w->ctx;
     TBK_HIP(hipSetDevice(ctx->device));
@@ -1045,6 +1102,32 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     A.nlinks = v.mesh[dir] - 1;
     A.sdir = v.stride[dir];
     other_axes(v, dir, -1, &A.other, &A.nstrings);
+    if (big) {
+        int* occ_dev = nullptr;
+        cd* dets = nullptr;
+        void* work = nullptr;
+        void* out_dev = nullptr;
+        size_t work_bytes = 0;
+        rc = big_scratch(w, occ, nocc, 1, (size_t)A.nstrings * sizeof(double), &occ_dev, &dets, &work, &work_bytes, &out_dev);
+        if (rc) return rc;
+        rc = launch_link_dets(w, occ_dev, nocc, dir, dets, work, work_bytes);
+        if (rc) return rc;
+        StringDetArgs S{};
+        S.dets = dets;
+        S.nlinks = A.nlinks;
+        S.sdir = A.sdir;
+        S.other = A.other;
+        S.nstrings = A.nstrings;
+        S.out = (double*)out_dev;
+        {
+            ProfScope ps(ctx, "string_from_dets");
+            hipLaunchKernelGGL(k_string_from_dets, dim3((unsigned)((A.nstrings + 255) / 256)), dim3(256), 0, ctx->stream, S);
+            TBK_HIP(hipGetLastError());
+        }
+        TBK_HIP(hipMemcpyAsync(out, out_dev, (size_t)A.nstrings * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        return TBK_OK;
+    }
     // segment length: enough threads to fill the chip, segments no shorter than 8 links
     const int64_t target = (int64_t)ctx->cus * 1024;
     int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + 7) / 8, target / std::max<int64_t>(A.nstrings, 1)));

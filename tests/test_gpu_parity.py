@@ -577,8 +577,23 @@ def test_large_nocc_and_unsupported_sizes(tb):
                               - orc.berry_flux(owfs, 2, occ, individual_phases=True, vectorised=True)))) < TOL_P
     got = w.berry_phase(occ, 0, contin=False, berry_evals=True)
     assert_phase_sets_close(got, orc.berry_phase(owfs, 2, occ, 0, contin=False, berry_evals=True), 1e-9)
-    with pytest.raises(_lib.TbkError, match="limit"):
-        w.berry_flux(list(range(17)))                         # nocc > TBK_MAX_NOCC fails loudly
+    # more than TBK_MAX_NOCC bands: link determinants by LU (flux and det-type Berry phases of any size) ...
+    for occ in (list(range(17)), list(range(20)), [19, 0, 7] + list(range(1, 7)) + list(range(8, 19))):
+        assert np.max(np.abs(wrap(w.berry_flux(occ, individual_phases=True)
+                                  - orc.berry_flux(owfs, 2, occ, individual_phases=True, vectorised=True)))) < TOL_P
+        assert abs(w.berry_flux(occ) - orc.berry_flux(owfs, 2, occ, vectorised=True)) < 1e-9
+        for d in (0, 1):
+            got = w.berry_phase(occ, d, contin=False)
+            assert np.max(np.abs(wrap(got - orc.berry_phase(owfs, 2, occ, d, contin=False)))) < TOL_P
+    with pytest.raises(_lib.TbkError, match="limit"):         # ... but the Wilson-loop eigenphases stay limited
+        w.berry_phase(list(range(17)), 0, contin=False, berry_evals=True)
+    # a ribbon with 70 occupied bands of 140 (the LU matrix no longer fits in LDS) and a 1-D string
+    rib = hp.haldane(tb.tb_model, 1.2).cut_piece(70, 1)        # trivial phase: the ribbon is gapped at half filling
+    wr = tb.wf_array(rib, [9])
+    wr.solve_on_grid([0.0])
+    orib, _ = orc.solve_on_grid(rib, [9], [0.0], vectorised=True)
+    for occ in (list(range(70)), list(range(140))):
+        assert abs(wrap(wr.berry_phase(occ, contin=False) - orc.berry_phase(orib, 1, occ, None, contin=False))) < 1e-8
     big = hp.quiet(tb.tb_model, 1, 1, [[1.0]], 2100)
     with pytest.raises(_lib.TbkError, match="limit"):
         big.solve_all([0.1])                                   # nsta > TBK_MAX_NSTA fails loudly
