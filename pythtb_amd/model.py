@@ -4,7 +4,7 @@ Same constructor, setters, attribute names and call signatures as the reference
 (`pythtb.py:29-560`, `:862-1103`, `:1792-2026`), so scripts written for PythTB
 run unchanged; `_gen_ham`, `_sol_ham`, `solve_all` and `solve_one` execute on the
 MI355X through libtbk (no CPU path).  The model->model transforms live in
-transforms.py; plotting is outside this package's scope.
+transforms.py, the text report and the sketch plot in report.py / plotting.py.
 """
 import ctypes as C
 
@@ -551,6 +551,10 @@ class tb_model(object):
         return (k_vec, k_dist, k_node)
 
 
+from . import plotting as _plotting  # noqa: E402
+from . import report as _report  # noqa: E402
 from . import transforms as _transforms  # noqa: E402
 
 _transforms.install(tb_model)
+tb_model.display = _report.display
+tb_model.visualize = _plotting.visualize

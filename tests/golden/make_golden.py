@@ -371,7 +371,58 @@ def full_size():
     save("full_size", **out)
 
 
+def display_reports():
+    """Text printed by tb_model.display() for a few models (expected output only)."""
+    import json
+    out = {}
+    flake = haldane(0.2).cut_piece(2, 0).cut_piece(2, 1)            # 0-D: hoppings without lattice vectors
+    for name, m in (("haldane02", haldane(0.2)), ("km_odd", kane_mele("odd")), ("chain3", chain3(-1.0, 2.0, 0.3)),
+                    ("per02", per02()), ("molecule", molecule()), ("haldane_flake_2x2", flake)):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            m.display()
+        out[name] = buf.getvalue()
+    with open(os.path.join(HERE, "display_reports.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("display_reports.json", {k: len(v) for k, v in out.items()})
+
+
+def visualize_artists():
+    """What tb_model.visualize() draws (line data, marker sizes, z-orders, colours, axis limits)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.colors as mcolors
+    import matplotlib.pyplot as plt
+    out = {}
+    rng = np.random.default_rng(0)
+    for name, m, dirs in (("haldane02", haldane(0.2), (0, 1)), ("chain3", chain3(-1.0, 2.0, 0.3), (0, None)),
+                          ("flake", haldane(0.2).cut_piece(3, 0).cut_piece(2, 1), (1, 0))):
+        e = rng.normal(size=m._norb) + 1j * rng.normal(size=m._norb)
+        e /= np.linalg.norm(e)
+        out[name + "/eig"] = e
+        for scheme, vec in (("plain", None), ("wheel", e), ("red-blue", e), ("black", e)):
+            fig, ax = m.visualize(dirs[0], dirs[1], eig_dr=vec, ph_color="black" if scheme == "plain" else scheme)
+            rows = []
+            for ln in ax.get_lines():
+                x, y = np.asarray(ln.get_xdata(), float), np.asarray(ln.get_ydata(), float)
+                pad = np.full(3 - len(x), np.nan)
+                rows.append(np.concatenate([np.concatenate([x, pad]), np.concatenate([y, pad]),
+                                            [ln.get_markersize(), ln.get_zorder(), ln.get_linewidth()],
+                                            mcolors.to_rgba(ln.get_color())]))
+            out["%s/%s/lines" % (name, scheme)] = np.array(rows)
+            out["%s/%s/lims" % (name, scheme)] = np.array(list(ax.get_xlim()) + list(ax.get_ylim()))
+            plt.close(fig)
+    np.savez_compressed(os.path.join(HERE, "visualize_artists.npz"), **out)
+    print("visualize_artists.npz", len(out))
+
+
 if __name__ == "__main__":
+    if "--visualize" in sys.argv:
+        visualize_artists()
+        sys.exit(0)
+    if "--display" in sys.argv:
+        display_reports()
+        sys.exit(0)
     if "--quad4" in sys.argv:
         grid_case("quad4_4354", quad4(), [4, 3, 5, 4], [0.1, -0.2, 0.3, 0.05], [[0], [0, 1]], [],
                   flux_dirs=[[0, 1], [2, 3], [3, 1]])

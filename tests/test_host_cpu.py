@@ -236,3 +236,59 @@ def test_phase_continuity_helpers_match_oracle():
         assert np.allclose(_array_phases_cont(arr, c0), orc.array_phases_cont(arr, c0), atol=1e-14)
     arr = np.array([[0.1, 0.1, 3.0], [0.1, 3.0, 0.1]])        # exact ties follow the reference's last-wins rule
     assert np.allclose(_array_phases_cont(arr, arr[0]), orc.array_phases_cont(arr, arr[0]))
+
+
+def test_display_report_matches_reference_text(capsys):
+    """tb_model.display(): same text as the reference prints (tests/golden/display_reports.json)."""
+    import json
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "display_reports.json")))
+    per02 = hp.quiet(tb.tb_model, 2, 3, [[3.0, 0.1, 0.4], [0.1, 3.1, 1.2], [0.8, 0.2, 3.5]],
+                     [[0.3, 0.1, 0.2], [0.1, 0.8, 0.3], [0.2, 0.3, 0.4]], per=[0, 2])
+    per02.set_onsite([-2.3, 0.5, 0.1])
+    per02.set_hop(0.24, 0, 1, [1, 0, 2])
+    per02.set_hop(0.42, 0, 1, [3, 0, 2])
+    per02.set_hop(-0.12, 1, 2, [2, 0, 3])
+    per02.set_hop(-0.34, 2, 0, [-1, 0, 2])
+    mol = hp.quiet(tb.tb_model, 0, 1, [[1.0]], [[0.0], [0.5], [0.8]])
+    mol.set_onsite([0.1, -0.4, 0.7])
+    mol.set_hop(3.0, 0, 1)
+    mol.set_hop(0.5 + 0.25j, 1, 2)
+    models = {"haldane02": hp.haldane(tb.tb_model, 0.2), "km_odd": hp.kane_mele(tb.tb_model, "odd"),
+              "chain3": hp.chain3(tb.tb_model, -1.0, 2.0, 0.3), "per02": per02, "molecule": mol,
+              "haldane_flake_2x2": hp.haldane(tb.tb_model, 0.2).cut_piece(2, 0).cut_piece(2, 1)}
+    capsys.readouterr()
+    for name, m in models.items():
+        m.display()
+        assert capsys.readouterr().out == want[name], name
+
+
+def test_visualize_draws_what_the_reference_draws():
+    """tb_model.visualize(): same artists (geometry, sizes, z-order, colours) and axis limits as the
+    reference (tests/golden/visualize_artists.npz); eigenstate colouring in all three schemes."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.colors as mcolors
+    import matplotlib.pyplot as plt
+    g = np.load(os.path.join(ROOT, "tests", "golden", "visualize_artists.npz"))
+    models = {"haldane02": (hp.haldane(tb.tb_model, 0.2), (0, 1)), "chain3": (hp.chain3(tb.tb_model, -1.0, 2.0, 0.3), (0, None)),
+              "flake": (hp.haldane(tb.tb_model, 0.2).cut_piece(3, 0).cut_piece(2, 1), (1, 0))}
+    for name, (m, dirs) in models.items():
+        e = g[name + "/eig"]
+        for scheme, vec in (("plain", None), ("wheel", e), ("red-blue", e), ("black", e)):
+            fig, ax = m.visualize(dirs[0], dirs[1], eig_dr=vec, ph_color="black" if scheme == "plain" else scheme)
+            rows = []
+            for ln in ax.get_lines():
+                x, y = np.asarray(ln.get_xdata(), float), np.asarray(ln.get_ydata(), float)
+                pad = np.full(3 - len(x), np.nan)
+                rows.append(np.concatenate([np.concatenate([x, pad]), np.concatenate([y, pad]),
+                                            [ln.get_markersize(), ln.get_zorder(), ln.get_linewidth()],
+                                            mcolors.to_rgba(ln.get_color())]))
+            got, want = np.array(rows), g["%s/%s/lines" % (name, scheme)]
+            assert got.shape == want.shape, (name, scheme)
+            assert np.allclose(got, want, rtol=0, atol=1e-12, equal_nan=True), (name, scheme)   # same order, same artists
+            assert np.allclose(list(ax.get_xlim()) + list(ax.get_ylim()), g["%s/%s/lims" % (name, scheme)], atol=1e-12)
+            plt.close(fig)
+    h = hp.haldane(tb.tb_model, 0.2)
+    for bad in (lambda: h.visualize(0), lambda: h.visualize(0, 1, ph_color="rainbow"), lambda: h.visualize(0, 1, eig_dr=np.ones(3))):
+        with pytest.raises(Exception):
+            bad()
