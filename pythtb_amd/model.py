@@ -268,7 +268,10 @@ class tb_model(object):
     def _device_model(self):
         ctx = _lib.default_context()
         c = self._tbk_cache
-        if c is not None and c[0] == self._tbk_epoch and c[1] is ctx:
+        # the epoch counts edits made through the setters/transforms; the fingerprint also catches scripts
+        # that write `_orb` / `_site_energies` / `_hoppings` (length) directly, as some of the reference's do
+        mark = (self._tbk_epoch, len(self._hoppings), self._orb.tobytes(), np.asarray(self._site_energies).tobytes())
+        if c is not None and c[0] == mark and c[1] is ctx:
             return c[2]
         if c is not None:
             _lib.lib.tbk_model_free(c[2])
@@ -280,7 +283,7 @@ class tb_model(object):
             _lib.dptr(onsite.view(float)), len(hop_i), _lib.iptr(hop_i), _lib.iptr(hop_j),
             _lib.iptr(hop_R.reshape(-1)) if hop_R.size else None,
             _lib.dptr(hop_amp.view(float)) if hop_amp.size else None, C.byref(h)))
-        self._tbk_cache = (self._tbk_epoch, ctx, h)
+        self._tbk_cache = (mark, ctx, h)
         return h
 
     # ------------------------------------------------------------------ solve

@@ -137,3 +137,19 @@ def test_smallest_models(tb):                               # tests/test_pythtb.
     k_vec, k_dist, k_node = chain.k_path([[0.0], [0.5]], 5, report=False)
     assert k_vec.shape == (5, 1) and k_dist.shape == (5,) and len(k_node) == 2
     assert k_dist[0] == pytest.approx(0.0) and k_dist[-1] > 0.0
+
+
+def test_direct_table_edits_are_seen(tb):
+    """Scripts sometimes write the private tables directly; the device copy must follow."""
+    m = quiet(tb.tb_model, 1, 1, [[1.0]], [[0.0], [0.5]])
+    m.set_onsite([0.0, 0.0])
+    m.set_hop(1.0, 0, 1, [0])
+    e0 = m.solve_one([0.0])
+    m._site_energies[1] = 3.0                      # no setter involved
+    e1 = m.solve_one([0.0])
+    assert not np.allclose(e0, e1) and np.allclose(np.sort(e1), np.linalg.eigvalsh(np.array([[0.0, 1.0], [1.0, 3.0]])))
+    m._orb[1, 0] = 0.25                            # orbital moved: eigenvector phases change, energies do not
+    v0 = m.solve_one([0.3], eig_vectors=True)[1]
+    m._orb[1, 0] = 0.75
+    v1 = m.solve_one([0.3], eig_vectors=True)[1]
+    assert not np.allclose(np.abs(v0[0, 1] / v0[0, 0] - v1[0, 1] / v1[0, 0]), 0.0)
