@@ -703,7 +703,7 @@ struct WaveLds {
 
 // NT = 64: one wavefront per matrix, matrices in LDS.  NT = 256 (n = 65..256): one
 // workgroup per matrix, matrices in a global workspace (L2-resident), always cold-started.
-template <int MODE, bool VEC, int NT>
+template <int MODE, bool VEC, int NT, bool LDSWS = (NT == 64)>
 __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int64_t nk,
                                                    const ListArgs L, const GridArgs G,
                                                    int* noconv_flag, const int run, cd* work) {
@@ -723,6 +723,11 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
         S.Vt = S.A + n * ld;
         S.T = S.Vt + n * ld;                 // present only when runs are longer than one point
         S.rot = run > 1 ? S.T + n * ld : S.T;
+    } else if constexpr (LDSWS) {           // a whole workgroup on one LDS-resident matrix (few matrices: latency)
+        S.A = (cd*)lds_raw;
+        S.Vt = S.A + n * ld;
+        S.T = S.Vt;                          // unused: cold start
+        S.rot = S.Vt + n * ld;
     } else {
         S.A = work + (size_t)blockIdx.x * 2 * n * ld;
         S.Vt = S.A + n * ld;
@@ -1148,10 +1153,15 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         if ((n >= 15 || (!VEC && n >= 13)) && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0))
             return launch_row16<MODE, VEC>(ctx, mv, nk, L, G);
     }
-    if (n > 64) {
-        // ---- workgroup per matrix (n = 65..256): 256 threads, A and V^T in a global
-        // workspace, cold start.  Ribbon / slab models: few, large matrices.
-        const size_t lds = wave_lds_bytes(n, false) - (size_t)2 * n * (n + 1) * sizeof(cd);   // small arrays only
+    // Few matrices of 9..64 states (a finite chain, a short k path): one wavefront per matrix would leave the
+    // chip idle and spend ~2 us per Jacobi round on 64 lanes; give each matrix a 256-thread workgroup instead,
+    // matrix still in LDS (n = 30, one matrix: 0.77 -> 0.34 ms, profiles/call_latency.py).
+    const bool few = n <= 64 && nk_eff <= (int64_t)ctx->cus;
+    if (n > 64 || few) {
+        // ---- workgroup per matrix: 256 threads, cold start; n = 65..256: A and V^T in a global workspace
+        // (ribbon / slab models: few, large matrices), n <= 64: in LDS.
+        const size_t lds = few ? wave_lds_bytes(n, false, mv.nR)
+                               : wave_lds_bytes(n, false) - (size_t)2 * n * (n + 1) * sizeof(cd);   // small arrays only
         const int64_t cap = std::max<int64_t>(64, (int64_t)ctx->cus * 4);
         int64_t run, nblocks;
         if (MODE == 1) {
@@ -1166,7 +1176,19 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
             nblocks = (nk + run - 1) / run;
         }
         TBK_REQUIRE(nblocks < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many k-points for one launch");
-        const size_t wbytes = (size_t)nblocks * 2 * n * (n + 1) * sizeof(cd);
+        const size_t wbytes = few ? 0 : (size_t)nblocks * 2 * n * (n + 1) * sizeof(cd);
+        if (few) {
+            static bool attr_few[2][3] = {{false, false, false}, {false, false, false}};
+            if (lds > 64 * 1024 && !attr_few[VEC][MODE]) {
+                TBK_HIP(hipFuncSetAttribute((const void*)k_solve_wave<MODE, VEC, 256, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_few[VEC][MODE] = true;
+            }
+            hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 256, true>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, mv, nk,
+                               L, G2, flag, (int)run, (cd*)nullptr);
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
         if (wbytes > ctx->work_bytes) {
             TBK_HIP(hipStreamSynchronize(ctx->stream));
             if (ctx->work) TBK_HIP(hipFree(ctx->work));
