@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""One-off differential sweep: random models of many sizes through every solver regime against the oracle
+(eigenvalues, residuals, mesh gaps, flux, Berry phases).  Prints one line per case and a summary.
+
+A flagged flux/phase error of exactly pi is not necessarily a defect: on these deliberately coarse meshes a
+link overlap matrix can be numerically singular (det ~ 1e-17), and then the phase of the determinant is noise
+in the reference's formula too -- the oracle's own loop and vectorised variants disagree by pi on such a
+plaquette (seed 3, case 91; the occupied projectors of both solvers agree to 2e-15 there)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "tests"))
+import pythtb_amd as tb  # noqa: E402
+import helpers as hp  # noqa: E402
+from oracle import tb_oracle as orc  # noqa: E402
+
+
+def wrap(x):
+    return (np.asarray(x) + np.pi) % (2 * np.pi) - np.pi
+
+
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+rng = np.random.default_rng(seed0)
+worst = {"eval": 0.0, "resid": 0.0, "orth": 0.0, "gap": 0.0, "flux": 0.0, "phase": 0.0}
+bad = []
+t_start = time.time()
+for case in range(ncase):
+    dim_k = int(rng.integers(1, 4))
+    nspin = int(rng.integers(1, 3))
+    norb = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 15, 16, 17, 20, 24, 31, 32, 33, 40]))
+    if nspin == 2:
+        norb = max(1, norb // 2 + int(rng.integers(0, 2)))
+    n = norb * nspin
+    dense = bool(rng.integers(0, 2))
+    nhop = int(norb * norb * (1.5 if dense else 0.3)) + 2
+    rmax = int(rng.integers(1, 3))
+    m = hp.random_model(tb.tb_model, norb, dim_k, nspin, int(rng.integers(0, 10 ** 6)), nhop=nhop, rmax=rmax)
+    k = rng.uniform(-0.7, 0.7, size=(int(rng.integers(1, 40)), dim_k))
+    ev, vec = m.solve_all(k, eig_vectors=True)
+    ev_only = m.solve_all(k)
+    ref = orc.solve_all_vec(m, k)
+    scale = max(1.0, np.abs(ref).max())
+    e_err = max(np.abs(ev - ref).max(), np.abs(ev_only - ref).max()) / scale
+    ham = orc.ham_batch(m, k)
+    V = vec.reshape(n, len(k), n)
+    r_err = max(np.abs(ham[i] @ V[:, i].T - V[:, i].T * ev[:, i]).max() for i in range(len(k))) / scale
+    o_err = max(np.abs(V[:, i].conj() @ V[:, i].T - np.eye(n)).max() for i in range(len(k)))
+    mesh = [int(rng.integers(3, 7)) for _ in range(dim_k)]
+    start = list(rng.uniform(-0.5, 0.5, size=dim_k))
+    w = tb.wf_array(m, mesh)
+    gaps = w.solve_on_grid(start)
+    owfs, ogaps = orc.solve_on_grid(m, mesh, start, vectorised=True)
+    g_err = 0.0 if n == 1 else np.abs(gaps - ogaps).max() / scale
+    # gauge-invariant Berry quantities need an isolated band group: pick the widest gap of the mesh
+    f_err = p_err = 0.0
+    if n > 1 and ogaps.max() > 0.05 * scale:
+        nocc = int(np.argmax(ogaps)) + 1
+        occ = list(range(nocc))
+        if dim_k >= 2:
+            got = w.berry_flux(occ, dirs=[0, dim_k - 1], individual_phases=True)
+            want = orc.berry_flux(owfs, dim_k, occ, [0, dim_k - 1], individual_phases=True, vectorised=True)
+            f_err = np.abs(wrap(got - want)).max()
+        d = int(rng.integers(0, dim_k))
+        got = w.berry_phase(occ, d if dim_k > 1 else None, contin=False)
+        want = orc.berry_phase(owfs, dim_k, occ, d if dim_k > 1 else None, contin=False)
+        p_err = np.abs(wrap(got - want)).max()
+    errs = dict(eval=e_err, resid=r_err, orth=o_err, gap=g_err, flux=f_err, phase=p_err)
+    for key, v in errs.items():
+        worst[key] = max(worst[key], float(v))
+    flag = e_err > 1e-12 or r_err > 1e-11 or o_err > 1e-12 or g_err > 1e-11 or f_err > 1e-8 or p_err > 1e-8
+    if flag:
+        bad.append((case, dim_k, nspin, norb, dense, errs))
+    print("case %3d dim_k %d nspin %d n %3d %s  eval %.1e resid %.1e orth %.1e gap %.1e flux %.1e phase %.1e%s" %
+          (case, dim_k, nspin, n, "dense " if dense else "sparse", e_err, r_err, o_err, g_err, f_err, p_err, "  <-- CHECK" if flag else ""))
+print("worst:", {k: "%.2e" % v for k, v in worst.items()}, " flagged:", len(bad), " %.0f s" % (time.time() - t_start))
+for b in bad:
+    print("FLAG", b)
