@@ -33,7 +33,8 @@ t_start = time.time()
 for case in range(ncase):
     dim_k = int(rng.integers(1, 4))
     nspin = int(rng.integers(1, 3))
-    norb = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13, 15, 16, 17, 20, 24, 31, 32, 33, 40]))
+    sizes = [int(x) for x in os.environ.get("FUZZ_SIZES", "1,2,3,4,5,6,7,8,9,11,13,15,16,17,20,24,31,32,33,40").split(",")]
+    norb = int(rng.choice(sizes))
     if nspin == 2:
         norb = max(1, norb // 2 + int(rng.integers(0, 2)))
     n = norb * nspin
@@ -41,7 +42,7 @@ for case in range(ncase):
     nhop = int(norb * norb * (1.5 if dense else 0.3)) + 2
     rmax = int(rng.integers(1, 3))
     m = hp.random_model(tb.tb_model, norb, dim_k, nspin, int(rng.integers(0, 10 ** 6)), nhop=nhop, rmax=rmax)
-    k = rng.uniform(-0.7, 0.7, size=(int(rng.integers(1, 40)), dim_k))
+    k = rng.uniform(-0.7, 0.7, size=(int(rng.integers(1, int(os.environ.get("FUZZ_NK", "40")))), dim_k))
     ev, vec = m.solve_all(k, eig_vectors=True)
     ev_only = m.solve_all(k)
     ref = orc.solve_all_vec(m, k)
