@@ -1153,10 +1153,18 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         if ((n >= 15 || (!VEC && n >= 13)) && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0))
             return launch_row16<MODE, VEC>(ctx, mv, nk, L, G);
     }
-    // Few matrices of 9..64 states (a finite chain, a short k path): one wavefront per matrix would leave the
-    // chip idle and spend ~2 us per Jacobi round on 64 lanes; give each matrix a 256-thread workgroup instead,
-    // matrix still in LDS (n = 30, one matrix: 0.77 -> 0.34 ms, profiles/call_latency.py).
-    const bool few = n <= 64 && nk_eff <= (int64_t)ctx->cus;
+    // A 256-thread workgroup per LDS-resident matrix instead of one wavefront:
+    //  * n >= 32, any batch: with its warm-start buffer a wavefront's matrix takes 3 n(n+1) 16 B of LDS (n = 48:
+    //    113 KB, ONE wavefront per CU); four wavefronts sharing A and V^T (2 n(n+1) 16 B) keep 8-12 wavefronts per CU
+    //    busy even though they start cold.  Eigenvalues of 16384 ribbon matrices: n = 32 11.0 -> 9.2 ms, n = 48
+    //    92 -> 41 ms, n = 64 (8192) 209 -> 65 ms; at 1024 matrices n = 40 4.7 -> 1.8 ms.
+    //  * n < 32: only while the batch cannot fill the chip with wavefronts (one 30x30 matrix: 0.77 -> 0.34 ms);
+    //    large mesh-ordered batches keep the warm-started wavefront kernel (n = 24, 65536 k: 13.6 vs 20.5 ms).
+    static const int64_t few_max = [] {   // tuning knob: largest n < 32 batch that gets a workgroup per matrix
+        const char* e = getenv("TBK_FEW_MAX");
+        return e ? (int64_t)atoll(e) : (int64_t)-1;
+    }();
+    const bool few = n <= 64 && (n >= 32 || nk_eff <= (few_max >= 0 ? few_max : (int64_t)ctx->cus * 8));
     if (n > 64 || few) {
         // ---- workgroup per matrix: 256 threads, cold start; n = 65..256: A and V^T in a global workspace
         // (ribbon / slab models: few, large matrices), n <= 64: in LDS.
