@@ -737,7 +737,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
     S.eo = S.rot + 2 * half;                 // doubles as the per-R phase table during assembly
     S.ev = (double*)(S.eo + (n > mv.nR ? n : mv.nR));
     S.red = S.ev + n;
-    S.pq = (int*)(S.red + 8);
+    S.pq = (int*)(S.red + 32);              // red: two doubles per wavefront of the workgroup (<= 16)
     S.perm = S.pq + half;
 
     // A wavefront walks a short chain of consecutive points.  After the first one, Jacobi is
@@ -1038,7 +1038,7 @@ static size_t wave_lds_bytes(int n, bool with_t, int nR = 0) {
     size_t b = (size_t)(with_t ? 3 : 2) * n * ld * sizeof(cd);  // A, Vt (, T)
     b += (size_t)2 * half * sizeof(cd);          // rot
     b += (size_t)std::max(n, nR) * sizeof(cd);   // eo (also the per-R phases during assembly)
-    b += (size_t)(n + 8) * sizeof(double);       // ev, red
+    b += (size_t)(n + 32) * sizeof(double);      // ev, red
     b += (size_t)(half + n) * sizeof(int);       // pq, perm
     return (b + 15) & ~(size_t)15;
 }
@@ -1186,14 +1186,29 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         TBK_REQUIRE(nblocks < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many k-points for one launch");
         const size_t wbytes = few ? 0 : (size_t)nblocks * 2 * n * (n + 1) * sizeof(cd);
         if (few) {
-            static bool attr_few[2][3] = {{false, false, false}, {false, false, false}};
-            if (lds > 64 * 1024 && !attr_few[VEC][MODE]) {
-                TBK_HIP(hipFuncSetAttribute((const void*)k_solve_wave<MODE, VEC, 256, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_few[VEC][MODE] = true;
+            // threads per matrix, measured (eigenvalues, ms; 256 / 512 / 1024 threads): 16384 matrices n=32 9.1 / 12.3 /
+            // 19.8, n=48 41 / 33 / 42, 8192 of n=64 66 / 46 / 39; a single matrix n=50 1.13 / 0.84 / 0.70, n=64 1.96 / 1.41 / 1.18
+            int nt;
+            if (nk_eff > (int64_t)ctx->cus) nt = n <= 40 ? 256 : (n <= 56 ? 512 : 1024);
+            else nt = n <= 24 ? 256 : (n <= 36 ? 512 : 1024);
+            if (const char* e = getenv("TBK_FEW_NT")) nt = atoi(e) >= 1024 ? 1024 : (atoi(e) >= 512 ? 512 : 256);   // tuning knob
+            static bool attr_few[2][3][3] = {};
+            const int ti = nt == 256 ? 0 : (nt == 512 ? 1 : 2);
+            if (lds > 64 * 1024 && !attr_few[VEC][MODE][ti]) {
+                const void* fn = nt == 256 ? (const void*)k_solve_wave<MODE, VEC, 256, true>
+                                 : nt == 512 ? (const void*)k_solve_wave<MODE, VEC, 512, true> : (const void*)k_solve_wave<MODE, VEC, 1024, true>;
+                TBK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_few[VEC][MODE][ti] = true;
             }
-            hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 256, true>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, mv, nk,
-                               L, G2, flag, (int)run, (cd*)nullptr);
+            if (nt == 256)
+                hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 256, true>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, mv, nk, L,
+                                   G2, flag, (int)run, (cd*)nullptr);
+            else if (nt == 512)
+                hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 512, true>), dim3((unsigned)nblocks), dim3(512), lds, ctx->stream, mv, nk, L,
+                                   G2, flag, (int)run, (cd*)nullptr);
+            else
+                hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 1024, true>), dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream, mv, nk,
+                                   L, G2, flag, (int)run, (cd*)nullptr);
             TBK_HIP(hipGetLastError());
             return TBK_OK;
         }
