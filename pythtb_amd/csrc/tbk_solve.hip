@@ -1133,7 +1133,10 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         nk_eff = 1;
         for (int d = 0; d < G.wv.dim_arr; ++d) nk_eff *= G.gmesh[d];
     }
-    if (n >= big_from || (n > 64 && nk_eff <= 160)) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
+    // Larger batches of 65..256 states (ms; workgroup solver with 1024 threads | whole chip): eigenvalues only 512 x n=128
+    // 97 | 81, 256 x n=200 261 | 196, 256 x n=256 648 | 333 (the whole-chip solver skips V then); with vectors 109 | 145,
+    // 277 | 335, 670 | 648.
+    if (n >= big_from || (n > 64 && (nk_eff <= 160 || !VEC || n > 224))) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
     static const bool use_reg = [] {   // TBK_REG=0: fall back to the wavefront-per-matrix kernel (A/B runs)
         const char* e = getenv("TBK_REG");
         return !(e && atoi(e) == 0);
@@ -1221,8 +1224,16 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
             TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "eigen-solver workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
             ctx->work_bytes = wbytes;
         }
-        hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 256>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, mv, nk, L,
-                           G2, flag, (int)run, (cd*)ctx->work);
+        static const int wg_nt = [] {   // tuning knob: threads of the global-workspace workgroup solver
+            const char* e = getenv("TBK_WG_NT");
+            return e ? atoi(e) : 1024;
+        }();
+        if (wg_nt >= 1024)
+            hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 1024, false>), dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream, mv, nk,
+                               L, G2, flag, (int)run, (cd*)ctx->work);
+        else
+            hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 256>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, mv, nk, L,
+                               G2, flag, (int)run, (cd*)ctx->work);
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }
