@@ -706,7 +706,7 @@ struct WaveLds {
 template <int MODE, bool VEC, int NT, bool LDSWS = (NT == 64)>
 __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int64_t nk,
                                                    const ListArgs L, const GridArgs G,
-                                                   int* noconv_flag, const int run, cd* work) {
+                                                   int* noconv_flag, const int run, cd* work, const int warm) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int n = mv.nsta;
     const int ld = n + 1;
@@ -726,8 +726,8 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
     } else if constexpr (LDSWS) {           // a whole workgroup on one LDS-resident matrix (few matrices: latency)
         S.A = (cd*)lds_raw;
         S.Vt = S.A + n * ld;
-        S.T = S.Vt;                          // unused: cold start
-        S.rot = S.Vt + n * ld;
+        S.T = S.Vt + n * ld;                 // present only when the workgroup warm-starts along its run
+        S.rot = warm ? S.T + n * ld : S.T;
     } else {
         S.A = work + (size_t)blockIdx.x * 2 * n * ld;
         S.Vt = S.A + n * ld;
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
         it_end = it_begin + run < nk ? it_begin + run : nk;
     }
     for (int64_t it = it_begin; it < it_end; ++it) {
-        bool cold = it == it_begin || NT > 64;
+        bool cold = it == it_begin || !warm;
         bool store = true;
         int64_t id = it;
         double kk[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1157,33 +1157,44 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
             return launch_row16<MODE, VEC>(ctx, mv, nk, L, G);
     }
     // A 256-thread workgroup per LDS-resident matrix instead of one wavefront:
-    //  * n >= 32, any batch: with its warm-start buffer a wavefront's matrix takes 3 n(n+1) 16 B of LDS (n = 48:
-    //    113 KB, ONE wavefront per CU); four wavefronts sharing A and V^T (2 n(n+1) 16 B) keep 8-12 wavefronts per CU
-    //    busy even though they start cold.  Eigenvalues of 16384 ribbon matrices: n = 32 11.0 -> 9.2 ms, n = 48
-    //    92 -> 41 ms, n = 64 (8192) 209 -> 65 ms; at 1024 matrices n = 40 4.7 -> 1.8 ms.
-    //  * n < 32: only while the batch cannot fill the chip with wavefronts (one 30x30 matrix: 0.77 -> 0.34 ms);
-    //    large mesh-ordered batches keep the warm-started wavefront kernel (n = 24, 65536 k: 13.6 vs 20.5 ms).
-    static const int64_t few_max = [] {   // tuning knob: largest n < 32 batch that gets a workgroup per matrix
+    //  * n >= 22, any batch: a wavefront's matrix with its warm-start buffer takes 3 n(n+1) 16 B of LDS (n = 48:
+    //    113 KB, ONE wavefront per CU); several wavefronts sharing one matrix keep 8-16 wavefronts per CU busy, and
+    //    large batches warm-start along their runs as well where that still leaves two matrices per CU (n <= 40).
+    //    Eigenvalues, mesh-ordered k (ms, wavefront kernel -> this one): 65536 x n=24 13.6 -> 10.6, 16384 x n=32
+    //    11.0 -> 5.5, n=40 (4.7 at 1024 k) -> 11.7 (1.8), n=48 92 -> 33, 8192 x n=64 209 -> 39; n=22 9.4 -> 8.3 is
+    //    the crossover (n=20: 6.7 vs 7.5).
+    //  * n < 22: only while the batch cannot fill the chip with wavefronts (one 30x30 matrix: 0.77 -> 0.31 ms).
+    static const int64_t few_max = [] {   // tuning knob: largest n < 22 batch that gets a workgroup per matrix
         const char* e = getenv("TBK_FEW_MAX");
         return e ? (int64_t)atoll(e) : (int64_t)-1;
     }();
-    const bool few = n <= 64 && (n >= 32 || nk_eff <= (few_max >= 0 ? few_max : (int64_t)ctx->cus * 8));
+    const bool few = n <= 64 && (n >= 22 || nk_eff <= (few_max >= 0 ? few_max : (int64_t)ctx->cus * 8));
     if (n > 64 || few) {
         // ---- workgroup per matrix: 256 threads, cold start; n = 65..256: A and V^T in a global workspace
         // (ribbon / slab models: few, large matrices), n <= 64: in LDS.
-        const size_t lds = few ? wave_lds_bytes(n, false, mv.nR)
-                               : wave_lds_bytes(n, false) - (size_t)2 * n * (n + 1) * sizeof(cd);   // small arrays only
+        // a large batch walks runs of consecutive points per workgroup anyway: warm-start along them when the
+        // extra buffer still leaves two matrices per CU (TBK_FEW_WARM=0 disables)
+        static const bool warm_knob = [] {
+            const char* e = getenv("TBK_FEW_WARM");
+            return !(e && atoi(e) == 0);
+        }();
         const int64_t cap = std::max<int64_t>(64, (int64_t)ctx->cus * 4);
+        const int warm_few = few && warm_knob && nk_eff >= 2 * cap && wave_lds_bytes(n, true, mv.nR) <= 80 * 1024 ? 1 : 0;
+        const size_t lds = few ? wave_lds_bytes(n, warm_few != 0, mv.nR)
+                               : wave_lds_bytes(n, false) - (size_t)2 * n * (n + 1) * sizeof(cd);   // small arrays only
         int64_t run, nblocks;
         if (MODE == 1) {
             const int last = G.last;
             const int64_t off = G.off[last], nl = G.wv.mesh[last];
-            run = std::max<int64_t>(1, (G.wv.npts + cap - 1) / cap);
+            // (warm runs must not depend on the window: the run length comes from the global mesh size)
+            run = std::max<int64_t>(1, ((warm_few ? nk_eff : G.wv.npts) + cap - 1) / cap);
+            if (warm_few) run = std::min<int64_t>(run, 16);
             G2.wcfirst = off / run;
             G2.wnchunk = (int)((off + nl - 1) / run - G2.wcfirst + 1);
             nblocks = (G.wv.npts / nl) * G2.wnchunk;
         } else {
             run = std::max<int64_t>(1, (nk + cap - 1) / cap);
+            if (warm_few) run = std::min<int64_t>(run, 64);   // short chains: V's orthonormality drift stays ~1e-15
             nblocks = (nk + run - 1) / run;
         }
         TBK_REQUIRE(nblocks < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many k-points for one launch");
@@ -1205,13 +1216,13 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
             }
             if (nt == 256)
                 hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 256, true>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, mv, nk, L,
-                                   G2, flag, (int)run, (cd*)nullptr);
+                                   G2, flag, (int)run, (cd*)nullptr, warm_few);
             else if (nt == 512)
                 hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 512, true>), dim3((unsigned)nblocks), dim3(512), lds, ctx->stream, mv, nk, L,
-                                   G2, flag, (int)run, (cd*)nullptr);
+                                   G2, flag, (int)run, (cd*)nullptr, warm_few);
             else
                 hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 1024, true>), dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream, mv, nk,
-                                   L, G2, flag, (int)run, (cd*)nullptr);
+                                   L, G2, flag, (int)run, (cd*)nullptr, warm_few);
             TBK_HIP(hipGetLastError());
             return TBK_OK;
         }
@@ -1230,10 +1241,10 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         }();
         if (wg_nt >= 1024)
             hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 1024, false>), dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream, mv, nk,
-                               L, G2, flag, (int)run, (cd*)ctx->work);
+                               L, G2, flag, (int)run, (cd*)ctx->work, 0);
         else
             hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 256>), dim3((unsigned)nblocks), dim3(256), lds, ctx->stream, mv, nk, L,
-                               G2, flag, (int)run, (cd*)ctx->work);
+                               G2, flag, (int)run, (cd*)ctx->work, 0);
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }
@@ -1271,7 +1282,7 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     TBK_REQUIRE(nblocks < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many k-points for one launch");
     const unsigned blocks = (unsigned)nblocks;
     hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 64>), dim3(blocks), dim3(64), lds, ctx->stream, mv, nk, L, G2, flag, (int)run,
-                       (cd*)nullptr);
+                       (cd*)nullptr, 1);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
