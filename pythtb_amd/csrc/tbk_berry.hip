@@ -1093,7 +1093,8 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     TBK_REQUIRE(dir >= 0 && dir < v.dim_arr, TBK_EINVAL, "Wrong direction for Berry phase calculation!");
     ChainArgs A{};
     const bool big = nocc > TBK_MAX_NOCC && !berry_evals;   // det of the string = product of link dets (LU per link)
-    int rc = big ? check_occ(w, occ, nocc) : fill_occ(w, occ, nocc, A.occ);
+    const bool big_ev = nocc > TBK_MAX_NOCC && berry_evals;  // polar factors and QR in a per-thread global workspace
+    int rc = (big || big_ev) ? check_occ(w, occ, nocc) : fill_occ(w, occ, nocc, A.occ);
     if (rc) return rc;
     tbk_ctx* ctx = w->ctx;
     TBK_HIP(hipSetDevice(ctx->device));
@@ -1126,6 +1127,59 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         }
         TBK_HIP(hipMemcpyAsync(out, out_dev, (size_t)A.nstrings * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         TBK_HIP(hipStreamSynchronize(ctx->stream));
+        return TBK_OK;
+    }
+    if (big_ev) {
+        const size_t nn = (size_t)nocc * nocc;
+        // threads = strings x segments, bounded by 1 GiB of workspace (4 nocc^2 c128 per thread)
+        const int64_t tmax = std::max<int64_t>(A.nstrings, (int64_t)(((size_t)1 << 30) / (4 * nn * sizeof(cd))));
+        int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + 3) / 4, std::min<int64_t>(tmax, (int64_t)ctx->cus * 64) /
+                                                                                    std::max<int64_t>(A.nstrings, 1)));
+        ChainBigArgs B{};
+        B.v = v;
+        B.nocc = nocc;
+        B.nlinks = A.nlinks;
+        B.sdir = A.sdir;
+        B.other = A.other;
+        B.nstrings = A.nstrings;
+        B.seg_len = (int)((A.nlinks + nseg - 1) / nseg);
+        B.nseg = (A.nlinks + B.seg_len - 1) / B.seg_len;
+        const int64_t nthreads = A.nstrings * B.nseg;
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t ob = al((size_t)nocc * sizeof(int));
+        const size_t pb = al((size_t)nthreads * nn * sizeof(cd));
+        const size_t wb = al((size_t)nthreads * 4 * nn * sizeof(cd));
+        const size_t outb = al((size_t)A.nstrings * nocc * sizeof(double));
+        void* base = nullptr;
+        rc = tbk_ctx_scratch(ctx, 256 + ob + pb + wb + outb, &base);
+        if (rc) return rc;
+        unsigned char* p = (unsigned char*)base + 256;
+        int* occ_dev = (int*)p;
+        B.occ = occ_dev;
+        B.partial = (cd*)(p + ob);
+        B.work = (cd*)(p + ob + pb);
+        B.out = (double*)(p + ob + pb + wb);
+        B.flags = ctx->flags_dev;
+        TBK_HIP(hipMemcpyAsync(occ_dev, occ, (size_t)nocc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        {
+            ProfScope ps(ctx, "chain_partial_evals_big");
+            hipLaunchKernelGGL(k_chain_partial_big, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, ctx->stream, B);
+            TBK_HIP(hipGetLastError());
+        }
+        {
+            ProfScope ps(ctx, "chain_final_big");
+            hipLaunchKernelGGL(k_chain_final_big, dim3((unsigned)((A.nstrings + 63) / 64)), dim3(64), 0, ctx->stream, B);
+            TBK_HIP(hipGetLastError());
+        }
+        int flag = 0;
+        TBK_HIP(hipMemcpyAsync(out, B.out, (size_t)A.nstrings * nocc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        TBK_HIP(hipMemcpyAsync(&flag, ctx->flags_dev + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (flag) {
+            TBK_HIP(hipMemsetAsync(ctx->flags_dev + 1, 0, sizeof(int), ctx->stream));
+            tbk_set_error("tbk_berry_phase: QR iteration for Wilson-loop eigenvalues did not converge");
+            return TBK_ENOCONV;
+        }
         return TBK_OK;
     }
     // segment length: enough threads to fill the chip, segments no shorter than 8 links

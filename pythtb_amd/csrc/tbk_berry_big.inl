@@ -6,8 +6,13 @@
 //   berry_flux plaquette = -arg det[M(00,10) M(10,11) M(11,01) M(01,00)]          (pythtb.py:3840-3865)
 // need nothing but the determinants of the link matrices M_mn = <u_m(p)|u_n(p + e_dir)>.  One
 // workgroup per link forms M and reduces it by LU with partial pivoting (what numpy.linalg.det
-// does); two small kernels then combine the link determinants.  The Wilson-loop eigenphases
-// (berry_evals=True) need the polar factors of every link and stay limited to TBK_MAX_NOCC.
+// does); two small kernels then combine the link determinants.
+//
+// The Wilson-loop eigenphases (berry_evals=True) need the polar factor of every link and the spectrum of
+// their ordered product (pythtb.py:3825-3838).  Above TBK_MAX_NOCC the same per-thread routines as for small
+// sets (one-sided Jacobi polar factor, Householder-Hessenberg + shifted QR) run on matrices kept in a global
+// per-thread workspace instead of registers/local memory: thread = (string, segment of links), then one
+// thread per string.  Slow per thread, but this is the rarely used corner of the path.
 
 struct LinkDetArgs {
     WfsView v;
@@ -192,3 +197,78 @@ static int launch_link_dets(tbk_wfs* w, const int* occ_dev, int nocc, int dir, c
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
+
+// ---- Wilson-loop eigenphases for large occupied sets: matrices in a per-thread global workspace
+struct ChainBigArgs {
+    WfsView v;
+    const int* occ;
+    int nocc;
+    int nlinks;
+    int64_t sdir;
+    AxisSet other;
+    int64_t nstrings;
+    int seg_len, nseg;
+    cd* partial;   // [nseg][nstrings][nocc*nocc]
+    cd* work;      // [threads][4*nocc*nocc]
+    double* out;   // [nstrings][nocc]
+    int* flags;
+};
+
+__global__ __launch_bounds__(64) void k_chain_partial_big(const ChainBigArgs A) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= A.nstrings * A.nseg) return;
+    const int64_t seg = t / A.nstrings, s = t - seg * A.nstrings;
+    const int nocc = A.nocc, ncomp = A.v.ncomp, nn = nocc * nocc;
+    const int64_t plane = A.v.npts * ncomp;
+    cd* R = A.work + (size_t)t * 4 * nn;
+    cd *M = R + nn, *V = M + nn, *T = V + nn;
+    const int i0 = (int)seg * A.seg_len, i1 = min(i0 + A.seg_len, A.nlinks);
+    const cd* P = A.v.data + (axis_offset(A.other, s) + (int64_t)i0 * A.sdir) * ncomp;
+    const int64_t step = A.sdir * ncomp;
+    for (int a = 0; a < nocc; ++a)
+        for (int b = 0; b < nocc; ++b) R[a * nocc + b] = cd{a == b ? 1.0 : 0.0, 0.0};
+    for (int i = i0; i < i1; ++i, P += step) {
+        link_matrix_dyn(P, P + step, A.occ, nocc, ncomp, plane, M);
+        polar_dyn(nocc, M, V, T);                       // M <- U Vh of its SVD   (pythtb.py:3825-3826)
+        for (int a = 0; a < nocc; ++a)
+            for (int b = 0; b < nocc; ++b) {
+                cd acc{0.0, 0.0};
+                for (int j = 0; j < nocc; ++j) cfma(acc, R[a * nocc + j], M[j * nocc + b]);
+                T[a * nocc + b] = acc;
+            }
+        for (int e = 0; e < nn; ++e) R[e] = T[e];
+    }
+    cd* o = A.partial + ((int64_t)seg * A.nstrings + s) * nn;
+    for (int e = 0; e < nn; ++e) o[e] = R[e];
+}
+
+__global__ __launch_bounds__(64) void k_chain_final_big(const ChainBigArgs A) {
+    const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= A.nstrings) return;
+    const int nocc = A.nocc, nn = nocc * nocc;
+    cd* R = A.work + (size_t)s * 4 * nn;
+    cd *T = R + nn, *ev = T + nn, *rc = ev + nocc, *rs = rc + nocc;
+    for (int e = 0; e < nn; ++e) R[e] = A.partial[s * nn + e];
+    for (int g = 1; g < A.nseg; ++g) {
+        const cd* M = A.partial + ((int64_t)g * A.nstrings + s) * nn;
+        for (int a = 0; a < nocc; ++a)
+            for (int b = 0; b < nocc; ++b) {
+                cd acc{0.0, 0.0};
+                for (int j = 0; j < nocc; ++j) cfma(acc, R[a * nocc + j], M[j * nocc + b]);
+                T[a * nocc + b] = acc;
+            }
+        for (int e = 0; e < nn; ++e) R[e] = T[e];
+    }
+    if (!eigvals_dyn(nocc, R, ev, rc, rs)) atomicExch(A.flags + 1, 1);
+    double* o = A.out + s * nocc;   // sort(-angle(eigvals))   (pythtb.py:3834-3838)
+    for (int j = 0; j < nocc; ++j) {
+        const double ph = -atan2(ev[j].y, ev[j].x);
+        int pos = j;
+        while (pos > 0 && o[pos - 1] > ph) {
+            o[pos] = o[pos - 1];
+            --pos;
+        }
+        o[pos] = ph;
+    }
+}
+

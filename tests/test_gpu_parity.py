@@ -585,8 +585,9 @@ def test_large_nocc_and_unsupported_sizes(tb):
         for d in (0, 1):
             got = w.berry_phase(occ, d, contin=False)
             assert np.max(np.abs(wrap(got - orc.berry_phase(owfs, 2, occ, d, contin=False)))) < TOL_P
-    with pytest.raises(_lib.TbkError, match="limit"):         # ... but the Wilson-loop eigenphases stay limited
-        w.berry_phase(list(range(17)), 0, contin=False, berry_evals=True)
+        for d in (0, 1):                                      # ... and the Wilson-loop eigenphases too
+            got = w.berry_phase(occ, d, contin=False, berry_evals=True)
+            assert_phase_sets_close(got, orc.berry_phase(owfs, 2, occ, d, contin=False, berry_evals=True), 1e-9)
     # a ribbon with 70 occupied bands of 140 (the LU matrix no longer fits in LDS) and a 1-D string
     rib = hp.haldane(tb.tb_model, 1.2).cut_piece(70, 1)        # trivial phase: the ribbon is gapped at half filling
     wr = tb.wf_array(rib, [9])
@@ -594,6 +595,8 @@ def test_large_nocc_and_unsupported_sizes(tb):
     orib, _ = orc.solve_on_grid(rib, [9], [0.0], vectorised=True)
     for occ in (list(range(70)), list(range(140))):
         assert abs(wrap(wr.berry_phase(occ, contin=False) - orc.berry_phase(orib, 1, occ, None, contin=False))) < 1e-8
+    got = wr.berry_phase(list(range(70)), contin=False, berry_evals=True)          # 70 hybrid Wannier centres of the ribbon
+    assert_phase_sets_close(got, orc.berry_phase(orib, 1, list(range(70)), None, contin=False, berry_evals=True), 1e-8)
     big = hp.quiet(tb.tb_model, 1, 1, [[1.0]], 2100)
     with pytest.raises(_lib.TbkError, match="limit"):
         big.solve_all([0.1])                                   # nsta > TBK_MAX_NSTA fails loudly
