@@ -357,10 +357,13 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     int pmax = 0;
     for (int64_t t = 0; t < nterm; ++t) pmax = std::max(pmax, std::abs(R4[t * 4 + last]));
     const int npow = 2 * pmax + 1;
-    std::vector<int32_t> cell_ptr((size_t)nslot * npow + 1, 0);
-    for (int s = 0; s < nslot; ++s)
-        for (int t = slot_ptr[s]; t < slot_ptr[s + 1]; ++t) cell_ptr[(size_t)s * npow + (R4[t * 4 + last] + pmax) + 1]++;
-    for (size_t c = 0; c + 1 < cell_ptr.size(); ++c) cell_ptr[c + 1] += cell_ptr[c];
+    // (only the n <= 4 mesh-row kernel reads it: a 2048-state model would carry 6 M useless entries)
+    std::vector<int32_t> cell_ptr(n <= 4 ? (size_t)nslot * npow + 1 : 1, 0);
+    if (n <= 4) {
+        for (int s = 0; s < nslot; ++s)
+            for (int t = slot_ptr[s]; t < slot_ptr[s + 1]; ++t) cell_ptr[(size_t)s * npow + (R4[t * 4 + last] + pmax) + 1]++;
+        for (size_t c = 0; c + 1 < cell_ptr.size(); ++c) cell_ptr[c + 1] += cell_ptr[c];
+    }
     std::vector<double> orb4((size_t)n * 4, 0.0);
     for (int a = 0; a < n; ++a)
         for (int d = 0; d < dim_k; ++d) orb4[a * 4 + d] = orb[(a / ns) * dim_k + d];
