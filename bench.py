@@ -13,8 +13,11 @@ in HBM before the timed region; nothing crosses PCIe inside it.
 
 N > 1 (weak scaling): the global mesh is (2048*N + 1) x 2049; rank r owns the slab
 of 2048 plaquette rows starting at global row 2048*r and recomputes its one halo
-row, so there is no data-path collective.  The only exchange is one RCCL all-gather
-of [partial flux, min gap] per rank after the timed loop.
+row, so there is no data-path collective.  The only exchange is the gather of
+[partial flux, min gap, elapsed] per rank after the timed loop: through gloo for the
+reported line, and once more through the RCCL all-gather (tbk_comm_*) as a check of
+that path, under a watchdog so that a communicator that never comes up cannot cost
+the measurement.
 
 Prints ONE JSON line on rank 0.
 """
@@ -159,57 +162,14 @@ def main():
         import torch
         mine = np.array([tot[0], gaps[0], elapsed])
 
-        def all_ok(ok):
-            """Every rank takes the same branch: true only if the step succeeded everywhere."""
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return bool(flag.item())
+        # results first through gloo (3 doubles per rank, outside the timed region): the line below must not
+        # depend on anything that can hang
+        buf = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(buf, torch.from_numpy(mine))
+        allv = np.stack([b.numpy() for b in buf])
+        gather = "gloo"
 
-        # the one collective of the path: RCCL all-gather over xGMI (tbk_comm_*).  Each stage is
-        # agreed on by all ranks, so a failure anywhere sends everybody to the gloo gather together.
-        err = ""
-        uid_bytes = None
-        if rank == 0:
-            try:
-                uid = (C.c_ubyte * 128)()
-                _lib.check(lib.tbk_comm_unique_id(uid))
-                uid_bytes = bytes(uid)
-            except Exception as e:
-                err = "unique_id: %s" % e
-        box = [uid_bytes]
-        dist.broadcast_object_list(box, src=0)
-        ok = box[0] is not None
-        if ok:
-            try:
-                uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
-                _lib.check(lib.tbk_comm_init(ctx.handle, uid, world, rank))
-            except Exception as e:
-                ok, err = False, "init: %s" % e
-        ok = all_ok(ok)
-        if ok:
-            try:
-                send, recv = C.c_void_p(), C.c_void_p()
-                _lib.check(lib.tbk_dev_alloc(ctx.handle, 24, C.byref(send)))
-                _lib.check(lib.tbk_dev_alloc(ctx.handle, 24 * world, C.byref(recv)))
-                _lib.check(lib.tbk_dev_upload(ctx.handle, send, mine.ctypes.data_as(C.c_void_p), 24))
-                _lib.check(lib.tbk_comm_allgather_f64(ctx.handle, send, recv, 3))
-                got = np.zeros((world, 3))
-                _lib.check(lib.tbk_dev_download(ctx.handle, got.ctypes.data_as(C.c_void_p), recv, 24 * world))
-            except Exception as e:
-                ok, err = False, "allgather: %s" % e
-            ok = all_ok(ok)
-        if ok:
-            allv, gather = got, "rccl_allgather"
-        else:                                       # keep the measurement; say what happened
-            if err:
-                sys.stderr.write("[bench] rank %d: RCCL gather unavailable (%s); using the gloo gather\n"
-                                 % (rank, " ".join(str(err).split())))
-            buf = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(buf, torch.from_numpy(mine))
-            allv = np.stack([b.numpy() for b in buf])
-            gather = "gloo_fallback"
-
-    if rank == 0:
+    def report(gather):
         t_max = float(allv[:, 2].max())
         nk_step = MESH * MESH * world
         chern = float(allv[:, 0].sum() / (2 * np.pi))
@@ -254,7 +214,71 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         assert args.no_check or abs(chern + 1.0) < 1e-9, "Chern number %r != -1" % chern
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        # The path's one collective, the RCCL all-gather over xGMI (tbk_comm_*), run on the same numbers and
+        # checked against the gloo result.  A communicator that never comes up must not cost the measurement:
+        # a watchdog prints the line (rank 0) and ends the process if the RCCL stage is still stuck after 90 s.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                report("gloo (rccl all-gather timed out)")
+            os._exit(0)
+
+        dog = threading.Timer(float(os.environ.get("TBK_BENCH_RCCL_TIMEOUT", "90")), give_up)
+        dog.daemon = True
+        dog.start()
+
+        def all_ok(ok):
+            """Every rank takes the same branch: true only if the step succeeded everywhere."""
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        err = ""
+        uid_bytes = None
+        if rank == 0:
+            try:
+                uid = (C.c_ubyte * 128)()
+                _lib.check(lib.tbk_comm_unique_id(uid))
+                uid_bytes = bytes(uid)
+            except Exception as e:
+                err = "unique_id: %s" % e
+        box = [uid_bytes]
+        dist.broadcast_object_list(box, src=0)
+        ok = box[0] is not None
+        if ok:
+            try:
+                uid = (C.c_ubyte * 128).from_buffer_copy(box[0])
+                _lib.check(lib.tbk_comm_init(ctx.handle, uid, world, rank))
+            except Exception as e:
+                ok, err = False, "init: %s" % e
+        ok = all_ok(ok)
+        if ok:
+            try:
+                send, recv = C.c_void_p(), C.c_void_p()
+                _lib.check(lib.tbk_dev_alloc(ctx.handle, 24, C.byref(send)))
+                _lib.check(lib.tbk_dev_alloc(ctx.handle, 24 * world, C.byref(recv)))
+                _lib.check(lib.tbk_dev_upload(ctx.handle, send, mine.ctypes.data_as(C.c_void_p), 24))
+                _lib.check(lib.tbk_comm_allgather_f64(ctx.handle, send, recv, 3))
+                got = np.zeros((world, 3))
+                _lib.check(lib.tbk_dev_download(ctx.handle, got.ctypes.data_as(C.c_void_p), recv, 24 * world))
+                if not np.array_equal(got, allv):
+                    ok, err = False, "allgather: result differs from the gloo gather"
+            except Exception as e:
+                ok, err = False, "allgather: %s" % e
+            ok = all_ok(ok)
+        dog.cancel()
+        if ok:
+            gather = "rccl_allgather (equal to the gloo gather)"
+        else:
+            gather = "gloo (rccl all-gather unavailable)"
+            if err:
+                sys.stderr.write("[bench] rank %d: RCCL gather unavailable (%s)\n" % (rank, " ".join(str(err).split())))
+    if rank == 0:
+        report(gather)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
