@@ -525,6 +525,8 @@ class tb_model(object):
         k_vec[0] = nodes[0]
         for s in range(1, n_nodes):
             lo, hi = node_index[s - 1], node_index[s]
+            if hi == lo:        # two nodes on one path index: the reference's 0/0 (pythtb.py:1991)
+                raise ZeroDivisionError("float division by zero")
             frac = (np.arange(lo, hi + 1) - lo).astype(float) / float(hi - lo)
             k_dist[lo:hi + 1] = k_node[s - 1] + frac * (k_node[s] - k_node[s - 1])
             k_vec[lo:hi + 1] = nodes[s - 1] + frac[:, None] * (nodes[s] - nodes[s - 1])

@@ -35,7 +35,7 @@ def cut_piece(self, num, fin_dir, glue_edgs=False):
     if per.count(fin_dir) != 1:
         raise Exception("\n\nCan not make model finite along this direction!")
     per.remove(fin_dir)
-    out = type(self)(self._dim_k - 1, self._dim_r, copy.deepcopy(self._lat), orbs, per, self._nspin)
+    out = type(self)(self._dim_k - 1, self._dim_r, copy.deepcopy(self._lat), orbs if no else [], per, self._nspin)
     out._assume_position_operator_diagonal = self._assume_position_operator_diagonal
     out.set_onsite(onsite, mode="reset")
     total = no * num

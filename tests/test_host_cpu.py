@@ -292,3 +292,19 @@ def test_visualize_draws_what_the_reference_draws():
     for bad in (lambda: h.visualize(0), lambda: h.visualize(0, 1, ph_color="rainbow"), lambda: h.visualize(0, 1, eig_dr=np.ones(3))):
         with pytest.raises(Exception):
             bad()
+
+
+def test_k_path_too_few_points_raises_like_reference():
+    """Two nodes landing on one path index is a 0/0 in the reference's interpolation loop
+    (pythtb.py:1985-1996), which raises ZeroDivisionError; found by tests/golden/diff_fuzz_host.py."""
+    from pythtb_amd import tb_model
+    m = tb_model(1, 1, [[1.0]], [[0.0]])
+    with pytest.raises(ZeroDivisionError):
+        m.k_path([[-0.80], [-0.82], [0.35], [0.89]], 5, report=False)
+
+
+def test_cut_piece_of_an_orbital_free_model_raises_like_reference():
+    from pythtb_amd import tb_model
+    m = tb_model(1, 1, [[1.0]], [[0.0]]).remove_orb(0)
+    with pytest.raises(Exception, match="Wrong orb array rank"):
+        m.cut_piece(2, 0)
