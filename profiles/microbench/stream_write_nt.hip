@@ -1,3 +1,4 @@
+#include <cstdlib>
 // Variants of the streaming-write ceiling: plain vs nontemporal stores, grid-stride vs
 // block-contiguous addressing (268 MB, 16 B per lane).
 // hipcc --offload-arch=gfx950 -O3 stream_write_nt.hip -o stream_write_nt && ./stream_write_nt
@@ -41,11 +42,13 @@ static void run(double* p, size_t n, size_t bytes, int grid, const char* name) {
     }
     printf("%-28s grid %6d: %.1f us  %.2f TB/s\n", name, grid, best * 1e3, bytes / (best * 1e-3) / 1e12);
 }
-int main() {
-    const size_t bytes = 268435456, n = bytes / 16;
+int main(int argc, char** argv) {
+    // optional argument: buffer size in MiB (default 256, the size of the 2049 x 2049 Haldane grid)
+    const size_t bytes = (argc > 1 ? (size_t)atoll(argv[1]) : 256) << 20, n = bytes / 16;
     double* p;
     hipMalloc(&p, bytes);
-    for (int grid : {1024, 2048, 8192, 65536}) {
+    printf("buffer %zu MiB\n", bytes >> 20);
+    for (int grid : {2048, 8192, 65536}) {
         run<0, 0>(p, n, bytes, grid, "plain grid-stride");
         run<1, 0>(p, n, bytes, grid, "nontemporal grid-stride");
         run<0, 1>(p, n, bytes, grid, "plain block-contiguous");
