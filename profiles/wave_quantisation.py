@@ -18,7 +18,7 @@ lib, ctx = _lib.lib, _lib.default_context()
 m = hp.haldane(tb.tb_model, 0.0)
 hm = m._device_model()
 start = np.array([-0.5, -0.5])
-for rows in ((2049,) if os.environ.get("TBK_GRID_TAIL_PCT") else (205, 410, 615, 820, 1024, 1229, 1434, 1638, 1843, 2049, 2254, 2458, 2663, 2868, 3072, 3277, 3482, 3686, 4097)):
+for rows in ((int(os.environ["WQ_ROWS"]),) if os.environ.get("WQ_ROWS") else (205, 410, 615, 820, 1024, 1229, 1434, 1638, 1843, 2049, 2254, 2458, 2663, 2868, 3072, 3277, 3482, 3686, 4097)):
     mesh = [rows, 2049]
     hw, pbc = grid_handle(ctx, m, mesh)
     t = timed(ctx, lambda: _lib.check(lib.tbk_wfs_solve_grid_async(hw, hm, _lib.dptr(start), _lib.dptr(pbc.view(float)), 0, mesh[0])), int(os.environ.get("WQ_REPS", "8")))
