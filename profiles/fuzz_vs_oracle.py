@@ -71,6 +71,11 @@ for case in range(ncase):
         got = w.berry_phase(occ, d if dim_k > 1 else None, contin=False)
         want = orc.berry_phase(owfs, dim_k, occ, d if dim_k > 1 else None, contin=False)
         p_err = np.abs(wrap(got - want)).max()
+        if nocc > 1:             # Wilson-loop eigenphases, compared as sets on the circle
+            got = np.sort(w.berry_phase(occ, d if dim_k > 1 else None, contin=False, berry_evals=True), -1)
+            want = np.sort(orc.berry_phase(owfs, dim_k, occ, d if dim_k > 1 else None, contin=False, berry_evals=True), -1)
+            w_err = min(np.abs(wrap(np.roll(got, sh, -1) - want)).max() for sh in (-1, 0, 1))
+            p_err = max(p_err, w_err)
     errs = dict(eval=e_err, resid=r_err, orth=o_err, gap=g_err, flux=f_err, phase=p_err)
     for key, v in errs.items():
         worst[key] = max(worst[key], float(v))

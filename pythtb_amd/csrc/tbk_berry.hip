@@ -1093,7 +1093,12 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     TBK_REQUIRE(dir >= 0 && dir < v.dim_arr, TBK_EINVAL, "Wrong direction for Berry phase calculation!");
     ChainArgs A{};
     const bool big = nocc > TBK_MAX_NOCC && !berry_evals;   // det of the string = product of link dets (LU per link)
-    const bool big_ev = nocc > TBK_MAX_NOCC && berry_evals;  // polar factors and QR in a per-thread global workspace
+    // Wilson-loop eigenphases: closed forms up to two bands; from three on the workgroup-level pipeline, which
+    // measured 3x (3 bands) to 160x (16 bands) faster than the per-thread polar/QR kernels at every string count
+    // and length tried (profiles/wilson_small_probe.py)
+    int ev_from = 3;
+    if (const char* e = getenv("TBK_WILSON_BIG_FROM")) ev_from = std::max(2, atoi(e));    // tuning knob
+    const bool big_ev = nocc >= ev_from && berry_evals;  // workgroup-level polar factors, product tree, Cayley + eigh
     int rc = (big || big_ev) ? check_occ(w, occ, nocc) : fill_occ(w, occ, nocc, A.occ);
     if (rc) return rc;
     tbk_ctx* ctx = w->ctx;
@@ -1130,55 +1135,107 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         return TBK_OK;
     }
     if (big_ev) {
+        // workgroup-level pipeline (tbk_berry_big.inl): link polar factors, pairwise product tree, Cayley
+        // transform + Hermitian eigen-solve.  Strings go in batches whose two ping-pong link arrays fit 1 GiB.
         const size_t nn = (size_t)nocc * nocc;
-        // threads = strings x segments, bounded by 1 GiB of workspace (4 nocc^2 c128 per thread)
-        const int64_t tmax = std::max<int64_t>(A.nstrings, (int64_t)(((size_t)1 << 30) / (4 * nn * sizeof(cd))));
-        int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + 3) / 4, std::min<int64_t>(tmax, (int64_t)ctx->cus * 64) /
-                                                                                    std::max<int64_t>(A.nstrings, 1)));
-        ChainBigArgs B{};
-        B.v = v;
-        B.nocc = nocc;
-        B.nlinks = A.nlinks;
-        B.sdir = A.sdir;
-        B.other = A.other;
-        B.nstrings = A.nstrings;
-        B.seg_len = (int)((A.nlinks + nseg - 1) / nseg);
-        B.nseg = (A.nlinks + B.seg_len - 1) / B.seg_len;
-        const int64_t nthreads = A.nstrings * B.nseg;
+        const int L = A.nlinks;
+        const int64_t cap = std::max<int64_t>(1, (int64_t)(((size_t)1 << 30) / (2 * (size_t)L * nn * sizeof(cd))));
+        const int64_t nsb = std::min<int64_t>(A.nstrings, cap);
+        const unsigned nblk = (unsigned)std::min<int64_t>(nsb * L, (int64_t)ctx->cus * 4);
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t ob = al((size_t)nocc * sizeof(int));
-        const size_t pb = al((size_t)nthreads * nn * sizeof(cd));
-        const size_t wb = al((size_t)nthreads * 4 * nn * sizeof(cd));
-        const size_t outb = al((size_t)A.nstrings * nocc * sizeof(double));
+        const size_t bb = al((size_t)nsb * L * nn * sizeof(cd));
+        const size_t yb = al((size_t)nblk * nn * sizeof(cd));
+        const size_t abb = al((size_t)nsb * 2 * nn * sizeof(cd));
+        const size_t hb = al((size_t)nsb * nn * sizeof(cd));
+        const size_t eb = al((size_t)nsb * nocc * sizeof(double));
+        const size_t mb = al((size_t)nsb * sizeof(double));
         void* base = nullptr;
-        rc = tbk_ctx_scratch(ctx, 256 + ob + pb + wb + outb, &base);
+        rc = tbk_ctx_scratch(ctx, 256 + ob + 2 * bb + yb + abb + hb + 2 * eb + mb, &base);
         if (rc) return rc;
         unsigned char* p = (unsigned char*)base + 256;
         int* occ_dev = (int*)p;
-        B.occ = occ_dev;
-        B.partial = (cd*)(p + ob);
-        B.work = (cd*)(p + ob + pb);
-        B.out = (double*)(p + ob + pb + wb);
-        B.flags = ctx->flags_dev;
+        p += ob;
+        cd* buf0 = (cd*)p;
+        p += bb;
+        cd* buf1 = (cd*)p;
+        p += bb;
+        cd* ywork = (cd*)p;
+        p += yb;
+        cd* ab = (cd*)p;
+        p += abb;
+        cd* herm = (cd*)p;
+        p += hb;
+        double* ev_dev = (double*)p;
+        p += eb;
+        double* out_dev = (double*)p;
+        p += eb;
+        double* hmax_dev = (double*)p;
         TBK_HIP(hipMemcpyAsync(occ_dev, occ, (size_t)nocc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        {
-            ProfScope ps(ctx, "chain_partial_evals_big");
-            hipLaunchKernelGGL(k_chain_partial_big, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, ctx->stream, B);
-            TBK_HIP(hipGetLastError());
-        }
-        {
-            ProfScope ps(ctx, "chain_final_big");
-            hipLaunchKernelGGL(k_chain_final_big, dim3((unsigned)((A.nstrings + 63) / 64)), dim3(64), 0, ctx->stream, B);
-            TBK_HIP(hipGetLastError());
-        }
-        int flag = 0;
-        TBK_HIP(hipMemcpyAsync(out, B.out, (size_t)A.nstrings * nocc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        TBK_HIP(hipMemcpyAsync(&flag, ctx->flags_dev + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        TBK_HIP(hipStreamSynchronize(ctx->stream));
-        if (flag) {
-            TBK_HIP(hipMemsetAsync(ctx->flags_dev + 1, 0, sizeof(int), ctx->stream));
-            tbk_set_error("tbk_berry_phase: QR iteration for Wilson-loop eigenvalues did not converge");
-            return TBK_ENOCONV;
+        std::vector<double> out_h((size_t)nsb * nocc), hmax_h((size_t)nsb), best((size_t)nsb);
+        double alphas[4] = {0.7390851332151607, 2.3, 3.9, 5.5};
+        if (const char* a0 = getenv("TBK_WILSON_ALPHA")) alphas[0] = atof(a0);   // test hook: put the pole on an eigenphase
+        for (int64_t s0 = 0; s0 < A.nstrings; s0 += nsb) {
+            const int64_t ns = std::min<int64_t>(nsb, A.nstrings - s0);
+            WilsonBigArgs W{};
+            W.v = v;
+            W.occ = occ_dev;
+            W.nocc = nocc;
+            W.nlinks = L;
+            W.sdir = A.sdir;
+            W.other = A.other;
+            W.s0 = s0;
+            W.ns = ns;
+            W.buf0 = buf0;
+            W.buf1 = buf1;
+            W.ywork = ywork;
+            {
+                ProfScope ps(ctx, "link_polar_big");
+                hipLaunchKernelGGL(k_link_polar_big, dim3((unsigned)std::min<int64_t>(ns * L, nblk)), dim3(256), 0, ctx->stream, W);
+                TBK_HIP(hipGetLastError());
+            }
+            cd *cur = buf0, *nxt = buf1;
+            for (int st = 1; st < L; st *= 2) {
+                WilsonTreeArgs T{cur, nxt, nocc, L, st, ns};
+                const int64_t items = ns * ((L + 2 * st - 1) / (2 * st));
+                ProfScope ps(ctx, "wilson_tree");
+                hipLaunchKernelGGL(k_wilson_tree, dim3((unsigned)std::min<int64_t>(items, (int64_t)ctx->cus * 4)), dim3(256), 0,
+                                   ctx->stream, T);
+                TBK_HIP(hipGetLastError());
+                std::swap(cur, nxt);
+            }
+            std::fill(best.begin(), best.begin() + ns, 1e300);
+            for (int attempt = 0; attempt < 4; ++attempt) {
+                const double alpha = alphas[attempt];
+                CayleyArgs C{cur, (size_t)L * nn, ab, herm, nocc, cos(alpha), sin(alpha)};
+                {
+                    ProfScope ps(ctx, "wilson_cayley");
+                    hipLaunchKernelGGL(k_wilson_cayley, dim3((unsigned)ns), dim3(256), 0, ctx->stream, C);
+                    TBK_HIP(hipGetLastError());
+                }
+                rc = tbk_eigh_dev(ctx, nocc, herm, ns, ev_dev, nullptr, "wilson_eigh");
+                if (rc) return rc;
+                {
+                    ProfScope ps(ctx, "wilson_phases");
+                    hipLaunchKernelGGL(k_wilson_phases, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, ctx->stream,
+                                       (const double*)ev_dev, ns, nocc, alpha, out_dev, hmax_dev);
+                    TBK_HIP(hipGetLastError());
+                }
+                TBK_HIP(hipMemcpyAsync(out_h.data(), out_dev, (size_t)ns * nocc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                TBK_HIP(hipMemcpyAsync(hmax_h.data(), hmax_dev, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                TBK_HIP(hipStreamSynchronize(ctx->stream));
+                rc = tbk_eigh_check(ctx, nocc);
+                if (rc) return rc;
+                bool all_ok = true;
+                for (int64_t s = 0; s < ns; ++s) {
+                    if (hmax_h[s] < best[s]) {      // also false for NaN
+                        best[s] = hmax_h[s];
+                        memcpy(out + (size_t)(s0 + s) * nocc, out_h.data() + (size_t)s * nocc, (size_t)nocc * sizeof(double));
+                    }
+                    if (!(best[s] <= 1e4)) all_ok = false;
+                }
+                if (all_ok) break;
+            }
         }
         return TBK_OK;
     }

@@ -9,10 +9,7 @@
 // does); two small kernels then combine the link determinants.
 //
 // The Wilson-loop eigenphases (berry_evals=True) need the polar factor of every link and the spectrum of
-// their ordered product (pythtb.py:3825-3838).  Above TBK_MAX_NOCC the same per-thread routines as for small
-// sets (one-sided Jacobi polar factor, Householder-Hessenberg + shifted QR) run on matrices kept in a global
-// per-thread workspace instead of registers/local memory: thread = (string, segment of links), then one
-// thread per string.  Slow per thread, but this is the rarely used corner of the path.
+// their ordered product (pythtb.py:3825-3838): second half of this file, also workgroup-level.
 
 struct LinkDetArgs {
     WfsView v;
@@ -198,71 +195,242 @@ static int launch_link_dets(tbk_wfs* w, const int* occ_dev, int nocc, int dir, c
     return TBK_OK;
 }
 
-// ---- Wilson-loop eigenphases for large occupied sets: matrices in a per-thread global workspace
-struct ChainBigArgs {
-    WfsView v;
-    const int* occ;
-    int nocc;
-    int nlinks;
-    int64_t sdir;
-    AxisSet other;
-    int64_t nstrings;
-    int seg_len, nseg;
-    cd* partial;   // [nseg][nstrings][nocc*nocc]
-    cd* work;      // [threads][4*nocc*nocc]
-    double* out;   // [nstrings][nocc]
-    int* flags;
-};
+// ---- Wilson-loop eigenphases for large occupied sets, workgroup level.
+// Every step is a dense nocc x nocc operation shared by the 256 threads of a workgroup, matrices in global
+// memory (L2-resident: 78 KB at nocc = 70):
+//   1. link polar factors  W = M (M^H M)^(-1/2)  (= U Vh of the SVD, pythtb.py:3825-3826) by the Newton-Schulz
+//      iteration X <- X (3 I - X^H X) / 2, which needs only products and converges quadratically from the singular
+//      values of an overlap matrix (all in (0, 1]);
+//   2. the ordered product of a string's factors by a pairwise tree, one launch per level;
+//   3. the spectrum of the unitary product P through the Cayley transform of Q = e^{-i alpha} P,
+//      H = i (I - Q)(I + Q)^(-1), Hermitian with eigenvalues tan((theta - alpha) / 2): one Gauss-Jordan solve,
+//      then the batched Hermitian eigen-solver of tbk_solve.hip; theta -> sort(-angle)  (pythtb.py:3834-3838).
+//      The map has a pole at theta = alpha + pi; an eigenphase closer than ~2e-4 to it (|h| > 1e4) would lose
+//      digits, so the host repeats step 3 with another alpha for such strings.
 
-__global__ __launch_bounds__(64) void k_chain_partial_big(const ChainBigArgs A) {
-    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= A.nstrings * A.nseg) return;
-    const int64_t seg = t / A.nstrings, s = t - seg * A.nstrings;
-    const int nocc = A.nocc, ncomp = A.v.ncomp, nn = nocc * nocc;
-    const int64_t plane = A.v.npts * ncomp;
-    cd* R = A.work + (size_t)t * 4 * nn;
-    cd *M = R + nn, *V = M + nn, *T = V + nn;
-    const int i0 = (int)seg * A.seg_len, i1 = min(i0 + A.seg_len, A.nlinks);
-    const cd* P = A.v.data + (axis_offset(A.other, s) + (int64_t)i0 * A.sdir) * ncomp;
-    const int64_t step = A.sdir * ncomp;
-    for (int a = 0; a < nocc; ++a)
-        for (int b = 0; b < nocc; ++b) R[a * nocc + b] = cd{a == b ? 1.0 : 0.0, 0.0};
-    for (int i = i0; i < i1; ++i, P += step) {
-        link_matrix_dyn(P, P + step, A.occ, nocc, ncomp, plane, M);
-        polar_dyn(nocc, M, V, T);                       // M <- U Vh of its SVD   (pythtb.py:3825-3826)
-        for (int a = 0; a < nocc; ++a)
-            for (int b = 0; b < nocc; ++b) {
-                cd acc{0.0, 0.0};
-                for (int j = 0; j < nocc; ++j) cfma(acc, R[a * nocc + j], M[j * nocc + b]);
-                T[a * nocc + b] = acc;
+// workgroup-cooperative C = sAB * op(A) B + sD * D (m x m, row-major); op(A) = A^H when HA.  2 x 2 register tiles.
+// Returns this thread's share of ||C - I||_F^2 when RES.
+template <bool HA, bool RES>
+__device__ double wg_matmul(const int m, const cd* __restrict__ A, const cd* __restrict__ B, cd* __restrict__ C,
+                            const double sAB, const cd* __restrict__ D, const double sD) {
+    const int mt = (m + 1) >> 1;
+    double res = 0.0;
+    for (int e = threadIdx.x; e < mt * mt; e += blockDim.x) {
+        const int ta = e / mt, tb = e - ta * mt;
+        const int a0 = 2 * ta, b0 = 2 * tb;
+        const int a1 = min(a0 + 1, m - 1), b1 = min(b0 + 1, m - 1);
+        cd c00{0.0, 0.0}, c01{0.0, 0.0}, c10{0.0, 0.0}, c11{0.0, 0.0};
+        for (int j = 0; j < m; ++j) {
+            const cd y0 = B[j * m + b0], y1 = B[j * m + b1];
+            if (HA) {
+                const cd x0 = A[j * m + a0], x1 = A[j * m + a1];
+                cfmac(c00, x0, y0);
+                cfmac(c01, x0, y1);
+                cfmac(c10, x1, y0);
+                cfmac(c11, x1, y1);
+            } else {
+                const cd x0 = A[a0 * m + j], x1 = A[a1 * m + j];
+                cfma(c00, x0, y0);
+                cfma(c01, x0, y1);
+                cfma(c10, x1, y0);
+                cfma(c11, x1, y1);
             }
-        for (int e = 0; e < nn; ++e) R[e] = T[e];
+        }
+        auto put = [&](int a, int b, cd c) {
+            cd o = cscale(c, sAB);
+            if (D) {
+                const cd d = D[a * m + b];
+                o.x += sD * d.x;
+                o.y += sD * d.y;
+            }
+            C[a * m + b] = o;
+            if (RES) {
+                const double dx = o.x - (a == b ? 1.0 : 0.0);
+                res += dx * dx + o.y * o.y;
+            }
+        };
+        put(a0, b0, c00);
+        if (b0 + 1 < m) put(a0, b1, c01);
+        if (a0 + 1 < m) {
+            put(a1, b0, c10);
+            if (b0 + 1 < m) put(a1, b1, c11);
+        }
     }
-    cd* o = A.partial + ((int64_t)seg * A.nstrings + s) * nn;
-    for (int e = 0; e < nn; ++e) o[e] = R[e];
+    return res;
 }
 
-__global__ __launch_bounds__(64) void k_chain_final_big(const ChainBigArgs A) {
-    const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (s >= A.nstrings) return;
-    const int nocc = A.nocc, nn = nocc * nocc;
-    cd* R = A.work + (size_t)s * 4 * nn;
-    cd *T = R + nn, *ev = T + nn, *rc = ev + nocc, *rs = rc + nocc;
-    for (int e = 0; e < nn; ++e) R[e] = A.partial[s * nn + e];
-    for (int g = 1; g < A.nseg; ++g) {
-        const cd* M = A.partial + ((int64_t)g * A.nstrings + s) * nn;
-        for (int a = 0; a < nocc; ++a)
-            for (int b = 0; b < nocc; ++b) {
-                cd acc{0.0, 0.0};
-                for (int j = 0; j < nocc; ++j) cfma(acc, R[a * nocc + j], M[j * nocc + b]);
-                T[a * nocc + b] = acc;
+struct WilsonBigArgs {
+    WfsView v;
+    const int* occ;
+    int nocc, nlinks;
+    int64_t sdir;
+    AxisSet other;
+    int64_t s0;      // first string of this batch
+    int64_t ns;      // strings in this batch
+    cd* buf0;        // [ns][nlinks][nocc^2]  link factors (result of step 1), then tree levels
+    cd* buf1;        // same size, ping-pong partner
+    cd* ywork;       // [gridDim.x][nocc^2]
+};
+
+__global__ __launch_bounds__(256) void k_link_polar_big(const WilsonBigArgs A) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x, m = A.nocc, nn = m * m, ncomp = A.v.ncomp;
+    cd* Y = A.ywork + (size_t)blockIdx.x * nn;
+    for (int64_t item = blockIdx.x; item < A.ns * A.nlinks; item += gridDim.x) {
+        const int64_t s = item / A.nlinks;
+        const int i = (int)(item - s * A.nlinks);
+        cd* const home = A.buf0 + (size_t)item * nn;
+        cd* X = home;
+        cd* X2 = A.buf1 + (size_t)item * nn;
+        const int64_t p = axis_offset(A.other, A.s0 + s) + (int64_t)i * A.sdir, q = p + A.sdir;
+        for (int e = tid; e < nn; e += 256) {
+            const int a = e / m, b = e - a * m;
+            const cd* up = wf_at(A.v, A.occ[a], p);
+            const cd* uq = wf_at(A.v, A.occ[b], q);
+            cd acc{0.0, 0.0};
+            for (int c = 0; c < ncomp; ++c) cfmac(acc, up[c], uq[c]);
+            X[e] = acc;
+        }
+        __syncthreads();
+        for (int it = 0; it < 200; ++it) {
+            red[tid] = wg_matmul<true, true>(m, X, X, Y, 1.0, nullptr, 0.0);      // Y = X^H X, residual ||Y - I||_F^2
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if (tid < w) red[tid] += red[tid + w];
+                __syncthreads();
             }
-        for (int e = 0; e < nn; ++e) R[e] = T[e];
+            const double r2 = red[0];
+            wg_matmul<false, false>(m, X, Y, X2, -0.5, X, 1.5);                    // X <- (3 X - X Y) / 2
+            __syncthreads();
+            cd* t = X;
+            X = X2;
+            X2 = t;
+            if (r2 < 1e-14) break;      // residual 1e-7 before this update, its square after it
+        }
+        if (X != home) {
+            for (int e = tid; e < nn; e += 256) home[e] = X[e];
+        }
+        __syncthreads();
     }
-    if (!eigvals_dyn(nocc, R, ev, rc, rs)) atomicExch(A.flags + 1, 1);
-    double* o = A.out + s * nocc;   // sort(-angle(eigvals))   (pythtb.py:3834-3838)
-    for (int j = 0; j < nocc; ++j) {
-        const double ph = -atan2(ev[j].y, ev[j].x);
+}
+
+struct WilsonTreeArgs {
+    const cd* in;
+    cd* out;
+    int m, nlinks, st;
+    int64_t ns;
+};
+// one level of the ordered pairwise product: out[j] = in[j] in[j + st] for j = 0, 2 st, 4 st, ...
+__global__ __launch_bounds__(256) void k_wilson_tree(const WilsonTreeArgs A) {
+    const int nn = A.m * A.m;
+    const int npair = (A.nlinks + 2 * A.st - 1) / (2 * A.st);
+    for (int64_t item = blockIdx.x; item < A.ns * npair; item += gridDim.x) {
+        const int64_t s = item / npair;
+        const int j = (int)(item - s * npair) * 2 * A.st;
+        const cd* a = A.in + ((size_t)s * A.nlinks + j) * nn;
+        cd* o = A.out + ((size_t)s * A.nlinks + j) * nn;
+        if (j + A.st < A.nlinks)
+            wg_matmul<false, false>(A.m, a, A.in + ((size_t)s * A.nlinks + j + A.st) * nn, o, 1.0, nullptr, 0.0);
+        else
+            for (int e = threadIdx.x; e < nn; e += 256) o[e] = a[e];
+    }
+}
+
+struct CayleyArgs {
+    const cd* prod;      // string s: prod + s * pstride
+    size_t pstride;
+    cd* ab;              // [ns][2][nocc^2]
+    cd* herm;            // [ns][nocc^2]
+    int m;
+    double ca, sa;       // cos / sin of alpha
+};
+__global__ __launch_bounds__(256) void k_wilson_cayley(const CayleyArgs C) {
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    const int tid = threadIdx.x, m = C.m, nn = m * m;
+    const cd* P = C.prod + (size_t)blockIdx.x * C.pstride;
+    cd* A = C.ab + (size_t)blockIdx.x * 2 * nn;
+    cd* B = A + nn;
+    for (int e = tid; e < nn; e += 256) {
+        const cd pv = P[e];
+        const cd q{C.ca * pv.x + C.sa * pv.y, C.ca * pv.y - C.sa * pv.x};      // e^{-i alpha} P
+        const double d = (e / m == e % m) ? 1.0 : 0.0;
+        A[e] = cd{d + q.x, q.y};              // I + Q
+        B[e] = cd{q.y, d - q.x};              // i (I - Q)
+    }
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {             // Gauss-Jordan on [A | B] with partial pivoting
+        double best = -1.0;
+        int bi = k;
+        for (int i = k + tid; i < m; i += 256) {
+            const double a = cabs2(A[i * m + k]);
+            if (a > best) {
+                best = a;
+                bi = i;
+            }
+        }
+        s_val[tid] = best;
+        s_idx[tid] = bi;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) {
+                const double o = s_val[tid + w];
+                const int oi = s_idx[tid + w];
+                if (o > s_val[tid] || (o == s_val[tid] && oi < s_idx[tid])) {
+                    s_val[tid] = o;
+                    s_idx[tid] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        const int r = s_idx[0];
+        const cd piv = A[r * m + k];
+        __syncthreads();
+        const double ip = 1.0 / fmax(cabs2(piv), 1e-300);
+        const cd inv{piv.x * ip, -piv.y * ip};
+        // row k <- (row r) / pivot, row r <- old row k   (columns k.. of A, all of B)
+        for (int e = tid; e < 2 * m; e += 256) {
+            cd* row = e < m ? A : B;
+            const int j = e < m ? e : e - m;
+            if (e < m && j < k) continue;
+            const cd top = row[k * m + j], low = row[r * m + j];
+            row[r * m + j] = top;
+            row[k * m + j] = cmul(low, inv);
+        }
+        __syncthreads();
+        const int wa = m - k - 1, width = wa + m;
+        for (int e = tid; e < m * width; e += 256) {
+            const int i = e / width, jj = e - i * width;
+            if (i == k) continue;
+            const cd f = A[i * m + k];
+            cd* row = jj < wa ? A : B;
+            const int j = jj < wa ? k + 1 + jj : jj - wa;
+            const cd t = cmul(f, row[k * m + j]);
+            row[i * m + j] = cd{row[i * m + j].x - t.x, row[i * m + j].y - t.y};
+        }
+        __syncthreads();
+    }
+    cd* H = C.herm + (size_t)blockIdx.x * nn;
+    for (int e = tid; e < nn; e += 256) {
+        const int a = e / m, b = e - a * m;
+        const cd u = B[a * m + b], w = B[b * m + a];
+        H[e] = cd{0.5 * (u.x + w.x), 0.5 * (u.y - w.y)};
+    }
+}
+
+// eigenvalues h[j][s] of the Cayley transforms -> sort(-angle) per string, and max |h| per string
+__global__ __launch_bounds__(64) void k_wilson_phases(const double* __restrict__ h, const int64_t ns, const int m,
+                                                     const double alpha, double* __restrict__ out,
+                                                     double* __restrict__ hmax) {
+    const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= ns) return;
+    double* o = out + s * m;
+    double big = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const double hv = h[(int64_t)j * ns + s];
+        big = fmax(big, fabs(hv));
+        const double th = alpha + 2.0 * atan(hv);
+        const double ph = -atan2(sin(th), cos(th));
         int pos = j;
         while (pos > 0 && o[pos - 1] > ph) {
             o[pos] = o[pos - 1];
@@ -270,5 +438,5 @@ __global__ __launch_bounds__(64) void k_chain_final_big(const ChainBigArgs A) {
         }
         o[pos] = ph;
     }
+    hmax[s] = big;
 }
-

@@ -597,6 +597,20 @@ def test_large_nocc_and_unsupported_sizes(tb):
         assert abs(wrap(wr.berry_phase(occ, contin=False) - orc.berry_phase(orib, 1, occ, None, contin=False))) < 1e-8
     got = wr.berry_phase(list(range(70)), contin=False, berry_evals=True)          # 70 hybrid Wannier centres of the ribbon
     assert_phase_sets_close(got, orc.berry_phase(orib, 1, list(range(70)), None, contin=False, berry_evals=True), 1e-8)
+    # the Cayley transform behind these eigenphases has a pole at theta = alpha + pi: put it exactly on one of
+    # the eigenphases (output = -theta) and the call must notice and redo that string with another alpha
+    os.environ["TBK_WILSON_ALPHA"] = repr(float(-got[35] - np.pi))
+    ctx = _lib.default_context()
+    ctx.prof_enable(1)
+    ctx.prof_reset()
+    try:
+        again = wr.berry_phase(list(range(70)), contin=False, berry_evals=True)
+        launches = ctx.prof_report()["wilson_cayley"]["launches"]
+    finally:
+        del os.environ["TBK_WILSON_ALPHA"]
+        ctx.prof_enable(0)
+    assert launches == 2                                       # first alpha rejected, second accepted
+    assert_phase_sets_close(again, got, 1e-11)
     big = hp.quiet(tb.tb_model, 1, 1, [[1.0]], 2100)
     with pytest.raises(_lib.TbkError, match="limit"):
         big.solve_all([0.1])                                   # nsta > TBK_MAX_NSTA fails loudly
