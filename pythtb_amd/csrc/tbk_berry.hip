@@ -716,7 +716,9 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     TBK_REQUIRE(dir0 >= 0 && dir1 >= 0 && dir0 < v.dim_arr && dir1 < v.dim_arr, TBK_EINVAL,
                 "Direction for Berry flux calculation out of bounds.");
     FluxArgs A{};
-    const bool big = nocc > TBK_MAX_NOCC;     // link determinants by LU (tbk_berry_big.inl)
+    int det_from = 9;      // up to 8 bands the register LU per thread wins; from 9 the workgroup-per-link LU is 4-100x faster (profiles/det_big_probe.py)
+    if (const char* e = getenv("TBK_DET_BIG_FROM")) det_from = std::max(2, atoi(e));    // tuning knob
+    const bool big = nocc >= det_from;        // link determinants by LU (tbk_berry_big.inl)
     int rc = big ? check_occ(w, occ, nocc) : fill_occ(w, occ, nocc, A.occ);
     if (rc) return rc;
     tbk_ctx* ctx = w->ctx;
@@ -1092,7 +1094,9 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     const WfsView& v = w->view;
     TBK_REQUIRE(dir >= 0 && dir < v.dim_arr, TBK_EINVAL, "Wrong direction for Berry phase calculation!");
     ChainArgs A{};
-    const bool big = nocc > TBK_MAX_NOCC && !berry_evals;   // det of the string = product of link dets (LU per link)
+    int det_from = 9;      // up to 8 bands the register LU per thread wins; from 9 the workgroup-per-link LU is 4-100x faster (profiles/det_big_probe.py)
+    if (const char* e = getenv("TBK_DET_BIG_FROM")) det_from = std::max(2, atoi(e));    // tuning knob
+    const bool big = nocc >= det_from && !berry_evals;      // det of the string = product of link dets (LU per link)
     // Wilson-loop eigenphases: closed forms up to two bands; from three on the workgroup-level pipeline, which
     // measured 3x (3 bands) to 160x (16 bands) faster than the per-thread polar/QR kernels at every string count
     // and length tried (profiles/wilson_small_probe.py)
