@@ -53,6 +53,8 @@ struct ListArgs {
     const cd* ham;    // [nk][n][n] (eigh of supplied matrices) or null
     double* eval;     // [n][nk]
     cd* evec;         // [n][nk][n] or null
+    int natural;      // k_solve_row16 only: leave the eigenpairs in Jacobi's own order (column j grown out of e_j, so the
+                      // eigenvector matrix stays as close to the identity as the rotations allow) instead of sorting
 };
 
 __device__ __forceinline__ cd expi2pi(double x) {
@@ -1098,6 +1100,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 #include "tbk_solve_big.inl"   // n > 256: one kernel launch per Jacobi round, whole chip per batch
 #include "tbk_solve_reg.inl"   // n = 5..8: register-resident cyclic Jacobi, 1/2/4 lanes per matrix
 #include "tbk_solve_row16.inl" // n = 15, 16 on lists: one DPP row of 16 lanes per matrix, rows of A in registers
+#include "tbk_solve_blk.inl"   // batches of wide matrices: block Jacobi, 16x16 subproblems through k_solve_row16
 
 // ---------------------------------------------------------------------------
 // host-side launchers
@@ -1136,6 +1139,16 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // Larger batches of 65..256 states (ms; workgroup solver with 1024 threads | whole chip): eigenvalues only 512 x n=128
     // 97 | 81, 256 x n=200 261 | 196, 256 x n=256 648 | 333 (the whole-chip solver skips V then); with vectors 109 | 145,
     // 277 | 335, 670 | 648.
+    if (n > 64) {
+        // Block Jacobi (tbk_solve_blk.inl) makes n/8 - 1 passes over A and V per sweep instead of n - 1, but every pass
+        // costs three launches and the latency of a 16x16 sub-solve (~0.19 ms x n in total): it wins once the batch
+        // carries enough work.  Measured (profiles/blocked_bench.py, ms, eigenvalues / with vectors): 512 x n=128
+        // 87 / 105 -> 35 / 55, 101 x n=300 249 / 452 -> 100 / 143, 8 x n=800 364 / 631 -> 213 / 270; but 64 x n=128
+        // 11.8 / 19.3 -> 18.7 / 21.0, 2 x n=800 120 / 189 -> 157 / 172.
+        const char* e = getenv("TBK_BLOCKED");        // tuning knob: 1 forces the block-Jacobi solver, 0 forbids it
+        const bool blk = e ? atoi(e) == 1 : (n >= 96 && (double)nk_eff * n * n >= 1.4e6);
+        if (blk) return launch_blocked<MODE, VEC>(ctx, mv, n, nk, L, G);
+    }
     if (n >= big_from || (n > 64 && (nk_eff <= 160 || !VEC || n > 224))) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
     static const bool use_reg = [] {   // TBK_REG=0: fall back to the wavefront-per-matrix kernel (A/B runs)
         const char* e = getenv("TBK_REG");

@@ -32,6 +32,9 @@ struct BigWs {
     int* pending;     // [1]
     int n;
     int nbn;          // norm blocks per matrix
+    int ld;           // row pitch of A0/A1/Vt and per-matrix stride of ev/perm: n here, n rounded up to the block
+                      // grid in the blocked solver (tbk_solve_blk.inl), whose padding rows/columns are decoupled
+    double* padval;   // [B] blocked solver: diagonal value of the first padding index (null otherwise)
 };
 
 template <int MODE>
@@ -39,18 +42,19 @@ __global__ __launch_bounds__(256) void k_big_init(const ModelView mv, const int6
                                                   const GridArgs G, const BigWs W, const int vec) {
     const int mat = blockIdx.y;
     const int64_t id = base + mat;
-    const int n = W.n;
-    const int64_t nn = (int64_t)n * n;
-    cd* A = W.A0 + (size_t)mat * nn;
-    cd* Vt = W.Vt + (size_t)mat * nn;
+    const int n = W.n, ld = W.ld;
+    const int64_t nn = (int64_t)n * n, ll = (int64_t)ld * ld;
+    cd* A = W.A0 + (size_t)mat * ll;
+    cd* Vt = W.Vt + (size_t)mat * ll;
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
     if (tid == 0) {
         W.done[mat] = 0;
         W.fpar[mat] = 0;
     }
-    for (int64_t e = tid; e < nn; e += nth) {
-        const int a = (int)(e / n), b = (int)(e - (int64_t)a * n);
+    for (int64_t e = tid; e < ll; e += nth) {
+        const int a = (int)(e / ld), b = (int)(e - (int64_t)a * ld);
         Vt[e] = cd{a == b ? 1.0 : 0.0, 0.0};
+        if (a >= n || b >= n) A[e] = cd{0.0, 0.0};     // padding (blocked solver): decoupled, diagonal set later
     }
     if constexpr (MODE == 2) {
         const cd* h = L.ham + id * nn;
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void k_big_init(const ModelView mv, const int6
             const int a = (int)(e / n), b = (int)(e - (int64_t)a * n);
             cd v = a <= b ? h[e] : cconj(h[(int64_t)b * n + a]);   // one triangle, like the reference's eigh
             if (a == b) v.y = 0.0;
-            A[e] = v;
+            A[(int64_t)a * ld + b] = v;
         }
         if (vec)
             for (int64_t o = tid; o < n; o += nth) W.eo[(size_t)mat * n + o] = cd{1.0, 0.0};
@@ -82,10 +86,10 @@ __global__ __launch_bounds__(256) void k_big_init(const ModelView mv, const int6
             cd acc{0.0, 0.0};
             for (int t = t0; t < t1; ++t) cfma(acc, mv.term_amp[t], phase_of_R(z, mv.term_R[t]));
             if (a == b) {
-                A[(int64_t)a * n + a] = cd{acc.x, 0.0};
+                A[(int64_t)a * ld + a] = cd{acc.x, 0.0};
             } else {
-                A[(int64_t)a * n + b] = acc;
-                A[(int64_t)b * n + a] = cconj(acc);
+                A[(int64_t)a * ld + b] = acc;
+                A[(int64_t)b * ld + a] = cconj(acc);
             }
         }
         if (vec)
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void k_big_init(const ModelView mv, const int6
 __global__ __launch_bounds__(256) void k_big_norm1(const BigWs W, const int par) {
     const int mat = blockIdx.y;
     if (W.done[mat]) return;
-    const int n = W.n;
+    const int n = W.ld;        // padding: exact zeros off the diagonal; its diagonal is taken out again in stage 2
     const int64_t nn = (int64_t)n * n;
     const cd* A = (par ? W.A1 : W.A0) + (size_t)mat * nn;
     double off = 0.0, dia = 0.0;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void k_big_norm1(const BigWs W, const int par)
 
 // stage 2: one thread per matrix decides convergence (same criterion as k_solve_wave)
 __global__ __launch_bounds__(64) void k_big_norm2(const BigWs W, const int nmat, const int par, const int force,
-                                                  int* noconv_flag) {
+                                                  int* noconv_flag, const int pads_set = 0) {
     const int mat = blockIdx.x * 64 + threadIdx.x;
     if (mat >= nmat || W.done[mat]) return;
     double off = 0.0, dia = 0.0;
@@ -142,6 +146,17 @@ __global__ __launch_bounds__(64) void k_big_norm2(const BigWs W, const int nmat,
     for (int b = 0; b < W.nbn; ++b) {
         off += p[2 * b];
         dia += p[2 * b + 1];
+    }
+    if (W.padval) {
+        if (pads_set) {      // the padding diagonal is not part of the matrix
+            for (int x = 0; x < W.ld - W.n; ++x) {
+                const double v = W.padval[mat] + x;
+                dia -= v * v;
+            }
+            dia = fmax(dia, 0.0);
+        } else {
+            W.padval[mat] = sqrt(dia + off) + 1.0;      // above every eigenvalue (Frobenius norm + 1)
+        }
     }
     if (off <= 2.0e-32 * (dia + off)) {
         W.done[mat] = 1;
@@ -278,17 +293,17 @@ __global__ __launch_bounds__(256) void k_big_sort(const BigWs W, const int64_t b
     double* ev = (double*)lds_raw;
     const int mat = blockIdx.x;
     const int64_t id = base + mat;
-    const int n = W.n;
-    const int64_t nn = (int64_t)n * n;
+    const int n = W.n, ld = W.ld;     // the padding entries (blocked solver) exceed every eigenvalue: they sort last
+    const int64_t nn = (int64_t)ld * ld;
     const cd* A = (W.fpar[mat] ? W.A1 : W.A0) + (size_t)mat * nn;
-    for (int x = threadIdx.x; x < n; x += 256) ev[x] = A[(int64_t)x * n + x].x;
+    for (int x = threadIdx.x; x < ld; x += 256) ev[x] = A[(int64_t)x * ld + x].x;
     __syncthreads();
-    int* perm = W.perm + (size_t)mat * n;
-    double* sorted = W.ev + (size_t)mat * n;
-    for (int x = threadIdx.x; x < n; x += 256) {
+    int* perm = W.perm + (size_t)mat * ld;
+    double* sorted = W.ev + (size_t)mat * ld;
+    for (int x = threadIdx.x; x < ld; x += 256) {
         const double mine = ev[x];
         int r = 0;
-        for (int j = 0; j < n; ++j) {
+        for (int j = 0; j < ld; ++j) {
             const double o = ev[j];
             r += (o < mine) || (o == mine && j < x);
         }
@@ -313,14 +328,14 @@ __global__ __launch_bounds__(256) void k_big_write(const BigWs W, const int64_t 
                                                    const ListArgs L, const GridArgs G) {
     const int mat = blockIdx.y;
     const int64_t id = base + mat;
-    const int n = W.n;
+    const int n = W.n, ld = W.ld;
     const int64_t nn = (int64_t)n * n;
-    const cd* Vt = W.Vt + (size_t)mat * nn;
+    const cd* Vt = W.Vt + (size_t)mat * ld * ld;
     const cd* eo = W.eo + (size_t)mat * n;
-    const int* perm = W.perm + (size_t)mat * n;
+    const int* perm = W.perm + (size_t)mat * ld;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (int64_t)gridDim.x * 256) {
         const int rb = (int)(e / n), o = (int)(e - (int64_t)rb * n);
-        const cd v = cmul(Vt[(int64_t)perm[rb] * n + o], eo[o]);
+        const cd v = cmul(Vt[(int64_t)perm[rb] * ld + o], eo[o]);
         if constexpr (MODE == 1) wf_at(G.wv, rb, id)[o] = v;
         else L.evec[((int64_t)rb * nk + id) * n + o] = v;
     }
@@ -370,6 +385,8 @@ static int launch_big(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     W.fpar = (int*)p;
     W.n = n;
     W.nbn = nbn;
+    W.ld = n;
+    W.padval = nullptr;
     // al() of a per-matrix block only pads the END of each region; matrices inside a region are
     // contiguous (stride n*n), which is what the kernels index with.
     const int m = (n + 1) & ~1, half = m >> 1;

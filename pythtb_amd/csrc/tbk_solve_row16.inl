@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void k_solve_row16(const ModelView mv, const i
         const bool before = real_row ? (jr && (ev[j] < mine || (ev[j] == mine && j < x))) : (jr || j < x);
         rk += before ? 1 : 0;
     }
+    if (Lst.natural) rk = x;
     const double sorted_here = perm_push_d(rowbase4 + 4 * rk, mine);   // lane r now holds the r-th eigenvalue
     if constexpr (MODE == 1) {
         const I2 sh = __builtin_bit_cast(I2, sorted_here);

@@ -648,6 +648,41 @@ def test_wide_models_workgroup_kernel(tb):
     assert np.max(np.abs(e0 - orc.solve_all_vec(m2, [[0.1, 0.2]])[:, 0])) < 1e-11 * np.abs(e0).max()
 
 
+def test_wide_batches_block_jacobi(tb):
+    """Batches of wide matrices (nk n^2 >= 1.4e6, n >= 96): block Jacobi with 16x16 sub-solves; n = 100 is padded
+    to 112 with decoupled diagonal entries that must never surface."""
+    from oracle import tb_oracle as orc
+    rib = hp.haldane(tb.tb_model, 1.2).cut_piece(50, 1)                     # 100 bands, gapped at half filling
+    k = np.linspace(0.0, 1.0, 160, endpoint=False) + 0.013
+    ham = orc.ham_batch(rib, k.reshape(-1, 1))
+    ref = np.linalg.eigvalsh(ham).T
+    scale = np.abs(ref).max()
+    ev, vec = rib.solve_all(k, eig_vectors=True)
+    assert np.max(np.abs(ev - ref)) < 2e-12 * scale
+    assert np.max(np.abs(rib.solve_all(k) - ref)) < 2e-12 * scale            # eigenvalue-only variant
+    for ik in (0, 7, 80, 159):
+        V = vec[:, ik, :]
+        assert np.max(np.abs(V.conj() @ V.T - np.identity(100))) < 1e-11
+        assert np.max(np.abs(ham[ik] @ V.T - V.T * ev[:, ik])) < 1e-11 * scale
+    os.environ["TBK_BLOCKED"] = "0"                                        # same batch through the other solvers
+    try:
+        ev0 = rib.solve_all(k)
+    finally:
+        del os.environ["TBK_BLOCKED"]
+    assert np.max(np.abs(ev0 - ev)) < 2e-12 * scale
+    w = tb.wf_array(rib, [161])                                            # mesh mode: gaps, images, Berry phase
+    gaps = w.solve_on_grid([0.0])
+    owfs, ogaps = orc.solve_on_grid(rib, [161], [0.0], vectorised=True)
+    assert np.max(np.abs(gaps - ogaps)) < 1e-10 * scale
+    occ = list(range(50))
+    assert abs(wrap(w.berry_phase(occ) - orc.berry_phase(owfs, 1, occ))) < 1e-8
+    m2 = hp.random_model(tb.tb_model, 64, 1, 2, 9, nhop=400, rmax=2)        # 128 states, spinor: no padding
+    k2 = np.linspace(-0.5, 0.5, 90)
+    ev2 = m2.solve_all(k2)
+    ref2 = orc.solve_all_vec(m2, k2.reshape(-1, 1))
+    assert np.max(np.abs(ev2 - ref2)) < 2e-12 * np.abs(ref2).max()
+
+
 def test_very_wide_models_whole_chip_jacobi(tb):
     """nsta > 256 (flakes, thick slabs): one kernel launch per Jacobi round over all 2x2 blocks."""
     from oracle import tb_oracle as orc
