@@ -34,7 +34,7 @@ extern "C" {
 
 #define TBK_MAX_DIM 4      /* dim_k, dim_arr <= 4      (pythtb.py:99)   */
 #define TBK_MAX_NSTA 2048  /* states per k in this build                */
-#define TBK_MAX_NOCC 16    /* bands handled in registers/local memory by the Berry kernels; larger sets take the workgroup / global-workspace paths */
+#define TBK_MAX_NOCC 16    /* largest band set of the per-thread Berry kernels (used up to 8 bands, 2 for Wilson-loop eigenphases); larger sets take the workgroup-level paths, any size */
 
 typedef struct tbk_ctx tbk_ctx;     /* device + stream + workspaces          */
 typedef struct tbk_model tbk_model; /* flattened hopping table on the device */
