@@ -8,10 +8,14 @@
 // Identities used (checked against the reference):
 //   det(M1 M2 ...) = det M1 * det M2 * ...      -> link determinants are scalars
 //   -angle(det prod) for a string / plaquette   -> one complex product, one atan2
-//   polar(M) = U Vh of svd(M)                   -> closed form (nocc<=2) or
-//                                                  one-sided Jacobi (nocc>2)
+//   polar(M) = U Vh of svd(M)                   -> closed form (nocc<=2); from 3 bands on the
+//                                                  workgroup-level pipeline of tbk_berry_big.inl
+//                                                  (Newton-Schulz, product tree, Cayley + eigh)
 // Ordered nocc x nocc products are split into per-thread segments and combined
-// in order (matrix products are associative, not commutative).
+// in order (matrix products are associative, not commutative).  From 9 bands on the link
+// determinants come from one workgroup per link (LU, tbk_berry_big.inl).  The per-thread
+// one-sided-Jacobi / QR routines for 3..16 bands stay reachable through TBK_WILSON_BIG_FROM /
+// TBK_DET_BIG_FROM for A/B runs.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

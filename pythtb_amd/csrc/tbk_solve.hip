@@ -12,9 +12,13 @@
 // from wave-uniform (scalar) table reads.
 //
 //   nsta <= 4 : one thread per k, S and V in registers, cyclic Jacobi
-//               (nsta == 2: the single exact rotation).
-//   nsta  > 4 : one 64-lane wavefront per k, S and V in LDS, parallel-ordered
-//               (round-robin) Jacobi, nsta/2 disjoint rotations per round.
+//               (nsta == 2: the single exact rotation); meshes: k_grid_rows.
+//   5..8      : one thread per k, registers (tbk_solve_reg.inl).
+//   9..64     : one 64-lane wavefront (large batches up to 21) or one workgroup per k,
+//               S and V in LDS, parallel-ordered (round-robin) Jacobi, nsta/2 disjoint
+//               rotations per round; 13..16 on lists: one DPP row per k (tbk_solve_row16.inl).
+//   65..2048  : workgroup per k on an L2 workspace, whole-chip rounds (tbk_solve_big.inl) or,
+//               for batches, block Jacobi (tbk_solve_blk.inl) -- see launch_wave().
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
