@@ -288,7 +288,7 @@ class tb_model(object):
 
     # ------------------------------------------------------------------ solve
     def _k_array(self, k_list):
-        k = np.array(k_list, dtype=float)
+        k = np.asarray(k_list, dtype=float)          # no copy of an array that is already float64
         if k.size == 0:                               # empty list: the reference's loop runs zero times
             return np.zeros((0, self._dim_k), dtype=float)
         if self._dim_k == 1 and k.ndim == 1:
@@ -346,8 +346,8 @@ class tb_model(object):
         else:
             k = self._k_array(k_list) if self._dim_k > 0 else None
             nk = len(k_list)
-        ev = np.zeros((n, nk), dtype=float)
-        vec = np.zeros((n, nk, n), dtype=complex) if eig_vectors else None
+        ev = np.empty((n, nk), dtype=float)                   # filled completely by the device-to-host copies
+        vec = np.empty((n, nk, n), dtype=complex) if eig_vectors else None
         if nk > 0:
             _lib.check(_lib.lib.tbk_solve_list(self._device_model(), _lib.dptr(k), nk, _lib.dptr(ev),
                                                _lib.dptr(vec.view(float)) if eig_vectors else None))
@@ -491,7 +491,7 @@ class tb_model(object):
         if self._dim_k not in (1, 2, 3):
             raise Exception("\n\nUnsupported dim_k!")
         idx = np.indices(tuple(use)).reshape(self._dim_k, -1).T
-        return idx / use.astype(float)
+        return np.divide(idx, use.astype(float), order='C')     # C-contiguous: solve_all hands it to the device as is
 
     def k_path(self, kpts, nk, report=True):
         """Piecewise-linear path through `kpts` with `nk` points, spaced by the
