@@ -681,6 +681,26 @@ def test_wide_batches_block_jacobi(tb):
     ev2 = m2.solve_all(k2)
     ref2 = orc.solve_all_vec(m2, k2.reshape(-1, 1))
     assert np.max(np.abs(ev2 - ref2)) < 2e-12 * np.abs(ref2).max()
+    # supplied matrices through the same solver, with the special cases a Jacobi method can trip over
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(4)
+    n, nk = 99, 150                                                        # padded to 112
+    a = rng.normal(size=(nk, n, n)) + 1j * rng.normal(size=(nk, n, n))
+    hmat = np.ascontiguousarray(a + a.conj().transpose(0, 2, 1))
+    hmat[3] = np.diag(np.arange(n, dtype=float)[::-1])                      # diagonal, descending
+    hmat[4] = np.ones((n, n))                                               # rank one: n-1 degenerate eigenvalues
+    hmat[5] = 0.0
+    hmat[6] = np.identity(n)
+    hmat[7] = np.kron(np.identity(n // 3), np.array([[0, 1j, 0], [-1j, 0, 2], [0, 2, 0]]))   # 33 identical blocks
+    e = np.zeros((n, nk))
+    v = np.zeros((n, nk, n), dtype=complex)
+    _lib.check(_lib.lib.tbk_eigh_batch(_lib.default_context().handle, n, _lib.dptr(hmat), nk, _lib.dptr(e), _lib.dptr(v)))
+    for i in (0, 3, 4, 5, 6, 7, 149):
+        want = np.linalg.eigvalsh(hmat[i])
+        sc = max(1.0, np.abs(want).max())
+        assert np.max(np.abs(e[:, i] - want)) < 2e-12 * sc
+        assert np.max(np.abs(hmat[i] @ v[:, i].T - v[:, i].T * e[:, i])) < 1e-11 * sc
+        assert np.max(np.abs(v[:, i].conj() @ v[:, i].T - np.identity(n))) < 1e-11
 
 
 def test_very_wide_models_whole_chip_jacobi(tb):
