@@ -434,12 +434,19 @@ __device__ __forceinline__ cd one_link_det(const cd* P, const cd* Q, const int* 
 __device__ __forceinline__ double arg_small_first(double y, double x) {
     if (x > 0.0 && fabs(y) <= 0.015625 * x) {
         const double t = y / x, t2 = t * t;
+        // three-operand v_fma_f64 spelled out: the compiler otherwise copies each coefficient into the
+        // accumulator register first (v_mov_b64 + v_fmac_f64), one extra issue slot per Horner step
+        auto fma3 = [](double a, double b, double c) {
+            double d;
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+            return d;
+        };
         double p = -1.0 / 13.0;
-        p = fma(p, t2, 1.0 / 11.0);
-        p = fma(p, t2, -1.0 / 9.0);
-        p = fma(p, t2, 1.0 / 7.0);
-        p = fma(p, t2, -1.0 / 5.0);
-        p = fma(p, t2, 1.0 / 3.0);
+        p = fma3(p, t2, 1.0 / 11.0);
+        p = fma3(p, t2, -1.0 / 9.0);
+        p = fma3(p, t2, 1.0 / 7.0);
+        p = fma3(p, t2, -1.0 / 5.0);
+        p = fma3(p, t2, 1.0 / 3.0);
         return fma(-(t * t2), p, t);
     }
     return atan2(y, x);
@@ -468,9 +475,9 @@ __device__ __forceinline__ cd det_overlap(const cd (&p)[NOCC][NCOMP], const cd (
     for (int a = 0; a < NOCC; ++a)
 #pragma unroll
         for (int b = 0; b < NOCC; ++b) {
-            cd acc{0.0, 0.0};
+            cd acc = cmulc(p[a][0], q[b][0]);      // (not 0 + ...: the add of a literal zero is not free)
 #pragma unroll
-            for (int o = 0; o < NCOMP; ++o) cfmac(acc, p[a][o], q[b][o]);
+            for (int o = 1; o < NCOMP; ++o) cfmac(acc, p[a][o], q[b][o]);
             M[a][b] = acc;
         }
     return det_small<NOCC>(M);
