@@ -842,7 +842,7 @@ def test_sharded_windows_equal_unsharded(tb):
         assert np.array_equal(np.concatenate(bp), ref_bp)
 
 
-@pytest.mark.parametrize("half,mesh", [(3, [23, 53]), (6, [41, 53]), (12, [41, 53])])
+@pytest.mark.parametrize("half,mesh", [(3, [23, 53]), (6, [41, 53]), (7, [41, 53]), (8, [41, 53]), (12, [41, 53])])
 def test_warm_started_solver_keeps_images_and_windows_bit_identical(tb, half, mesh):
     """The n = 9..21 wavefront kernel and the n = 22..40 workgroup kernel warm-start Jacobi along the last mesh
     axis on meshes of more than ~2000 points (the eigenvector gauge then depends on the chain of predecessors;
