@@ -1154,7 +1154,9 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         // transform + Hermitian eigen-solve.  Strings go in batches whose two ping-pong link arrays fit 1 GiB.
         const size_t nn = (size_t)nocc * nocc;
         const int L = A.nlinks;
-        const int64_t cap = std::max<int64_t>(1, (int64_t)(((size_t)1 << 30) / (2 * (size_t)L * nn * sizeof(cd))));
+        size_t batch_bytes = (size_t)1 << 30;
+        if (const char* e = getenv("TBK_WILSON_BATCH_BYTES")) batch_bytes = (size_t)std::max(1ll, atoll(e));   // test hook
+        const int64_t cap = std::max<int64_t>(1, (int64_t)(batch_bytes / (2 * (size_t)L * nn * sizeof(cd))));
         const int64_t nsb = std::min<int64_t>(A.nstrings, cap);
         const unsigned nblk = (unsigned)std::min<int64_t>(nsb * L, (int64_t)ctx->cus * 4);
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };

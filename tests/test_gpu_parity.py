@@ -616,6 +616,29 @@ def test_large_nocc_and_unsupported_sizes(tb):
         big.solve_all([0.1])                                   # nsta > TBK_MAX_NSTA fails loudly
 
 
+def test_wilson_pipeline_batches_and_axes(tb):
+    """Workgroup-level Wilson-loop eigenphases (3 or more bands): strings along every axis of a 3-D mesh, band
+    lists in arbitrary order, and the string batching (forced to a few strings per batch) must not change a bit."""
+    from oracle import tb_oracle as orc
+    m = hp.random_model(tb.tb_model, 7, 3, 1, 21, nhop=30, rmax=1)
+    mesh = [5, 6, 7]
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid([0.05, -0.1, 0.2])
+    owfs, ogaps = orc.solve_on_grid(m, mesh, [0.05, -0.1, 0.2], vectorised=True)
+    for occ in ([0, 1, 2], [4, 2, 3, 0], list(range(7))):
+        for d in range(3):
+            got = w.berry_phase(occ, d, contin=False, berry_evals=True)
+            ref = orc.berry_phase(owfs, 3, occ, d, contin=False, berry_evals=True)
+            assert got.shape == ref.shape
+            assert_phase_sets_close(got, ref, 1e-9)
+            os.environ["TBK_WILSON_BATCH_BYTES"] = str(2 * (mesh[d] - 1) * len(occ) ** 2 * 16 * 4)   # four strings per batch
+            try:
+                again = w.berry_phase(occ, d, contin=False, berry_evals=True)
+            finally:
+                del os.environ["TBK_WILSON_BATCH_BYTES"]
+            assert np.array_equal(again, got)
+
+
 def test_wide_models_workgroup_kernel(tb):
     """65 <= nsta <= 256 (ribbons, slabs): one workgroup per matrix, matrices in global memory."""
     from oracle import tb_oracle as orc
