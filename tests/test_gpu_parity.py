@@ -654,6 +654,11 @@ def test_wide_models_workgroup_kernel(tb):
         assert np.max(np.abs(V[:, ik].conj() @ V[:, ik].T - np.identity(90))) < 1e-12
         assert np.max(np.abs(ham[ik] @ V[:, ik].T - V[:, ik].T * ev[:, ik])) < 1e-11 * scale
     assert np.max(np.abs(m.solve_all(k) - ref)) < 1e-12 * scale              # eigenvalue-only variant
+    os.environ["TBK_BIG_BATCH"] = "5"                                      # whole-chip solver in several batches: same bits
+    try:
+        assert np.array_equal(m.solve_all(k), m.solve_all(k)) and np.array_equal(m.solve_all(k[:7]), m.solve_all(k)[:, :7])
+    finally:
+        del os.environ["TBK_BIG_BATCH"]
     w = tb.wf_array(m, [14])
     gaps = w.solve_on_grid([0.0])
     owfs, ogaps = orc.solve_on_grid(m, [14], [0.0], vectorised=True)
@@ -704,6 +709,12 @@ def test_wide_batches_block_jacobi(tb):
     ev2 = m2.solve_all(k2)
     ref2 = orc.solve_all_vec(m2, k2.reshape(-1, 1))
     assert np.max(np.abs(ev2 - ref2)) < 2e-12 * np.abs(ref2).max()
+    os.environ["TBK_BIG_BATCH"] = "37"                                     # several workspace batches: same bits
+    try:
+        ev_b, vec_b = rib.solve_all(k, eig_vectors=True)
+    finally:
+        del os.environ["TBK_BIG_BATCH"]
+    assert np.array_equal(ev_b, ev) and np.array_equal(vec_b, vec)
     # supplied matrices through the same solver, with the special cases a Jacobi method can trip over
     from pythtb_amd import _lib
     rng = np.random.default_rng(4)
