@@ -637,6 +637,20 @@ def test_wilson_pipeline_batches_and_axes(tb):
             finally:
                 del os.environ["TBK_WILSON_BATCH_BYTES"]
             assert np.array_equal(again, got)
+    # nine or more bands: link determinants by one workgroup per link, on slices / strings of a 3-D mesh
+    m2 = hp.random_model(tb.tb_model, 12, 3, 1, 5, nhop=60, rmax=1)
+    mesh2 = [4, 5, 6]
+    w2 = tb.wf_array(m2, mesh2)
+    w2.solve_on_grid([0.0, 0.1, -0.2])
+    o2, _ = orc.solve_on_grid(m2, mesh2, [0.0, 0.1, -0.2], vectorised=True)
+    for occ in (list(range(9)), [11, 3] + list(range(4, 11)) + [0, 1, 2]):
+        for dirs in ([0, 2], [1, 2], [2, 0]):
+            got = w2.berry_flux(occ, dirs=dirs, individual_phases=True)
+            ref = orc.berry_flux(o2, 3, occ, dirs, individual_phases=True, vectorised=True)
+            assert got.shape == ref.shape and np.max(np.abs(wrap(got - ref))) < 1e-9
+            assert np.max(np.abs(w2.berry_flux(occ, dirs=dirs) - orc.berry_flux(o2, 3, occ, dirs, vectorised=True))) < 1e-8
+        for d in range(3):
+            assert np.max(np.abs(wrap(w2.berry_phase(occ, d, contin=False) - orc.berry_phase(o2, 3, occ, d, contin=False)))) < 1e-9
 
 
 def test_wide_models_workgroup_kernel(tb):
