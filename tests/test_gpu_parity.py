@@ -616,6 +616,50 @@ def test_large_nocc_and_unsupported_sizes(tb):
         big.solve_all([0.1])                                   # nsta > TBK_MAX_NSTA fails loudly
 
 
+@pytest.mark.parametrize("norb", [1, 2, 3, 4])
+def test_mesh_kernels_long_range_hops_and_fallback(tb, norb):
+    """n <= 4 meshes: hops reaching three and five cells along the last axis take the run-time-degree form of the
+    row-polynomial kernel (k_grid_rows<N,-1>); TBK_GRID_KERNEL=1 selects the term-walking kernel that serves
+    models whose row table would not fit in LDS.  Both against the oracle, and against each other."""
+    from oracle import tb_oracle as orc
+    rng = np.random.default_rng(100 + norb)
+    m = hp.quiet(tb.tb_model, 2, 2, [[1.0, 0.0], [0.3, 0.9]], rng.random((norb, 2)))
+    m.set_onsite([-8.0] + list(rng.standard_normal(norb - 1)))          # band 0 stays isolated
+    for (i, j, R) in [(0, norb - 1, [0, 3]), (0, 0, [1, -5]), (norb - 1, 0, [2, 1]), (0, norb - 1, [1, 0])] + \
+                     [(i, i + 1, [0, 1]) for i in range(norb - 1)]:
+        m.set_hop(0.4 * complex(rng.standard_normal(), rng.standard_normal()), i, j, R, mode="add")
+    mesh, start = [37, 70], [0.13, -0.41]
+    w = tb.wf_array(m, mesh)
+    gaps = w.solve_on_grid(start)
+    host = w._wfs.copy()
+    owfs, ogaps = orc.solve_on_grid(m, mesh, start, vectorised=True)
+    if norb > 1:
+        assert np.max(np.abs(gaps - ogaps)) < 1e-11
+    ref_e = orc.solve_all_vec(m, orc.mesh_points(mesh, start) if hasattr(orc, "mesh_points") else np.array(
+        [[start[0] + a / (mesh[0] - 1), start[1] + b / (mesh[1] - 1)] for a in range(mesh[0]) for b in range(mesh[1])]))
+    ham = orc.ham_batch(m, np.array([[start[0] + a / (mesh[0] - 1), start[1] + b / (mesh[1] - 1)] for a in (0, 17, 35) for b in (0, 33, 68)]))
+    V = host.reshape(mesh[0], mesh[1], norb, norb)
+    for idx, (a, b) in enumerate([(a, b) for a in (0, 17, 35) for b in (0, 33, 68)]):
+        vec = V[a, b]                                           # [band][orb]
+        e = np.real(np.einsum('bi,ij,bj->b', vec.conj(), ham[idx], vec))
+        assert np.max(np.abs(ham[idx] @ vec.T - vec.T * e)) < 1e-11
+        assert np.max(np.abs(e - ref_e[:, a * mesh[1] + b])) < 1e-11
+    occ = [0]
+    assert norb == 1 or ogaps[0] > 1.0
+    flux = w.berry_flux(occ, individual_phases=True)
+    assert np.max(np.abs(wrap(flux - orc.berry_flux(owfs, 2, occ, individual_phases=True, vectorised=True)))) < 1e-9
+    os.environ["TBK_GRID_KERNEL"] = "1"
+    try:
+        w2 = tb.wf_array(m, mesh)
+        gaps2 = w2.solve_on_grid(start)
+        flux2 = w2.berry_flux(occ, individual_phases=True)
+    finally:
+        del os.environ["TBK_GRID_KERNEL"]
+    if norb > 1:
+        assert np.max(np.abs(gaps2 - gaps)) < 1e-12
+    assert np.max(np.abs(wrap(flux2 - flux))) < 1e-9
+
+
 def test_wilson_pipeline_batches_and_axes(tb):
     """Workgroup-level Wilson-loop eigenphases (3 or more bands): strings along every axis of a 3-D mesh, band
     lists in arbitrary order, and the string batching (forced to a few strings per batch) must not change a bit."""
