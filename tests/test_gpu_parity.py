@@ -681,6 +681,23 @@ def test_wilson_pipeline_batches_and_axes(tb):
             finally:
                 del os.environ["TBK_WILSON_BATCH_BYTES"]
             assert np.array_equal(again, got)
+    # the reference's continuity post-processing on top of the pipeline's raw eigenphases (2-D mesh, smooth model)
+    h3 = hp.quiet(tb.tb_model, 2, 2, [[1.0, 0.0], [0.0, 1.0]], [[0.0, 0.0], [0.3, 0.1], [0.6, 0.5], [0.1, 0.7], [0.8, 0.2]])
+    h3.set_onsite([-3.0, -2.6, -2.2, 2.5, 3.0])
+    rng = np.random.default_rng(8)
+    for i in range(5):
+        for j in range(i + 1, 5):
+            for R in ([0, 0], [1, 0], [0, 1]):
+                h3.set_hop(0.3 * complex(rng.standard_normal(), rng.standard_normal()), i, j, R)
+    w3 = tb.wf_array(h3, [21, 25])
+    w3.solve_on_grid([0.0, 0.0])
+    o3, g3 = orc.solve_on_grid(h3, [21, 25], [0.0, 0.0], vectorised=True)
+    assert g3[2] > 2.0
+    for d in (0, 1):
+        got = w3.berry_phase([0, 1, 2], d, contin=True, berry_evals=True)
+        ref = orc.berry_phase(o3, 2, [0, 1, 2], d, contin=True, berry_evals=True)
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) < 1e-8
+        assert np.max(np.abs(w3.berry_phase([0, 1, 2], d, contin=True) - orc.berry_phase(o3, 2, [0, 1, 2], d, contin=True))) < 1e-8
     # nine or more bands: link determinants by one workgroup per link, on slices / strings of a 3-D mesh
     m2 = hp.random_model(tb.tb_model, 12, 3, 1, 5, nhop=60, rmax=1)
     mesh2 = [4, 5, 6]
