@@ -111,6 +111,15 @@ int tbk_wfs_free(tbk_wfs* wfs);
 int tbk_wfs_upload(tbk_wfs* wfs, const double* host_c128);
 int tbk_wfs_download(tbk_wfs* wfs, double* host_c128);
 int tbk_wfs_device_ptr(tbk_wfs* wfs, void** ptr_dev, int64_t* bytes);
+/* wf_array.__getitem__/__setitem__ (pythtb.py:2644-2672) on a resident array: copy the states of
+ * npoints mesh points (row-major mesh indices) to/from host[npoints][nsta_arr][ncomp] c128 without
+ * moving the rest of the array.                                                              */
+int tbk_wfs_download_points(tbk_wfs* wfs, const int64_t* point_index, int64_t npoints, double* host_c128);
+int tbk_wfs_upload_points(tbk_wfs* wfs, const int64_t* point_index, int64_t npoints, const double* host_c128);
+/* bytes and calls of wf_array traffic across PCIe since the last reset (whole-array upload/download
+ * and the per-point forms): lets callers and tests assert that a script causes no re-uploads. */
+int tbk_ctx_transfer_stats(tbk_ctx* ctx, int64_t* h2d_bytes, int64_t* d2h_bytes, int64_t* h2d_calls,
+                           int64_t* d2h_calls, int reset);
 
 /* solve_on_grid (pythtb.py:2421-2532): every mesh point i_d < N_d-1 solved at
  * start_k[d] + i_d/(N_d-1); the points with i_d == N_d-1 are the impose_pbc
@@ -170,6 +179,13 @@ int tbk_berry_phase(tbk_wfs* wfs, const int32_t* occ, int nocc, int dir, int ber
  *                  orbital_basis != 0 [nk][nsub][ncomp] expanded on the orbitals (:2262-2277) */
 int tbk_position_hwf(tbk_ctx* ctx, const double* evec, int64_t nk, int nsub, int ncomp,
                      const double* pos, double* xmat, double* hwfc, double* hwf, int orbital_basis);
+
+/* The same on the states `occ[nocc]` of a RESIDENT wf_array (wf_array.position_matrix / _expectation /
+ * _hwf, pythtb.py:2793-2861): nothing but the results crosses PCIe.  point_index (nullable): row-major
+ * mesh indices of the npoints points wanted; NULL = every mesh point in order (npoints ignored).
+ * Output shapes as above with nk = number of points, nsub = nocc.                                   */
+int tbk_wfs_position_hwf(tbk_wfs* wfs, const int64_t* point_index, int64_t npoints, const int32_t* occ, int nocc,
+                         const double* pos, double* xmat, double* hwfc, double* hwf, int orbital_basis);
 
 /* ---- k generators on the device, eigenvalue reductions (third "next" row) ----
  * tb_model.k_uniform_mesh (pythtb.py:1792-1861): k_dev[prod(mesh)][dim_k], point

@@ -12,18 +12,26 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    name = name.split("(")[0]
-    for key in ("k_grid_rows", "k_grid_small", "k_grid_tables", "k_solve_small", "k_solve_wave", "k_flux_reduce",
-                "k_flux_rows", "k_flux", "k_chain_partial", "k_chain_final", "k_gen_ham", "k_fill_u64", "k_impose",
-                "k_relayout", "k_arm_gaps"):
-        if key in name:
-            return key
-    return name[:60]
+    """Kernel name WITH its template arguments (k_grid_rows<2, 1> and <4, 1> are different kernels), without
+    the return type and the parameter list."""
+    name = name.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    depth, cut = 0, len(name)
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    return name[:cut].replace(" ", "")[:80]
 
 
 # kernel trace -> durations
 dur = defaultdict(list)
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+for f in glob.glob(os.path.join(src, "trace*", "**", "*kernel_trace.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         dur[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
 with open(os.path.join(dst, "kernel_stats.csv"), "w") as out:
@@ -32,7 +40,7 @@ with open(os.path.join(dst, "kernel_stats.csv"), "w") as out:
         out.write("%s,%d,%.1f,%.2f,%.2f,%.2f\n" % (k, len(v), sum(v) / 1e3, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3))
 
 # the tool's own stats file, verbatim
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+for f in glob.glob(os.path.join(src, "trace*", "**", "*kernel_stats.csv"), recursive=True):
     open(os.path.join(dst, "rocprofv3_kernel_stats.csv"), "w").write(open(f).read())
 
 # PMC passes -> per kernel mean of each counter per dispatch
@@ -53,10 +61,11 @@ for k, cs in table.items():
         traffic[k] = {"fetch_bytes_raw": rd, "fetch_bytes_x2": 2.0 * rd, "write_bytes": wr,
                       "hbm_bytes_per_launch": 2.0 * rd + wr}
 # aliases under the names bench.py uses for its HIP-event brackets
-for alias, names in (("solve_grid", ("k_grid_rows", "k_grid_small", "k_solve_wave")), ("berry_flux", ("k_flux_rows", "k_flux"))):
+for alias, names in (("solve_grid", ("k_grid_rows", "k_grid_small", "k_solve_wave")), ("berry_flux", ("k_flux_rows", "k_flux<"))):
     for nm in names:
-        if nm in traffic and alias not in traffic:
-            traffic[alias] = dict(traffic[nm], kernel=nm)
+        for full in sorted(traffic):
+            if full.startswith(nm) and alias not in traffic:
+                traffic[alias] = dict(traffic[full], kernel=full)
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, "kernel_stats.csv")).read())
 print(json.dumps(traffic, indent=1))

@@ -62,6 +62,10 @@ SIGNATURES = {
     "tbk_wfs_upload": (_i, [_p, _dp]),
     "tbk_wfs_download": (_i, [_p, _dp]),
     "tbk_wfs_device_ptr": (_i, [_p, _pp, C.POINTER(C.c_int64)]),
+    "tbk_wfs_download_points": (_i, [_p, C.POINTER(C.c_int64), _i64, _dp]),
+    "tbk_wfs_upload_points": (_i, [_p, C.POINTER(C.c_int64), _i64, _dp]),
+    "tbk_ctx_transfer_stats": (_i, [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64), _i]),
     "tbk_wfs_solve_grid": (_i, [_p, _p, _dp, _dp, _i64, _i64, _dp]),
     "tbk_wfs_solve_grid_async": (_i, [_p, _p, _dp, _dp, _i64, _i64]),
     "tbk_wfs_solve_grid_result": (_i, [_p, _dp]),
@@ -72,6 +76,7 @@ SIGNATURES = {
     "tbk_berry_flux_result": (_i, [_p, _dp, _dp]),
     "tbk_berry_phase": (_i, [_p, _ip, _i, _i, _i, _dp]),
     "tbk_position_hwf": (_i, [_p, _dp, _i64, _i, _i, _dp, _dp, _dp, _dp, _i]),
+    "tbk_wfs_position_hwf": (_i, [_p, C.POINTER(C.c_int64), _i64, _ip, _i, _dp, _dp, _dp, _dp, _i]),
     "tbk_k_uniform_mesh_dev": (_i, [_p, _i, _ip, _p]),
     "tbk_k_path_dev": (_i, [_p, _i, _i, _dp, _ip, _i64, _p]),
     "tbk_solve_mesh": (_i, [_p, _ip, _dp, _dp]),
@@ -142,6 +147,12 @@ class Context(object):
         hbm = C.c_int64(0)
         check(lib.tbk_ctx_device_info(self.handle, name, 256, C.byref(cus), C.byref(hbm)))
         return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=hbm.value)
+
+    def transfer_stats(self, reset=False):
+        """wf_array bytes/calls across PCIe since the last reset: dict(h2d_bytes, d2h_bytes, h2d_calls, d2h_calls)."""
+        v = [C.c_int64(0) for _ in range(4)]
+        check(lib.tbk_ctx_transfer_stats(self.handle, *[C.byref(x) for x in v], 1 if reset else 0))
+        return dict(h2d_bytes=v[0].value, d2h_bytes=v[1].value, h2d_calls=v[2].value, d2h_calls=v[3].value)
 
     # ---- timing helpers (HIP events on this context's stream)
     def timer_begin(self):

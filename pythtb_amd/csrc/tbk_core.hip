@@ -600,6 +600,8 @@ extern "C" int tbk_wfs_upload(tbk_wfs* w, const double* host) {
     if (w->view.nsta == 1) {  // the two layouts coincide
         TBK_HIP(hipMemcpyAsync(w->view.data, host, (size_t)w->bytes, hipMemcpyHostToDevice, ctx->stream));
         TBK_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->xfer_h2d_bytes += w->bytes;
+        ctx->xfer_h2d_calls += 1;
         return TBK_OK;
     }
     cd* tmp = nullptr;
@@ -612,6 +614,8 @@ extern "C" int tbk_wfs_upload(tbk_wfs* w, const double* host) {
     hipStreamSynchronize(ctx->stream);
     hipFree(tmp);
     if (rc == TBK_EHIP) tbk_set_error("tbk_wfs_upload: host to device copy failed");
+    ctx->xfer_h2d_bytes += w->bytes;
+    ctx->xfer_h2d_calls += 1;
     return rc;
 }
 
@@ -622,6 +626,8 @@ extern "C" int tbk_wfs_download(tbk_wfs* w, double* host) {
     if (w->view.nsta == 1) {
         TBK_HIP(hipMemcpyAsync(host, w->view.data, (size_t)w->bytes, hipMemcpyDeviceToHost, ctx->stream));
         TBK_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->xfer_d2h_bytes += w->bytes;
+        ctx->xfer_d2h_calls += 1;
         return TBK_OK;
     }
     cd* tmp = nullptr;
@@ -635,7 +641,71 @@ extern "C" int tbk_wfs_download(tbk_wfs* w, double* host) {
     }
     hipStreamSynchronize(ctx->stream);
     hipFree(tmp);
+    ctx->xfer_d2h_bytes += w->bytes;
+    ctx->xfer_d2h_calls += 1;
     return rc;
+}
+
+// ---- single mesh points of a resident array (wf[i,j] reads and writes, pythtb.py:2644-2672,
+// without moving the whole array): host layout [point][band][comp] <-> device planes
+__global__ __launch_bounds__(256) void k_points_copy(const WfsView v, const int64_t* __restrict__ idx, const int64_t np,
+                                                     cd* __restrict__ buf, const int to_device) {
+    const int64_t per = (int64_t)v.nsta * v.ncomp;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= np * per) return;
+    const int64_t p = e / per;
+    const int r = (int)(e - p * per);
+    const int b = r / v.ncomp, o = r - b * v.ncomp;
+    cd* dev = v.data + ((int64_t)b * v.npts + idx[p]) * v.ncomp + o;
+    if (to_device) *dev = buf[e]; else buf[e] = *dev;
+}
+
+static int points_copy(tbk_wfs* w, const int64_t* point_index, int64_t np, double* host, int to_device, const char* who) {
+    TBK_REQUIRE(w && (np == 0 || (point_index && host)) && np >= 0, TBK_EINVAL, "%s: bad argument", who);
+    if (np == 0) return TBK_OK;
+    const WfsView& v = w->view;
+    for (int64_t i = 0; i < np; ++i)
+        TBK_REQUIRE(point_index[i] >= 0 && point_index[i] < v.npts, TBK_EINVAL, "%s: point %lld outside the mesh of %lld points",
+                    who, (long long)point_index[i], (long long)v.npts);
+    tbk_ctx* ctx = w->ctx;
+    TBK_HIP(hipSetDevice(ctx->device));
+    const size_t ib = (((size_t)np * sizeof(int64_t)) + 255) & ~(size_t)255;
+    const size_t vb = (size_t)np * v.nsta * v.ncomp * sizeof(cd);
+    void* base = nullptr;
+    int rc = tbk_ctx_scratch(ctx, 256 + ib + vb, &base);
+    if (rc) return rc;
+    int64_t* idx_dev = (int64_t*)((unsigned char*)base + 256);
+    cd* buf_dev = (cd*)((unsigned char*)base + 256 + ib);
+    TBK_HIP(hipMemcpyAsync(idx_dev, point_index, (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (to_device) TBK_HIP(hipMemcpyAsync(buf_dev, host, vb, hipMemcpyHostToDevice, ctx->stream));
+    const int64_t total = np * v.nsta * v.ncomp;
+    hipLaunchKernelGGL(k_points_copy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, v, idx_dev, np, buf_dev,
+                       to_device);
+    TBK_HIP(hipGetLastError());
+    if (!to_device) TBK_HIP(hipMemcpyAsync(host, buf_dev, vb, hipMemcpyDeviceToHost, ctx->stream));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    (to_device ? ctx->xfer_h2d_bytes : ctx->xfer_d2h_bytes) += (int64_t)vb;
+    (to_device ? ctx->xfer_h2d_calls : ctx->xfer_d2h_calls) += 1;
+    return TBK_OK;
+}
+
+extern "C" int tbk_wfs_download_points(tbk_wfs* w, const int64_t* point_index, int64_t npoints, double* host) {
+    return points_copy(w, point_index, npoints, host, 0, "tbk_wfs_download_points");
+}
+
+extern "C" int tbk_wfs_upload_points(tbk_wfs* w, const int64_t* point_index, int64_t npoints, const double* host) {
+    return points_copy(w, point_index, npoints, const_cast<double*>(host), 1, "tbk_wfs_upload_points");
+}
+
+extern "C" int tbk_ctx_transfer_stats(tbk_ctx* c, int64_t* h2d_bytes, int64_t* d2h_bytes, int64_t* h2d_calls, int64_t* d2h_calls,
+                                      int reset) {
+    TBK_REQUIRE(c, TBK_EINVAL, "tbk_ctx_transfer_stats: null context");
+    if (h2d_bytes) *h2d_bytes = c->xfer_h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = c->xfer_d2h_bytes;
+    if (h2d_calls) *h2d_calls = c->xfer_h2d_calls;
+    if (d2h_calls) *d2h_calls = c->xfer_d2h_calls;
+    if (reset) c->xfer_h2d_bytes = c->xfer_d2h_bytes = c->xfer_h2d_calls = c->xfer_d2h_calls = 0;
+    return TBK_OK;
 }
 
 extern "C" int tbk_wfs_device_ptr(tbk_wfs* w, void** p, int64_t* bytes) {

@@ -84,6 +84,8 @@ struct tbk_ctx {
     int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
     void* work = nullptr;      // workspace of the workgroup-per-matrix eigen-solver (n > 64)
     size_t work_bytes = 0;
+    // whole-array / per-point wf_array transfers across PCIe (tbk_ctx_transfer_stats)
+    int64_t xfer_h2d_bytes = 0, xfer_d2h_bytes = 0, xfer_h2d_calls = 0, xfer_d2h_calls = 0;
     // RCCL
     void* rccl_lib = nullptr;
     void* comm = nullptr;

@@ -417,9 +417,7 @@ class tb_model(object):
     def ignore_position_operator_offdiagonal(self):
         self._assume_position_operator_diagonal = True
 
-    def _position_call(self, evec, dir, want_x, want_c, want_w, orbital):
-        """Shared driver of position_matrix/expectation/hwf.  `evec` is one point
-        [band,orb(,spin)] or a batch [point,band,orb(,spin)] (extension)."""
+    def _position_dir_check(self, dir):
         if dir in self._per:
             raise Exception("Can not compute position matrix elements along periodic direction!")
         if dir < 0 or dir >= self._dim_r:
@@ -427,47 +425,68 @@ class tb_model(object):
         if self._assume_position_operator_diagonal == False:  # noqa: E712
             raise Exception("\n\nPosition-operator objects of Wannier90 models need "
                             "my_model.ignore_position_operator_offdiagonal()")
-        ev = np.array(evec, dtype=complex)
-        tail = 2 if self._nspin == 2 else 1
-        batched = ev.ndim == tail + 2
-        if ev.ndim not in (tail + 1, tail + 2) or ev.shape[-tail:] != ((self._norb, 2) if tail == 2 else (self._norb,)):
-            raise Exception("\n\nWrong shape of the eigenvector array")
-        nsub = ev.shape[-tail - 1]
+
+    def _position_call(self, evec, dir, want_x, want_c, want_w, orbital, wfs=None):
+        """Shared driver of position_matrix/expectation/hwf.  `evec` is one point
+        [band,orb(,spin)] or a batch [point,band,orb(,spin)] (extension).  With
+        wfs = (device handle, point indices or None, occ) the states are read from a
+        resident wf_array instead and `evec` is ignored (always batched)."""
+        self._position_dir_check(dir)
         ncomp = self._norb * self._nspin
-        nk = ev.shape[0] if batched else 1
-        flat = np.ascontiguousarray(ev.reshape(nk, nsub, ncomp))
         pos = np.ascontiguousarray(np.repeat(self._orb[:, dir], self._nspin), dtype=float)   # pythtb.py:2078-2083
+        if wfs is None:
+            ev = np.array(evec, dtype=complex)
+            tail = 2 if self._nspin == 2 else 1
+            batched = ev.ndim == tail + 2
+            if ev.ndim not in (tail + 1, tail + 2) or ev.shape[-tail:] != ((self._norb, 2) if tail == 2 else (self._norb,)):
+                raise Exception("\n\nWrong shape of the eigenvector array")
+            nsub = ev.shape[-tail - 1]
+            nk = ev.shape[0] if batched else 1
+            flat = np.ascontiguousarray(ev.reshape(nk, nsub, ncomp))
+        else:
+            handle, pts, occ, npts_all = wfs
+            batched = True
+            nsub = len(occ)
+            nk = npts_all if pts is None else len(pts)
         xmat = np.zeros((nk, nsub, nsub), dtype=complex) if want_x else None
         hwfc = np.zeros((nk, nsub), dtype=float) if want_c else None
         width = ncomp if orbital else nsub
         hwf = np.zeros((nk, nsub, width), dtype=complex) if want_w else None
-        _lib.check(_lib.lib.tbk_position_hwf(
-            _lib.default_context().handle, _lib.dptr(flat.view(float)), nk, nsub, ncomp, _lib.dptr(pos),
-            _lib.dptr(xmat.view(float)) if want_x else None, _lib.dptr(hwfc),
-            _lib.dptr(hwf.view(float)) if want_w else None, 1 if orbital else 0))
+        outs = (_lib.dptr(xmat.view(float)) if want_x else None, _lib.dptr(hwfc),
+                _lib.dptr(hwf.view(float)) if want_w else None, 1 if orbital else 0)
+        if wfs is None:
+            _lib.check(_lib.lib.tbk_position_hwf(
+                _lib.default_context().handle, _lib.dptr(flat.view(float)), nk, nsub, ncomp, _lib.dptr(pos), *outs))
+        else:
+            import ctypes as C
+            occ32 = np.ascontiguousarray(occ, dtype=np.int32)
+            p64 = None if pts is None else np.ascontiguousarray(pts, dtype=np.int64)
+            _lib.check(_lib.lib.tbk_wfs_position_hwf(
+                handle, None if p64 is None else p64.ctypes.data_as(C.POINTER(C.c_int64)), nk, _lib.iptr(occ32), nsub,
+                _lib.dptr(pos), *outs))
         if want_w and orbital and self._nspin == 2:
             hwf = hwf.reshape(nk, nsub, self._norb, 2)
         pick = (lambda a: a) if batched else (lambda a: None if a is None else a[0])
         return pick(xmat), pick(hwfc), pick(hwf)
 
-    def position_matrix(self, evec, dir):
+    def position_matrix(self, evec, dir, _wfs=None):
         """X_mn = <u_m| r_dir |u_n> for the states `evec` of one k-point (pythtb.py:2034-2098)."""
-        xmat, _, _ = self._position_call(evec, dir, True, False, False, False)
+        xmat, _, _ = self._position_call(evec, dir, True, False, False, False, _wfs)
         herm = xmat - np.swapaxes(xmat.conj(), -1, -2)
         if np.max(herm) > 1.0E-9:
             raise Exception("\n\n Position matrix is not hermitian?!")
         return xmat
 
-    def position_expectation(self, evec, dir):
+    def position_expectation(self, evec, dir, _wfs=None):
         """Diagonal of the position matrix (pythtb.py:2100-2141)."""
-        xmat = self.position_matrix(evec, dir)
+        xmat = self.position_matrix(evec, dir, _wfs)
         return np.array(np.real(np.diagonal(xmat, axis1=-2, axis2=-1)), dtype=float)
 
-    def position_hwf(self, evec, dir, hwf_evec=False, basis="orbital"):
+    def position_hwf(self, evec, dir, hwf_evec=False, basis="orbital", _wfs=None):
         """Hybrid Wannier centres (and functions) = eigen-decomposition of the position
         matrix (pythtb.py:2143-2279)."""
         if not hwf_evec:
-            _, hwfc, _ = self._position_call(evec, dir, False, True, False, False)
+            _, hwfc, _ = self._position_call(evec, dir, False, True, False, False, _wfs)
             return hwfc
         which = basis.lower().strip()
         if which in ("wavefunction", "bloch"):
@@ -476,7 +495,7 @@ class tb_model(object):
             orbital = True
         else:
             raise Exception("\n\nBasis must be either 'wavefunction', 'bloch', or 'orbital'")
-        _, hwfc, hwf = self._position_call(evec, dir, False, True, True, orbital)
+        _, hwfc, hwf = self._position_call(evec, dir, False, True, True, orbital, _wfs)
         return (hwfc, hwf)
 
     # ------------------------------------------------------------------ k generators (host)

@@ -79,11 +79,22 @@ class wf_array(object):
             raise Exception("\n\nDimension of wf_array object in each direction must be 2 or larger.")
         self._host = None          # NumPy mirror (allocated on first use)
         self._host_valid = False
+        self._host_exported = False  # the writable mirror has been handed out through `_wfs` (sticky)
         self._dev = None           # tbk_wfs handle
         self._dev_shape = None
         self._dev_valid = False
 
     # ------------------------------------------------------------------ storage
+    # Two copies of the array exist: the device buffer (what every kernel reads and writes) and a lazily
+    # created NumPy mirror.  Who is authoritative:
+    #   * device, after solve_on_grid / impose_* and as long as the caller only uses wf[i,j] (read-only
+    #     views / single-point transfers), wf[i,j] = v (single-point upload), berry_*, position_*;
+    #   * host, once the caller has taken the writable mirror through the private attribute `_wfs` (in the
+    #     reference that attribute IS the storage, so a script may keep the array and write to it at any
+    #     time): from then on the mirror is re-uploaded before every device use and refreshed after every
+    #     device-side write, until release_host() is called.
+    _SMALL_MIRROR_BYTES = 32 << 20    # wf[i,j] on a resident array at most this big mirrors it whole
+
     def _shape(self, nsta=None):
         shp = [int(x) for x in self._mesh_arr] + [int(self._nsta_arr if nsta is None else nsta), self._norb]
         if self._nspin == 2:
@@ -105,14 +116,39 @@ class wf_array(object):
     @property
     def _wfs(self):
         arr = self._host_array()
-        self._dev_valid = False            # the caller may write through the returned array
+        self._host_exported = True         # the caller may keep the array and write through it at any time
         return arr
 
     @_wfs.setter
     def _wfs(self, value):
         self._host = np.ascontiguousarray(value, dtype=complex)
         self._host_valid = True
+        self._host_exported = False
         self._dev_valid = False
+
+    def mark_dirty(self):
+        """Extension: declare that the host mirror was modified in place (only needed after
+        release_host(); while the mirror is exported every device use re-uploads it anyway)."""
+        if self._host is not None and self._host_valid:
+            self._dev_valid = False
+
+    def release_host(self):
+        """Extension: promise that no array obtained from `_wfs` will be written to any more.  The device
+        copy becomes authoritative again and Berry calls stop re-uploading the mirror."""
+        self._host_exported = False
+
+    def to_host(self):
+        """Extension: read-only NumPy snapshot of the whole array (one download, no later re-uploads)."""
+        out = self._host_array().view()
+        out.flags.writeable = False
+        return out
+
+    def _device_wrote(self):
+        """A kernel has just changed the device copy."""
+        self._dev_valid = True
+        self._host_valid = False
+        if self._host_exported:            # keep the array the caller holds live, like the reference's storage
+            self._host_array()
 
     def _free_dev(self):
         if self._dev is not None:
@@ -137,7 +173,7 @@ class wf_array(object):
         return h
 
     def _ensure_dev(self):
-        if self._dev_valid and self._dev is not None:
+        if self._dev_valid and self._dev is not None and not (self._host_exported and self._host_valid):
             return self._dev
         host = self._host_array()
         if not host.flags["C_CONTIGUOUS"]:
@@ -154,6 +190,7 @@ class wf_array(object):
         st["_dev"] = None
         st["_dev_shape"] = None
         st["_dev_valid"] = False
+        st["_host_exported"] = False
         return st
 
     def __del__(self):
@@ -194,8 +231,7 @@ class wf_array(object):
         n0 = int(self._mesh_arr[0])
         _lib.check(_lib.lib.tbk_wfs_solve_grid(h, m._device_model(), _lib.dptr(start),
                                                _lib.dptr(pbc.view(float)), 0, n0, _lib.dptr(gaps)))
-        self._dev_valid = True
-        self._host_valid = False
+        self._device_wrote()
         if n <= 1:
             return None
         return gaps[:n - 1]
@@ -224,17 +260,13 @@ class wf_array(object):
         gaps = np.zeros(max(n - 1, 1), dtype=float)
         _lib.check(_lib.lib.tbk_wfs_solve_grid_result(h, _lib.dptr(gaps)))
         self._start_k = start_k
-        self._dev_valid = True
-        self._host_valid = False
+        self._device_wrote()
         return None if n <= 1 else gaps[:n - 1]
 
     def solve_on_one_point(self, kpt, mesh_indices):
         """Solve at one k and store at mesh_indices (pythtb.py:2534-2566)."""
         (eval, evec) = self._model.solve_one(kpt, eig_vectors=True)
-        if _is_int(mesh_indices):
-            self._wfs[(mesh_indices,)] = evec
-        else:
-            self._wfs[tuple(mesh_indices)] = evec
+        self[mesh_indices if _is_int(mesh_indices) else tuple(mesh_indices)] = evec
 
     def choose_states(self, subset):
         """New wf_array holding a subset of the states (pythtb.py:2568-2608)."""
@@ -272,13 +304,46 @@ class wf_array(object):
                 if k < -self._mesh_arr[i] or k >= self._mesh_arr[i]:
                     raise IndexError("Key outside the range!")
 
+    def _flat_index(self, key):
+        key = (key,) if self._dim_arr == 1 else tuple(key)
+        idx = 0
+        for d, k in enumerate(key):
+            n = int(self._mesh_arr[d])
+            idx = idx * n + (int(k) + n if k < 0 else int(k))
+        return idx
+
+    def _device_only(self):
+        """The device copy is current and the host mirror is not."""
+        return self._dev_valid and self._dev is not None and not (self._host_valid and self._host is not None)
+
     def __getitem__(self, key):
+        """States at one mesh point, `(nsta_arr, norb[, 2])` (pythtb.py:2644-2661).  The result is READ-ONLY
+        (write with `wf[i,j] = value`): a view of the host mirror when there is one, else -- for a large
+        resident array -- just this point fetched from the device."""
         self._check_key(key)
-        return self._wfs[key]
+        if self._device_only() and int(np.prod(self._shape())) * 16 > self._SMALL_MIRROR_BYTES:
+            out = np.zeros(self._shape()[self._dim_arr:], dtype=complex)
+            idx = np.array([self._flat_index(key)], dtype=np.int64)
+            _lib.check(_lib.lib.tbk_wfs_download_points(self._dev, idx.ctypes.data_as(C.POINTER(C.c_int64)), 1,
+                                                        _lib.dptr(out.view(float))))
+        else:
+            out = self._host_array()[key].view()
+        out.flags.writeable = False
+        return out
 
     def __setitem__(self, key, value):
+        """pythtb.py:2663-2672.  On a resident array only this point crosses PCIe."""
         self._check_key(key)
-        self._wfs[key] = np.array(value, dtype=complex)
+        val = np.array(value, dtype=complex)
+        if self._dev_valid and self._dev is not None:
+            pt = np.ascontiguousarray(np.broadcast_to(val, self._shape()[self._dim_arr:]))
+            idx = np.array([self._flat_index(key)], dtype=np.int64)
+            _lib.check(_lib.lib.tbk_wfs_upload_points(self._dev, idx.ctypes.data_as(C.POINTER(C.c_int64)), 1,
+                                                      _lib.dptr(pt.view(float))))
+            if self._host is not None and self._host_valid:
+                self._host[key] = val
+        else:
+            self._host_array()[key] = val
 
     # ------------------------------------------------------------------ boundary conditions
     def impose_pbc(self, mesh_dir, k_dir):
@@ -292,7 +357,7 @@ class wf_array(object):
         phase = np.ascontiguousarray(np.repeat(fac, self._nspin))
         h = self._ensure_dev()
         _lib.check(_lib.lib.tbk_wfs_impose(h, int(mesh_dir), _lib.dptr(phase.view(float))))
-        self._host_valid = False
+        self._device_wrote()
 
     def impose_loop(self, mesh_dir):
         """Last slice along mesh_dir = first slice (pythtb.py:2751-2791)."""
@@ -300,39 +365,59 @@ class wf_array(object):
             raise Exception("\n\nWrong value of mesh_dir.")
         h = self._ensure_dev()
         _lib.check(_lib.lib.tbk_wfs_impose(h, int(mesh_dir), None))
-        self._host_valid = False
+        self._device_wrote()
 
     # ------------------------------------------------------------------ position operator
-    def _occ_states(self, key, occ):
+    def _occ_list(self, occ):
         if isinstance(occ, str) and occ == "All":
             occ = np.arange(self._nsta_arr, dtype=int)
         else:
             occ = np.array(occ, dtype=int)
         if occ.ndim != 1:
             raise Exception("\n\nParameter occ must be a one-dimensional array or string \"All\".")
-        return self._host_array()[tuple(key)][occ]
+        return occ
+
+    def _position_src(self, key, occ):
+        """(evec, wfs) arguments for the model's position_* driver: the states stay on the device when the
+        device copy is current (only the small results come back), else they are taken from the host mirror."""
+        occ = self._occ_list(occ)
+        self._check_key(key)
+        if self._dev_valid and self._dev is not None and not (self._host_exported and self._host_valid):
+            if np.any(occ < 0) or np.any(occ >= self._nsta_arr):
+                raise IndexError("state index outside the range!")
+            return None, (self._dev, [self._flat_index(key)], occ, None)
+        return self._host_array()[key if self._dim_arr == 1 else tuple(key)][occ], None
 
     def position_matrix(self, key, occ, dir):
         """tb_model.position_matrix for the states `occ` stored at mesh point `key` (pythtb.py:2793-2810)."""
-        return self._model.position_matrix(self._occ_states(key, occ), dir)
+        ev, src = self._position_src(key, occ)
+        res = self._model.position_matrix(ev, dir, src)
+        return res if src is None else res[0]
 
     def position_expectation(self, key, occ, dir):
         """pythtb.py:2812-2829."""
-        return self._model.position_expectation(self._occ_states(key, occ), dir)
+        ev, src = self._position_src(key, occ)
+        res = self._model.position_expectation(ev, dir, src)
+        return res if src is None else res[0]
 
     def position_hwf(self, key, occ, dir, hwf_evec=False, basis="wavefunction"):
         """pythtb.py:2831-2861 (note the default basis differs from tb_model.position_hwf)."""
-        return self._model.position_hwf(self._occ_states(key, occ), dir, hwf_evec, basis)
+        ev, src = self._position_src(key, occ)
+        res = self._model.position_hwf(ev, dir, hwf_evec, basis, src)
+        if src is None:
+            return res
+        return (res[0][0], res[1][0]) if hwf_evec else res[0]
 
     def position_hwf_mesh(self, occ, dir, hwf_evec=False, basis="wavefunction"):
-        """Extension: position_hwf for every mesh point in one batched device call.  Returns
-        hwfc[mesh..., nocc] (and hwf[mesh..., nocc, x]) -- the loop the reference's examples
+        """Extension: position_hwf for every mesh point in one batched device call on the resident array.
+        Returns hwfc[mesh..., nocc] (and hwf[mesh..., nocc, x]) -- the loop the reference's examples
         write around position_hwf (e.g. examples/cubic_slab_hwf.py)."""
-        occ = np.arange(self._nsta_arr, dtype=int) if isinstance(occ, str) and occ == "All" else np.array(occ, dtype=int)
-        host = self._host_array()
+        occ = self._occ_list(occ)
+        if np.any(occ < 0) or np.any(occ >= self._nsta_arr):
+            raise IndexError("state index outside the range!")
         mesh = tuple(int(x) for x in self._mesh_arr)
-        ev = np.take(host.reshape((-1,) + host.shape[self._dim_arr:]), occ, axis=1)
-        res = self._model.position_hwf(ev, dir, hwf_evec, basis)
+        h = self._ensure_dev()
+        res = self._model.position_hwf(None, dir, hwf_evec, basis, (h, None, occ, int(np.prod(mesh))))
         if not hwf_evec:
             return res.reshape(mesh + res.shape[1:])
         hwfc, hwf = res

@@ -1,0 +1,126 @@
+"""wf_array keeps its data in HBM: which copy is authoritative, and what crosses PCIe (pythtb.py:2644-2672
+for wf[i,j]; the reference's `_wfs` attribute is its live storage).  Counted with tbk_ctx_transfer_stats."""
+import numpy as np
+import pytest
+
+import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tb():
+    import pythtb_amd
+    return pythtb_amd
+
+
+def stats(tb, reset=False):
+    return tb._lib.default_context().transfer_stats(reset)
+
+
+def test_reading_points_between_berry_calls_moves_no_array(tb):
+    """examples/kane_mele.py-style use: solve, look at wf[i,j], Berry phases, look again, flux."""
+    m = hp.kane_mele(tb.tb_model, "odd")
+    w = tb.wf_array(m, [1025, 513])            # 1025*513*4*4*16 B = 134 MB: larger than the whole-mirror bound
+    w.solve_on_grid([-0.5, -0.5])
+    stats(tb, reset=True)
+    a = np.array(w[3, 4])
+    wl = w.berry_phase([0, 1], 0, contin=False, berry_evals=True)
+    b = w[3, 4]
+    assert np.array_equal(a, b) and a.shape == (4, 2, 2)
+    with pytest.raises(ValueError):
+        b[0, 0, 0] = 1.0                       # views are read-only: writes go through wf[i,j] = value
+    fl = w.berry_flux([0, 1])
+    c = w[-1, -1]
+    assert np.max(np.abs(c - w[0, 0] * np.exp(-2j * np.pi * (m._orb[:, 0] + m._orb[:, 1]))[None, :, None])) < 1e-14
+    st = stats(tb)
+    assert st["h2d_calls"] == 0 and st["h2d_bytes"] == 0
+    assert st["d2h_bytes"] <= 5 * 4 * 4 * 16   # five single points
+    assert wl.shape == (513, 2) and np.isfinite(fl)
+    # a small array is mirrored whole on the first read, and still never re-uploaded
+    s = tb.wf_array(hp.haldane(tb.tb_model, 0.2), [31, 31])
+    s.solve_on_grid([0.0, 0.0])
+    stats(tb, reset=True)
+    p1 = s.berry_phase([0], 1)
+    x = s[5, 6]
+    p2 = s.berry_phase([0], 1)
+    st = stats(tb)
+    assert st["h2d_calls"] == 0 and st["d2h_calls"] == 1
+    assert np.array_equal(p1, p2) and x.shape == (2, 2)
+
+
+def test_setitem_on_resident_array_uploads_one_point(tb):
+    from oracle import tb_oracle as orc
+    m = hp.haldane(tb.tb_model, 0.3)
+    mesh, start = [40, 33], [0.1, 0.2]
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid(start)
+    host = np.array(w.to_host())
+    stats(tb, reset=True)
+    v = host[7, 9] * np.exp(0.3j)             # a gauge change at one point leaves plaquette sums unchanged ...
+    w[7, 9] = v
+    rot = np.array([[np.cos(0.4), np.sin(0.4)], [-np.sin(0.4), np.cos(0.4)]]) @ host[11, 3]
+    w[11, 3] = rot                             # ... a band rotation does not
+    st = stats(tb)
+    assert st["h2d_calls"] == 2 and st["h2d_bytes"] == 2 * 2 * 2 * 16
+    host[7, 9] = v
+    host[11, 3] = rot
+    ref = orc.berry_flux(host, 2, [0], individual_phases=True, vectorised=True)
+    got = w.berry_flux([0], individual_phases=True)
+    assert np.max(np.abs((got - ref + np.pi) % (2 * np.pi) - np.pi)) < 1e-10
+    assert np.array_equal(w[11, 3], rot) and np.array_equal(w.to_host(), host)
+    assert stats(tb)["h2d_calls"] == 2
+
+
+def test_exported_mirror_stays_live(tb):
+    """A script may keep the array it got from `_wfs` and write to it at any time: every later
+    device call must see those writes, and device-side writes must show up in the held array."""
+    from oracle import tb_oracle as orc
+    m = hp.haldane(tb.tb_model, 0.3)
+    mesh, start = [24, 19], [0.0, 0.0]
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid(start)
+    held = w._wfs                               # exported: host is authoritative from here on
+    f0 = w.berry_flux([0], individual_phases=True)
+    held[5, 5] = held[5, 5][::-1].copy()        # swap the bands at one point, through the held array
+    f1 = w.berry_flux([0], individual_phases=True)
+    ref = orc.berry_flux(np.array(held), 2, [0], individual_phases=True, vectorised=True)
+    assert np.max(np.abs((f1 - ref + np.pi) % (2 * np.pi) - np.pi)) < 1e-10
+    assert np.max(np.abs(f1 - f0)) > 1e-3
+    w.solve_on_grid(start)                      # device-side write: the held array is refreshed in place
+    assert held is w._wfs
+    fresh = tb.wf_array(m, mesh)
+    fresh.solve_on_grid(start)
+    assert np.array_equal(held, fresh.to_host())
+    w.impose_loop(0)
+    assert np.array_equal(held[-1], held[0])
+    w.release_host()                            # promise: no more writes through `held`
+    stats(tb, reset=True)
+    w.berry_flux([0])
+    w.berry_phase([0], 1)
+    assert stats(tb)["h2d_calls"] == 0
+
+
+def test_position_hwf_mesh_reads_the_resident_array(tb):
+    """cubic slab HWF loop (examples/cubic_slab_hwf.py) without the array leaving the device."""
+    m3 = hp.quiet(tb.tb_model, 3, 3, np.identity(3), [[0, 0, 0]])
+    for R in ([1, 0, 0], [0, 1, 0], [0, 0, 1]):
+        m3.set_hop(-1.0, 0, 0, R)
+    slab = m3.cut_piece(9, 2, glue_edgs=False)
+    w = tb.wf_array(slab, [120, 90])
+    w.solve_on_grid([0.0, 0.0])
+    stats(tb, reset=True)
+    hwfc = w.position_hwf_mesh(range(4), 2)
+    one = w.position_hwf([7, 8], range(4), 2)
+    ex = w.position_expectation([7, 8], [0, 2], 2)
+    st = stats(tb)
+    assert st["h2d_calls"] == 0 and st["d2h_calls"] == 0
+    assert hwfc.shape == (120, 90, 4) and np.array_equal(hwfc[7, 8], one)
+    host = w.to_host()
+    ref = slab.position_hwf(host[7, 8][:4], 2)
+    assert np.max(np.abs(ref - one)) < 1e-12
+    assert np.max(np.abs(ex - slab.position_expectation(host[7, 8][[0, 2]], 2))) < 1e-13
+    hw2, vec2 = w.position_hwf_mesh(range(4), 2, hwf_evec=True, basis="orbital")
+    r2, v2 = slab.position_hwf(host.reshape(-1, 9, 9)[:, :4], 2, hwf_evec=True, basis="orbital")
+    assert np.max(np.abs(hw2.reshape(-1, 4) - r2)) < 1e-12
+    assert np.max(np.abs(np.abs(vec2.reshape(-1, 4, 9)) - np.abs(v2))) < 1e-9
