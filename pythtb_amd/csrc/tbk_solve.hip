@@ -1104,6 +1104,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 #include "tbk_solve_big.inl"   // n > 256: one kernel launch per Jacobi round, whole chip per batch
 #include "tbk_solve_reg.inl"   // n = 5..8: register-resident cyclic Jacobi, 1/2/4 lanes per matrix
 #include "tbk_solve_row16.inl" // n = 15, 16 on lists: one DPP row of 16 lanes per matrix, rows of A in registers
+#include "tbk_solve_ql16.inl"  // n = 9..16: Householder + implicit QL in registers, one DPP row of 16 lanes per matrix
 #include "tbk_solve_blk.inl"   // batches of wide matrices: block Jacobi, 16x16 subproblems through k_solve_row16
 
 // ---------------------------------------------------------------------------
@@ -1168,6 +1169,15 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // 6.8-7.1 ms eigenvalues against 13.1 (mesh order) / 19.0 (random order) ms, 12.1 against 12.5 / 17.5 ms
     // with vectors; at n = 12 and below the LDS kernel wins).  Mesh solves keep the warm-started LDS kernel
     // (a fine mesh needs ~3 sweeps there).  Needs the R-grouped table unless the matrices are supplied.
+    static const bool use_ql16 = [] {   // TBK_QL16=0: the Jacobi kernels instead (A/B runs)
+        const char* e = getenv("TBK_QL16");
+        return !(e && atoi(e) == 0);
+    }();
+    // n = 9..16: the direct solver (Householder + implicit QL in registers, tbk_solve_ql16.inl) on meshes, k lists and
+    // supplied matrices alike; it needs the R-grouped table unless the matrices are supplied, and a batch that fills
+    // the chip with 16-lane rows (a handful of matrices is latency-bound: the workgroup-per-matrix Jacobi below)
+    if (n >= 9 && n <= 16 && use_ql16 && (MODE == 2 || mv.nR > 0) && nk_eff > (int64_t)ctx->cus * 8)
+        return launch_ql16<MODE, VEC>(ctx, mv, nk, L, G);
     if constexpr (MODE != 1) {
         // (eigenvalues only: already from n = 13, where the LDS kernel takes ~9-10 ms for the same 262144 k)
         if ((n >= 15 || (!VEC && n >= 13)) && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0))

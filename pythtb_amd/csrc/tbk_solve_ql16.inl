@@ -1,0 +1,373 @@
+// tbk_solve_ql16.inl -- included by tbk_solve.hip (after tbk_solve_row16.inl, whose DPP helpers it uses).
+//
+// n = 9..16 states per k: a DIRECT Hermitian eigen-solver in registers -- Householder
+// tridiagonalisation followed by implicit-shift QL with accumulated eigenvectors (what LAPACK's
+// zhetrd + zsteqr do for the reference's numpy.linalg.eigh, pythtb.py:939-947) -- one DPP row of 16
+// lanes per matrix, four matrices per wavefront, no LDS storage, no barriers.
+//
+// Why not Jacobi here: a cyclic Jacobi sweep of a 16 x 16 matrix is 120 rotations of O(n) work on A and
+// V each, and 4-7 sweeps are needed (~1e6 flops per matrix); tridiagonalisation is (16/3) n^3 flops once
+// and QL converges in ~1.7 shifts per eigenvalue with O(n) rotations each (~1e5 flops per matrix).  The
+// LDS wavefront-per-matrix Jacobi kernel issues 18.5 k VALU + 2.7 k LDS wave-instructions per matrix
+// (profiles/r02a); this kernel ~7 k VALU per matrix and nothing else.
+//
+// Layout.  Lane x of a row holds ROW x of A (a[16]) and ROW x of the accumulated transformation Z
+// (z[b] = component x of eigenvector b at the end).  The tridiagonal (d, e) is DISTRIBUTED: lane j keeps
+// d_j and e_j (the coupling between j and j+1; e_15 = 0).
+//
+//  1. Householder, step K = 0..13 (unrolled: register indices are static).  The column below the diagonal
+//     is one register per lane (a[K] of lanes x > K), so forming u needs one row reduction; p = beta A u and
+//     w = beta Z u are local dot products of the lane's rows with u, whose elements arrive one at a time by
+//     DPP row broadcast; the rank-2 update A -= u q^+ + q u^+ and Z -= w u^+ are local too.  H_K = I - beta
+//     u u^+ is Hermitian and maps the column onto -phase * norm * e_{K+1}; the complex subdiagonal is made
+//     real by a diagonal unitary D folded into Z column by column (Z = H_0 ... H_13 D).
+//  2. Implicit QL (EISPACK tql2 / LAPACK zsteqr recurrences).  All four matrices of a wavefront run the
+//     same instruction stream: every iteration is one shift and one FULL-range sweep i = 14 .. 0 in which a
+//     position takes part only if it lies in that matrix's active block [l, m) (EXEC-masked).  The
+//     rotation recurrence is scalar work replicated over the 16 lanes of a row; each lane applies the
+//     rotation to its own row of Z (columns i, i+1: static registers).  d_i, d_{i+1}, e_i are read by row
+//     broadcast -- a sweep only ever reads values from before the sweep -- and the new d_{i+1}, e_{i+1} are
+//     kept by their owner lane.  Negligible couplings are found by one compare + ballot per iteration.
+//
+// Every point is solved on its own (no warm start), so periodic images, halo rows and shard windows are
+// bit-identical by construction.  Matrices smaller than 16 are padded with decoupled zero rows (they
+// never mix and are ranked last).
+
+template <int N>
+__device__ __forceinline__ double row_ror_d(const double v) {   // value of lane (x + N) mod 16 of the same row
+    const I2 i = __builtin_bit_cast(I2, v);
+    const I2 o{__builtin_amdgcn_update_dpp(i.lo, i.lo, 0x120 + N, 0xf, 0xf, false),
+               __builtin_amdgcn_update_dpp(i.hi, i.hi, 0x120 + N, 0xf, 0xf, false)};
+    return __builtin_bit_cast(double, o);
+}
+// sum over the 16 lanes of a row, the same bits in every lane (each step adds a value to its mirror image)
+__device__ __forceinline__ double row_allsum(double v) {
+    v += row_ror_d<8>(v);
+    v += row_ror_d<4>(v);
+    v += row_ror_d<2>(v);
+    v += row_ror_d<1>(v);
+    return v;
+}
+template <int SRC>
+__device__ __forceinline__ cd rowbcast_c(const cd v) { return cd{rowbcast_d<SRC>(v.x), rowbcast_d<SRC>(v.y)}; }
+
+// 1 / sqrt(t) to full double precision from the hardware estimate (relative error 5e-8 measured,
+// profiles/microbench/rsq_precision.hip) by one cubically convergent step:
+// with e = 1 - t y^2,  1/sqrt(t) = y (1 - e)^(-1/2) = y (1 + e/2 + 3 e^2/8 + O(e^3)),  e^3 ~ 1e-21
+__device__ __forceinline__ double rsqrt_full(const double t) {
+    const double y = __builtin_amdgcn_rsq(t);
+    const double e = fma(-t * y, y, 1.0);
+    const double ye = y * e;
+    return fma(ye, fma(e, 0.375, 0.5), y);
+}
+
+// ---- Householder step K: pass 1 (p = A u, w = Z u over the columns c > K) and pass 2 (rank-2 updates)
+template <int K, int CIDX, bool VEC>
+__device__ __forceinline__ void ql16_pass1(const cd (&a)[16], const cd (&z)[16], const cd u, cd& p, cd& w) {
+    const cd uc = rowbcast_c<CIDX>(u);
+    cfma(p, a[CIDX], uc);
+    if (VEC) cfma(w, z[CIDX], uc);
+    if constexpr (CIDX + 1 < 16) ql16_pass1<K, CIDX + 1, VEC>(a, z, u, p, w);
+}
+template <int K, int CIDX, bool VEC>
+__device__ __forceinline__ void ql16_pass2(cd (&a)[16], cd (&z)[16], const cd u, const cd q, const cd w) {
+    const cd uc = rowbcast_c<CIDX>(u), qc = rowbcast_c<CIDX>(q);
+    // A[x][c] -= u_x conj(q_c) + q_x conj(u_c)
+    a[CIDX].x -= (u.x * qc.x + u.y * qc.y) + (q.x * uc.x + q.y * uc.y);
+    a[CIDX].y -= (u.y * qc.x - u.x * qc.y) + (q.y * uc.x - q.x * uc.y);
+    if (VEC) {   // Z[x][c] -= w_x conj(u_c)
+        z[CIDX].x -= w.x * uc.x + w.y * uc.y;
+        z[CIDX].y -= w.y * uc.x - w.x * uc.y;
+    }
+    if constexpr (CIDX + 1 < 16) ql16_pass2<K, CIDX + 1, VEC>(a, z, u, q, w);
+}
+
+// returns the complex subdiagonal element t_K = T[K+1][K] (the same in every lane of the row)
+template <int K, bool VEC>
+__device__ __forceinline__ cd ql16_house(cd (&a)[16], cd (&z)[16], const int x) {
+    const bool below = x > K;
+    const cd xk = below ? a[K] : cd{0.0, 0.0};
+    const double sigma = row_allsum(cabs2(xk));          // |column below the diagonal|^2
+    const cd alpha = rowbcast_c<K + 1>(a[K]);            // A[K+1][K]
+    const double absa2 = cabs2(alpha);
+    cd tK{0.0, 0.0};
+    // nothing below the subdiagonal and a real non-negative... any subdiagonal: a reflection is only needed to
+    // annihilate rows > K+1; with sigma == |alpha|^2 the column is already in place
+    if (sigma > absa2) {                                 // row-uniform
+        const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
+        double absa = 0.0;
+        cd ph{1.0, 0.0};
+        if (absa2 > 0.0) {
+            const double inv_a = rsqrt_full(absa2);
+            absa = absa2 * inv_a;
+            ph = cd{alpha.x * inv_a, alpha.y * inv_a};
+        }
+        // u = column + phase * norm * e_{K+1};  H u-reflection maps the column to -phase * norm * e_{K+1}
+        const cd u = x == K + 1 ? cd{ph.x * (absa + nrm), ph.y * (absa + nrm)} : xk;
+        const double beta = 1.0 / (nrm * (nrm + absa));  // 2 / (u^+ u)
+        tK = cd{-ph.x * nrm, -ph.y * nrm};
+        cd p{0.0, 0.0}, w{0.0, 0.0};
+        ql16_pass1<K, K + 1, VEC>(a, z, u, p, w);
+        p = cd{p.x * beta, p.y * beta};
+        w = cd{w.x * beta, w.y * beta};
+        // kappa = beta/2 u^+ p  (real: u^+ A u of a Hermitian A; u_x = 0 for x <= K masks those lanes' p)
+        const double kappa = 0.5 * beta * row_allsum(u.x * p.x + u.y * p.y);
+        const cd q = below ? cd{p.x - kappa * u.x, p.y - kappa * u.y} : cd{0.0, 0.0};
+        ql16_pass2<K, K + 1, VEC>(a, z, u, q, w);
+    } else {
+        tK = alpha;
+    }
+    return tK;
+}
+
+struct Ql16State {
+    double s, c, p, g;   // rotation recurrence (replicated over the lanes of a row)
+    bool alive;          // false once this matrix's sweep hit an exact-zero rotation (underflow guard)
+};
+
+// position I of a sweep: rotation in the (I, I+1) plane
+// (di1 = d_{I+1} as it was before the sweep: the caller's own d_I broadcast, taken before position I+1 could change it --
+// it cannot: position I+1 writes lane I+2)
+template <int I, bool VEC>
+__device__ __forceinline__ void ql16_pos(Ql16State& S, cd (&z)[16], double& dd, double& ee, const int x, const int l, const int m,
+                                         const double di1) {
+    const double di = rowbcast_d<I>(dd), ei = rowbcast_d<I>(ee);   // pre-sweep values
+    if (S.alive && I >= l && I < m) {
+        const double f = S.s * ei, b = S.c * ei;
+        const double t = f * f + S.g * S.g;
+        if (t > 0.0) {
+            const double inv = rsqrt_full(t), r = t * inv;
+            S.s = f * inv;
+            S.c = S.g * inv;
+            double g = di1 - S.p;
+            const double r2 = (di - g) * S.s + 2.0 * S.c * b;
+            S.p = S.s * r2;
+            if (x == I + 1) {
+                ee = r;
+                dd = g + S.p;
+            }
+            S.g = S.c * r2 - b;
+            if (VEC) {
+                const cd zi = z[I], zj = z[I + 1];
+                z[I + 1] = cd{S.s * zi.x + S.c * zj.x, S.s * zi.y + S.c * zj.y};
+                z[I] = cd{S.c * zi.x - S.s * zj.x, S.c * zi.y - S.s * zj.y};
+            }
+        } else {   // r == 0 (underflow): tql2's recovery -- d[i+1] -= p, e[m] = 0, start the block over
+            if (x == I + 1) dd -= S.p;
+            S.alive = false;
+        }
+    }
+    if constexpr (I > 0) ql16_pos<I - 1, VEC>(S, z, dd, ee, x, l, m, di);
+}
+
+template <int J>
+__device__ __forceinline__ void ql16_bcast_ev(const double dd, double (&ev)[16]) {
+    ev[J] = rowbcast_d<J>(dd);
+    if constexpr (J + 1 < 16) ql16_bcast_ev<J + 1>(dd, ev);
+}
+
+#define TBK_QL_MAX_ITER 480   // 30 shifts per eigenvalue, LAPACK's limit
+
+// MODE 0: k list, 1: regular mesh into a wf_array (+ min gaps), 2: supplied matrices
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G,
+                                                     int* noconv_flag) {
+    const int lane = threadIdx.x & 63;
+    const int x = lane & 15;
+    const int rowbase4 = (lane & 48) * 4;
+    const int64_t mat = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = mat < nk;
+    const int64_t id = live ? mat : nk - 1;   // idle tail rows shadow the last point
+    const int n = mv.nsta;
+    const bool real_row = x < n;
+    double kk[4] = {0.0, 0.0, 0.0, 0.0};
+    bool wrap[4] = {false, false, false, false};
+    cd a[16], z[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        a[c] = cd{0.0, 0.0};
+        z[c] = cd{c == x ? 1.0 : 0.0, 0.0};
+    }
+    if constexpr (MODE == 2) {
+        const cd* h = Lst.ham + id * (int64_t)n * n;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (real_row && c < n) {   // upper triangle, mirrored (the reference's eigh reads one triangle)
+                cd t = c >= x ? h[x * n + c] : cconj(h[c * n + x]);
+                if (c == x) t.y = 0.0;
+                a[c] = t;
+            }
+        }
+    } else {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d < mv.dim_k) kk[d] = Lst.k[id * mv.dim_k + d];
+        } else {
+            grid_point(G, id, kk, wrap);
+        }
+        cd zk[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) zk[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
+        // S[x][c] = sum_R U_R[slot(min,max)] e^{2 pi i k.R}  (conjugated below the diagonal)
+        int sidx[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int lo = x < c ? x : c, hi = x < c ? c : x;
+            sidx[c] = real_row && c < n ? lo * n - lo * (lo - 1) / 2 + (hi - lo) : -1;
+        }
+        for (int base = 0; base < mv.nR; base += 16) {
+            const int mine = base + x;
+            const cd ph = mine < mv.nR ? phase_of_R(zk, mv.rvec[mine]) : cd{0.0, 0.0};
+            cd phs[16];
+            row16_bcast_phase<0>(ph, phs);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (base + j < mv.nR) {
+                    const cd* u = mv.rblock + (size_t)(base + j) * mv.nslot;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (sidx[c] >= 0) cfma(a[c], u[sidx[c]], phs[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < x) a[c].y = -a[c].y;
+            if (c == x) a[c].y = 0.0;
+        }
+    }
+
+    // ---- 1. tridiagonalisation; lane j ends up with d_j, e_j = |T[j+1][j]| and Z = H_0 ... H_13 D
+    double ee = 0.0;
+    {
+        cd delta{1.0, 0.0};   // D_{K+1} = D_K t_K / |t_K|
+        auto step_phase = [&](const cd t, const int col) {
+            const double t2 = cabs2(t);
+            double mag = 0.0;
+            if (t2 > 0.0) {
+                const double inv = rsqrt_full(t2);
+                mag = t2 * inv;
+                delta = cmul(delta, cd{t.x * inv, t.y * inv});
+            }
+            if (x == col - 1) ee = mag;
+            return mag;
+        };
+#define TBK_QL_HOUSE(KK)                                              \
+    {                                                                 \
+        const cd t = ql16_house<KK, VEC>(a, z, x);                    \
+        step_phase(t, KK + 1);                                        \
+        if (VEC) z[KK + 1] = cmul(z[KK + 1], delta);                  \
+    }
+        TBK_QL_HOUSE(0) TBK_QL_HOUSE(1) TBK_QL_HOUSE(2) TBK_QL_HOUSE(3) TBK_QL_HOUSE(4) TBK_QL_HOUSE(5) TBK_QL_HOUSE(6)
+        TBK_QL_HOUSE(7) TBK_QL_HOUSE(8) TBK_QL_HOUSE(9) TBK_QL_HOUSE(10) TBK_QL_HOUSE(11) TBK_QL_HOUSE(12) TBK_QL_HOUSE(13)
+#undef TBK_QL_HOUSE
+        const cd t14 = rowbcast_c<15>(a[14]);            // T[15][14]: never reflected
+        step_phase(t14, 15);
+        if (VEC) z[15] = cmul(z[15], delta);
+    }
+    double dd = sel16<0>(a, x, cd{0.0, 0.0}).x;          // d_x = A[x][x]
+
+    // ---- 2. implicit QL; l = first row of the block being worked on, m = its last row
+    int l = 0;
+    bool done = false;
+    for (int iter = 0; iter <= TBK_QL_MAX_ITER; ++iter) {
+        // negligible couplings: |e_j| <= eps (|d_j| + |d_j+1|)   (e_15 = 0: always)
+        const I2 di = __builtin_bit_cast(I2, dd);
+        const I2 dn{__builtin_amdgcn_update_dpp(0, di.lo, 0x101, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, di.hi, 0x101, 0xf, 0xf, true)};
+        const double dnext = __builtin_bit_cast(double, dn);                       // row_shl:1 = d_{x+1} (0 for x = 15)
+        const bool negl = fabs(ee) <= 2.220446049250313e-16 * (fabs(dd) + fabs(dnext));
+        const unsigned long long bal = __ballot(negl);
+        const unsigned mask16 = (unsigned)(bal >> (lane & 48)) & 0xffffu;
+        int m = 15;
+        if (!done) {
+            const unsigned open = ~mask16 & (0xffffu << l) & 0xffffu;
+            if (open == 0) {
+                done = true;
+            } else {
+                l = __builtin_ctz(open);
+                m = __builtin_ctz(mask16 & (0xffffu << l));
+            }
+        }
+        if (__all(done)) break;
+        if (iter == TBK_QL_MAX_ITER) {
+            if (!done && x == 0) atomicExch(noconv_flag, 1);
+            break;
+        }
+        Ql16State S{1.0, 1.0, 0.0, 0.0, !done};
+        if (!done) {
+            // Wilkinson-type shift from the leading 2 x 2 of the block (its accuracy only affects the
+            // speed of convergence, so hardware reciprocal / square root estimates are good enough)
+            const double dl = bperm_d(rowbase4 + 4 * l, dd), dl1 = bperm_d(rowbase4 + 4 * l + 4, dd);
+            const double el = bperm_d(rowbase4 + 4 * l, ee), dm = bperm_d(rowbase4 + 4 * m, dd);
+            double g = (dl1 - dl) * (0.5 * __builtin_amdgcn_rcp(el));
+            const double r = __builtin_amdgcn_sqrt(fma(g, g, 1.0));
+            S.g = dm - dl + el * __builtin_amdgcn_rcp(g + copysign(r, g));
+        }
+        ql16_pos<14, VEC>(S, z, dd, ee, x, l, m, rowbcast_d<15>(dd));
+        if (!done) {
+            if (S.alive && x == l) {
+                dd -= S.p;
+                ee = S.g;
+            }
+            if (x == m) ee = 0.0;
+        }
+    }
+
+    // ---- eigenvalues in stable ascending order (padding rows rank last)
+    double ev[16];
+    ql16_bcast_ev<0>(dd, ev);
+    const double mine = dd;
+    int rk = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool jr = j < n;
+        const bool before = real_row ? (jr && (ev[j] < mine || (ev[j] == mine && j < x))) : (jr || j < x);
+        rk += before ? 1 : 0;
+    }
+    const double sorted_here = perm_push_d(rowbase4 + 4 * rk, mine);   // lane r now holds the r-th eigenvalue
+    if constexpr (MODE == 1) {
+        const I2 sh = __builtin_bit_cast(I2, sorted_here);
+        const I2 nx{__builtin_amdgcn_update_dpp(0, sh.lo, 0x101, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, sh.hi, 0x101, 0xf, 0xf, false)};
+        double gap = live && x + 1 < n ? __builtin_bit_cast(double, nx) - sorted_here : INFINITY;   // row_shl:1 = next lane's value
+        gap = fmin(gap, __shfl_xor(gap, 16));
+        gap = fmin(gap, __shfl_xor(gap, 32));
+        if (lane < 16 && x + 1 < n) {
+            unsigned long long* slot = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * n + x;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(fmax(gap, 0.0));
+            if (bits < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, bits);
+        }
+    } else {
+        if (live && real_row) Lst.eval[(int64_t)x * nk + id] = sorted_here;
+    }
+    if (VEC) {
+        int rks[16];
+        row16_bcast_rank<0>(rk, rks);
+        if (live && real_row) {
+            cd f{1.0, 0.0};
+            if constexpr (MODE != 2) f = cconj(expi2pi(kdot(kk, mv.orb[x])));
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (wrap[d]) f = cmul(f, G.pbc[d * n + x]);
+            }
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                if (b < n) {
+                    const cd val = cmul(z[b], f);
+                    if constexpr (MODE == 1) wf_at(G.wv, rks[b], id)[x] = val;
+                    else Lst.evec[((int64_t)rks[b] * nk + id) * n + x] = val;
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, bool VEC>
+static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G) {
+    TBK_REQUIRE(nk * 16 < (int64_t)0x7fffffff * 256, TBK_EUNSUPPORTED, "too many k-points for one launch");
+    const unsigned blocks = (unsigned)((nk * 16 + 255) / 256);
+    hipLaunchKernelGGL((k_solve_ql16<MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}

@@ -35,12 +35,13 @@ __device__ __forceinline__ double perm_push_d(const int addr, const double v) { 
 template <int SRC>
 __device__ __forceinline__ double rowbcast_d(const double v) {   // value of lane SRC of each 16-lane row
     const I2 i = __builtin_bit_cast(I2, v);
-    const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x150 + SRC, 0xf, 0xf, false),
-               __builtin_amdgcn_update_dpp(0, i.hi, 0x150 + SRC, 0xf, 0xf, false)};
+    // (old = the source itself: every lane has a valid source, and a constant would cost a v_mov to materialise)
+    const I2 o{__builtin_amdgcn_update_dpp(i.lo, i.lo, 0x150 + SRC, 0xf, 0xf, false),
+               __builtin_amdgcn_update_dpp(i.hi, i.hi, 0x150 + SRC, 0xf, 0xf, false)};
     return __builtin_bit_cast(double, o);
 }
 template <int SRC>
-__device__ __forceinline__ int rowbcast_i(const int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xf, 0xf, false); }
+__device__ __forceinline__ int rowbcast_i(const int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + SRC, 0xf, 0xf, false); }
 
 // round R of the 15-round tournament on 16 players: pair l = 0 is (15, R), pair l = 1..7 is
 // ((R+l) mod 15, (R-l) mod 15)

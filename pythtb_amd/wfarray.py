@@ -266,7 +266,16 @@ class wf_array(object):
     def solve_on_one_point(self, kpt, mesh_indices):
         """Solve at one k and store at mesh_indices (pythtb.py:2534-2566)."""
         (eval, evec) = self._model.solve_one(kpt, eig_vectors=True)
-        self[mesh_indices if _is_int(mesh_indices) else tuple(mesh_indices)] = evec
+        if _is_int(mesh_indices):
+            if self._dim_arr > 1:          # the reference broadcasts over the remaining axes (pythtb.py:2563-2564)
+                self._wfs[(mesh_indices,)] = evec
+                return
+            key = mesh_indices
+        else:
+            key = tuple(mesh_indices)
+            if self._dim_arr == 1 and len(key) == 1:
+                key = key[0]
+        self[key] = evec
 
     def choose_states(self, subset):
         """New wf_array holding a subset of the states (pythtb.py:2568-2608)."""
@@ -381,6 +390,10 @@ class wf_array(object):
         """(evec, wfs) arguments for the model's position_* driver: the states stay on the device when the
         device copy is current (only the small results come back), else they are taken from the host mirror."""
         occ = self._occ_list(occ)
+        if not _is_int(key):                   # the reference indexes _wfs[tuple(key)] (pythtb.py:2808)
+            key = tuple(key)
+            if self._dim_arr == 1 and len(key) == 1:
+                key = key[0]
         self._check_key(key)
         if self._dev_valid and self._dev is not None and not (self._host_exported and self._host_valid):
             if np.any(occ < 0) or np.any(occ >= self._nsta_arr):
