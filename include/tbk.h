@@ -43,6 +43,10 @@ typedef struct tbk_wfs tbk_wfs;     /* device-resident wf_array._wfs         */
 const char* tbk_last_error(void);
 int tbk_version(void);
 int tbk_device_count(int* count);
+/* TBK_* environment knobs are parsed once, on first use; re-read them after changing one */
+int tbk_knobs_reload(void);
+/* 1 if this library was built with -DTBK_DIAG (ablation branches compiled into the kernels), else 0 */
+int tbk_build_has_diagnostics(void);
 
 /* ---- context -------------------------------------------------------- */
 int tbk_ctx_create(int device, tbk_ctx** out);
@@ -84,6 +88,14 @@ int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, const double*
                      const int32_t* hop_j, const int32_t* hop_R, const double* hop_amp,
                      tbk_model** out);
 int tbk_model_free(tbk_model* model);
+/* Host-only introspection of what tbk_model_upload builds (no device needed): the merged term list of
+ * S_ab(k) = sum_t amp_t exp(2 pi i k.R_t), a <= b, slot = a*n - a(a-1)/2 + (b-a), in the order the kernels
+ * read it.  term_cap = capacity of term_slot[], term_R[][4], term_amp[] (c128); *nterm = number of terms
+ * (call with term_cap = 0 to size).  info[4] = {pmax, nR, nnz, nslot}.  For tests and sanitizer builds.   */
+int tbk_model_flatten_host(int dim_k, int norb, int nspin, const double* orb, const double* onsite,
+                           int64_t nhop, const int32_t* hop_i, const int32_t* hop_j, const int32_t* hop_R,
+                           const double* hop_amp, int64_t term_cap, int64_t* nterm, int32_t* term_slot,
+                           int32_t* term_R, double* term_amp, int32_t* info);
 int tbk_model_info(tbk_model* model, int* dim_k, int* nsta, int64_t* nterm);
 
 /* ---- H(k) and eigen-solve ------------------------------------------- */

@@ -26,6 +26,7 @@ for width, nk in cases:
     line = "n %4d x %4d k:" % (n, nk)
     for knob in ("0", "1"):
         os.environ["TBK_BLOCKED"] = knob
+        tb._lib.lib.tbk_knobs_reload()
         for vec in (False, True):
             rib.solve_all(k[:2], eig_vectors=vec)
             t0 = time.perf_counter()
@@ -42,3 +43,4 @@ for width, nk in cases:
             line += "  %s%s %8.1f ms (err %.0e%s)" % ("blocked" if knob == "1" else "default", " +vec" if vec else "     ", t * 1e3, err, ", res %.0e" % res if vec else "")
     print(line)
 os.environ.pop("TBK_BLOCKED", None)
+tb._lib.lib.tbk_knobs_reload()

@@ -35,6 +35,7 @@ for nc in (3, 4, 6, 8, 9, 12, 16):
             os.environ.pop("TBK_DET_BIG_FROM", None)
             if knob:
                 os.environ["TBK_DET_BIG_FROM"] = knob
+            tb._lib.lib.tbk_knobs_reload()
             tf, f = timeit(lambda: w.berry_flux(occ, individual_phases=True))
             tp, ph = timeit(lambda: w.berry_phase(occ, 0, contin=False))
             res.append((tf, tp, f, ph))

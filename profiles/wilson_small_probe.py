@@ -29,8 +29,10 @@ for nc in (2, 3, 4, 6, 8, 12, 16):
         w.solve_on_grid([0.0, 0.0])
         occ = list(range(nc))
         os.environ.pop("TBK_WILSON_BIG_FROM", None)
+        tb._lib.lib.tbk_knobs_reload()
         ta, ra = timeit(w, occ, 0)
         os.environ["TBK_WILSON_BIG_FROM"] = "2"
+        tb._lib.lib.tbk_knobs_reload()
         tb_, rb = timeit(w, occ, 0)
         d = np.abs(np.sort(ra, -1) - np.sort(rb, -1))
         print("nocc %2d  strings %4d x links %4d   per-thread %8.2f ms   workgroup %8.2f ms   diff %.1e" % (nc, mesh[1], mesh[0] - 1, ta * 1e3, tb_ * 1e3, np.minimum(d, 2 * np.pi - d).max()))

@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtbk.so")
+# TBK_LIBRARY selects another build of the same sources (libtbk_diag.so: ablation branches; libtbk_asan.so:
+# host code under AddressSanitizer/UBSan), for profiles/ and the sanitizer run only
+LIB_PATH = os.environ.get("TBK_LIBRARY") or os.path.join(_HERE, "libtbk.so")
 
 MAX_DIM = 4
 MAX_NSTA = 2048
@@ -35,6 +37,9 @@ SIGNATURES = {
     "tbk_last_error": (C.c_char_p, []),
     "tbk_version": (_i, []),
     "tbk_device_count": (_i, [C.POINTER(C.c_int)]),
+    "tbk_knobs_reload": (_i, []),
+    "tbk_build_has_diagnostics": (_i, []),
+    "tbk_model_flatten_host": (_i, [_i, _i, _i, _dp, _dp, _i64, _ip, _ip, _ip, _dp, _i64, C.POINTER(C.c_int64), _ip, _ip, _dp, _ip]),
     "tbk_ctx_create": (_i, [_i, _pp]),
     "tbk_ctx_destroy": (_i, [_p]),
     "tbk_ctx_sync": (_i, [_p]),
@@ -116,6 +121,30 @@ def iptr(a):
         return None
     assert a.flags["C_CONTIGUOUS"] and a.dtype == np.int32
     return a.ctypes.data_as(_ip)
+
+
+class knob(object):
+    """Context manager for A/B runs and tests: set one TBK_* environment knob and make the library re-read it."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = os.environ.get(self.name)
+        if self.value is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = str(self.value)
+        lib.tbk_knobs_reload()
+        return self
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.old
+        lib.tbk_knobs_reload()
+        return False
 
 
 class Context(object):

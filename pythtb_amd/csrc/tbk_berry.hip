@@ -410,7 +410,9 @@ struct FluxArgs {
     int fused;         // row kernel: last-arriving block finishes the sum (else k_flux_reduce does)
     unsigned* counters;  // [nslices][16] arrival tickets (8 shards + top), zero between launches
     double* totals;    // [nslices]
-    int ablate;        // diagnostics only (TBK_ABLATE_FLUX): 1 = no atan2, 2 = no prefetch loads
+#ifdef TBK_DIAG
+    int ablate;        // diagnostic build only (TBK_ABLATE_FLUX): 1 = no atan2, 2 = no prefetch loads
+#endif
 };
 
 template <int NOCC, int MAXN>
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
     double sum = 0.0;
     for (int ia = ia0; ia < ia1; ++ia) {
         // prefetch mesh row ia+2 while row ia+1 is consumed (the tile's last row re-reads itself)
-        if (ia + 1 < ia1 && A.ablate != 2) col += rstep;
+        if (ia + 1 < ia1 && TBK_ABLATE(A.ablate) != 2) col += rstep;
         load_vectors<NOCC, NCOMP>(col, A.occ, plane, pn);
         load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, pr);
         const cd dV = det_overlap<NOCC, NCOMP>(cur, nxt);
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
         const cd z = cmul(cmul(dV, dHn), cconj(cmul(dVr, dHc)));
         double pha = 0.0;
         if (has_plaq) {
-            pha = A.ablate == 1 ? -z.y : -arg_small_first(z.y, z.x);
+            pha = TBK_ABLATE(A.ablate) == 1 ? -z.y : -arg_small_first(z.y, z.x);
             if (A.swap) pha = -pha;
             if (A.plaq)
                 A.plaq[slice * per + (A.swap ? (int64_t)jb * A.na + ia : (int64_t)ia * A.nb + jb)] = pha;
@@ -728,7 +730,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
                 "Direction for Berry flux calculation out of bounds.");
     FluxArgs A{};
     int det_from = 9;      // up to 8 bands the register LU per thread wins; from 9 the workgroup-per-link LU is 4-100x faster (profiles/det_big_probe.py)
-    if (const char* e = getenv("TBK_DET_BIG_FROM")) det_from = std::max(2, atoi(e));    // tuning knob
+    if (tbk_knobs().det_big_from >= 0) det_from = std::max(2, tbk_knobs().det_big_from);
     const bool big = nocc >= det_from;        // link determinants by LU (tbk_berry_big.inl)
     int rc = big ? check_occ(w, occ, nocc) : fill_occ(w, occ, nocc, A.occ);
     if (rc) return rc;
@@ -756,15 +758,17 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         const int64_t want = (int64_t)ctx->cus * 32;
         int64_t ti = ((int64_t)A.na * A.ncolw * nslices + want - 1) / want;
         A.ti = (int)std::max<int64_t>(4, std::min<int64_t>(64, ti));
-        if (const char* tk = getenv("TBK_FLUX_TI")) A.ti = std::max(1, atoi(tk));   // tuning knob
+        if (tbk_knobs().flux_ti >= 0) A.ti = std::max(1, tbk_knobs().flux_ti);
         A.bps = ((A.na + A.ti - 1) / A.ti) * A.ncolw;
     } else {
         A.bps = (int)((per + 255) / 256);
     }
     A.nwaves = nslices * A.bps;
     A.bpb = (A.bps + 3) / 4;
-    { const char* fu = getenv("TBK_FLUX_FUSED"); A.fused = fu ? atoi(fu) : 0; }
-    { const char* ab = getenv("TBK_ABLATE_FLUX"); A.ablate = ab ? atoi(ab) : 0; }
+    A.fused = tbk_knobs().flux_fused;
+#ifdef TBK_DIAG
+    A.ablate = tbk_knobs().ablate_flux;
+#endif
     TBK_REQUIRE(nslices * A.bps < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many plaquette blocks");
     if (w->flux_nslices_cap < nslices) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1106,13 +1110,13 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     TBK_REQUIRE(dir >= 0 && dir < v.dim_arr, TBK_EINVAL, "Wrong direction for Berry phase calculation!");
     ChainArgs A{};
     int det_from = 9;      // up to 8 bands the register LU per thread wins; from 9 the workgroup-per-link LU is 4-100x faster (profiles/det_big_probe.py)
-    if (const char* e = getenv("TBK_DET_BIG_FROM")) det_from = std::max(2, atoi(e));    // tuning knob
+    if (tbk_knobs().det_big_from >= 0) det_from = std::max(2, tbk_knobs().det_big_from);
     const bool big = nocc >= det_from && !berry_evals;      // det of the string = product of link dets (LU per link)
     // Wilson-loop eigenphases: closed forms up to two bands; from three on the workgroup-level pipeline, which
     // measured 3x (3 bands) to 160x (16 bands) faster than the per-thread polar/QR kernels at every string count
     // and length tried (profiles/wilson_small_probe.py)
     int ev_from = 3;
-    if (const char* e = getenv("TBK_WILSON_BIG_FROM")) ev_from = std::max(2, atoi(e));    // tuning knob
+    if (tbk_knobs().wilson_big_from >= 0) ev_from = std::max(2, tbk_knobs().wilson_big_from);
     const bool big_ev = nocc >= ev_from && berry_evals;  // workgroup-level polar factors, product tree, Cayley + eigh
     int rc = (big || big_ev) ? check_occ(w, occ, nocc) : fill_occ(w, occ, nocc, A.occ);
     if (rc) return rc;
@@ -1155,7 +1159,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         const size_t nn = (size_t)nocc * nocc;
         const int L = A.nlinks;
         size_t batch_bytes = (size_t)1 << 30;
-        if (const char* e = getenv("TBK_WILSON_BATCH_BYTES")) batch_bytes = (size_t)std::max(1ll, atoll(e));   // test hook
+        if (tbk_knobs().wilson_batch_bytes >= 0) batch_bytes = (size_t)std::max(1ll, tbk_knobs().wilson_batch_bytes);   // test hook
         const int64_t cap = std::max<int64_t>(1, (int64_t)(batch_bytes / (2 * (size_t)L * nn * sizeof(cd))));
         const int64_t nsb = std::min<int64_t>(A.nstrings, cap);
         const unsigned nblk = (unsigned)std::min<int64_t>(nsb * L, (int64_t)ctx->cus * 4);
@@ -1191,7 +1195,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         TBK_HIP(hipMemcpyAsync(occ_dev, occ, (size_t)nocc * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         std::vector<double> out_h((size_t)nsb * nocc), hmax_h((size_t)nsb), best((size_t)nsb);
         double alphas[4] = {0.7390851332151607, 2.3, 3.9, 5.5};
-        if (const char* a0 = getenv("TBK_WILSON_ALPHA")) alphas[0] = atof(a0);   // test hook: put the pole on an eigenphase
+        if (tbk_knobs().wilson_alpha_set) alphas[0] = tbk_knobs().wilson_alpha;   // test hook: put the pole on an eigenphase
         for (int64_t s0 = 0; s0 < A.nstrings; s0 += nsb) {
             const int64_t ns = std::min<int64_t>(nsb, A.nstrings - s0);
             WilsonBigArgs W{};

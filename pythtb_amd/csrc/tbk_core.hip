@@ -19,6 +19,57 @@ void tbk_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* tbk_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ knobs
+static TbkKnobs g_knobs;
+static bool g_knobs_parsed = false;
+static void knobs_parse() {
+    TbkKnobs k;
+    auto geti = [](const char* name, int& dst) { if (const char* e = getenv(name)) dst = atoi(e); };
+    auto getl = [](const char* name, long long& dst) { if (const char* e = getenv(name)) dst = atoll(e); };
+    geti("TBK_BIG_FROM", k.big_from);
+    geti("TBK_BLOCKED", k.blocked);
+    geti("TBK_REG", k.use_reg);
+    geti("TBK_ROW16", k.use_row16);
+    geti("TBK_QL16", k.use_ql16);
+    getl("TBK_FEW_MAX", k.few_max);
+    geti("TBK_FEW_WARM", k.few_warm);
+    geti("TBK_FEW_NT", k.few_nt);
+    geti("TBK_WG_NT", k.wg_nt);
+    geti("TBK_WAVE_RUN", k.wave_run);
+    geti("TBK_GRID_SEG", k.grid_seg);
+    geti("TBK_GRID_KERNEL", k.grid_kernel);
+    geti("TBK_FLUX_TI", k.flux_ti);
+    geti("TBK_FLUX_FUSED", k.flux_fused);
+    geti("TBK_DET_BIG_FROM", k.det_big_from);
+    geti("TBK_WILSON_BIG_FROM", k.wilson_big_from);
+    getl("TBK_WILSON_BATCH_BYTES", k.wilson_batch_bytes);
+    if (const char* e = getenv("TBK_WILSON_ALPHA")) {
+        k.wilson_alpha = atof(e);
+        k.wilson_alpha_set = true;
+    }
+    getl("TBK_BIG_BATCH", k.big_batch);
+    geti("TBK_REG_LANES", k.reg_lanes);
+    geti("TBK_ABLATE_GRID", k.ablate_grid);
+    geti("TBK_ABLATE_FLUX", k.ablate_flux);
+    g_knobs = k;
+    g_knobs_parsed = true;
+}
+const TbkKnobs& tbk_knobs() {
+    if (!g_knobs_parsed) knobs_parse();
+    return g_knobs;
+}
+extern "C" int tbk_knobs_reload(void) {
+    knobs_parse();
+    return TBK_OK;
+}
+extern "C" int tbk_build_has_diagnostics(void) {
+#ifdef TBK_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int tbk_version(void) { return 100; }
 
 extern "C" int tbk_device_count(int* count) {
@@ -271,11 +322,22 @@ struct TermKey {
 inline int slot_of(int n, int a, int b) { return a * n - a * (a - 1) / 2 + (b - a); }
 }  // namespace
 
-extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, const double* orb,
-                                const double* onsite, int64_t nhop, const int32_t* hop_i,
-                                const int32_t* hop_j, const int32_t* hop_R, const double* hop_amp,
-                                tbk_model** out) {
-    TBK_REQUIRE(ctx && out, TBK_EINVAL, "tbk_model_upload: null ctx/out");
+namespace {
+// Everything tbk_model_upload derives from the reference's tables, on the host: the slot-major term list and
+// the packed blob the kernels read, with the offsets of its pieces.
+struct FlatModel {
+    int n = 0, nslot = 0, pmax = 0, nR = 0, nnz = 0;
+    int64_t nterm = 0;
+    std::vector<int32_t> slot_ptr, R4;
+    std::vector<cd> amp;
+    std::vector<unsigned char> host;
+    size_t o_orb = 0, o_amp = 0, o_R = 0, o_ptr = 0, o_ab = 0, o_cell = 0, o_rvec = 0, o_rblk = 0, o_nz = 0, total = 0;
+};
+}  // namespace
+
+static int model_flatten(int dim_k, int norb, int nspin, const double* orb, const double* onsite, int64_t nhop,
+                         const int32_t* hop_i, const int32_t* hop_j, const int32_t* hop_R, const double* hop_amp,
+                         FlatModel& F) {
     TBK_REQUIRE(dim_k >= 0 && dim_k <= TBK_MAX_DIM, TBK_EINVAL, "tbk_model_upload: dim_k=%d", dim_k);
     TBK_REQUIRE(nspin == 1 || nspin == 2, TBK_EINVAL, "tbk_model_upload: nspin=%d", nspin);
     TBK_REQUIRE(norb >= 1, TBK_EINVAL, "tbk_model_upload: norb=%d", norb);
@@ -340,9 +402,11 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     }
     // CSR over slots (std::map iterates in slot-major order)
     const int nslot = n * (n + 1) / 2;
-    std::vector<int32_t> slot_ptr(nslot + 1, 0), slot_ab(nslot);
-    std::vector<cd> amp;
-    std::vector<int32_t> R4;
+    std::vector<int32_t>& slot_ptr = F.slot_ptr;
+    slot_ptr.assign(nslot + 1, 0);
+    std::vector<int32_t> slot_ab(nslot);
+    std::vector<cd>& amp = F.amp;
+    std::vector<int32_t>& R4 = F.R4;
     for (int a = 0; a < n; ++a)
         for (int b = a; b < n; ++b) slot_ab[slot_of(n, a, b)] = a | (b << 16);
     for (auto& kv : acc) {
@@ -418,7 +482,8 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     const size_t o_rblk = al(o_rvec + std::max<size_t>(rvec.size(), 4) * sizeof(int32_t));
     const size_t o_nz = al(o_rblk + std::max<size_t>(rblock.size(), 1) * sizeof(cd));
     const size_t total = al(o_nz + std::max<size_t>(nz.size(), 4) * sizeof(int32_t));
-    std::vector<unsigned char> host(total, 0);
+    std::vector<unsigned char>& host = F.host;
+    host.assign(total, 0);
     if (nnz > 0) memcpy(host.data() + o_nz, nz.data(), nz.size() * sizeof(int32_t));
     if (nR > 0) {
         memcpy(host.data() + o_rvec, rvec.data(), rvec.size() * sizeof(int32_t));
@@ -431,6 +496,65 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     memcpy(host.data() + o_ptr, slot_ptr.data(), slot_ptr.size() * sizeof(int32_t));
     memcpy(host.data() + o_ab, slot_ab.data(), slot_ab.size() * sizeof(int32_t));
 
+    F.n = n;
+    F.nslot = nslot;
+    F.pmax = pmax;
+    F.nR = nR;
+    F.nnz = nnz;
+    F.nterm = nterm;
+    F.o_orb = o_orb; F.o_amp = o_amp; F.o_R = o_R; F.o_ptr = o_ptr; F.o_ab = o_ab; F.o_cell = o_cell;
+    F.o_rvec = o_rvec; F.o_rblk = o_rblk; F.o_nz = o_nz; F.total = total;
+    return TBK_OK;
+}
+
+// Host-only view of the flatten step (no device needed): the merged slot-major term list exactly as the
+// kernels will read it.  Lets the CPU test-suite (and a sanitizer build) check the table construction
+// against the reference's _gen_ham without a GPU.  term_cap = capacity of the three output arrays;
+// *nterm receives the number of terms (call with term_cap = 0 to size).  info[4] = {pmax, nR, nnz, nslot}.
+extern "C" int tbk_model_flatten_host(int dim_k, int norb, int nspin, const double* orb, const double* onsite, int64_t nhop,
+                                      const int32_t* hop_i, const int32_t* hop_j, const int32_t* hop_R, const double* hop_amp,
+                                      int64_t term_cap, int64_t* nterm, int32_t* term_slot, int32_t* term_R, double* term_amp,
+                                      int32_t* info) {
+    TBK_REQUIRE(nterm, TBK_EINVAL, "tbk_model_flatten_host: null nterm");
+    FlatModel F;
+    int rc = model_flatten(dim_k, norb, nspin, orb, onsite, nhop, hop_i, hop_j, hop_R, hop_amp, F);
+    if (rc) return rc;
+    *nterm = F.nterm;
+    if (info) {
+        info[0] = F.pmax;
+        info[1] = F.nR;
+        info[2] = F.nnz;
+        info[3] = F.nslot;
+    }
+    if (term_cap >= F.nterm && term_slot && term_R && term_amp) {
+        for (int s = 0; s < F.nslot; ++s)
+            for (int t = F.slot_ptr[s]; t < F.slot_ptr[s + 1]; ++t) term_slot[t] = s;
+        for (int64_t t = 0; t < F.nterm; ++t) {
+            for (int d = 0; d < 4; ++d) term_R[t * 4 + d] = F.R4[t * 4 + d];
+            term_amp[2 * t] = F.amp[t].x;
+            term_amp[2 * t + 1] = F.amp[t].y;
+        }
+    }
+    return TBK_OK;
+}
+
+static int64_t g_model_uploads = 0;
+
+extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, const double* orb,
+                                const double* onsite, int64_t nhop, const int32_t* hop_i,
+                                const int32_t* hop_j, const int32_t* hop_R, const double* hop_amp,
+                                tbk_model** out) {
+    TBK_REQUIRE(ctx && out, TBK_EINVAL, "tbk_model_upload: null ctx/out");
+    FlatModel F;
+    {
+        int rc = model_flatten(dim_k, norb, nspin, orb, onsite, nhop, hop_i, hop_j, hop_R, hop_amp, F);
+        if (rc) return rc;
+    }
+    const int n = F.n, nslot = F.nslot, pmax = F.pmax, nR = F.nR, nnz = F.nnz;
+    const int64_t nterm = F.nterm;
+    const size_t total = F.total, o_orb = F.o_orb, o_amp = F.o_amp, o_R = F.o_R, o_ptr = F.o_ptr, o_ab = F.o_ab,
+                 o_cell = F.o_cell, o_rvec = F.o_rvec, o_rblk = F.o_rblk, o_nz = F.o_nz;
+    std::vector<unsigned char>& host = F.host;
     tbk_model* m = new (std::nothrow) tbk_model();
     TBK_REQUIRE(m, TBK_ENOMEM, "tbk_model_upload: out of host memory");
     m->ctx = ctx;
@@ -440,6 +564,7 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     m->nsta = n;
     m->nslot = nslot;
     m->nterm = nterm;
+    m->upload_id = ++g_model_uploads;
     TBK_HIP(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(&m->blob, total);
     if (e != hipSuccess) {

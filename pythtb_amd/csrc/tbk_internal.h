@@ -27,6 +27,45 @@ void tbk_set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
+// ---------------------------------------------------------------- run-time knobs
+// Every TBK_* environment variable the library honours, parsed ONCE (first use) into this struct;
+// tbk_knobs_reload() re-reads the environment (tests and A/B scripts that change a knob mid-process).
+// -1 / NaN = "not set: use the measured default at the point of use".  DESIGN.md section 8a lists them.
+struct TbkKnobs {
+    int big_from = -1;          // TBK_BIG_FROM      smallest n sent to the whole-chip solver regardless of batch size
+    int blocked = -1;           // TBK_BLOCKED       1 forces the block-Jacobi solver, 0 forbids it
+    int use_reg = 1;            // TBK_REG           0: n = 5..8 through the wavefront kernel
+    int use_row16 = 1;          // TBK_ROW16         0: no DPP-row Jacobi kernel
+    int use_ql16 = 1;           // TBK_QL16          0: n = 9..16 through the Jacobi kernels
+    long long few_max = -1;     // TBK_FEW_MAX       largest n < 22 batch that gets a workgroup per matrix
+    int few_warm = 1;           // TBK_FEW_WARM      0: workgroup solver always starts cold
+    int few_nt = -1;            // TBK_FEW_NT        threads of the LDS workgroup solver
+    int wg_nt = 1024;           // TBK_WG_NT         threads of the global-workspace workgroup solver
+    int wave_run = -1;          // TBK_WAVE_RUN      chain length of the wavefront solver (1 = always cold)
+    int grid_seg = -1;          // TBK_GRID_SEG      chunks per wave tile of k_grid_rows
+    int grid_kernel = 0;        // TBK_GRID_KERNEL   1: term-walking mesh kernel instead of the row-polynomial one
+    int flux_ti = -1;           // TBK_FLUX_TI       rows per flux tile
+    int flux_fused = 0;         // TBK_FLUX_FUSED    1: final flux sum inside the kernel
+    int det_big_from = -1;      // TBK_DET_BIG_FROM  smallest band count of the workgroup-level link determinants
+    int wilson_big_from = -1;   // TBK_WILSON_BIG_FROM  ... of the workgroup-level Wilson-loop pipeline
+    long long wilson_batch_bytes = -1;   // TBK_WILSON_BATCH_BYTES  test hook: workspace bound per batch of strings
+    double wilson_alpha = 0.0;  // TBK_WILSON_ALPHA  test hook: first Cayley angle
+    bool wilson_alpha_set = false;
+    long long big_batch = -1;   // TBK_BIG_BATCH     test hook: matrices per workspace batch
+    int reg_lanes = 0;          // TBK_REG_LANES     (multilane build only)
+    int ablate_grid = 0;        // TBK_ABLATE_GRID   -DTBK_DIAG builds only
+    int ablate_flux = 0;        // TBK_ABLATE_FLUX   -DTBK_DIAG builds only
+};
+const TbkKnobs& tbk_knobs();
+
+// Ablation branches of the hot kernels exist only in the diagnostic build (make -C pythtb_amd/csrc diag ->
+// libtbk_diag.so); in the shipped library the expression is never evaluated and the branches fold away.
+#ifdef TBK_DIAG
+#define TBK_ABLATE(expr) (expr)
+#else
+#define TBK_ABLATE(expr) 0
+#endif
+
 // ---------------------------------------------------------------- complex
 // c128 as a plain pair; every operation spelled out so the compiler emits
 // straight v_fma_f64 sequences (no library complex-multiply NaN fix-ups).
@@ -133,6 +172,7 @@ struct tbk_model {
     tbk_ctx* ctx = nullptr;
     int dim_k = 0, norb = 0, nspin = 1, nsta = 0, nslot = 0;
     int64_t nterm = 0;
+    int64_t upload_id = 0; // unique per tbk_model_upload (cache keys must not use the blob address: hipMalloc reuses it)
     void* blob = nullptr;  // one device allocation holding all tables
     ModelView view{};
 };

@@ -49,7 +49,9 @@ struct GridArgs {
     int seg;                 // chunks per wave tile (k_grid_rows)
     int tpr;                 // wave tiles per row
     int64_t ntiles;
-    int ablate;              // diagnostics only (TBK_ABLATE_GRID): 1 = no stores, 2 = no eigen-solve
+#ifdef TBK_DIAG
+    int ablate;              // diagnostic build only (TBK_ABLATE_GRID): 1 = no stores, 2 = no eigen-solve, ...
+#endif
 };
 
 struct ListArgs {
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
 
     SmallMat<N> M;
     init_vectors<N, true>(M);
-    if (G.ablate != 2) {
+    if (TBK_ABLATE(G.ablate) != 2) {
         assemble_small<N>(mv, z, M);
         jacobi_small<N, true>(M);
     } else {
@@ -479,7 +481,11 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
 #pragma unroll
         for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, sorted[b + 1] - sorted[b]);
     }
-    if (active && (G.ablate != 1 || sorted[0] == 1.2345e300)) {
+    bool do_store = active;
+#ifdef TBK_DIAG
+    if (G.ablate == 1) do_store = do_store && sorted[0] == 1.2345e300;   // "no stores" without letting the compiler drop the solve
+#endif
+    if (do_store) {
 #pragma unroll
         for (int b = 0; b < N; ++b) {
             cd* out = wf_at(G.wv, rk[b], point);
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     }
     __syncthreads();
     if (!live) return;
-    if (G.ablate == 4) {   // diagnostics: tile set-up only
+    if (TBK_ABLATE(G.ablate) == 4) {   // diagnostics: tile set-up only
         if (C[0].x == 1.2345e300) G.wv.data[0] = C[1];
         return;
     }
@@ -579,14 +585,14 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
         cd tfl[N];
 #pragma unroll
         for (int o = 0; o < N; ++o) tfl[o] = tf_next[o];
-        if (jc + 1 < jc1 && G.ablate != 5) {   // (ablate 5: diagnostics, no per-chunk table loads)
+        if (jc + 1 < jc1 && TBK_ABLATE(G.ablate) != 5) {   // (ablate 5: diagnostics, no per-chunk table loads)
             const int jn = min((jc + 1) * 64 + lane, nlast - 1);
             zl_next = G.tz[last][jn];
 #pragma unroll
             for (int o = 0; o < N; ++o) tf_next[o] = G.tf[last][(int64_t)jn * N + o];
         }
         SmallMat<N> M;
-        if (G.ablate == 2) {   // diagnostics: no assembly, no eigen-solve (the store stream alone)
+        if (TBK_ABLATE(G.ablate) == 2) {   // diagnostics: no assembly, no eigen-solve (the store stream alone)
 #pragma unroll
             for (int a = 0; a < N; ++a) {
                 M.dg[a] = a + zl.x;
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
         // LDS-staged store: per band plane the wave owns one contiguous run of
         // 64*N elements, so lanes trade elements through LDS and every store
         // instruction writes 1 KiB of consecutive bytes.
-        const int nvalid = G.ablate == 1 ? 0 : min(64, nlast - jc * 64) * N;   // (ablate 1: no stores, diagnostics)
+        const int nvalid = TBK_ABLATE(G.ablate) == 1 ? 0 : min(64, nlast - jc * 64) * N;   // (ablate 1: no stores, diagnostics)
         const int64_t point0 = (int64_t)row * nlast + (int64_t)jc * 64;
 #pragma unroll
         for (int r = 0; r < N; ++r) {
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
             }
         }
     };
-    const int jfull = G.ablate == 1 ? jc0 : max(jc0, min(jc1, nlast / 64));   // chunks [jc0, jfull) are complete
+    const int jfull = TBK_ABLATE(G.ablate) == 1 ? jc0 : max(jc0, min(jc1, nlast / 64));   // chunks [jc0, jfull) are complete
     for (int jc = jc0; jc < jfull; ++jc) chunk(jc, std::true_type{});
     for (int jc = jfull; jc < jc1; ++jc) chunk(jc, std::false_type{});
     if constexpr (N > 1) {
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
 
         // ---- parallel-ordered Jacobi sweeps
         bool converged = false;
-        const int sweep_cap = G.ablate >= 10 ? G.ablate - 10 : TBK_JACOBI_MAX_SWEEPS;   // diagnostics: TBK_ABLATE_GRID=10+k caps the sweeps at k
+        const int sweep_cap = TBK_ABLATE(G.ablate) >= 10 ? TBK_ABLATE(G.ablate) - 10 : TBK_JACOBI_MAX_SWEEPS;   // diagnostics: TBK_ABLATE_GRID=10+k caps the sweeps at k
         for (int sweep = 0; sweep < sweep_cap; ++sweep) {
             double off = 0.0, dia = 0.0;
             if (walker)
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
                 __syncthreads();
             }
         }
-        if (!converged && lane == 0 && G.ablate < 10) atomicExch(noconv_flag, 1);
+        if (!converged && lane == 0 && TBK_ABLATE(G.ablate) < 10) atomicExch(noconv_flag, 1);
 
         // ---- order eigenvalues (stable ascending), write out
         if (lane < n) S.ev[lane] = S.A[lane * ld + lane].x;
@@ -1129,10 +1135,8 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
                        const GridArgs& G) {
     int* flag = ctx->flags_dev;  // sticky until read by check_noconv
     GridArgs G2 = G;
-    static const int big_from = [] {   // tuning knob: smallest n sent to the whole-chip solver regardless of batch size
-        const char* e = getenv("TBK_BIG_FROM");
-        return e ? std::max(65, atoi(e)) : 257;
-    }();
+    const TbkKnobs& K = tbk_knobs();
+    const int big_from = K.big_from >= 0 ? std::max(65, K.big_from) : 257;   // smallest n sent to the whole-chip solver regardless of batch size
     // Few matrices (fewer than ~CUs/2) cannot fill the chip one workgroup each: give them the whole-chip
     // solver too (n = 128: 32 k-points 21.6 -> 10.5 ms; 128: equal; 512: 108 vs 134 ms).  A mesh window
     // decides on the size of the GLOBAL mesh, so every shard of an array takes the same route.
@@ -1150,29 +1154,17 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         // carries enough work.  Measured (profiles/blocked_bench.py, ms, eigenvalues / with vectors): 512 x n=128
         // 87 / 105 -> 35 / 55, 101 x n=300 249 / 452 -> 100 / 143, 8 x n=800 364 / 631 -> 213 / 270; but 64 x n=128
         // 11.8 / 19.3 -> 18.7 / 21.0, 2 x n=800 120 / 189 -> 157 / 172.
-        const char* e = getenv("TBK_BLOCKED");        // tuning knob: 1 forces the block-Jacobi solver, 0 forbids it
-        const bool blk = e ? atoi(e) == 1 : (n >= 96 && (double)nk_eff * n * n >= 1.4e6);
+        const bool blk = K.blocked >= 0 ? K.blocked == 1 : (n >= 96 && (double)nk_eff * n * n >= 1.4e6);
         if (blk) return launch_blocked<MODE, VEC>(ctx, mv, n, nk, L, G);
     }
     if (n >= big_from || (n > 64 && (nk_eff <= 160 || !VEC || n > 224))) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
-    static const bool use_reg = [] {   // TBK_REG=0: fall back to the wavefront-per-matrix kernel (A/B runs)
-        const char* e = getenv("TBK_REG");
-        return !(e && atoi(e) == 0);
-    }();
-    if (n <= 8 && use_reg) return launch_reg<MODE, VEC>(ctx, mv, n, nk, L, G);
-    static const bool use_row16 = [] {   // TBK_ROW16=0: wavefront-per-matrix LDS kernel instead (A/B runs)
-        const char* e = getenv("TBK_ROW16");
-        return !(e && atoi(e) == 0);
-    }();
+    if (n <= 8 && K.use_reg != 0) return launch_reg<MODE, VEC>(ctx, mv, n, nk, L, G);
+    const bool use_row16 = K.use_row16 != 0, use_ql16 = K.use_ql16 != 0;
     // One DPP row per matrix pays off where its fixed 16x16 cost is not wasted on padding and where the
     // LDS kernel cannot warm-start profitably: n = 15, 16 on k lists and supplied matrices (262144 k, n = 16:
     // 6.8-7.1 ms eigenvalues against 13.1 (mesh order) / 19.0 (random order) ms, 12.1 against 12.5 / 17.5 ms
     // with vectors; at n = 12 and below the LDS kernel wins).  Mesh solves keep the warm-started LDS kernel
     // (a fine mesh needs ~3 sweeps there).  Needs the R-grouped table unless the matrices are supplied.
-    static const bool use_ql16 = [] {   // TBK_QL16=0: the Jacobi kernels instead (A/B runs)
-        const char* e = getenv("TBK_QL16");
-        return !(e && atoi(e) == 0);
-    }();
     // n = 9..16: the direct solver (Householder + implicit QL in registers, tbk_solve_ql16.inl) on meshes, k lists and
     // supplied matrices alike; it needs the R-grouped table unless the matrices are supplied, and a batch that fills
     // the chip with 16-lane rows (a handful of matrices is latency-bound: the workgroup-per-matrix Jacobi below)
@@ -1191,20 +1183,14 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     //    11.0 -> 5.5, n=40 (4.7 at 1024 k) -> 11.7 (1.8), n=48 92 -> 33, 8192 x n=64 209 -> 39; n=22 9.4 -> 8.3 is
     //    the crossover (n=20: 6.7 vs 7.5).
     //  * n < 22: only while the batch cannot fill the chip with wavefronts (one 30x30 matrix: 0.77 -> 0.31 ms).
-    static const int64_t few_max = [] {   // tuning knob: largest n < 22 batch that gets a workgroup per matrix
-        const char* e = getenv("TBK_FEW_MAX");
-        return e ? (int64_t)atoll(e) : (int64_t)-1;
-    }();
+    const int64_t few_max = K.few_max;   // largest n < 22 batch that gets a workgroup per matrix
     const bool few = n <= 64 && (n >= 22 || nk_eff <= (few_max >= 0 ? few_max : (int64_t)ctx->cus * 8));
     if (n > 64 || few) {
         // ---- workgroup per matrix: 256 threads, cold start; n = 65..256: A and V^T in a global workspace
         // (ribbon / slab models: few, large matrices), n <= 64: in LDS.
         // a large batch walks runs of consecutive points per workgroup anyway: warm-start along them when the
         // extra buffer still leaves two matrices per CU (TBK_FEW_WARM=0 disables)
-        static const bool warm_knob = [] {
-            const char* e = getenv("TBK_FEW_WARM");
-            return !(e && atoi(e) == 0);
-        }();
+        const bool warm_knob = K.few_warm != 0;
         const int64_t cap = std::max<int64_t>(64, (int64_t)ctx->cus * 4);
         const int warm_few = few && warm_knob && nk_eff >= 2 * cap && wave_lds_bytes(n, true, mv.nR) <= 80 * 1024 ? 1 : 0;
         const size_t lds = few ? wave_lds_bytes(n, warm_few != 0, mv.nR)
@@ -1232,7 +1218,7 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
             int nt;
             if (nk_eff > (int64_t)ctx->cus) nt = n <= 40 ? 256 : (n <= 56 ? 512 : 1024);
             else nt = n <= 24 ? 256 : (n <= 36 ? 512 : 1024);
-            if (const char* e = getenv("TBK_FEW_NT")) nt = atoi(e) >= 1024 ? 1024 : (atoi(e) >= 512 ? 512 : 256);   // tuning knob
+            if (K.few_nt >= 0) nt = K.few_nt >= 1024 ? 1024 : (K.few_nt >= 512 ? 512 : 256);
             static bool attr_few[2][3][3] = {};
             const int ti = nt == 256 ? 0 : (nt == 512 ? 1 : 2);
             if (lds > 64 * 1024 && !attr_few[VEC][MODE][ti]) {
@@ -1262,10 +1248,7 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
             TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "eigen-solver workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
             ctx->work_bytes = wbytes;
         }
-        static const int wg_nt = [] {   // tuning knob: threads of the global-workspace workgroup solver
-            const char* e = getenv("TBK_WG_NT");
-            return e ? atoi(e) : 1024;
-        }();
+        const int wg_nt = K.wg_nt;
         if (wg_nt >= 1024)
             hipLaunchKernelGGL((k_solve_wave<MODE, VEC, 1024, false>), dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream, mv, nk,
                                L, G2, flag, (int)run, (cd*)ctx->work, 0);
@@ -1292,7 +1275,7 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     if (MODE == 1) {
         // mesh: fixed chain length, aligned to the global last-axis index (see the kernel)
         run = 16;
-        if (const char* rk = getenv("TBK_WAVE_RUN")) run = std::max(1, atoi(rk));   // tuning knob (1 = always cold)
+        if (K.wave_run >= 0) run = std::max(1, K.wave_run);   // (1 = always cold)
         if (!with_t) run = 1;
         const int last = G.last;
         const int64_t off = G.off[last], nl = G.wv.mesh[last];
@@ -1302,7 +1285,7 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     } else {
         // k list: contiguous runs by list position, at most 64 long
         run = std::max<int64_t>(1, std::min<int64_t>(64, (nk + want - 1) / want));
-        if (const char* rk = getenv("TBK_WAVE_RUN")) run = std::max(1, atoi(rk));
+        if (K.wave_run >= 0) run = std::max(1, K.wave_run);
         if (!with_t) run = 1;
         nblocks = (nk + run - 1) / run;
     }
@@ -1490,7 +1473,7 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
     G.pbc = w->pbc_dev;
     // everything the per-axis tables depend on; rebuild them only when it changes
     std::vector<double> key;
-    key.push_back((double)(uintptr_t)m->blob);
+    key.push_back((double)m->upload_id);
     for (int d = 0; d < D; ++d) {
         key.push_back(start_k[d]);
         key.push_back((double)offset[d]);
@@ -1541,10 +1524,9 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
     G.last = D - 1;
     G.cpr = (v.mesh[D - 1] + 63) / 64;
     G.nchunks = (v.npts / v.mesh[D - 1]) * G.cpr;
-    {
-        const char* ab = getenv("TBK_ABLATE_GRID");
-        G.ablate = ab ? atoi(ab) : 0;
-    }
+#ifdef TBK_DIAG
+    G.ablate = tbk_knobs().ablate_grid;
+#endif
     ProfScope ps(ctx, "solve_grid");
     if (n <= 4) {
         TBK_REQUIRE(v.npts / v.mesh[D - 1] < (int64_t)0xffffffffu && G.nchunks < (int64_t)0x7fffffff * 4, TBK_EUNSUPPORTED,
@@ -1552,13 +1534,12 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
         const int64_t nrows = v.npts / v.mesh[D - 1];
         const int64_t want = (int64_t)ctx->cus * 32;     // wave tiles that fill the chip
         G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, G.cpr), G.nchunks / want));
-        if (const char* sg = getenv("TBK_GRID_SEG")) G.seg = std::max(1, std::min(atoi(sg), G.cpr));   // tuning knob
+        if (tbk_knobs().grid_seg >= 0) G.seg = std::max(1, std::min(tbk_knobs().grid_seg, G.cpr));
         G.tpr = (G.cpr + G.seg - 1) / G.seg;
         G.seg = (G.cpr + G.tpr - 1) / G.tpr;             // balance the tiles of a row (33 chunks -> 7,7,7,7,5)
         G.ntiles = nrows * G.tpr;
         const size_t lds = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
-        const char* old = getenv("TBK_GRID_KERNEL");
-        if (lds <= 48 * 1024 && !(old && atoi(old) == 1)) {
+        if (lds <= 48 * 1024 && tbk_knobs().grid_kernel != 1) {
             const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
             const int64_t npart = G.ntiles * std::max(n - 1, 1);
             if (w->gap_part_cap < npart) {

@@ -117,7 +117,7 @@ static int launch_blocked(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, 
     TBK_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t budget = std::max<size_t>(per, std::min<size_t>((size_t)8 << 30, (free_b + ctx->work_bytes) / 2));
     int64_t B = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nk, 32768), (int64_t)(budget / per)));
-    if (const char* e = getenv("TBK_BIG_BATCH")) B = std::max<int64_t>(1, std::min<int64_t>(B, atoll(e)));   // test hook: matrices per batch
+    if (tbk_knobs().big_batch >= 0) B = std::max<int64_t>(1, std::min<int64_t>(B, tbk_knobs().big_batch));   // test hook: matrices per batch
     const size_t wbytes = (size_t)B * per + al((size_t)B * sizeof(int)) * 2 + al((size_t)B * sizeof(double)) + 4096;
     if (wbytes > ctx->work_bytes) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));

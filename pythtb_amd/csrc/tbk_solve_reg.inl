@@ -213,12 +213,8 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
 // lanes per matrix when eigenvectors are wanted
 static int reg_lanes(int) {
 #ifdef TBK_REG_MULTILANE
-    static const int forced = [] {
-        const char* e = getenv("TBK_REG_LANES");
-        const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 2 || v == 4) ? v : 0;
-    }();
-    if (forced) return forced;
+    const int v = tbk_knobs().reg_lanes;
+    if (v == 1 || v == 2 || v == 4) return v;
 #endif
     return 1;
 }

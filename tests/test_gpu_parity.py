@@ -599,15 +599,14 @@ def test_large_nocc_and_unsupported_sizes(tb):
     assert_phase_sets_close(got, orc.berry_phase(orib, 1, list(range(70)), None, contin=False, berry_evals=True), 1e-8)
     # the Cayley transform behind these eigenphases has a pole at theta = alpha + pi: put it exactly on one of
     # the eigenphases (output = -theta) and the call must notice and redo that string with another alpha
-    os.environ["TBK_WILSON_ALPHA"] = repr(float(-got[35] - np.pi))
     ctx = _lib.default_context()
     ctx.prof_enable(1)
     ctx.prof_reset()
     try:
-        again = wr.berry_phase(list(range(70)), contin=False, berry_evals=True)
+        with _lib.knob("TBK_WILSON_ALPHA", repr(float(-got[35] - np.pi))):
+            again = wr.berry_phase(list(range(70)), contin=False, berry_evals=True)
         launches = ctx.prof_report()["wilson_cayley"]["launches"]
     finally:
-        del os.environ["TBK_WILSON_ALPHA"]
         ctx.prof_enable(0)
     assert launches == 2                                       # first alpha rejected, second accepted
     assert_phase_sets_close(again, got, 1e-11)
@@ -648,13 +647,10 @@ def test_mesh_kernels_long_range_hops_and_fallback(tb, norb):
     assert norb == 1 or ogaps[0] > 1.0
     flux = w.berry_flux(occ, individual_phases=True)
     assert np.max(np.abs(wrap(flux - orc.berry_flux(owfs, 2, occ, individual_phases=True, vectorised=True)))) < 1e-9
-    os.environ["TBK_GRID_KERNEL"] = "1"
-    try:
+    with tb._lib.knob("TBK_GRID_KERNEL", 1):
         w2 = tb.wf_array(m, mesh)
         gaps2 = w2.solve_on_grid(start)
         flux2 = w2.berry_flux(occ, individual_phases=True)
-    finally:
-        del os.environ["TBK_GRID_KERNEL"]
     if norb > 1:
         assert np.max(np.abs(gaps2 - gaps)) < 1e-12
     assert np.max(np.abs(wrap(flux2 - flux))) < 1e-9
@@ -675,11 +671,8 @@ def test_wilson_pipeline_batches_and_axes(tb):
             ref = orc.berry_phase(owfs, 3, occ, d, contin=False, berry_evals=True)
             assert got.shape == ref.shape
             assert_phase_sets_close(got, ref, 1e-9)
-            os.environ["TBK_WILSON_BATCH_BYTES"] = str(2 * (mesh[d] - 1) * len(occ) ** 2 * 16 * 4)   # four strings per batch
-            try:
+            with tb._lib.knob("TBK_WILSON_BATCH_BYTES", 2 * (mesh[d] - 1) * len(occ) ** 2 * 16 * 4):   # four strings per batch
                 again = w.berry_phase(occ, d, contin=False, berry_evals=True)
-            finally:
-                del os.environ["TBK_WILSON_BATCH_BYTES"]
             assert np.array_equal(again, got)
     # the reference's continuity post-processing on top of the pipeline's raw eigenphases (2-D mesh, smooth model)
     h3 = hp.quiet(tb.tb_model, 2, 2, [[1.0, 0.0], [0.0, 1.0]], [[0.0, 0.0], [0.3, 0.1], [0.6, 0.5], [0.1, 0.7], [0.8, 0.2]])
@@ -729,11 +722,8 @@ def test_wide_models_workgroup_kernel(tb):
         assert np.max(np.abs(V[:, ik].conj() @ V[:, ik].T - np.identity(90))) < 1e-12
         assert np.max(np.abs(ham[ik] @ V[:, ik].T - V[:, ik].T * ev[:, ik])) < 1e-11 * scale
     assert np.max(np.abs(m.solve_all(k) - ref)) < 1e-12 * scale              # eigenvalue-only variant
-    os.environ["TBK_BIG_BATCH"] = "5"                                      # whole-chip solver in several batches: same bits
-    try:
+    with tb._lib.knob("TBK_BIG_BATCH", 5):                                  # whole-chip solver in several batches: same bits
         assert np.array_equal(m.solve_all(k), m.solve_all(k)) and np.array_equal(m.solve_all(k[:7]), m.solve_all(k)[:, :7])
-    finally:
-        del os.environ["TBK_BIG_BATCH"]
     w = tb.wf_array(m, [14])
     gaps = w.solve_on_grid([0.0])
     owfs, ogaps = orc.solve_on_grid(m, [14], [0.0], vectorised=True)
@@ -767,11 +757,8 @@ def test_wide_batches_block_jacobi(tb):
         V = vec[:, ik, :]
         assert np.max(np.abs(V.conj() @ V.T - np.identity(100))) < 1e-11
         assert np.max(np.abs(ham[ik] @ V.T - V.T * ev[:, ik])) < 1e-11 * scale
-    os.environ["TBK_BLOCKED"] = "0"                                        # same batch through the other solvers
-    try:
+    with tb._lib.knob("TBK_BLOCKED", 0):                                    # same batch through the other solvers
         ev0 = rib.solve_all(k)
-    finally:
-        del os.environ["TBK_BLOCKED"]
     assert np.max(np.abs(ev0 - ev)) < 2e-12 * scale
     w = tb.wf_array(rib, [161])                                            # mesh mode: gaps, images, Berry phase
     gaps = w.solve_on_grid([0.0])
@@ -784,11 +771,8 @@ def test_wide_batches_block_jacobi(tb):
     ev2 = m2.solve_all(k2)
     ref2 = orc.solve_all_vec(m2, k2.reshape(-1, 1))
     assert np.max(np.abs(ev2 - ref2)) < 2e-12 * np.abs(ref2).max()
-    os.environ["TBK_BIG_BATCH"] = "37"                                     # several workspace batches: same bits
-    try:
+    with tb._lib.knob("TBK_BIG_BATCH", 37):                                 # several workspace batches: same bits
         ev_b, vec_b = rib.solve_all(k, eig_vectors=True)
-    finally:
-        del os.environ["TBK_BIG_BATCH"]
     assert np.array_equal(ev_b, ev) and np.array_equal(vec_b, vec)
     # supplied matrices through the same solver, with the special cases a Jacobi method can trip over
     from pythtb_amd import _lib

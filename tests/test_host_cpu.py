@@ -308,3 +308,60 @@ def test_cut_piece_of_an_orbital_free_model_raises_like_reference():
     m = tb_model(1, 1, [[1.0]], [[0.0]]).remove_orb(0)
     with pytest.raises(Exception, match="Wrong orb array rank"):
         m.cut_piece(2, 0)
+
+
+def _flatten_host(m):
+    """tbk_model_flatten_host on a model's tables: (slot, R, amp) term list and info = {pmax, nR, nnz, nslot}."""
+    import ctypes as C
+    from pythtb_amd import _lib
+    orb_per, onsite, hop_i, hop_j, hop_R, hop_amp = m._flat_tables()
+    nterm = C.c_int64(0)
+    info = np.zeros(4, dtype=np.int32)
+    args = (m._dim_k, m._norb, m._nspin, _lib.dptr(orb_per), _lib.dptr(onsite.view(float)), len(hop_i),
+            _lib.iptr(hop_i), _lib.iptr(hop_j), _lib.iptr(np.ascontiguousarray(hop_R.reshape(-1))) if hop_R.size else None,
+            _lib.dptr(hop_amp.view(float)) if hop_amp.size else None)
+    _lib.check(_lib.lib.tbk_model_flatten_host(*args, 0, C.byref(nterm), None, None, None, _lib.iptr(info)))
+    n = nterm.value
+    slot = np.zeros(max(n, 1), dtype=np.int32)
+    R = np.zeros((max(n, 1), 4), dtype=np.int32)
+    amp = np.zeros(max(n, 1), dtype=complex)
+    _lib.check(_lib.lib.tbk_model_flatten_host(*args, n, C.byref(nterm), _lib.iptr(slot), _lib.iptr(R),
+                                               _lib.dptr(amp.view(float)), _lib.iptr(info)))
+    return slot[:n], R[:n], amp[:n], info
+
+
+@pytest.mark.parametrize("name", ["graphene", "haldane02", "km_odd", "chain3", "cubic16", "molecule", "per02", "spin_chain"])
+def test_flattened_term_table_reproduces_reference_hamiltonian(name):
+    """The host half of tbk_model_upload (merge of hoppings into slot-major (slot, R, amp) terms, pythtb.py:900-924
+    restated as S = D H D^+) needs no GPU: rebuild H(k) from the dumped table in NumPy and compare with the H(k)
+    the reference's _gen_ham produced for the same model (tests/golden/point_<name>.npz)."""
+    import pythtb_amd as tb
+    g = load_golden("point_" + name)
+    m = hp.model_from_tables(tb.tb_model, golden_tables(g))
+    slot, R, amp, info = _flatten_host(m)
+    n, dim_k = m._nsta, m._dim_k
+    assert info[3] == n * (n + 1) // 2
+    assert np.all(np.diff(slot) >= 0)                                       # slot-major
+    ab = [(a, b) for a in range(n) for b in range(a, n)]
+    orb = np.repeat(m._orb[:, m._per], m._nspin, axis=0) if dim_k else np.zeros((n, 0))
+    ks = g["k"][:16] if dim_k else [np.zeros(0)]                            # 0-D model: one Hamiltonian, no k
+    for ik, k in enumerate(ks):
+        S = np.zeros((n, n), dtype=complex)
+        for s_, r_, a_ in zip(slot, R, amp):
+            a, b = ab[s_]
+            v = a_ * np.exp(2j * np.pi * np.dot(k, r_[:dim_k]))
+            S[a, b] += v
+            if a != b:
+                S[b, a] += np.conj(v)
+        e = np.exp(2j * np.pi * orb @ k) if dim_k else np.ones(n)
+        H = np.conj(e)[:, None] * S * e[None, :]
+        ref = np.asarray(g["ham"][ik]).reshape(n, n)
+        assert np.max(np.abs(H - ref)) < 1e-13 * max(1.0, np.abs(ref).max())
+
+
+def test_knobs_are_parsed_once_and_reloadable():
+    from pythtb_amd import _lib
+    assert _lib.lib.tbk_build_has_diagnostics() == 0                        # the shipped library carries no ablation code
+    with _lib.knob("TBK_GRID_SEG", 3):
+        pass
+    assert os.environ.get("TBK_GRID_SEG") is None
