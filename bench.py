@@ -11,19 +11,35 @@ wf_array, periodic images included) followed by the Berry flux of the lower band
 over all plaquettes and its deterministic sum.  Inputs (model tables) are resident
 in HBM before the timed region; nothing crosses PCIe inside it.
 
+`value` = k-points of the K timed steps / wall time (max over ranks), exactly as the
+driver's contract asks.  Beside it, on ONE GPU, the same JSON line carries (all
+outside the timed region):
+  roofline        dominant kernel: algorithmic bytes / average launch duration from HIP events on the
+                  kernels' stream (the RAW bracket, event overhead included: conservative); frac_net
+                  = the same with the measured empty-bracket overhead subtracted; valu_frac = VALU
+                  issue-slot use at the fp64 rate from rocprofv3 instruction counts (profiles/valu.json)
+  sustained       >= 1 s of back-to-back steps (a 20-step burst is 1.6 ms: boost clocks, warm caches)
+  python_api      wall-clock of wf.solve_on_grid(); wf.berry_flux([0]) through the Python API
+  configs         the other single-GPU legs: the same kernels at 4096^2 (1.07 GB of eigenvectors, four
+                  times the 256 MiB last-level cache), BASELINE configs[3] (Kane-Mele 4096 x 512: solve +
+                  flux + Wilson loops) and configs[4] (cubic16 256^3: solve + Berry phase), each with
+                  HBM and VALU fractions
+  cpu_baseline    the oracle's per-k Python loop on 1 host core and on all of them (os.cpu_count())
+
 N > 1 (weak scaling): the global mesh is (2048*N + 1) x 2049; rank r owns the slab
 of 2048 plaquette rows starting at global row 2048*r and recomputes its one halo
 row, so there is no data-path collective.  The only exchange is the gather of
 [partial flux, min gap, elapsed] per rank after the timed loop: through gloo for the
 reported line, and once more through the RCCL all-gather (tbk_comm_*) as a check of
-that path, under a watchdog so that a communicator that never comes up cannot cost
-the measurement.
+that path, under a watchdog that prints the already-built line and exits non-zero
+if the communicator never comes up.  (configs[3]/[4] at N > 1: bench_configs.py --gpus N.)
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -32,12 +48,21 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MESH = 2048                      # plaquette rows per rank and plaquettes per row
 N_STA = 2                        # Haldane: two orbitals
-BYTES_SOLVE_PER_K = 16 * N_STA * N_STA        # solve_on_grid writes 16 n^2 B per k
-BYTES_FLUX_PER_K = 16 * 1 * N_STA             # berry_flux reads 16 nocc n B per k (nocc = 1)
-HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6     # vector fp64 peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+VALU_SLOTS_PER_S = 256 * 4 * 2.4e9 / 4.0   # wave64 VALU instructions the chip can issue per second at the fp64 rate
+
+
+def bytes_solve(n):
+    return 16 * n * n            # solve_on_grid writes 16 n^2 B per k
+
+
+def bytes_berry(nocc, n):
+    return 16 * nocc * n         # Berry kernels read 16 nocc n B per k
 
 
 def haldane(tb):
@@ -62,24 +87,254 @@ def haldane(tb):
     return m
 
 
-def cpu_baseline(sample_mesh=513):
-    """Oracle (a NumPy port of the reference's per-k / per-plaquette Python loops)
-    timed on one host core on a bounded sample of the same workload."""
+# ---------------------------------------------------------------- CPU baseline (oracle; runs BEFORE any GPU call)
+def _cpu_leg(args):
+    """One worker: the oracle's solve_on_grid + berry_flux on an n x n sub-mesh anchored at its own start_k."""
+    n, start = args
     from oracle import tb_oracle as orc
     m = orc.haldane(0.0)
-    n = sample_mesh
     t0 = time.perf_counter()
-    wfs, _ = orc.solve_on_grid(m, [n, n], [-0.5, -0.5])
+    wfs, _ = orc.solve_on_grid(m, [n, n], start)
     t1 = time.perf_counter()
     flux = orc.berry_flux(wfs, 2, [0])
     t2 = time.perf_counter()
+    return t1 - t0, t2 - t1, float(flux)
+
+
+def cpu_baseline(sample_mesh=257):
+    """Oracle (a NumPy port of the reference's per-k / per-plaquette Python loops, kind "port") on a bounded sample of
+    the headline workload: one host core, then one worker per host core on as many sub-meshes of the same size."""
+    import multiprocessing as mp
+    n = sample_mesh
     nk = (n - 1) * (n - 1)
-    return {
-        "value": nk / (t2 - t0), "unit": "k-points/s", "cores": 1, "kind": "port",
-        "sample": "Haldane %dx%d sub-mesh (%d k): oracle solve_on_grid %.2fs + berry_flux %.2fs, Chern %.6f"
-                  % (n - 1, n - 1, nk, t1 - t0, t2 - t1, flux / (2 * np.pi)),
-        "solve_kpts_per_s": nk / (t1 - t0), "flux_plaq_per_s": nk / (t2 - t1),
+    ts, tf, flux = _cpu_leg((n, [-0.5, -0.5]))
+    cores = os.cpu_count() or 1
+    out = {
+        "value": nk / (ts + tf), "unit": "k-points/s", "cores": 1, "kind": "port",
+        "sample": "Haldane %dx%d sub-mesh (%d k): oracle solve_on_grid %.2fs + berry_flux %.2fs on one core"
+                  % (n - 1, n - 1, nk, ts, tf),
+        "solve_kpts_per_s": nk / ts, "flux_plaq_per_s": nk / tf,
     }
+    if cores > 1:
+        try:
+            ctx = mp.get_context("fork")              # no exec; the GPU has not been touched yet
+            jobs = [(n, [-0.5 + 0.37 * i / cores, -0.5]) for i in range(cores)]
+            t0 = time.perf_counter()
+            with ctx.Pool(cores) as pool:
+                res = pool.map(_cpu_leg, jobs)
+            wall = time.perf_counter() - t0
+            out["all_cores"] = {
+                "value": nk * cores / wall, "unit": "k-points/s", "cores": cores, "kind": "port",
+                "sample": "%d workers (os.cpu_count()), each the same %dx%d sub-mesh solve + flux; wall %.2fs incl. fork"
+                          % (cores, n - 1, n - 1, wall),
+                "slowest_worker_s": max(r[0] + r[1] for r in res),
+            }
+        except Exception as e:                        # a sandbox without fork/semaphores must not cost the GPU numbers
+            out["all_cores"] = {"error": " ".join(str(e).split())[:200], "cores": cores}
+    return out
+
+
+# ---------------------------------------------------------------- helpers around the C ABI
+class Grid(object):
+    """A device-resident wf_array handle + everything tbk_wfs_solve_grid_async needs."""
+
+    def __init__(self, lib, _lib, ctx, model, mesh, row0=0, global_n0=None):
+        self.lib, self._lib, self.ctx, self.model = lib, _lib, ctx, model
+        self.mesh = [int(x) for x in mesh]
+        n = model._nsta
+        self.n = n
+        self.h = C.c_void_p()
+        m32 = np.ascontiguousarray(self.mesh, dtype=np.int32)
+        _lib.check(lib.tbk_wfs_create(ctx.handle, len(mesh), _lib.iptr(m32), n, n, C.byref(self.h)))
+        self.hm = model._device_model()
+        self.pbc = np.ascontiguousarray(np.array([np.repeat(np.exp(-2j * np.pi * model._orb[:, model._per[d]]), model._nspin)
+                                                  for d in range(len(mesh))]))
+        self.row0 = row0
+        self.g_n0 = self.mesh[0] if global_n0 is None else global_n0
+        self.start = None
+
+    def solve(self, start):
+        self.start = np.ascontiguousarray(start, dtype=float)
+        self._lib.check(self.lib.tbk_wfs_solve_grid_async(self.h, self.hm, self._lib.dptr(self.start),
+                                                          self._lib.dptr(self.pbc.view(float)), self.row0, self.g_n0))
+
+    def flux(self, occ32):
+        self._lib.check(self.lib.tbk_berry_flux_async(self.h, self._lib.iptr(occ32), len(occ32), 0, 1, 0))
+
+    def gaps(self):
+        g = np.zeros(max(self.n - 1, 1))
+        self._lib.check(self.lib.tbk_wfs_solve_grid_result(self.h, self._lib.dptr(g)))
+        return g
+
+    def flux_total(self, nslices=1):
+        t = np.zeros(nslices)
+        self._lib.check(self.lib.tbk_berry_flux_result(self.h, self._lib.dptr(t), None))
+        return t
+
+    def free(self):
+        self._lib.check(self.lib.tbk_wfs_free(self.h))
+
+
+def kernel_times(ctx, fn, reps, ev_ms):
+    """Per-kernel HIP-event brackets (every launch) around `reps` calls of fn: name -> raw and net average ms."""
+    ctx.prof_enable(1)
+    ctx.prof_reset()
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    ctx.prof_enable(0)
+    out = {}
+    for name, rec in ctx.prof_report().items():
+        raw = rec["total_ms"] / max(rec["launches"], 1)
+        out[name] = {"launches": rec["launches"], "avg_bracket_ms": raw, "avg_ms_net": max(raw - ev_ms, 0.25 * raw)}
+    return out
+
+
+def load_valu():
+    p = os.path.join(ROOT, "profiles", "valu.json")
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+def roof(alg_bytes, ms_raw, ms_net, valu_key=None, points=None, valu=None):
+    """Roofline block of one kernel launch: HBM fraction from the algorithmic bytes (raw bracket = conservative basis),
+    VALU fraction from the rocprofv3 instruction count per mesh point (profiles/valu.json) scaled to this launch."""
+    gbs = alg_bytes / (ms_raw * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "basis": "avg_bracket_ms (HIP events on the kernels' stream, event overhead included)",
+         "algorithmic_bytes": alg_bytes, "avg_launch_ms": ms_raw,
+         "frac_net": alg_bytes / (ms_net * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms_net": ms_net}
+    v = (valu or {}).get(valu_key) if valu_key else None
+    if v and points:
+        insts = v["valu_wave_insts_per_point"] * points
+        r["valu_frac"] = insts / (ms_raw * 1e-3) / VALU_SLOTS_PER_S
+        r["valu_fp64_equiv_tflops"] = insts * 128.0 / (ms_raw * 1e-3) / 1e12
+        r["valu_peak_tflops"] = FP64_VALU_PEAK_TFLOPS
+        r["valu_source"] = v.get("source")
+        r["valu_kernel"] = v.get("kernel")
+    return r
+
+
+# ---------------------------------------------------------------- the other single-GPU legs
+def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
+    import contextlib
+    import io
+    import helpers as hp
+    out = []
+    # ---- the headline kernels past the last-level cache: 4096^2 (1.07 GB of eigenvectors)
+    try:
+        m = haldane(tb)
+        g = Grid(lib, _lib, ctx, m, [4097, 4097])
+        occ = np.array([0], dtype=np.int32)
+        start = [-0.5, -0.5]
+
+        def step():
+            g.solve(start)
+            g.flux(occ)
+        step()
+        ctx.sync()
+        kt = kernel_times(ctx, step, 5, ev_ms)
+        npt = 4096 * 4096
+        chern = float(g.flux_total()[0] / (2 * np.pi))
+        out.append({"config": "Haldane solve_on_grid + berry_flux at 4096^2 (1.07 GB array: 4x the 256 MiB last-level cache)",
+                    "kpts": npt, "kernels": kt, "chern": chern,
+                    "roofline": {"solve_grid": roof(bytes_solve(2) * npt, kt["solve_grid"]["avg_bracket_ms"], kt["solve_grid"]["avg_ms_net"],
+                                                    "k_grid_rows<2,1>", 4097 * 4097, valu),
+                                 "berry_flux": roof(bytes_berry(1, 2) * npt, kt["berry_flux"]["avg_bracket_ms"], kt["berry_flux"]["avg_ms_net"],
+                                                    "k_flux_rows<1,2>", 4097 * 4097, valu)},
+                    "solve_kpts_per_s": npt / (kt["solve_grid"]["avg_bracket_ms"] * 1e-3)})
+        g.free()
+    except Exception as e:
+        out.append({"config": "4096^2", "error": " ".join(str(e).split())[:300]})
+    # ---- BASELINE configs[3]: Kane-Mele (4 states, spinor) 4096 x 512, solve + flux + Wilson loops, one GPU
+    try:
+        m = hp.kane_mele(tb.tb_model, "odd")
+        mesh = [4097, 513]
+        g = Grid(lib, _lib, ctx, m, mesh)
+        occ = np.array([0, 1], dtype=np.int32)
+        start = [-0.5, -0.5]
+        phases = np.zeros(mesh[1] * 2)
+
+        def step():
+            g.solve(start)
+            g.flux(occ)
+            _lib.check(lib.tbk_berry_phase(g.h, _lib.iptr(occ), 2, 0, 1, _lib.dptr(phases)))
+        step()
+        ctx.sync()
+        kt = kernel_times(ctx, step, 5, ev_ms)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        ctx.sync()
+        wall = (time.perf_counter() - t0) / 5
+        npt = 4096 * 512
+        gaps = g.gaps()
+        wl_ms = sum(v["avg_bracket_ms"] for k, v in kt.items() if k.startswith("chain"))
+        cen = np.sort(phases.reshape(mesh[1], 2) / (2 * np.pi) % 1.0, axis=1)
+        out.append({"config": "BASELINE configs[3] on one GPU: Kane-Mele (4 states) wf_array([4097,513]) solve_on_grid + berry_flux([0,1]) "
+                              "+ berry_phase([0,1], dir=0, berry_evals=True)",
+                    "kpts": npt, "kernels": kt, "wall_ms_per_pass_incl_result_download": wall * 1e3,
+                    "solve_kpts_per_s": npt / (kt["solve_grid"]["avg_bracket_ms"] * 1e-3),
+                    "wilson_links_per_s": 4096 * 513 / (wl_ms * 1e-3) if wl_ms > 0 else None,
+                    "roofline": {"solve_grid": roof(bytes_solve(4) * npt, kt["solve_grid"]["avg_bracket_ms"], kt["solve_grid"]["avg_ms_net"],
+                                                    "k_grid_rows<4,1>", 4097 * 513, valu),
+                                 "berry_flux": roof(bytes_berry(2, 4) * npt, kt["berry_flux"]["avg_bracket_ms"], kt["berry_flux"]["avg_ms_net"],
+                                                    "k_flux_rows<2,4>", 4097 * 513, valu)},
+                    "check": {"min_gaps": [float(x) for x in gaps[:3]],
+                              # time reversal maps the string at k_y to the one at -k_y: the two Wilson-loop spectra coincide
+                              "time_reversal_error": float(np.max(np.abs(np.exp(2j * np.pi * cen).sum(axis=1)
+                                                                         - np.exp(2j * np.pi * cen[::-1]).sum(axis=1))))}})
+        g.free()
+    except Exception as e:
+        out.append({"config": "configs[3]", "error": " ".join(str(e).split())[:300]})
+    # ---- BASELINE configs[4]: cubic16 on the full 256^3 mesh (69.5 GB of eigenvectors resident), one GPU
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = hp.cubic16(tb.tb_model)
+        info = ctx.info()
+        side = 257 if info["hbm_bytes"] > 100e9 else 65
+        mesh = [side, side, side]
+        g = Grid(lib, _lib, ctx, m, mesh)
+        occ = np.arange(8, dtype=np.int32)
+        start = [0.0, 0.0, 0.0]
+        phases = np.zeros(side * side)
+
+        def step():
+            g.solve(start)
+            _lib.check(lib.tbk_berry_phase(g.h, _lib.iptr(occ), 8, 2, 0, _lib.dptr(phases)))
+        step()
+        ctx.sync()
+        kt = kernel_times(ctx, step, 2, ev_ms)
+        npt = (side - 1) ** 3
+        gaps = g.gaps()
+        bp_ms = sum(v["avg_bracket_ms"] for k, v in kt.items() if k not in ("solve_grid", "grid_tables"))
+        out.append({"config": "BASELINE configs[4] on one GPU: cubic16 (16 orbitals, 888 hops) wf_array([%d]*3) solve_on_grid + "
+                              "berry_phase(range(8), dir=2)" % side,
+                    "kpts": npt, "kernels": kt, "solve_kpts_per_s": npt / (kt["solve_grid"]["avg_bracket_ms"] * 1e-3),
+                    "berry_links_per_s": side * side * (side - 1) / (bp_ms * 1e-3) if bp_ms > 0 else None,
+                    "roofline": {"solve_grid": roof(bytes_solve(16) * npt, kt["solve_grid"]["avg_bracket_ms"], kt["solve_grid"]["avg_ms_net"],
+                                                    "k_solve_ql16<1,true>", side ** 3, valu)},
+                    "check": {"gap78": float(gaps[7]), "phase_checksum": float(np.sum(np.cos(phases)))}})
+        g.free()
+    except Exception as e:
+        out.append({"config": "configs[4]", "error": " ".join(str(e).split())[:300]})
+    return out
+
+
+def python_api_leg(tb, model, reps=5):
+    """Wall-clock of the drop-in calls themselves (SURVEY.md 8d's end-to-end number): every call synchronises and
+    brings its small result (min gaps, one float) back to the host; the 268.7 MB array stays on the device."""
+    wf = tb.wf_array(model, [MESH + 1, MESH + 1])
+    wf.solve_on_grid([-0.5, -0.5])
+    wf.berry_flux([0])
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        gaps = wf.solve_on_grid([-0.5, -0.5])
+        flux = wf.berry_flux([0])
+        ts.append(time.perf_counter() - t0)
+    return {"call": "wf.solve_on_grid([-0.5,-0.5]); wf.berry_flux([0])  (wf_array([2049,2049]))", "reps": reps,
+            "ms_per_step_min": 1e3 * min(ts), "ms_per_step_median": 1e3 * sorted(ts)[len(ts) // 2],
+            "kpts_per_s": MESH * MESH / sorted(ts)[len(ts) // 2], "chern": float(flux / (2 * np.pi)), "min_gap": float(gaps[0])}
 
 
 def main():
@@ -88,6 +343,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the sustained / python-API / other-config legs")
     ap.add_argument("--no-check", action="store_true", help="diagnostics: skip the Chern-number assertion")
     args = ap.parse_args()
 
@@ -99,6 +355,10 @@ def main():
                      % (args.gpus, args.gpus))
         args.gpus = world
 
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()                        # forks workers: must precede every GPU call of this process
+
     dist = None
     if world > 1:                                   # rendezvous + barriers only; no tensors on the GPU
         import torch.distributed as dist
@@ -109,22 +369,19 @@ def main():
     lib = _lib.lib
     ctx = _lib.default_context()                    # device = LOCAL_RANK
     info = ctx.info()
+    valu = load_valu()
 
     model = haldane(tb)
-    hmodel = model._device_model()
     g_n0 = MESH * world + 1                         # global axis-0 mesh points
     row0, nrows = shard.split_rows(g_n0, world, rank)
     assert nrows == MESH + 1
-    mesh = np.array([nrows, MESH + 1], dtype=np.int32)
-    hw = C.c_void_p()
-    _lib.check(lib.tbk_wfs_create(ctx.handle, 2, _lib.iptr(mesh), N_STA, N_STA, C.byref(hw)))
-    start = np.array([-0.5, -0.5])
-    pbc = np.ascontiguousarray(np.exp(-2j * np.pi * model._orb[:, model._per].T))     # [dim][orb]
+    grid = Grid(lib, _lib, ctx, model, [nrows, MESH + 1], row0, g_n0)
+    start = [-0.5, -0.5]
     occ = np.array([0], dtype=np.int32)
 
     def step():
-        _lib.check(lib.tbk_wfs_solve_grid_async(hw, hmodel, _lib.dptr(start), _lib.dptr(pbc.view(float)), row0, g_n0))
-        _lib.check(lib.tbk_berry_flux_async(hw, _lib.iptr(occ), 1, 0, 1, 0))
+        grid.solve(start)
+        grid.flux(occ)
 
     def barrier():
         ctx.sync()
@@ -149,19 +406,38 @@ def main():
     ctx.prof_enable(False)
     elapsed = t1 - t0
     prof = ctx.prof_report()
+    ev_ms = ctx.prof_calibrate(50)                  # empty-bracket overhead, measured now: report() makes no GPU call
 
     # results of the last step (outside the timed region)
-    gaps = np.zeros(1)
-    tot = np.zeros(1)
-    _lib.check(lib.tbk_wfs_solve_grid_result(hw, _lib.dptr(gaps)))
-    _lib.check(lib.tbk_berry_flux_result(hw, _lib.dptr(tot), None))
+    gaps = grid.gaps()
+    tot = grid.flux_total()
+
+    extras = {}
+    if world == 1 and not args.headline_only:
+        # ---- sustained: at least one second of back-to-back steps (the K-step burst above is ~1.6 ms)
+        n_sus = max(args.steps, int(math.ceil(1.2 / max(elapsed / args.steps, 1e-6))))
+        ctx.sync()
+        s0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        ctx.sync()
+        s1 = time.perf_counter()
+        extras["sustained"] = {"steps": n_sus, "seconds": s1 - s0, "ms_per_step": 1e3 * (s1 - s0) / n_sus,
+                               "value": MESH * MESH * n_sus / (s1 - s0), "unit": "k-points/s",
+                               "chern": float(grid.flux_total()[0] / (2 * np.pi))}
+        # ---- the same kernels with every launch bracketed over 100 steps (per-kernel averages on a warm, busy chip)
+        extras["kernels_every_launch_bracketed"] = kernel_times(ctx, step, 100, ev_ms)
+        try:
+            extras["python_api"] = python_api_leg(tb, model)
+        except Exception as e:
+            extras["python_api"] = {"error": " ".join(str(e).split())[:300]}
+        extras["configs"] = extra_configs(tb, _lib, lib, ctx, ev_ms, valu)
 
     gather = "none"
     allv = np.array([[tot[0], gaps[0], elapsed]])
+    mine = np.array([tot[0], gaps[0], elapsed])
     if world > 1:
         import torch
-        mine = np.array([tot[0], gaps[0], elapsed])
-
         # results first through gloo (3 doubles per rank, outside the timed region): the line below must not
         # depend on anything that can hang
         buf = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
@@ -169,30 +445,28 @@ def main():
         allv = np.stack([b.numpy() for b in buf])
         gather = "gloo"
 
-    def report(gather):
+    def build_line(gather):
+        """Pure host arithmetic on numbers already in hand (no GPU or collective call: the watchdog may run it)."""
         t_max = float(allv[:, 2].max())
         nk_step = MESH * MESH * world
         chern = float(allv[:, 0].sum() / (2 * np.pi))
-        # a bracket = [event][kernel][event]; an empty bracket measured on the same stream gives
-        # the events' own share, which is subtracted (both numbers are reported)
-        ev_ms = ctx.prof_calibrate(50)
         kern = {}
         for name, rec in prof.items():
             raw = rec["total_ms"] / max(rec["launches"], 1)
-            kern[name] = {"launches": rec["launches"], "avg_ms": max(raw - ev_ms, 0.25 * raw), "avg_bracket_ms": raw}
-        alg = {"solve_grid": BYTES_SOLVE_PER_K * MESH * MESH, "berry_flux": BYTES_FLUX_PER_K * MESH * MESH}
-        dom = max(("solve_grid", "berry_flux"), key=lambda k: kern.get(k, {"avg_ms": 0})["avg_ms"])
+            kern[name] = {"launches": rec["launches"], "avg_bracket_ms": raw, "avg_ms_net": max(raw - ev_ms, 0.25 * raw)}
+        npt = MESH * MESH
+        alg = {"solve_grid": bytes_solve(N_STA) * npt, "berry_flux": bytes_berry(1, N_STA) * npt}
+        vkey = {"solve_grid": "k_grid_rows<2,1>", "berry_flux": "k_flux_rows<1,2>"}
+        dom = max(("solve_grid", "berry_flux"), key=lambda k: kern.get(k, {"avg_bracket_ms": 0})["avg_bracket_ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes (rocprofv3 --pmc), per launch
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-        roof = {}
+        roofs = {}
         for name in ("solve_grid", "berry_flux"):
             if name in kern:
-                gbs = alg[name] / (kern[name]["avg_ms"] * 1e-3) / 1e9
-                roof[name] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": alg[name],
-                              "avg_launch_ms": kern[name]["avg_ms"]}
+                roofs[name] = roof(alg[name], kern[name]["avg_bracket_ms"], kern[name]["avg_ms_net"], vkey[name],
+                                   (MESH + 1) * (MESH + 1), valu)
         out = {
             "metric": "k-points solved/sec (H(k)+eigh) and Berry-flux/sec, Haldane 2048^2 mesh",
             "value": nk_step * args.steps / t_max, "unit": "k-points/s",
@@ -203,29 +477,39 @@ def main():
                                    "%d x %d k-mesh per GPU (BASELINE.json configs[2])" % (MESH, MESH),
                        "global_mesh": [MESH * world, MESH], "start_k": [-0.5, -0.5],
                        "sharding": "k-slabs along mesh axis 0, halo row recomputed", "gather": gather},
-            "roofline": dict(roof.get(dom, {}), kernel=dom, traffic=traffic),
+            "roofline": dict(roofs.get(dom, {}), kernel=dom, traffic=traffic),
             "kernels": kern, "empty_bracket_ms": ev_ms,
-            "roofline_all": roof,
-            "solve_kpts_per_s": MESH * MESH / (kern["solve_grid"]["avg_ms"] * 1e-3) if "solve_grid" in kern else None,
-            "flux_plaq_per_s": MESH * MESH / (kern["berry_flux"]["avg_ms"] * 1e-3) if "berry_flux" in kern else None,
+            "roofline_all": roofs,
+            "solve_kpts_per_s": npt / (kern["solve_grid"]["avg_bracket_ms"] * 1e-3) if "solve_grid" in kern else None,
+            "flux_plaq_per_s": npt / (kern["berry_flux"]["avg_bracket_ms"] * 1e-3) if "berry_flux" in kern else None,
             "check": {"chern": chern, "min_gap": float(allv[:, 1].min())},
             "device": info["name"].strip() or "gfx950", "compute_units": info["compute_units"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        out.update(extras)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        return out, chern
+
+    def report(gather):
+        out, chern = build_line(gather)
         assert args.no_check or abs(chern + 1.0) < 1e-9, "Chern number %r != -1" % chern
         print(json.dumps(out), flush=True)
 
     if world > 1:
         # The path's one collective, the RCCL all-gather over xGMI (tbk_comm_*), run on the same numbers and
-        # checked against the gloo result.  A communicator that never comes up must not cost the measurement:
-        # a watchdog prints the line (rank 0) and ends the process if the RCCL stage is still stuck after 90 s.
+        # checked against the gloo result.  A communicator that never comes up must not cost the measurement,
+        # and must not be reported as success either: the watchdog prints the line built from numbers already
+        # on the host (no GPU call, nothing that can block behind a stuck collective) and exits with status 3.
         import threading
+        fallback = json.dumps(build_line("gloo (rccl all-gather timed out)")[0])
 
         def give_up():
-            if rank == 0:
-                report("gloo (rccl all-gather timed out)")
-            os._exit(0)
+            try:
+                if rank == 0:
+                    sys.stdout.write(fallback + "\n")
+                    sys.stdout.flush()
+            finally:
+                os._exit(3)
 
         dog = threading.Timer(float(os.environ.get("TBK_BENCH_RCCL_TIMEOUT", "90")), give_up)
         dog.daemon = True
@@ -282,7 +566,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    _lib.check(lib.tbk_wfs_free(hw))
+    grid.free()
 
 
 if __name__ == "__main__":

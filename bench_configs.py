@@ -1,31 +1,35 @@
 #!/usr/bin/env python3
-"""Secondary measurements: the other BASELINE.json configs on ONE GPU (device-resident
-timings from HIP events on the library's stream; not the driver's headline line --
-that is bench.py).  Prints one JSON object per config.
+"""Secondary measurements: the other BASELINE.json configs (device-resident timings from HIP events on the
+library's stream; not the driver's headline line -- that is bench.py).  One JSON object per config.
 
-    python bench_configs.py [B] [C] [D] [E] [--reps 5]
+    python bench_configs.py [B] [C] [D] [E] [--reps 5]                 one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench_configs.py --gpus N [D] [E] [--side 257]               N GPUs, one process each
+
+Multi-GPU legs (BASELINE configs[3] and [4]; drivers in pythtb_amd/multi.py):
+  D  Kane-Mele wf_array([4097,513]): the 513 Wilson loops along axis 0 are sharded along axis 1 (65 + 7 x 64 for
+     8 ranks); every rank solves its own window of the global mesh and the (513, 2) eigenphase array is assembled by
+     ONE all-gather-v.
+  E  cubic16 wf_array([257]*3): slabs along axis 0 with a recomputed halo plane, berry_phase(range(8), dir=2) per slab,
+     the (257, 257) phase array and the min gaps assembled by the gather.
+The gather runs through gloo for the reported numbers and once more through tbk_comm_allgatherv_f64 (RCCL over xGMI)
+under a watchdog; `gather` says which of them agreed.  Time per config = max over ranks of the device-resident
+compute (solve + Berry kernels), the gather reported separately.
 """
 import contextlib
 import ctypes as C
 import io
 import json
-import sys
-import time
-
 import os
+import sys
+import threading
+import time
 
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, _ROOT)
 sys.path.insert(0, os.path.join(_ROOT, "tests"))
-
-import pythtb_amd as tb  # noqa: E402
-from pythtb_amd import _lib  # noqa: E402
-
-import helpers as hp  # noqa: E402  (model builders written against the public API)
-
-lib = _lib.lib
 
 
 def timed(ctx, fn, reps):
@@ -39,7 +43,7 @@ def timed(ctx, fn, reps):
     return best
 
 
-def grid_handle(ctx, model, mesh):
+def grid_handle(_lib, lib, ctx, model, mesh):
     n = model._nsta
     h = C.c_void_p()
     m32 = np.ascontiguousarray(mesh, dtype=np.int32)
@@ -49,10 +53,11 @@ def grid_handle(ctx, model, mesh):
     return h, pbc
 
 
-def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    reps = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 5
-    which = args or ["B", "C", "D", "E"]
+def single_gpu(which, reps):
+    import pythtb_amd as tb
+    from pythtb_amd import _lib
+    import helpers as hp
+    lib = _lib.lib
     ctx = _lib.default_context()
     out = []
     if "B" in which:
@@ -67,6 +72,7 @@ def main():
         _lib.check(lib.tbk_dev_upload(ctx.handle, kd, k.ctypes.data_as(C.c_void_p), k.nbytes))
         t_val = timed(ctx, lambda: _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None)), reps)
         t_vec = timed(ctx, lambda: _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, vd)), reps)
+
         def wall(fn, reps=3):
             fn()
             best = 1e30
@@ -88,7 +94,7 @@ def main():
                                       ("D: Kane-Mele 4096x512", hp.kane_mele(tb.tb_model, "odd"), [4097, 513], [0, 1])):
             if tag[0] not in which:
                 continue
-            hw, pbc = grid_handle(ctx, model, mesh)
+            hw, pbc = grid_handle(_lib, lib, ctx, model, mesh)
             hm = model._device_model()
             start = np.array([-0.5, -0.5])
             n = model._nsta
@@ -117,7 +123,7 @@ def main():
         with contextlib.redirect_stdout(io.StringIO()):
             model = hp.cubic16(tb.tb_model)
         mesh = [65, 65, 65]                                   # 64^3 sub-mesh of the 256^3 config (4.4 GB of _wfs)
-        hw, pbc = grid_handle(ctx, model, mesh)
+        hw, pbc = grid_handle(_lib, lib, ctx, model, mesh)
         hm = model._device_model()
         start = np.zeros(3)
         nk = 64 ** 3
@@ -133,6 +139,112 @@ def main():
         _lib.check(lib.tbk_wfs_free(hw))
     for o in out:
         print(json.dumps(o))
+
+
+def multi_gpu(which, side):
+    """Launched under torch.distributed.run: rendezvous (gloo) BEFORE anything touches the GPU."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pythtb_amd as tb
+    from pythtb_amd import _lib, multi
+    import helpers as hp
+    lib = _lib.lib
+    ctx = _lib.default_context()                              # device = LOCAL_RANK
+    gloo = multi.GlooComm(dist)
+
+    def run(tag, fn):
+        """fn(comm) -> (array, gaps).  Timed with the gloo gather; then once more with the RCCL gather as a check."""
+        fn(gloo)                                              # warm-up (allocations, table builds)
+        ctx.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        arr, gaps = fn(gloo)
+        ctx.sync()
+        t1 = time.perf_counter()
+        tmax = gloo.allgatherv(np.array([t1 - t0]), [1] * world).max()
+        return arr, gaps, float(tmax)
+
+    results = []
+    if "D" in which:
+        m = hp.kane_mele(tb.tb_model, "odd")
+        mesh = [4097, 513]
+        arr, gaps, t = run("D", lambda comm: multi.wilson_loops_sharded(tb.wf_array, m, mesh, [-0.5, -0.5], [0, 1], comm, rank, world))
+        results.append(("D", arr, {"config": "configs[3]: Kane-Mele wf_array([4097,513]), 513 Wilson loops (2 bands) sharded over %d GPUs" % world,
+                                   "n_gpus": world, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": 4096 * 512 / t,
+                                   "strings_per_rank": [p[2] - p[1] for p in multi.plan_strings(mesh, 0, world)],
+                                   "checksum": float(np.sum(np.cos(arr)))}))
+    if "E" in which:
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = hp.cubic16(tb.tb_model)
+        mesh = [side, side, side]
+        arr, gaps, t = run("E", lambda comm: multi.mesh_phases_sharded(tb.wf_array, m, mesh, [0.0, 0.0, 0.0], list(range(8)), comm, rank, world))
+        results.append(("E", arr, {"config": "configs[4]: cubic16 wf_array([%d]*3), solve_on_grid + berry_phase(range(8), dir=2), axis-0 slabs over %d GPUs" % (side, world),
+                                   "n_gpus": world, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": (side - 1) ** 3 / t,
+                                   "planes_per_rank": [p[2] for p in multi.plan_slabs(side, world)],
+                                   "gap78": float(gaps[7]), "checksum": float(np.sum(np.cos(arr)))}))
+    # ---- the same gathers through RCCL, checked against the gloo results; a communicator that never comes up must not
+    # hang the job: the watchdog prints what is already known and exits with status 3
+    lines = [dict(r[2], gather="gloo") for r in results]
+
+    def give_up():
+        try:
+            if rank == 0:
+                for ln in lines:
+                    print(json.dumps(dict(ln, gather="gloo (rccl all-gather-v timed out)")), flush=True)
+        finally:
+            os._exit(3)
+    dog = threading.Timer(float(os.environ.get("TBK_BENCH_RCCL_TIMEOUT", "120")), give_up)
+    dog.daemon = True
+    dog.start()
+    gather = "gloo (rccl unavailable)"
+    try:
+        box = [None]
+        if rank == 0:
+            uid = (C.c_ubyte * 128)()
+            _lib.check(lib.tbk_comm_unique_id(uid))
+            box[0] = bytes(uid)
+        dist.broadcast_object_list(box, src=0)
+        rccl = multi.RcclComm(ctx, box[0], world, rank)
+        same = True
+        for tag, arr, _ in results:
+            flat = np.asarray(arr, dtype=float).reshape(-1)
+            counts = [len(x) for x in np.array_split(np.arange(flat.size), world)]
+            got = rccl.allgatherv(flat[sum(counts[:rank]):sum(counts[:rank + 1])], counts)   # uneven blocks of the known result
+            same = same and np.array_equal(got, flat)
+        rccl.close()
+        import torch
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather = "rccl all-gather-v (equal to the gloo gather)" if bool(flag.item()) else "gloo (rccl result differs)"
+    except Exception as e:
+        sys.stderr.write("[bench_configs] rank %d: RCCL gather unavailable (%s)\n" % (rank, " ".join(str(e).split())))
+    dog.cancel()
+    if rank == 0:
+        for ln in lines:
+            print(json.dumps(dict(ln, gather=gather)), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    flags = sys.argv[1:]
+
+    def opt(name, default):
+        return int(flags[flags.index(name) + 1]) if name in flags else default
+    skip = set()
+    for name in ("--reps", "--gpus", "--side"):
+        if name in flags:
+            skip.add(flags[flags.index(name) + 1])
+    which = [a for a in args if a not in skip] or None
+    gpus = opt("--gpus", int(os.environ.get("WORLD_SIZE", "1")))
+    if gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        if int(os.environ.get("WORLD_SIZE", "1")) != gpus:
+            sys.exit("bench_configs.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (gpus, gpus))
+        multi_gpu(which or ["D", "E"], opt("--side", 257))
+    else:
+        single_gpu(which or ["B", "C", "D", "E"], opt("--reps", 5))
 
 
 if __name__ == "__main__":

@@ -229,6 +229,12 @@ int tbk_comm_destroy(tbk_ctx* ctx);
 int tbk_comm_allgather_f64(tbk_ctx* ctx, const double* send_dev, double* recv_dev,
                            int64_t count);
 
+/* uneven contributions (513 Berry strings over 8 ranks; slabs of a 257-plane mesh): rank r contributes
+ * counts[r] doubles, received at recv_dev + displs[r] on every rank; counts/displs are HOST arrays of nranks
+ * entries and count must equal counts[own rank].  One grouped ncclSend/ncclRecv exchange.                  */
+int tbk_comm_allgatherv_f64(tbk_ctx* ctx, const double* send_dev, int64_t count, double* recv_dev,
+                            const int64_t* counts, const int64_t* displs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""profiles/valu.json: VALU wave-instructions per mesh point of the kernels bench.py quotes a VALU fraction for,
+from the committed rocprofv3 PMC summaries (SQ_INSTS_VALU per dispatch / mesh points of that dispatch).
+
+    python profiles/make_valu_json.py
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+# (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
+SOURCES = [
+    ("k_grid_rows<2,1>", "r02c/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r02c/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r02ccfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r02ccfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_solve_ql16<1,true>", "r02ccfg/pmc_per_dispatch.json", "k_solve_ql16<1,true>", 65 ** 3),
+    # fallbacks from earlier collections (used only while the entry above is missing)
+    ("k_grid_rows<2,1>", "r01g/pmc_per_dispatch.json", "k_grid_rows", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r01g/pmc_per_dispatch.json", "k_flux_rows", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r02a/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r02a/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+]
+out = {}
+for name, rel, key, points in SOURCES:
+    if name in out:
+        continue
+    path = os.path.join(HERE, rel)
+    if not os.path.exists(path):
+        continue
+    rec = json.load(open(path)).get(key)
+    if not rec or "SQ_INSTS_VALU" not in rec:
+        continue
+    out[name] = {"kernel": key, "source": "profiles/" + rel, "SQ_INSTS_VALU_per_dispatch": rec["SQ_INSTS_VALU"],
+                 "mesh_points_per_dispatch": points, "valu_wave_insts_per_point": rec["SQ_INSTS_VALU"] / points}
+json.dump(out, open(os.path.join(HERE, "valu.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1))

@@ -90,6 +90,7 @@ SIGNATURES = {
     "tbk_comm_init": (_i, [_p, C.POINTER(C.c_ubyte), _i, _i]),
     "tbk_comm_destroy": (_i, [_p]),
     "tbk_comm_allgather_f64": (_i, [_p, _p, _p, _i64]),
+    "tbk_comm_allgatherv_f64": (_i, [_p, _p, _i64, _p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

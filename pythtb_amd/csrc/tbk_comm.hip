@@ -15,6 +15,8 @@ typedef int (*fn_get_uid)(nccl_uid*);
 typedef int (*fn_init_rank)(void** comm, int nranks, nccl_uid id, int rank);
 typedef int (*fn_destroy)(void* comm);
 typedef int (*fn_allgather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t s);
+typedef int (*fn_sendrecv)(void* buf, size_t count, int dtype, int peer, void* comm, hipStream_t s);
+typedef int (*fn_group)(void);
 typedef const char* (*fn_errstr)(int);
 
 struct Rccl {
@@ -23,6 +25,8 @@ struct Rccl {
     fn_init_rank init_rank = nullptr;
     fn_destroy destroy = nullptr;
     fn_allgather allgather = nullptr;
+    fn_sendrecv send = nullptr, recv = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
     fn_errstr errstr = nullptr;
 };
 Rccl g_rccl;
@@ -40,6 +44,10 @@ int load_rccl() {
     g_rccl.init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
     g_rccl.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy");
     g_rccl.allgather = (fn_allgather)dlsym(lib, "ncclAllGather");
+    g_rccl.send = (fn_sendrecv)dlsym(lib, "ncclSend");
+    g_rccl.recv = (fn_sendrecv)dlsym(lib, "ncclRecv");
+    g_rccl.group_start = (fn_group)dlsym(lib, "ncclGroupStart");
+    g_rccl.group_end = (fn_group)dlsym(lib, "ncclGroupEnd");
     g_rccl.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
     TBK_REQUIRE(g_rccl.get_uid && g_rccl.init_rank && g_rccl.destroy && g_rccl.allgather, TBK_ECOMM,
                 "librccl.so lacks an expected symbol");
@@ -73,6 +81,8 @@ extern "C" int tbk_comm_init(tbk_ctx* ctx, const unsigned char id[128], int nran
     const int nrc = g_rccl.init_rank(&comm, nranks, uid, rank);
     TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, nccl_msg(nrc));
     ctx->comm = comm;
+    ctx->comm_nranks = nranks;
+    ctx->comm_rank = rank;
     return TBK_OK;
 }
 
@@ -83,6 +93,8 @@ extern "C" int tbk_comm_destroy(tbk_ctx* ctx) {
         g_rccl.destroy(ctx->comm);
     }
     ctx->comm = nullptr;
+    ctx->comm_nranks = 0;
+    ctx->comm_rank = -1;
     return TBK_OK;
 }
 
@@ -92,6 +104,34 @@ extern "C" int tbk_comm_allgather_f64(tbk_ctx* ctx, const double* send_dev, doub
     const int nccl_float64 = 8;  // ncclDouble
     const int nrc = g_rccl.allgather(send_dev, recv_dev, (size_t)count, nccl_float64, ctx->comm, ctx->stream);
     TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclAllGather: %s", nccl_msg(nrc));
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    return TBK_OK;
+}
+
+// Ranks contribute different counts (513 strings over 8 ranks, slabs of 257 planes): one grouped exchange in which
+// every rank sends its block to every rank and receives block r at displs[r] -- the standard all-gather-v on
+// point-to-point links, which is what xGMI is.  counts / displs are host arrays of nranks entries (in doubles).
+extern "C" int tbk_comm_allgatherv_f64(tbk_ctx* ctx, const double* send_dev, int64_t count, double* recv_dev,
+                                       const int64_t* counts, const int64_t* displs) {
+    TBK_REQUIRE(ctx && ctx->comm, TBK_ECOMM, "tbk_comm_allgatherv_f64: communicator not initialised");
+    TBK_REQUIRE(recv_dev && counts && displs && count >= 0 && (send_dev || count == 0), TBK_EINVAL,
+                "tbk_comm_allgatherv_f64: bad argument");
+    TBK_REQUIRE(g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end, TBK_ECOMM,
+                "librccl.so lacks ncclSend/ncclRecv/ncclGroupStart/ncclGroupEnd");
+    TBK_REQUIRE(ctx->comm_rank >= 0 && ctx->comm_rank < ctx->comm_nranks && counts[ctx->comm_rank] == count, TBK_EINVAL,
+                "tbk_comm_allgatherv_f64: counts[rank] (%lld) != count (%lld)",
+                (long long)(ctx->comm_rank >= 0 && ctx->comm_rank < ctx->comm_nranks ? counts[ctx->comm_rank] : -1), (long long)count);
+    const int nccl_float64 = 8;  // ncclDouble
+    int nrc = g_rccl.group_start();
+    TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclGroupStart: %s", nccl_msg(nrc));
+    for (int r = 0; r < ctx->comm_nranks && nrc == 0; ++r) {
+        if (count > 0) nrc = g_rccl.send(const_cast<double*>(send_dev), (size_t)count, nccl_float64, r, ctx->comm, ctx->stream);
+        if (nrc == 0 && counts[r] > 0)
+            nrc = g_rccl.recv(recv_dev + displs[r], (size_t)counts[r], nccl_float64, r, ctx->comm, ctx->stream);
+    }
+    const int erc = g_rccl.group_end();
+    TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclSend/ncclRecv: %s", nccl_msg(nrc));
+    TBK_REQUIRE(erc == 0, TBK_ECOMM, "ncclGroupEnd: %s", nccl_msg(erc));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
     return TBK_OK;
 }

@@ -128,6 +128,7 @@ struct tbk_ctx {
     // RCCL
     void* rccl_lib = nullptr;
     void* comm = nullptr;
+    int comm_nranks = 0, comm_rank = -1;
 };
 
 int tbk_ctx_scratch(tbk_ctx* ctx, size_t bytes, void** out);

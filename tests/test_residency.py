@@ -124,3 +124,60 @@ def test_position_hwf_mesh_reads_the_resident_array(tb):
     r2, v2 = slab.position_hwf(host.reshape(-1, 9, 9)[:, :4], 2, hwf_evec=True, basis="orbital")
     assert np.max(np.abs(hw2.reshape(-1, 4) - r2)) < 1e-12
     assert np.max(np.abs(np.abs(vec2.reshape(-1, 4, 9)) - np.abs(v2))) < 1e-9
+
+
+def test_multi_gpu_drivers_single_rank_rccl_and_every_ranks_share(tb):
+    """pythtb_amd/multi.py on the one GPU of the box: (i) world = 1 through the RCCL all-gather-v (send/recv to self),
+    (ii) every rank's share of a world of 3 and of 8 computed in turn with a recording communicator -- the
+    assembled arrays equal the unsharded calls bit for bit (configs[3]: strings along axis 0 cut along axis 1,
+    uneven counts; configs[4]: axis-0 slabs of a 3-D mesh)."""
+    import ctypes as C
+    from pythtb_amd import _lib, multi
+    lib, ctx = _lib.lib, _lib.default_context()
+    km = hp.kane_mele(tb.tb_model, "odd")
+    mesh, start = [65, 19], [-0.5, -0.5]
+    full = tb.wf_array(km, mesh)
+    full.solve_on_grid(start)
+    ref = full.berry_phase([0, 1], 0, contin=False, berry_evals=True)
+    m16 = hp.cubic16(tb.tb_model)
+    mesh3, start3 = [10, 9, 33], [0.0, 0.1, 0.2]
+    full3 = tb.wf_array(m16, mesh3)
+    g3 = full3.solve_on_grid(start3)
+    ref3 = full3.berry_phase(range(8), 2, contin=False)
+
+    uid = (C.c_ubyte * 128)()
+    _lib.check(lib.tbk_comm_unique_id(uid))
+    rccl = multi.RcclComm(ctx, bytes(uid), 1, 0)
+    try:
+        got, _ = multi.wilson_loops_sharded(tb.wf_array, km, mesh, start, [0, 1], rccl, 0, 1)
+        assert np.array_equal(got, ref)
+        got3, gaps3 = multi.mesh_phases_sharded(tb.wf_array, m16, mesh3, start3, list(range(8)), rccl, 0, 1)
+        assert np.array_equal(got3, ref3) and np.array_equal(gaps3, g3)
+        # uneven blocks through the all-gather-v itself (one rank: its own block at displacement 0)
+        x = np.arange(7, dtype=float)
+        assert np.array_equal(rccl.allgatherv(x, [7]), x)
+    finally:
+        rccl.close()
+
+    class Recorder(object):
+        """Stands in for the collective when the ranks run one after another on one GPU."""
+        def __init__(self, world):
+            self.world, self.parts, self.rank = world, {}, 0
+        def allgatherv(self, mine, counts):
+            key = len(self.parts.setdefault(self.rank, []))
+            self.parts[self.rank].append(np.array(mine, dtype=float).reshape(-1))
+            assert self.parts[self.rank][key].size == counts[self.rank]
+            return np.zeros(int(sum(counts)))                 # placeholder: assembled below from all ranks
+
+    for world in (3, 8):
+        rec = Recorder(world)
+        for r in range(world):
+            rec.rank = r
+            multi.wilson_loops_sharded(tb.wf_array, km, mesh, start, [0, 1], rec, r, world)
+        assert np.array_equal(np.concatenate([rec.parts[r][0] for r in range(world)]).reshape(19, 2), ref)
+        rec = Recorder(world)
+        for r in range(world):
+            rec.rank = r
+            multi.mesh_phases_sharded(tb.wf_array, m16, mesh3, start3, list(range(8)), rec, r, world)
+        assert np.array_equal(np.concatenate([rec.parts[r][0] for r in range(world)]).reshape(10, 9), ref3)
+        assert np.array_equal(np.min([rec.parts[r][1] for r in range(world)], axis=0), g3)

@@ -145,3 +145,94 @@ def test_two_rank_gloo_run(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "GLOO_SHARD_OK 2" in res.stdout
+
+
+# ---------------------------------------------------------------- multi-GPU drivers of configs[3] / [4] (pythtb_amd/multi.py)
+MULTI_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["TBK_ROOT"]); sys.path.insert(0, os.path.join(os.environ["TBK_ROOT"], "tests"))
+from oracle import tb_oracle as orc
+from pythtb_amd import multi
+import pythtb_amd as tb
+import helpers as hp
+
+
+class OracleWf(object):
+    '''Stand-in for wf_array on a box without a GPU: the oracle solves the GLOBAL mesh and hands out the window
+    (numpy's eigh is a function of the matrix alone, so this is what a window solve returns).'''
+    def __init__(self, model, mesh):
+        self.model, self.mesh = model, [int(x) for x in mesh]
+    def solve_on_grid_window(self, start, offset, gmesh):
+        wfs, gaps = orc.solve_on_grid(self.model, list(gmesh), start, vectorised=True)
+        sl = tuple(slice(o, o + n) for o, n in zip(offset, self.mesh))
+        self.wfs = wfs[sl]
+        # min gaps over THIS window's solved points
+        ev = []
+        idx = np.indices(self.mesh).reshape(len(self.mesh), -1).T
+        for ii in idx:
+            k = [start[d] + ((ii[d] + offset[d]) % (gmesh[d] - 1)) / (gmesh[d] - 1) for d in range(len(self.mesh))]
+            ev.append(np.linalg.eigvalsh(orc.gen_ham(self.model, k)))
+        return np.diff(np.array(ev), axis=1).min(axis=0)
+    def berry_phase(self, occ, dir, contin=True, berry_evals=False):
+        return orc.berry_phase(self.wfs, len(self.mesh), list(occ), dir, contin=contin, berry_evals=berry_evals)
+
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+comm = multi.GlooComm(dist)
+# configs[3] in small: Kane-Mele, 7 strings over `world` ranks (uneven for 2 and 3)
+km = hp.kane_mele(tb.tb_model, "odd")
+mesh, start = [9, 7], [-0.5, -0.5]
+got, _ = multi.wilson_loops_sharded(OracleWf, km, mesh, start, [0, 1], comm, rank, world)
+counts = [p[2] - p[1] for p in multi.plan_strings(mesh, 0, world)]
+assert sum(counts) == 7 and len(set(counts)) > 1, counts
+full, _ = orc.solve_on_grid(km, mesh, start, vectorised=True)
+ref = orc.berry_phase(full, 2, [0, 1], 0, contin=False, berry_evals=True)
+assert got.shape == (7, 2) and np.array_equal(got, ref), np.abs(got - ref).max()
+got1, _ = multi.wilson_loops_sharded(OracleWf, km, mesh, start, [2, 3], comm, rank, world, berry_evals=False)
+assert np.array_equal(got1, orc.berry_phase(full, 2, [2, 3], 0, contin=False))
+# configs[4] in small: a 3-orbital cubic model, slabs along axis 0 (5 plaquette rows over `world` ranks), strings along 2
+m3 = hp.random_model(tb.tb_model, 3, 3, 1, 11)
+mesh3, start3 = [6, 4, 5], [0.1, 0.2, 0.3]
+ph, gaps = multi.mesh_phases_sharded(OracleWf, m3, mesh3, start3, [0, 1], comm, rank, world, dir=2)
+full3, gaps3 = orc.solve_on_grid(m3, mesh3, start3, vectorised=True)
+assert ph.shape == (6, 4) and np.array_equal(ph, orc.berry_phase(full3, 3, [0, 1], 2, contin=False))
+assert np.max(np.abs(gaps - gaps3)) < 1e-12
+if rank == 0:
+    print("MULTI_DRIVERS_OK", world, counts)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_gpu_drivers_on_gloo_with_uneven_counts(tmp_path, world):
+    """The drivers bench_configs.py --gpus N runs for BASELINE configs[3] / [4], here with 2 and 3 gloo ranks, an
+    oracle-backed wf_array stand-in and string counts that do not divide evenly (all-gather-v)."""
+    pytest.importorskip("torch")
+    script = tmp_path / "multi_worker.py"
+    script.write_text(MULTI_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TBK_ROOT=ROOT, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "MULTI_DRIVERS_OK %d" % world in res.stdout
+
+
+def test_multi_plans_cover_every_string_and_plane_once():
+    from pythtb_amd import multi
+    for world in (1, 2, 3, 5, 8):
+        p = multi.plan_strings([4097, 513], 0, world)
+        assert [x[0] for x in p] == [1] * world
+        assert p[0][1] == 0 and p[-1][2] == 513 and all(p[i][2] == p[i + 1][1] for i in range(world - 1))
+        assert all(x[4] - x[3] >= 2 and x[3] <= x[1] and x[2] <= x[4] for x in p)
+        s = multi.plan_slabs(257, world)
+        assert sum(x[2] for x in s) == 257 and s[0][0] == 0 and s[-1][0] + s[-1][1] == 257
+    p = multi.plan_strings([9, 3], 0, 3)                      # one string per rank: windows widened to two points
+    assert [(x[1], x[2]) for x in p] == [(0, 1), (1, 2), (2, 3)] and all(x[4] - x[3] == 2 for x in p)
