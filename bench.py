@@ -101,6 +101,30 @@ def _cpu_leg(args):
     return t1 - t0, t2 - t1, float(flux)
 
 
+def usable_cores():
+    """Host cores this process may really use: os.cpu_count() capped by the scheduler affinity mask and by the cgroup
+    CPU quota (a container on a 256-thread host is often limited to a handful)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(sample_mesh=257):
     """Oracle (a NumPy port of the reference's per-k / per-plaquette Python loops, kind "port") on a bounded sample of
     the headline workload: one host core, then one worker per host core on as many sub-meshes of the same size."""
@@ -108,7 +132,7 @@ def cpu_baseline(sample_mesh=257):
     n = sample_mesh
     nk = (n - 1) * (n - 1)
     ts, tf, flux = _cpu_leg((n, [-0.5, -0.5]))
-    cores = os.cpu_count() or 1
+    cores = min(usable_cores(), 64)                 # (more workers than that only measures the fork)
     out = {
         "value": nk / (ts + tf), "unit": "k-points/s", "cores": 1, "kind": "port",
         "sample": "Haldane %dx%d sub-mesh (%d k): oracle solve_on_grid %.2fs + berry_flux %.2fs on one core"
@@ -118,15 +142,20 @@ def cpu_baseline(sample_mesh=257):
     if cores > 1:
         try:
             ctx = mp.get_context("fork")              # no exec; the GPU has not been touched yet
-            jobs = [(n, [-0.5 + 0.37 * i / cores, -0.5]) for i in range(cores)]
+            # one worker per usable core; the sub-mesh shrinks on many-core hosts so that the leg stays bounded even if
+            # the cores turn out to be shared (an oversubscribed host must not turn a 3 s leg into minutes)
+            nw = 257 if cores <= 16 else 129
+            nkw = (nw - 1) * (nw - 1)
+            jobs = [(nw, [-0.5 + 0.37 * i / cores, -0.5]) for i in range(cores)]
             t0 = time.perf_counter()
             with ctx.Pool(cores) as pool:
                 res = pool.map(_cpu_leg, jobs)
             wall = time.perf_counter() - t0
             out["all_cores"] = {
-                "value": nk * cores / wall, "unit": "k-points/s", "cores": cores, "kind": "port",
-                "sample": "%d workers (os.cpu_count()), each the same %dx%d sub-mesh solve + flux; wall %.2fs incl. fork"
-                          % (cores, n - 1, n - 1, wall),
+                "value": nkw * cores / wall, "unit": "k-points/s", "cores": cores, "kind": "port",
+                "os_cpu_count": os.cpu_count(),
+                "sample": "%d workers (usable cores: os.cpu_count() = %s capped by affinity and cgroup quota), each a %dx%d "
+                          "sub-mesh solve + flux; wall %.2fs incl. fork" % (cores, os.cpu_count(), nw - 1, nw - 1, wall),
                 "slowest_worker_s": max(r[0] + r[1] for r in res),
             }
         except Exception as e:                        # a sandbox without fork/semaphores must not cost the GPU numbers
