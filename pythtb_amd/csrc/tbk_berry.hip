@@ -491,7 +491,10 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
     const int slice = blockIdx.x / A.bpb;            // blocks never straddle slices
     const int blk = blockIdx.x - slice * A.bpb;
     const bool live = blk * 4 + wib < A.bps;         // idle waves shadow the last tile, contribute 0
-    const int t = live ? blk * 4 + wib : A.bps - 1;
+    // Tiles are dealt in DESCENDING row order: the array was usually written a moment ago by solve_on_grid, rows
+    // ascending, so the rows still sitting in the last-level cache (and not yet written back) are the last ones --
+    // reading newest-first takes them from the cache while the older rows' write-back drains.
+    const int t = live ? A.bps - 1 - (blk * 4 + wib) : A.bps - 1;
     const int trow = t / A.ncolw, colw = t - trow * A.ncolw;
     const int ia0 = trow * A.ti;
     const int ia1 = min(ia0 + A.ti, A.na);
@@ -1210,6 +1213,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             W.buf0 = buf0;
             W.buf1 = buf1;
             W.ywork = ywork;
+            W.flags = ctx->flags_dev;
             {
                 ProfScope ps(ctx, "link_polar_big");
                 hipLaunchKernelGGL(k_link_polar_big, dim3((unsigned)std::min<int64_t>(ns * L, nblk)), dim3(256), 0, ctx->stream, W);
@@ -1244,7 +1248,15 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 }
                 TBK_HIP(hipMemcpyAsync(out_h.data(), out_dev, (size_t)ns * nocc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                 TBK_HIP(hipMemcpyAsync(hmax_h.data(), hmax_dev, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                int polar_flag = 0;
+                TBK_HIP(hipMemcpyAsync(&polar_flag, ctx->flags_dev + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 TBK_HIP(hipStreamSynchronize(ctx->stream));
+                if (polar_flag) {
+                    TBK_HIP(hipMemsetAsync(ctx->flags_dev + 1, 0, sizeof(int), ctx->stream));
+                    tbk_set_error("tbk_berry_phase: a link overlap matrix is singular (no polar factor U Vh): the occupied "
+                                  "subspaces of two neighbouring points are orthogonal in some direction");
+                    return TBK_ENOCONV;
+                }
                 rc = tbk_eigh_check(ctx, nocc);
                 if (rc) return rc;
                 bool all_ok = true;

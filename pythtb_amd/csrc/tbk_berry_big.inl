@@ -270,6 +270,7 @@ struct WilsonBigArgs {
     cd* buf0;        // [ns][nlinks][nocc^2]  link factors (result of step 1), then tree levels
     cd* buf1;        // same size, ping-pong partner
     cd* ywork;       // [gridDim.x][nocc^2]
+    int* flags;      // ctx->flags_dev: word 1 is set when a polar iteration fails to converge (singular link matrix)
 };
 
 __global__ __launch_bounds__(256) void k_link_polar_big(const WilsonBigArgs A) {
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void k_link_polar_big(const WilsonBigArgs A) {
             X[e] = acc;
         }
         __syncthreads();
+        bool converged = false;
         for (int it = 0; it < 200; ++it) {
             red[tid] = wg_matmul<true, true>(m, X, X, Y, 1.0, nullptr, 0.0);      // Y = X^H X, residual ||Y - I||_F^2
             __syncthreads();
@@ -305,8 +307,14 @@ __global__ __launch_bounds__(256) void k_link_polar_big(const WilsonBigArgs A) {
             cd* t = X;
             X = X2;
             X2 = t;
-            if (r2 < 1e-14) break;      // residual 1e-7 before this update, its square after it
+            if (r2 < 1e-14) {           // residual 1e-7 before this update, its square after it
+                converged = true;
+                break;
+            }
         }
+        // A singular overlap matrix (orthogonal occupied subspaces at neighbouring points) has no polar factor: the
+        // iteration keeps its zero singular values at zero.  Report it instead of handing a non-unitary factor on.
+        if (!converged && tid == 0) atomicExch(A.flags + 1, 1);
         if (X != home) {
             for (int e = tid; e < nn; e += 256) home[e] = X[e];
         }

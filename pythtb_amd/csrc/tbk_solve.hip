@@ -241,6 +241,9 @@ struct Sweep {
 };
 
 template <int N, bool VEC>
+__device__ __forceinline__ void ql_small(SmallMat<N>& M);   // n = 3, 4: direct solver, defined below
+
+template <int N, bool VEC>
 __device__ __forceinline__ void jacobi_small(SmallMat<N>& M) {
     if constexpr (N == 1) {
         return;
@@ -274,6 +277,10 @@ __device__ __forceinline__ void jacobi_small(SmallMat<N>& M) {
             M.v[1][1] = cd{v0.x, -v0.y};
         }
     } else {
+#ifndef TBK_SMALL_JACOBI
+        ql_small<N, VEC>(M);      // n = 3, 4: Householder + implicit QL (-DTBK_SMALL_JACOBI keeps the cyclic Jacobi for A/B runs)
+        return;
+#endif
         for (int sweep = 0; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
             double off = 0.0, dia = 0.0;
 #pragma unroll
@@ -286,6 +293,189 @@ __device__ __forceinline__ void jacobi_small(SmallMat<N>& M) {
             Sweep<N, 0, 1, VEC>::run(M);
         }
     }
+}
+
+// 1 / sqrt(t) to full double precision from the hardware estimate (relative error 5e-8 measured,
+// profiles/microbench/rsq_precision.hip) by one cubically convergent step:
+// with e = 1 - t y^2,  1/sqrt(t) = y (1 - e)^(-1/2) = y (1 + e/2 + 3 e^2/8 + O(e^3)),  e^3 ~ 1e-21
+__device__ __forceinline__ double rsqrt_full(const double t) {
+    const double y = __builtin_amdgcn_rsq(t);
+    const double e = fma(-t * y, y, 1.0);
+    const double ye = y * e;
+    return fma(ye, fma(e, 0.375, 0.5), y);
+}
+
+// ---- n = 3, 4: the DIRECT solver, one matrix per thread, everything in registers with static indices:
+// Householder tridiagonalisation (N - 2 reflections) and implicit-shift QL with accumulated eigenvectors -- the
+// recurrences of LAPACK's zhetrd + zsteqr, which numpy.linalg.eigh runs for the reference (pythtb.py:939-947).
+// Cyclic Jacobi needs 4-5 sweeps of 6 rotations on a 4 x 4 matrix, each rotation touching two rows and columns
+// of A and all of V (~4.6 k wave-instructions per 64 points measured on Kane-Mele, profiles/r02a: the kernel is
+// VALU-bound at 78 % of the fp64 issue rate); tridiagonalisation costs a few hundred instructions once and QL
+// about two shifts of at most N - 1 plane rotations per eigenvalue.
+// Every thread runs the same full-range sweep i = N-2 .. 0; a position takes part only inside the thread's
+// active block [l, m) (EXEC-masked), so register indices stay static while l and m are data.
+template <int N, bool VEC>
+__device__ __forceinline__ void ql_small(SmallMat<N>& M) {
+    static_assert(N == 3 || N == 4, "ql_small: n = 3, 4");
+    cd a[N][N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        a[r][r] = cd{M.dg[r], 0.0};
+#pragma unroll
+        for (int c = r + 1; c < N; ++c) {
+            a[r][c] = M.up[r][c];
+            a[c][r] = cconj(M.up[r][c]);
+        }
+    }
+    double d[N], e[N];
+    cd delta{1.0, 0.0};                        // D_{K+1} = D_K t_K / |t_K| makes the subdiagonal real
+#pragma unroll
+    for (int K = 0; K + 1 < N; ++K) {
+        cd tK = a[K + 1][K];
+        if (K + 2 < N) {                       // a reflection annihilates rows K+2.. of column K
+            double sigma = 0.0;
+#pragma unroll
+            for (int r = K + 1; r < N; ++r) sigma += cabs2(a[r][K]);
+            const double absa2 = cabs2(tK);
+            if (sigma > absa2) {
+                const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
+                double absa = 0.0;
+                cd ph{1.0, 0.0};
+                if (absa2 > 0.0) {
+                    const double inv_a = rsqrt_full(absa2);
+                    absa = absa2 * inv_a;
+                    ph = cd{tK.x * inv_a, tK.y * inv_a};
+                }
+                cd u[N];
+#pragma unroll
+                for (int r = 0; r < N; ++r) u[r] = r > K + 1 ? a[r][K] : cd{0.0, 0.0};
+                u[K + 1] = cd{ph.x * (absa + nrm), ph.y * (absa + nrm)};
+                const double beta = 1.0 / (nrm * (nrm + absa));          // 2 / (u^+ u)
+                tK = cd{-ph.x * nrm, -ph.y * nrm};
+                cd p[N];
+                double upr = 0.0;
+#pragma unroll
+                for (int r = K + 1; r < N; ++r) {
+                    cd acc{0.0, 0.0};
+#pragma unroll
+                    for (int c = K + 1; c < N; ++c) cfma(acc, a[r][c], u[c]);
+                    p[r] = cd{acc.x * beta, acc.y * beta};
+                    upr += u[r].x * p[r].x + u[r].y * p[r].y;
+                }
+                const double kappa = 0.5 * beta * upr;
+                cd q[N];
+#pragma unroll
+                for (int r = K + 1; r < N; ++r) q[r] = cd{p[r].x - kappa * u[r].x, p[r].y - kappa * u[r].y};
+#pragma unroll
+                for (int r = K + 1; r < N; ++r)
+#pragma unroll
+                    for (int c = K + 1; c < N; ++c) {   // A -= u q^+ + q u^+
+                        a[r][c].x -= (u[r].x * q[c].x + u[r].y * q[c].y) + (q[r].x * u[c].x + q[r].y * u[c].y);
+                        a[r][c].y -= (u[r].y * q[c].x - u[r].x * q[c].y) + (q[r].y * u[c].x - q[r].x * u[c].y);
+                    }
+                if (VEC) {
+#pragma unroll
+                    for (int r = 0; r < N; ++r) {       // Z -= (beta Z u) u^+
+                        cd w{0.0, 0.0};
+#pragma unroll
+                        for (int c = K + 1; c < N; ++c) cfma(w, M.v[r][c], u[c]);
+                        w = cd{w.x * beta, w.y * beta};
+#pragma unroll
+                        for (int c = K + 1; c < N; ++c) {
+                            M.v[r][c].x -= w.x * u[c].x + w.y * u[c].y;
+                            M.v[r][c].y -= w.y * u[c].x - w.x * u[c].y;
+                        }
+                    }
+                }
+            }
+        }
+        d[K] = a[K][K].x;
+        const double t2 = cabs2(tK);
+        double mag = 0.0;
+        if (t2 > 0.0) {
+            const double inv = rsqrt_full(t2);
+            mag = t2 * inv;
+            delta = cmul(delta, cd{tK.x * inv, tK.y * inv});
+        }
+        e[K] = mag;
+        if (VEC) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) M.v[r][K + 1] = cmul(M.v[r][K + 1], delta);
+        }
+    }
+    d[N - 1] = a[N - 1][N - 1].x;
+    e[N - 1] = 0.0;
+
+    int l = 0;
+    for (int iter = 0; iter < 30 * N; ++iter) {
+        // first coupling at or after l that is not negligible, then the end m of its block
+        bool negl[N];
+#pragma unroll
+        for (int j = 0; j + 1 < N; ++j) negl[j] = fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1]));
+        negl[N - 1] = true;
+        int lo = N - 1;
+#pragma unroll
+        for (int j = N - 2; j >= 0; --j) lo = (j >= l && !negl[j]) ? j : lo;
+        if (lo == N - 1) break;
+        l = lo;
+        int m = N - 1;
+#pragma unroll
+        for (int j = N - 2; j >= 0; --j) m = (j > l && negl[j]) ? j : m;
+        double dl = d[0], dl1 = d[1], el = e[0], dm = d[N - 1];
+#pragma unroll
+        for (int j = 1; j + 1 < N; ++j) {
+            dl = l == j ? d[j] : dl;
+            dl1 = l == j ? d[j + 1] : dl1;
+            el = l == j ? e[j] : el;
+        }
+#pragma unroll
+        for (int j = 1; j + 1 < N; ++j) dm = m == j ? d[j] : dm;
+        // Wilkinson-type shift (its accuracy only affects the speed of convergence: hardware estimates are enough)
+        double g = (dl1 - dl) * (0.5 * __builtin_amdgcn_rcp(el));
+        const double rr = __builtin_amdgcn_sqrt(fma(g, g, 1.0));
+        g = dm - dl + el * __builtin_amdgcn_rcp(g + copysign(rr, g));
+        double sn = 1.0, cs = 1.0, pp = 0.0;
+        bool alive = true;
+#pragma unroll
+        for (int i = N - 2; i >= 0; --i) {
+            if (alive && i >= l && i < m) {
+                const double f = sn * e[i], b = cs * e[i];
+                const double t = f * f + g * g;
+                if (t > 0.0) {
+                    const double inv = rsqrt_full(t), r = t * inv;
+                    e[i + 1] = r;
+                    sn = f * inv;
+                    cs = g * inv;
+                    g = d[i + 1] - pp;
+                    const double r2 = (d[i] - g) * sn + 2.0 * cs * b;
+                    pp = sn * r2;
+                    d[i + 1] = g + pp;
+                    g = cs * r2 - b;
+                    if (VEC) {
+#pragma unroll
+                        for (int r_ = 0; r_ < N; ++r_) {
+                            const cd zi = M.v[r_][i], zj = M.v[r_][i + 1];
+                            M.v[r_][i + 1] = cd{sn * zi.x + cs * zj.x, sn * zi.y + cs * zj.y};
+                            M.v[r_][i] = cd{cs * zi.x - sn * zj.x, cs * zi.y - sn * zj.y};
+                        }
+                    }
+                } else {                       // r == 0 (underflow): tql2's recovery
+                    d[i + 1] -= pp;
+                    alive = false;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (alive && j == l) {
+                d[j] -= pp;
+                e[j] = g;
+            }
+            if (j == m) e[j] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) M.dg[j] = d[j];
 }
 
 // rank of each eigenvalue in ascending order (stable: ties keep index order)
@@ -561,6 +751,18 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     double gmin[N > 1 ? N - 1 : 1];
 #pragma unroll
     for (int b = 0; b + 1 < N; ++b) gmin[b] = __longlong_as_double(0x7ff0000000000000ll);
+    // Staging-buffer slots (16 B each).  A lane writes slot lane*N + o and reads slot i*64 + lane; ds_write_b128 serves
+    // 8 consecutive lanes per LDS cycle, and for even N those lanes' slots repeat mod 8 (2-way conflicts for N = 2, 4-way
+    // for N = 4: 3.5 conflict cycles per LDS instruction measured, profiles/r01g).  XOR-ing bits 0-1 of the slot with
+    // bits 3-4 spreads every 8-lane group over all 32 banks and only permutes slots inside aligned groups of four, so
+    // the contiguous reads stay conflict-free.
+    auto slot = [](const int s) { return (N & 1) ? s : (s ^ ((s >> 3) & 3)); };
+    int wslot[N], rslot[N];
+#pragma unroll
+    for (int o = 0; o < N; ++o) {
+        wslot[o] = slot(lane * N + o);
+        rslot[o] = slot(o * 64 + lane);
+    }
     // The per-point table entries of chunk jc+1 are fetched while chunk jc is being solved: vmcnt counts
     // loads and stores in issue order, so a load issued AFTER a chunk's stores could only be waited for
     // together with them -- every wavefront would sit out the full write latency once per chunk.
@@ -666,15 +868,15 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
                         val.y = rk[b] == r ? cand.y : val.y;
                     }
                 }
-                stage[lane * N + o] = val;
+                stage[wslot[o]] = val;
             }
             asm volatile("" ::: "memory");
             cd* dst = G.wv.data + ((int64_t)r * G.wv.npts + point0) * N;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const int e = i * 64 + lane;
-                if constexpr (FULL) dst[e] = stage[e];
-                else if (e < nvalid) dst[e] = stage[e];
+                if constexpr (FULL) dst[e] = stage[rslot[i]];
+                else if (e < nvalid) dst[e] = stage[rslot[i]];
             }
         }
     };

@@ -51,16 +51,6 @@ __device__ __forceinline__ double row_allsum(double v) {
 template <int SRC>
 __device__ __forceinline__ cd rowbcast_c(const cd v) { return cd{rowbcast_d<SRC>(v.x), rowbcast_d<SRC>(v.y)}; }
 
-// 1 / sqrt(t) to full double precision from the hardware estimate (relative error 5e-8 measured,
-// profiles/microbench/rsq_precision.hip) by one cubically convergent step:
-// with e = 1 - t y^2,  1/sqrt(t) = y (1 - e)^(-1/2) = y (1 + e/2 + 3 e^2/8 + O(e^3)),  e^3 ~ 1e-21
-__device__ __forceinline__ double rsqrt_full(const double t) {
-    const double y = __builtin_amdgcn_rsq(t);
-    const double e = fma(-t * y, y, 1.0);
-    const double ye = y * e;
-    return fma(ye, fma(e, 0.375, 0.5), y);
-}
-
 // ---- Householder step K: pass 1 (p = A u, w = Z u over the columns c > K) and pass 2 (rank-2 updates)
 template <int K, int CIDX, bool VEC>
 __device__ __forceinline__ void ql16_pass1(const cd (&a)[16], const cd (&z)[16], const cd u, cd& p, cd& w) {

@@ -181,3 +181,22 @@ def test_multi_gpu_drivers_single_rank_rccl_and_every_ranks_share(tb):
             multi.mesh_phases_sharded(tb.wf_array, m16, mesh3, start3, list(range(8)), rec, r, world)
         assert np.array_equal(np.concatenate([rec.parts[r][0] for r in range(world)]).reshape(10, 9), ref3)
         assert np.array_equal(np.min([rec.parts[r][1] for r in range(world)], axis=0), g3)
+
+
+def test_singular_link_matrix_is_reported_not_returned(tb):
+    """Wilson-loop eigenphases need the polar factor of every link overlap matrix; a rank-deficient one
+    (orthogonal occupied subspaces at neighbouring points) has none.  The workgroup-level pipeline (3+ bands) must
+    raise instead of multiplying a non-unitary factor into the loop."""
+    m = hp.quiet(tb.tb_model, 1, 1, [[1.0]], [[0.0], [0.2], [0.5], [0.7]])
+    m.set_hop(-1.0, 0, 1, [0])
+    w = tb.wf_array(m, [4])
+    e = np.identity(4, dtype=complex)
+    w[0] = e                                   # occupied {e0, e1, e2}
+    w[1] = e[[1, 2, 3, 0]]                     # occupied {e1, e2, e3}: overlap with the previous point has rank 2
+    w[2] = e
+    w[3] = e
+    with pytest.raises(tb._lib.TbkError, match="singular"):
+        w.berry_phase([0, 1, 2], berry_evals=True, contin=False)
+    w[1] = e                                   # repaired: a trivial loop, all eigenphases zero; the sticky flag was cleared
+    got = w.berry_phase([0, 1, 2], berry_evals=True, contin=False)
+    assert np.max(np.abs(got)) < 1e-12
