@@ -335,7 +335,9 @@ def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
         kt = kernel_times(ctx, step, 2, ev_ms)
         npt = (side - 1) ** 3
         gaps = g.gaps()
-        bp_ms = sum(v["avg_bracket_ms"] for k, v in kt.items() if k not in ("solve_grid", "grid_tables"))
+        # (chain_links / chain_lu are brackets INSIDE chain_partial_det: not added twice)
+        bp_ms = sum(v["avg_bracket_ms"] * v["launches"] / max(kt["solve_grid"]["launches"], 1) for k, v in kt.items()
+                    if k not in ("solve_grid", "grid_tables", "chain_links", "chain_lu"))
         out.append({"config": "BASELINE configs[4] on one GPU: cubic16 (16 orbitals, 888 hops) wf_array([%d]*3) solve_on_grid + "
                               "berry_phase(range(8), dir=2)" % side,
                     "kpts": npt, "kernels": kt, "solve_kpts_per_s": npt / (kt["solve_grid"]["avg_bracket_ms"] * 1e-3),

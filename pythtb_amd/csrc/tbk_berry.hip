@@ -919,6 +919,161 @@ struct ChainArgs {
     int* flags;
 };
 
+// ---- det-type Berry phase, 5..8 occupied bands of WIDE states (ncomp >= 8; BASELINE configs[4]: 8 of 16 bands,
+// 16 components): two kernels, each a WAVEFRONT per (string, segment).
+// With a thread per string every lane walks its own 256-byte rows and a load instruction touches 64 different
+// cache lines: strings along the last mesh axis over-fetched 8x and ran at 0.4 TB/s (82 ms for the 257^3 array,
+// profiles/r02a).
+//   k_chain_links_wave  streams the points of ONE string: a point's occupied vectors are NOCC rows of ncomp
+//     contiguous c128, loaded by the whole wave (each point once, two points ahead in flight), staged in LDS; the link
+//     matrix M[a][b] = <u_a(i) | u_b(i+1)> is one entry per lane (lane = a NOCC + b) and leaves as one contiguous
+//     NOCC^2 x 16 B store.  Few registers, 4 KB of LDS per wave: full occupancy.
+//   k_chain_lu_wave     reads the link matrices back 32 at a time (coalesced), turns them through LDS so that a lane
+//     holds one whole matrix, runs the register-resident pivoted LU (det_small) -- one LU shared by 64 lanes through
+//     shuffles would cost ~600 instructions per link, this ~25 -- and multiplies the determinants with a fixed-shape
+//     tree, passes in order: bit-reproducible.
+// The workspace holds NOCC^2 c128 per link; strings go in batches that bound it (tbk_berry_phase).
+// LDS hand-off between the lanes of ONE wavefront: wait for this wave's LDS operations only.  (A release fence
+// would also wait for vmcnt(0) -- every global prefetch and every store in flight: measured 15 us per link.)
+__device__ __forceinline__ void lds_sync_wave() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");   // LDS address space only
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+template <int NOCC, int NLD>   // NLD = ceil(NOCC * ncomp / 64): 16-byte loads per lane and point
+__global__ __launch_bounds__(256) void k_chain_links_wave(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ ws) {
+    extern __shared__ __align__(16) unsigned char chainw_lds[];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wib;
+    if (t >= ns * A.nseg) return;                    // (no workgroup barrier below: waves are independent)
+    const int64_t seg = t / ns, sl = t - seg * ns, s = s0 + sl;
+    const int ncomp = A.v.ncomp;
+    const int ldp = ncomp + 1;                       // row stride of a staged point: rows of different bands on distinct banks
+    const int pbuf = NOCC * ldp + 1;                 // (+1: the slot where lanes past the point's last element park)
+    cd* bufP = reinterpret_cast<cd*>(chainw_lds) + (size_t)wib * 2 * pbuf;
+    cd* bufN = bufP + pbuf;
+    const int64_t plane = A.v.npts * ncomp;
+    const int i0 = (int)seg * A.seg_len;
+    const int i1 = min(i0 + A.seg_len, A.nlinks);
+    const cd* P = A.v.data + (axis_offset(A.other, s) + (int64_t)i0 * A.sdir) * ncomp;
+    const int64_t step = A.sdir * ncomp;
+    const int nel = NOCC * ncomp;                    // c128 per point
+    const int a_of = lane / NOCC, b_of = lane - a_of * NOCC;
+    const bool pair = lane < NOCC * NOCC;
+    // element e = j * 64 + lane of a point: band slot e / ncomp, component e % ncomp.  Loads and LDS writes are
+    // UNCONDITIONAL (a lane past the last element re-reads element 0 and parks it in the spare slot): a fixed number of
+    // memory operations per step keeps the values in registers and the waits counted.
+    int64_t goff[NLD];
+    int dst[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = j * 64 + lane;
+        const bool ok = e < nel;
+        const int a = ok ? e / ncomp : 0, c = ok ? e - a * ncomp : 0;
+        goff[j] = (int64_t)A.occ[a] * plane + c;
+        dst[j] = ok ? a * ldp + c : NOCC * ldp;
+    }
+    // (named scalars, not arrays: as arrays the two register sets of the pipeline ended up in scratch memory, with a
+    // full vmcnt wait behind every prefetch)
+    typedef double v2d __attribute__((ext_vector_type(2)));   // (a first-class vector value: the struct cd stayed an alloca here)
+    v2d a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;   // a* = point i + 1 (then i + 2), b* = the point after it
+#define TBK_LD4(x0, x1, x2, x3, ptr)                                                  \
+    {                                                                                 \
+        x0 = *reinterpret_cast<const v2d*>((ptr) + goff[0]);                          \
+        if constexpr (NLD > 1) x1 = *reinterpret_cast<const v2d*>((ptr) + goff[1]);   \
+        if constexpr (NLD > 2) x2 = *reinterpret_cast<const v2d*>((ptr) + goff[2]);   \
+        if constexpr (NLD > 3) x3 = *reinterpret_cast<const v2d*>((ptr) + goff[3]);   \
+    }
+#define TBK_PARK4(buf, x0, x1, x2, x3)                                                \
+    {                                                                                 \
+        *reinterpret_cast<v2d*>((buf) + dst[0]) = x0;                                 \
+        if constexpr (NLD > 1) *reinterpret_cast<v2d*>((buf) + dst[1]) = x1;          \
+        if constexpr (NLD > 2) *reinterpret_cast<v2d*>((buf) + dst[2]) = x2;          \
+        if constexpr (NLD > 3) *reinterpret_cast<v2d*>((buf) + dst[3]) = x3;          \
+    }
+    TBK_LD4(a0, a1, a2, a3, P)
+    TBK_PARK4(bufP, a0, a1, a2, a3)
+    {
+        const cd* p1 = P + step;                                      // point i0 + 1
+        const cd* p2 = P + (int64_t)min(2, i1 - i0) * step;           // point i0 + 2 (clamped: the segment's last point again)
+        TBK_LD4(a0, a1, a2, a3, p1)
+        TBK_LD4(b0, b1, b2, b3, p2)
+    }
+    cd* out = ws + ((int64_t)sl * A.nlinks + i0) * (NOCC * NOCC);
+    for (int i = i0; i < i1; ++i) {
+        TBK_PARK4(bufN, a0, a1, a2, a3)                               // point i + 1 has arrived
+        const cd* p3 = P + (int64_t)min(i + 3 - i0, i1 - i0) * step;  // point i + 3 goes in flight under the products
+        a0 = b0;
+        a1 = b1;
+        a2 = b2;
+        a3 = b3;
+        TBK_LD4(b0, b1, b2, b3, p3)
+        lds_sync_wave();
+        if (pair) {
+            const cd* ua = bufP + a_of * ldp;
+            const cd* ub = bufN + b_of * ldp;
+            // two interleaved accumulators per part: the dependent chain is ncomp/2 FMAs long instead of ncomp
+            cd m0 = cmulc(ua[0], ub[0]), m1 = cmulc(ua[1], ub[1]);
+            int c = 2;
+            for (; c + 1 < ncomp; c += 2) {
+                cfmac(m0, ua[c], ub[c]);
+                cfmac(m1, ua[c + 1], ub[c + 1]);
+            }
+            if (c < ncomp) cfmac(m0, ua[c], ub[c]);
+            out[(int64_t)(i - i0) * (NOCC * NOCC) + lane] = cadd(m0, m1);
+        }
+        cd* tmp = bufP;
+        bufP = bufN;
+        bufN = tmp;
+        lds_sync_wave();
+    }
+#undef TBK_LD4
+#undef TBK_PARK4
+}
+
+#define TBK_CHAINW_PASS 32
+template <int NOCC>
+__global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, const int64_t s0, const int64_t ns, const cd* __restrict__ ws) {
+    extern __shared__ __align__(16) unsigned char chainw_lds[];
+    constexpr int NN = NOCC * NOCC, LDM = NN + 1;    // padded row: 32 readers on distinct banks
+    cd* Mbuf = reinterpret_cast<cd*>(chainw_lds);
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    const int64_t seg = t / ns, sl = t - seg * ns, s = s0 + sl;
+    const int i0 = (int)seg * A.seg_len;
+    const int i1 = min(i0 + A.seg_len, A.nlinks);
+    const cd* in = ws + ((int64_t)sl * A.nlinks + i0) * NN;
+    cd acc{1.0, 0.0};
+    for (int ib = i0; ib < i1; ib += TBK_CHAINW_PASS) {
+        const int nb = min(TBK_CHAINW_PASS, i1 - ib);
+        const int total = nb * NN;                   // contiguous c128 of this pass
+        for (int e = lane; e < total; e += 64) {
+            const int j = e / NN, k = e - j * NN;
+            Mbuf[j * LDM + k] = in[(int64_t)(ib - i0) * NN + e];
+        }
+        lds_sync_wave();
+        cd d{1.0, 0.0};
+        if (lane < nb) {
+            cd M[NOCC][NOCC];
+#pragma unroll
+            for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+                for (int b = 0; b < NOCC; ++b) M[a][b] = Mbuf[lane * LDM + a * NOCC + b];
+            d = det_small<NOCC>(M);
+        }
+        // ordered fixed-shape product over the pass: lane l takes (l, l+16), then (l, l+8), ...
+#pragma unroll
+        for (int o = TBK_CHAINW_PASS / 2; o > 0; o >>= 1) {
+            const cd other{__shfl_down(d.x, o), __shfl_down(d.y, o)};
+            d = cmul(d, other);
+        }
+        acc = cmul(acc, d);                          // lane 0 holds the pass product
+        lds_sync_wave();
+    }
+    if (lane == 0) A.partial[seg * A.nstrings + s] = acc;
+}
+
 // ordered product over one segment of one string
 template <int NOCC, int MAXN, bool EVALS>
 __global__ __launch_bounds__(256) void k_chain_partial(const ChainArgs A) {
@@ -1272,9 +1427,14 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         }
         return TBK_OK;
     }
-    // segment length: enough threads to fill the chip, segments no shorter than 8 links
-    const int64_t target = (int64_t)ctx->cus * 1024;
-    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + 7) / 8, target / std::max<int64_t>(A.nstrings, 1)));
+    // 5..8 bands of wide states, determinant form: a wavefront per (string, segment) with coalesced loads
+    // (k_chain_det_wave); TBK_CHAIN_WAVE=0 keeps the thread-per-string kernel (A/B runs)
+    const bool wave_chain = !berry_evals && nocc >= 5 && nocc <= 8 && v.ncomp >= 8 && nocc * v.ncomp <= 256 &&
+                            tbk_knobs().chain_wave != 0;
+    // segment length: enough threads (wavefronts) to fill the chip, segments no shorter than 8 links (one pass of 32)
+    const int64_t target = wave_chain ? (int64_t)ctx->cus * 64 : (int64_t)ctx->cus * 1024;
+    const int min_seg = wave_chain ? TBK_CHAINW_PASS : 8;
+    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + min_seg - 1) / min_seg, target / std::max<int64_t>(A.nstrings, 1)));
     A.seg_len = (int)((A.nlinks + nseg - 1) / nseg);
     A.nseg = (A.nlinks + A.seg_len - 1) / A.seg_len;
     const bool ev = berry_evals != 0;
@@ -1293,7 +1453,52 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     const dim3 grid((unsigned)((nthreads + 255) / 256)), blk(256);
     {
         ProfScope ps(ctx, ev ? "chain_partial_evals" : "chain_partial_det");
-        if (!ev) {
+        if (wave_chain) {
+            // link matrices of a batch of strings -> workspace (nocc^2 c128 per link, at most ~1 GiB), then their determinants
+            const int nn = nocc * nocc;
+            const size_t per_string = (size_t)A.nlinks * nn * sizeof(cd);
+            const int64_t nsb = std::max<int64_t>(1, std::min<int64_t>(A.nstrings, (int64_t)(((size_t)1 << 30) / per_string)));
+            const size_t wbytes = (size_t)nsb * per_string;
+            if (wbytes > ctx->work_bytes) {
+                TBK_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->work) TBK_HIP(hipFree(ctx->work));
+                ctx->work = nullptr;
+                ctx->work_bytes = 0;
+                hipError_t e = hipMalloc(&ctx->work, wbytes);
+                TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "link-matrix workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
+                ctx->work_bytes = wbytes;
+            }
+            cd* ws = (cd*)ctx->work;
+            const size_t lds_a = (size_t)4 * 2 * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);
+            const size_t lds_b = (size_t)TBK_CHAINW_PASS * (nn + 1) * sizeof(cd);
+            for (int64_t s0 = 0; s0 < A.nstrings; s0 += nsb) {
+                const int64_t ns = std::min<int64_t>(nsb, A.nstrings - s0);
+                const int64_t nw = ns * A.nseg;
+                const dim3 ga((unsigned)((nw + 3) / 4)), gb((unsigned)nw);
+                const int nld = (nocc * v.ncomp + 63) / 64;
+#define TBK_CHAINW(NN, LL)                                                                                                          \
+    {                                                                                                                               \
+        { ProfScope p1(ctx, "chain_links"); hipLaunchKernelGGL((k_chain_links_wave<NN, LL>), ga, blk, lds_a, ctx->stream, A, s0, ns, ws); } \
+        { ProfScope p2(ctx, "chain_lu"); hipLaunchKernelGGL((k_chain_lu_wave<NN>), gb, dim3(64), lds_b, ctx->stream, A, s0, ns, (const cd*)ws); } \
+    }
+#define TBK_CHAINW_N(NN)                                  \
+    switch (nld) {                                        \
+        case 1: TBK_CHAINW(NN, 1) break;                  \
+        case 2: TBK_CHAINW(NN, 2) break;                  \
+        case 3: TBK_CHAINW(NN, 3) break;                  \
+        default: TBK_CHAINW(NN, 4) break;                 \
+    }
+                switch (nocc) {
+                    case 5: TBK_CHAINW_N(5) break;
+                    case 6: TBK_CHAINW_N(6) break;
+                    case 7: TBK_CHAINW_N(7) break;
+                    default: TBK_CHAINW_N(8) break;
+                }
+#undef TBK_CHAINW_N
+#undef TBK_CHAINW
+                TBK_HIP(hipGetLastError());
+            }
+        } else if (!ev) {
             switch (nocc) {
                 case 1: hipLaunchKernelGGL((k_chain_partial<1, 1, false>), grid, blk, 0, ctx->stream, A); break;
                 case 2: hipLaunchKernelGGL((k_chain_partial<2, 1, false>), grid, blk, 0, ctx->stream, A); break;

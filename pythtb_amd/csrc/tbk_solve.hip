@@ -430,10 +430,18 @@ __device__ __forceinline__ void ql_small(SmallMat<N>& M) {
         }
 #pragma unroll
         for (int j = 1; j + 1 < N; ++j) dm = m == j ? d[j] : dm;
-        // Wilkinson-type shift (its accuracy only affects the speed of convergence: hardware estimates are enough)
-        double g = (dl1 - dl) * (0.5 * __builtin_amdgcn_rcp(el));
-        const double rr = __builtin_amdgcn_sqrt(fma(g, g, 1.0));
-        g = dm - dl + el * __builtin_amdgcn_rcp(g + copysign(rr, g));
+        // Wilkinson shift = the eigenvalue of the block's leading 2 x 2 nearer to d_l, to full precision: for a block of
+        // two it is exact and the block deflates in ONE sweep (with hardware-estimate reciprocals, 5e-8, it took two:
+        // 8.1 instead of 7.1 sweeps per Kane-Mele matrix)
+        auto recip = [](const double x) {
+            double y = __builtin_amdgcn_rcp(x);
+            y = y * fma(-x, y, 2.0);
+            return y * fma(-x, y, 2.0);
+        };
+        double g = (dl1 - dl) * (0.5 * recip(el));
+        const double t1 = fma(g, g, 1.0);
+        const double rr = t1 * rsqrt_full(t1);
+        g = dm - dl + el * recip(g + copysign(rr, g));
         double sn = 1.0, cs = 1.0, pp = 0.0;
         bool alive = true;
 #pragma unroll
