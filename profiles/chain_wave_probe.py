@@ -31,3 +31,15 @@ for nocc in (8, 5, 6, 7):
             print("   kernels:", {k: round(v["total_ms"], 3) for k, v in ctx.prof_report().items()})
         print("nocc %d dir %d: wave %.2f ms   thread %.2f ms   max diff %.1e" % (
             nocc, d, res[1][0] * 1e3, res[0][0] * 1e3, np.abs(wrap(res[1][1] - res[0][1])).max()))
+print("berry_flux(range(8)) on the three plane orientations of the same array:")
+for dirs in ([0, 1], [1, 2], [2, 0]):
+    res = {}
+    for knob in (1, 0):
+        with _lib.knob("TBK_CHAIN_WAVE", knob):
+            w.berry_flux(range(8), dirs=dirs)
+            ctx.sync()
+            t0 = time.perf_counter()
+            fl = w.berry_flux(range(8), dirs=dirs)
+            res[knob] = (time.perf_counter() - t0, fl)
+    print("dirs %s: wave-link path %.2f ms   thread-per-plaquette %.2f ms   max diff %.1e" % (
+        dirs, res[1][0] * 1e3, res[0][0] * 1e3, np.abs(res[1][1] - res[0][1]).max()))

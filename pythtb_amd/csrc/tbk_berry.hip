@@ -723,6 +723,9 @@ static void launch_flux(tbk_ctx* ctx, const FluxArgs& A, int64_t nslices) {
     hipLaunchKernelGGL((k_flux<NOCC, MAXN>), dim3((unsigned)(nslices * A.bps)), dim3(256), 0, ctx->stream, A);
 }
 
+static int chain_wave_link_dets(tbk_wfs* w, const int32_t* occ, int nocc, int dir, cd* dets_out);   // defined with its kernels below
+static bool chain_wave_applies(const WfsView& v, int nocc);
+
 extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, int dir0, int dir1,
                                     int want_plaq) {
     TBK_REQUIRE(w, TBK_EINVAL, "tbk_berry_flux: null wfs");
@@ -814,7 +817,34 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         A.plaq = w->flux_plaq_dev;
     }
     A.partial = w->flux_partial_dev;
-    if (big) {
+    if (!big && chain_wave_applies(v, nocc)) {
+        // 5..8 bands of wide states: every lane of the plaquette kernel would walk its own 256-byte rows; instead the link
+        // determinants along both directions come from the wave-per-string kernels (coalesced), then the same combine
+        // kernel as for large band sets
+        void* base = nullptr;
+        const size_t db = ((size_t)v.npts * sizeof(cd) + 255) & ~(size_t)255;
+        rc = tbk_ctx_scratch(ctx, 256 + 2 * db, &base);
+        if (rc) return rc;
+        cd* dets = (cd*)((unsigned char*)base + 256);
+        rc = chain_wave_link_dets(w, occ, nocc, dir0, dets);
+        if (rc) return rc;
+        rc = chain_wave_link_dets(w, occ, nocc, dir1, (cd*)((unsigned char*)dets + db));
+        if (rc) return rc;
+        PlaqDetArgs P{};
+        P.d0 = dets;
+        P.d1 = (cd*)((unsigned char*)dets + db);
+        P.n0 = A.n0;
+        P.n1 = A.n1;
+        P.s0 = A.s0;
+        P.s1 = A.s1;
+        P.other = A.other;
+        P.bps = A.bps;
+        P.plaq = A.plaq;
+        P.partial = A.partial;
+        ProfScope ps(ctx, "berry_flux");
+        hipLaunchKernelGGL(k_flux_from_dets, dim3((unsigned)(nslices * A.bps)), dim3(256), 0, ctx->stream, P);
+        TBK_HIP(hipGetLastError());
+    } else if (big) {
         int* occ_dev = nullptr;
         cd* dets = nullptr;
         void* work = nullptr;
@@ -1034,7 +1064,8 @@ __global__ __launch_bounds__(256) void k_chain_links_wave(const ChainArgs A, con
 
 #define TBK_CHAINW_PASS 32
 template <int NOCC>
-__global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, const int64_t s0, const int64_t ns, const cd* __restrict__ ws) {
+__global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, const int64_t s0, const int64_t ns, const cd* __restrict__ ws,
+                                                         cd* __restrict__ dets_out) {
     extern __shared__ __align__(16) unsigned char chainw_lds[];
     constexpr int NN = NOCC * NOCC, LDM = NN + 1;    // padded row: 32 readers on distinct banks
     cd* Mbuf = reinterpret_cast<cd*>(chainw_lds);
@@ -1061,6 +1092,8 @@ __global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, cons
 #pragma unroll
                 for (int b = 0; b < NOCC; ++b) M[a][b] = Mbuf[lane * LDM + a * NOCC + b];
             d = det_small<NOCC>(M);
+            // berry_flux wants the determinant of every link on its own, filed under the link's first point
+            if (dets_out) dets_out[axis_offset(A.other, s) + (int64_t)(ib + lane) * A.sdir] = d;
         }
         // ordered fixed-shape product over the pass: lane l takes (l, l+16), then (l, l+8), ...
 #pragma unroll
@@ -1071,7 +1104,85 @@ __global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, cons
         acc = cmul(acc, d);                          // lane 0 holds the pass product
         lds_sync_wave();
     }
-    if (lane == 0) A.partial[seg * A.nstrings + s] = acc;
+    if (lane == 0 && !dets_out) A.partial[seg * A.nstrings + s] = acc;
+}
+
+// 5..8 bands of wide states: link matrices of a batch of strings -> workspace (nocc^2 c128 per link, at most ~1 GiB per
+// batch), then their determinants -- multiplied per (string, segment) into A.partial (dets_out == null: berry_phase) or
+// filed one by one under the link's first point (berry_flux).  A.seg_len / A.nseg must be set.
+static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A, int nocc, cd* dets_out) {
+    const int nn = nocc * nocc;
+    const size_t per_string = (size_t)A.nlinks * nn * sizeof(cd);
+    const int64_t nsb = std::max<int64_t>(1, std::min<int64_t>(A.nstrings, (int64_t)(((size_t)1 << 30) / per_string)));
+    const size_t wbytes = (size_t)nsb * per_string;
+    if (wbytes > ctx->work_bytes) {
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->work) TBK_HIP(hipFree(ctx->work));
+        ctx->work = nullptr;
+        ctx->work_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->work, wbytes);
+        TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "link-matrix workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
+        ctx->work_bytes = wbytes;
+    }
+    cd* ws = (cd*)ctx->work;
+    const size_t lds_a = (size_t)4 * 2 * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);
+    const size_t lds_b = (size_t)TBK_CHAINW_PASS * (nn + 1) * sizeof(cd);
+    const int nld = (nocc * v.ncomp + 63) / 64;
+    const dim3 blk(256);
+    for (int64_t s0 = 0; s0 < A.nstrings; s0 += nsb) {
+        const int64_t ns = std::min<int64_t>(nsb, A.nstrings - s0);
+        const int64_t nw = ns * A.nseg;
+        const dim3 ga((unsigned)((nw + 3) / 4)), gb((unsigned)nw);
+#define TBK_CHAINW(NN, LL)                                                                                                          \
+    {                                                                                                                               \
+        { ProfScope p1(ctx, "chain_links"); hipLaunchKernelGGL((k_chain_links_wave<NN, LL>), ga, blk, lds_a, ctx->stream, A, s0, ns, ws); } \
+        { ProfScope p2(ctx, "chain_lu"); hipLaunchKernelGGL((k_chain_lu_wave<NN>), gb, dim3(64), lds_b, ctx->stream, A, s0, ns, (const cd*)ws, dets_out); } \
+    }
+#define TBK_CHAINW_N(NN)                                  \
+    switch (nld) {                                        \
+        case 1: TBK_CHAINW(NN, 1) break;                  \
+        case 2: TBK_CHAINW(NN, 2) break;                  \
+        case 3: TBK_CHAINW(NN, 3) break;                  \
+        default: TBK_CHAINW(NN, 4) break;                 \
+    }
+        switch (nocc) {
+            case 5: TBK_CHAINW_N(5) break;
+            case 6: TBK_CHAINW_N(6) break;
+            case 7: TBK_CHAINW_N(7) break;
+            default: TBK_CHAINW_N(8) break;
+        }
+#undef TBK_CHAINW_N
+#undef TBK_CHAINW
+        TBK_HIP(hipGetLastError());
+    }
+    return TBK_OK;
+}
+
+static bool chain_wave_applies(const WfsView& v, int nocc) {
+    return nocc >= 5 && nocc <= 8 && v.ncomp >= 8 && nocc * v.ncomp <= 256 && tbk_knobs().chain_wave != 0;
+}
+
+// segments of the strings along `dir`: enough wavefronts to fill the chip, no shorter than one pass of the LU kernel
+static void chain_wave_segments(tbk_ctx* ctx, ChainArgs& A) {
+    const int64_t target = (int64_t)ctx->cus * 64;
+    const int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + TBK_CHAINW_PASS - 1) / TBK_CHAINW_PASS,
+                                                                 target / std::max<int64_t>(A.nstrings, 1)));
+    A.seg_len = (int)((A.nlinks + nseg - 1) / nseg);
+    A.nseg = (A.nlinks + A.seg_len - 1) / A.seg_len;
+}
+
+// berry_flux of 5..8 wide bands: determinants of all links along `dir`, dets_out[point] (see tbk_berry_flux_async)
+static int chain_wave_link_dets(tbk_wfs* w, const int32_t* occ, int nocc, int dir, cd* dets_out) {
+    const WfsView& v = w->view;
+    ChainArgs A{};
+    A.v = v;
+    A.nocc = nocc;
+    for (int i = 0; i < nocc; ++i) A.occ[i] = occ[i];
+    A.nlinks = v.mesh[dir] - 1;
+    A.sdir = v.stride[dir];
+    other_axes(v, dir, -1, &A.other, &A.nstrings);
+    chain_wave_segments(w->ctx, A);
+    return launch_chain_wave(w->ctx, v, A, nocc, dets_out);
 }
 
 // ordered product over one segment of one string
@@ -1428,15 +1539,14 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         return TBK_OK;
     }
     // 5..8 bands of wide states, determinant form: a wavefront per (string, segment) with coalesced loads
-    // (k_chain_det_wave); TBK_CHAIN_WAVE=0 keeps the thread-per-string kernel (A/B runs)
-    const bool wave_chain = !berry_evals && nocc >= 5 && nocc <= 8 && v.ncomp >= 8 && nocc * v.ncomp <= 256 &&
-                            tbk_knobs().chain_wave != 0;
-    // segment length: enough threads (wavefronts) to fill the chip, segments no shorter than 8 links (one pass of 32)
-    const int64_t target = wave_chain ? (int64_t)ctx->cus * 64 : (int64_t)ctx->cus * 1024;
-    const int min_seg = wave_chain ? TBK_CHAINW_PASS : 8;
-    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + min_seg - 1) / min_seg, target / std::max<int64_t>(A.nstrings, 1)));
+    // (k_chain_links_wave + k_chain_lu_wave); TBK_CHAIN_WAVE=0 keeps the thread-per-string kernel (A/B runs)
+    const bool wave_chain = !berry_evals && chain_wave_applies(v, nocc);
+    // segment length: enough threads to fill the chip, segments no shorter than 8 links
+    const int64_t target = (int64_t)ctx->cus * 1024;
+    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((A.nlinks + 7) / 8, target / std::max<int64_t>(A.nstrings, 1)));
     A.seg_len = (int)((A.nlinks + nseg - 1) / nseg);
     A.nseg = (A.nlinks + A.seg_len - 1) / A.seg_len;
+    if (wave_chain) chain_wave_segments(ctx, A);
     const bool ev = berry_evals != 0;
     const int64_t per = ev ? (int64_t)nocc * nocc : 1;
     const int64_t nout = A.nstrings * (ev ? nocc : 1);
@@ -1454,50 +1564,8 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     {
         ProfScope ps(ctx, ev ? "chain_partial_evals" : "chain_partial_det");
         if (wave_chain) {
-            // link matrices of a batch of strings -> workspace (nocc^2 c128 per link, at most ~1 GiB), then their determinants
-            const int nn = nocc * nocc;
-            const size_t per_string = (size_t)A.nlinks * nn * sizeof(cd);
-            const int64_t nsb = std::max<int64_t>(1, std::min<int64_t>(A.nstrings, (int64_t)(((size_t)1 << 30) / per_string)));
-            const size_t wbytes = (size_t)nsb * per_string;
-            if (wbytes > ctx->work_bytes) {
-                TBK_HIP(hipStreamSynchronize(ctx->stream));
-                if (ctx->work) TBK_HIP(hipFree(ctx->work));
-                ctx->work = nullptr;
-                ctx->work_bytes = 0;
-                hipError_t e = hipMalloc(&ctx->work, wbytes);
-                TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "link-matrix workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
-                ctx->work_bytes = wbytes;
-            }
-            cd* ws = (cd*)ctx->work;
-            const size_t lds_a = (size_t)4 * 2 * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);
-            const size_t lds_b = (size_t)TBK_CHAINW_PASS * (nn + 1) * sizeof(cd);
-            for (int64_t s0 = 0; s0 < A.nstrings; s0 += nsb) {
-                const int64_t ns = std::min<int64_t>(nsb, A.nstrings - s0);
-                const int64_t nw = ns * A.nseg;
-                const dim3 ga((unsigned)((nw + 3) / 4)), gb((unsigned)nw);
-                const int nld = (nocc * v.ncomp + 63) / 64;
-#define TBK_CHAINW(NN, LL)                                                                                                          \
-    {                                                                                                                               \
-        { ProfScope p1(ctx, "chain_links"); hipLaunchKernelGGL((k_chain_links_wave<NN, LL>), ga, blk, lds_a, ctx->stream, A, s0, ns, ws); } \
-        { ProfScope p2(ctx, "chain_lu"); hipLaunchKernelGGL((k_chain_lu_wave<NN>), gb, dim3(64), lds_b, ctx->stream, A, s0, ns, (const cd*)ws); } \
-    }
-#define TBK_CHAINW_N(NN)                                  \
-    switch (nld) {                                        \
-        case 1: TBK_CHAINW(NN, 1) break;                  \
-        case 2: TBK_CHAINW(NN, 2) break;                  \
-        case 3: TBK_CHAINW(NN, 3) break;                  \
-        default: TBK_CHAINW(NN, 4) break;                 \
-    }
-                switch (nocc) {
-                    case 5: TBK_CHAINW_N(5) break;
-                    case 6: TBK_CHAINW_N(6) break;
-                    case 7: TBK_CHAINW_N(7) break;
-                    default: TBK_CHAINW_N(8) break;
-                }
-#undef TBK_CHAINW_N
-#undef TBK_CHAINW
-                TBK_HIP(hipGetLastError());
-            }
+            rc = launch_chain_wave(ctx, v, A, nocc, nullptr);
+            if (rc) return rc;
         } else if (!ev) {
             switch (nocc) {
                 case 1: hipLaunchKernelGGL((k_chain_partial<1, 1, false>), grid, blk, 0, ctx->stream, A); break;
