@@ -1213,9 +1213,38 @@ __global__ __launch_bounds__(256) void k_chain_partial(const ChainArgs A) {
         A.partial[seg * A.nstrings + s] = acc;
     } else if constexpr (NOCC == 2) {
         cd R[2][2] = {{cd{1.0, 0.0}, cd{0.0, 0.0}}, {cd{0.0, 0.0}, cd{1.0, 0.0}}};
+        // states of at most four components (BASELINE configs[3]: two spinor bands of Kane-Mele): the point at the right end of
+        // a link is the left end of the next one -- keep it in registers instead of loading every point twice (the PMC run
+        // of round 1 showed 2x the algorithmic bytes fetched, profiles/r02a)
+        const bool narrow = ncomp <= 4;
+        cd prev[2][4], cur[2][4];
+        auto load_pt = [&](const cd* pt, cd (&u)[2][4]) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) u[a][o] = o < ncomp ? pt[A.occ[a] * plane + o] : cd{0.0, 0.0};
+        };
+        if (narrow) load_pt(P, prev);
         for (int i = i0; i < i1; ++i, P += step) {
             cd M[2][2];
-            link_matrix<2>(P, P + step, A.occ, ncomp, plane, M);
+            if (narrow) {
+                load_pt(P + step, cur);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        cd m = cmulc(prev[a][0], cur[b][0]);
+#pragma unroll
+                        for (int o = 1; o < 4; ++o) cfmac(m, prev[a][o], cur[b][o]);
+                        M[a][b] = m;
+                    }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) prev[a][o] = cur[a][o];
+            } else {
+                link_matrix<2>(P, P + step, A.occ, ncomp, plane, M);
+            }
             polar2(M);
             cd T[2][2];
 #pragma unroll
