@@ -15,7 +15,7 @@ import csv, glob, collections, sys
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/pmc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_solve' in r['Kernel_Name']:
+        if 'k_solve' in r['Kernel_Name'] or 'k_ql16' in r['Kernel_Name']:
             acc[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
 for kn, cs in acc.items():
     print(kn)
