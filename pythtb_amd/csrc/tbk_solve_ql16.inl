@@ -36,8 +36,8 @@
 template <int N>
 __device__ __forceinline__ double row_ror_d(const double v) {   // value of lane (x + N) mod 16 of the same row
     const I2 i = __builtin_bit_cast(I2, v);
-    const I2 o{__builtin_amdgcn_update_dpp(i.lo, i.lo, 0x120 + N, 0xf, 0xf, false),
-               __builtin_amdgcn_update_dpp(i.hi, i.hi, 0x120 + N, 0xf, 0xf, false)};
+    const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x120 + N, 0xf, 0xf, true),
+               __builtin_amdgcn_update_dpp(0, i.hi, 0x120 + N, 0xf, 0xf, true)};
     return __builtin_bit_cast(double, o);
 }
 // sum over the 16 lanes of a row, the same bits in every lane (each step adds a value to its mirror image)

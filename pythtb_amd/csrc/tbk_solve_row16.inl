@@ -35,13 +35,14 @@ __device__ __forceinline__ double perm_push_d(const int addr, const double v) { 
 template <int SRC>
 __device__ __forceinline__ double rowbcast_d(const double v) {   // value of lane SRC of each 16-lane row
     const I2 i = __builtin_bit_cast(I2, v);
-    // (old = the source itself: every lane has a valid source, and a constant would cost a v_mov to materialise)
-    const I2 o{__builtin_amdgcn_update_dpp(i.lo, i.lo, 0x150 + SRC, 0xf, 0xf, false),
-               __builtin_amdgcn_update_dpp(i.hi, i.hi, 0x150 + SRC, 0xf, 0xf, false)};
+    // (bound_ctrl with full row/bank masks: the old value is dead, so the compiler emits ONE v_mov_b32_dpp per dword --
+    // with a live old operand it was a plain v_mov to seed the destination plus the DPP move)
+    const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x150 + SRC, 0xf, 0xf, true),
+               __builtin_amdgcn_update_dpp(0, i.hi, 0x150 + SRC, 0xf, 0xf, true)};
     return __builtin_bit_cast(double, o);
 }
 template <int SRC>
-__device__ __forceinline__ int rowbcast_i(const int v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + SRC, 0xf, 0xf, false); }
+__device__ __forceinline__ int rowbcast_i(const int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xf, 0xf, true); }
 
 // round R of the 15-round tournament on 16 players: pair l = 0 is (15, R), pair l = 1..7 is
 // ((R+l) mod 15, (R-l) mod 15)
