@@ -249,6 +249,39 @@ def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
     import io
     import helpers as hp
     out = []
+    # ---- BASELINE configs[1]: Haldane (delta = 0.2) solve_all on the 1024 x 1024 uniform k list, buffers resident
+    try:
+        m = hp.haldane(tb.tb_model, 0.2)
+        k = m.k_uniform_mesh([1024, 1024])
+        nk = len(k)
+        hm = m._device_model()
+        kd, ed, vd = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, k.nbytes, C.byref(kd)))
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 2 * 8, C.byref(ed)))
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 4 * 16, C.byref(vd)))
+        _lib.check(lib.tbk_dev_upload(ctx.handle, kd, k.ctypes.data_as(C.c_void_p), k.nbytes))
+        _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, vd))
+        ctx.sync()
+        kt = kernel_times(ctx, lambda: (_lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None)),
+                                        _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, vd))), 10, ev_ms)
+        ev = np.zeros((2, nk))
+        _lib.check(lib.tbk_dev_download(ctx.handle, ev.ctypes.data_as(C.c_void_p), ed, ev.nbytes))
+        t0 = time.perf_counter()
+        ev_api = m.solve_all(k)
+        t_api = time.perf_counter() - t0
+        out.append({"config": "BASELINE configs[1] on one GPU: Haldane (delta 0.2) solve_all on k_uniform_mesh([1024,1024]), k list and results resident",
+                    "kpts": nk, "kernels": kt,
+                    "kpts_per_s_eigenvalues": nk / (kt["solve_list_val"]["avg_bracket_ms"] * 1e-3),
+                    "kpts_per_s_with_vectors": nk / (kt["solve_list_vec"]["avg_bracket_ms"] * 1e-3),
+                    "roofline": {"solve_list_val": roof(8 * (2 + 2) * nk, kt["solve_list_val"]["avg_bracket_ms"], kt["solve_list_val"]["avg_ms_net"]),
+                                 "solve_list_vec": roof((8 * (2 + 2) + 16 * 4) * nk, kt["solve_list_vec"]["avg_bracket_ms"], kt["solve_list_vec"]["avg_ms_net"])},
+                    "python_call_incl_pcie_s": t_api,
+                    "check": {"sum": float(ev.sum()), "min": float(ev.min()), "max": float(ev.max()),
+                              "api_equals_resident": bool(np.array_equal(ev_api, ev))}})
+        for ptr in (kd, ed, vd):
+            _lib.check(lib.tbk_dev_free(ctx.handle, ptr))
+    except Exception as e:
+        out.append({"config": "configs[1]", "error": " ".join(str(e).split())[:300]})
     # ---- the headline kernels past the last-level cache: 4096^2 (1.07 GB of eigenvectors)
     try:
         m = haldane(tb)
