@@ -949,8 +949,8 @@ struct ChainArgs {
     int* flags;
 };
 
-// ---- det-type Berry phase, 5..8 occupied bands of WIDE states (ncomp >= 8; BASELINE configs[4]: 8 of 16 bands,
-// 16 components): two kernels, each a WAVEFRONT per (string, segment).
+// ---- det-type Berry phase and flux, 1..8 occupied bands of WIDE states (ncomp >= 8; BASELINE configs[4]: 8 of 16
+// bands, 16 components): two kernels, each a WAVEFRONT per (string, segment).
 // With a thread per string every lane walks its own 256-byte rows and a load instruction touches 64 different
 // cache lines: strings along the last mesh axis over-fetched 8x and ran at 0.4 TB/s (82 ms for the 257^3 array,
 // profiles/r02a).
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_chain_links_wave(const ChainArgs A, con
     // (named scalars, not arrays: as arrays the two register sets of the pipeline ended up in scratch memory, with a
     // full vmcnt wait behind every prefetch)
     typedef double v2d __attribute__((ext_vector_type(2)));   // (a first-class vector value: the struct cd stayed an alloca here)
-    v2d a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;   // a* = point i + 1 (then i + 2), b* = the point after it
+    v2d a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;   // two points in flight
 #define TBK_LD4(x0, x1, x2, x3, ptr)                                                  \
     {                                                                                 \
         x0 = *reinterpret_cast<const v2d*>((ptr) + goff[0]);                          \
@@ -1031,33 +1031,42 @@ __global__ __launch_bounds__(256) void k_chain_links_wave(const ChainArgs A, con
         TBK_LD4(b0, b1, b2, b3, p2)
     }
     cd* out = ws + ((int64_t)sl * A.nlinks + i0) * (NOCC * NOCC);
-    for (int i = i0; i < i1; ++i) {
-        TBK_PARK4(bufN, a0, a1, a2, a3)                               // point i + 1 has arrived
-        const cd* p3 = P + (int64_t)min(i + 3 - i0, i1 - i0) * step;  // point i + 3 goes in flight under the products
-        a0 = b0;
-        a1 = b1;
-        a2 = b2;
-        a3 = b3;
-        TBK_LD4(b0, b1, b2, b3, p3)
-        lds_sync_wave();
-        if (pair) {
-            const cd* ua = bufP + a_of * ldp;
-            const cd* ub = bufN + b_of * ldp;
-            // two interleaved accumulators per part: the dependent chain is ncomp/2 FMAs long instead of ncomp
-            cd m0 = cmulc(ua[0], ub[0]), m1 = cmulc(ua[1], ub[1]);
-            int c = 2;
-            for (; c + 1 < ncomp; c += 2) {
-                cfmac(m0, ua[c], ub[c]);
-                cfmac(m1, ua[c + 1], ub[c + 1]);
-            }
-            if (c < ncomp) cfmac(m0, ua[c], ub[c]);
-            out[(int64_t)(i - i0) * (NOCC * NOCC) + lane] = cadd(m0, m1);
-        }
-        cd* tmp = bufP;
-        bufP = bufN;
-        bufN = tmp;
-        lds_sync_wave();
+    // One link: the register set that holds point i + 1 is parked in LDS and immediately re-used for the load of point
+    // i + 3, while the OTHER set (point i + 2) stays in flight.  The loop is unrolled by two with the sets swapping roles --
+    // rotating them with register copies made every iteration wait for the younger load (a v_mov of a value still in flight),
+    // i.e. one point of prefetch instead of two: 1.0 ms per 2.1 M links whatever the band count, 0.58 ms like this.  (Three
+    // sets, unrolled by three, fell back to 1.0 ms: the waits at the merged loop head became vmcnt(0) again.)
+#define TBK_LINK_STEP(i, x0, x1, x2, x3)                                                                  \
+    {                                                                                                     \
+        TBK_PARK4(bufN, x0, x1, x2, x3)                               /* point i + 1 has arrived */        \
+        const cd* p3 = P + (int64_t)min((i) + 3 - i0, i1 - i0) * step; /* point i + 3 goes in flight */    \
+        TBK_LD4(x0, x1, x2, x3, p3)                                                                       \
+        lds_sync_wave();                                                                                  \
+        if (pair) {                                                                                       \
+            const cd* ua = bufP + a_of * ldp;                                                             \
+            const cd* ub = bufN + b_of * ldp;                                                             \
+            /* two interleaved accumulators per part: the dependent chain is ncomp/2 FMAs long */         \
+            cd m0 = cmulc(ua[0], ub[0]), m1 = cmulc(ua[1], ub[1]);                                        \
+            int c = 2;                                                                                    \
+            for (; c + 1 < ncomp; c += 2) {                                                               \
+                cfmac(m0, ua[c], ub[c]);                                                                  \
+                cfmac(m1, ua[c + 1], ub[c + 1]);                                                          \
+            }                                                                                             \
+            if (c < ncomp) cfmac(m0, ua[c], ub[c]);                                                       \
+            out[(int64_t)((i) - i0) * (NOCC * NOCC) + lane] = cadd(m0, m1);                               \
+        }                                                                                                 \
+        cd* tmp = bufP;                                                                                   \
+        bufP = bufN;                                                                                      \
+        bufN = tmp;                                                                                       \
+        lds_sync_wave();                                                                                  \
     }
+    int i = i0;
+    for (; i + 1 < i1; i += 2) {
+        TBK_LINK_STEP(i, a0, a1, a2, a3)
+        TBK_LINK_STEP(i + 1, b0, b1, b2, b3)
+    }
+    if (i < i1) TBK_LINK_STEP(i, a0, a1, a2, a3)
+#undef TBK_LINK_STEP
 #undef TBK_LD4
 #undef TBK_PARK4
 }
@@ -1146,6 +1155,10 @@ static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A,
         default: TBK_CHAINW(NN, 4) break;                 \
     }
         switch (nocc) {
+            case 1: TBK_CHAINW_N(1) break;
+            case 2: TBK_CHAINW_N(2) break;
+            case 3: TBK_CHAINW_N(3) break;
+            case 4: TBK_CHAINW_N(4) break;
             case 5: TBK_CHAINW_N(5) break;
             case 6: TBK_CHAINW_N(6) break;
             case 7: TBK_CHAINW_N(7) break;
@@ -1159,7 +1172,8 @@ static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A,
 }
 
 static bool chain_wave_applies(const WfsView& v, int nocc) {
-    return nocc >= 5 && nocc <= 8 && v.ncomp >= 8 && nocc * v.ncomp <= 256 && tbk_knobs().chain_wave != 0;
+    const int from = tbk_knobs().chain_wave_from >= 1 ? tbk_knobs().chain_wave_from : 1;   // (measured faster from one band on, profiles/chain_wave_small_probe.py)
+    return nocc >= from && nocc <= 8 && v.ncomp >= 8 && nocc * v.ncomp <= 256 && tbk_knobs().chain_wave != 0;
 }
 
 // segments of the strings along `dir`: enough wavefronts to fill the chip, no shorter than one pass of the LU kernel
