@@ -1088,9 +1088,26 @@ __global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, cons
     for (int ib = i0; ib < i1; ib += TBK_CHAINW_PASS) {
         const int nb = min(TBK_CHAINW_PASS, i1 - ib);
         const int total = nb * NN;                   // contiguous c128 of this pass
-        for (int e = lane; e < total; e += 64) {
-            const int j = e / NN, k = e - j * NN;
-            Mbuf[j * LDM + k] = in[(int64_t)(ib - i0) * NN + e];
+        // eight loads in flight per lane (one at a time, each waited for, was 20 us per pass: the whole kernel)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d* src = reinterpret_cast<const v2d*>(in + (int64_t)(ib - i0) * NN);
+        constexpr int PER = (TBK_CHAINW_PASS * NN + 63) / 64;
+#pragma unroll
+        for (int g = 0; g < PER; g += 8) {
+            v2d r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = (g + u) * 64 + lane;
+                r[u] = g + u < PER && e < total ? src[e] : v2d{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = (g + u) * 64 + lane;
+                if (g + u < PER && e < total) {
+                    const int j = e / NN, k = e - j * NN;
+                    *reinterpret_cast<v2d*>(Mbuf + j * LDM + k) = r[u];
+                }
+            }
         }
         lds_sync_wave();
         cd d{1.0, 0.0};
