@@ -42,7 +42,8 @@ for case in range(ncase):
     nhop = int(norb * norb * (1.5 if dense else 0.3)) + 2
     rmax = int(rng.integers(1, 3))
     m = hp.random_model(tb.tb_model, norb, dim_k, nspin, int(rng.integers(0, 10 ** 6)), nhop=nhop, rmax=rmax)
-    k = rng.uniform(-0.7, 0.7, size=(int(rng.integers(1, int(os.environ.get("FUZZ_NK", "40")))), dim_k))
+    nk_max = int(os.environ.get("FUZZ_NK", "40"))
+    k = rng.uniform(-0.7, 0.7, size=(int(rng.integers(max(1, nk_max // 2), nk_max)) if nk_max > 100 else int(rng.integers(1, nk_max)), dim_k))
     ev, vec = m.solve_all(k, eig_vectors=True)
     ev_only = m.solve_all(k)
     ref = orc.solve_all_vec(m, k)
@@ -52,7 +53,14 @@ for case in range(ncase):
     V = vec.reshape(n, len(k), n)
     r_err = max(np.abs(ham[i] @ V[:, i].T - V[:, i].T * ev[:, i]).max() for i in range(len(k))) / scale
     o_err = max(np.abs(V[:, i].conj() @ V[:, i].T - np.eye(n)).max() for i in range(len(k)))
-    mesh = [int(rng.integers(3, 7)) for _ in range(dim_k)]
+    # FUZZ_MESH_TOTAL: meshes of at least that many points (batches above ~2048 matrices take the chip-filling kernels:
+    # the direct n = 9..16 solver, the wave-per-string link kernels), else tiny ones
+    tot = int(os.environ.get("FUZZ_MESH_TOTAL", "0"))
+    if tot > 0:
+        side = int(np.ceil(tot ** (1.0 / dim_k)))
+        mesh = [side + int(rng.integers(0, 3)) for _ in range(dim_k)]
+    else:
+        mesh = [int(rng.integers(3, 7)) for _ in range(dim_k)]
     start = list(rng.uniform(-0.5, 0.5, size=dim_k))
     w = tb.wf_array(m, mesh)
     gaps = w.solve_on_grid(start)
