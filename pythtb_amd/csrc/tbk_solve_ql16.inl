@@ -158,10 +158,117 @@ __device__ __forceinline__ void ql16_bcast_ev(const double dd, double (&ev)[16])
 
 #define TBK_QL_MAX_ITER 480   // 30 shifts per eigenvalue, LAPACK's limit
 
+// ---- eigenvalues only: after the tridiagonalisation nothing is left to do on Z, and the QL recurrence replicated over the
+// 16 lanes of a matrix would be ALL of the remaining work (~5 k wave-instructions per matrix).  So the eigenvalue-only solve
+// is two kernels: k_solve_ql16<.., false, 1> stops after the tridiagonalisation and leaves (d_j, e_j) in a workspace laid out
+// [j][matrix]; k_tridiag_eigvals then gives every LANE one matrix -- static register indices, nothing replicated, coalesced
+// loads and stores -- ~0.4 k wave-instructions per matrix.
+template <int I>
+__device__ __forceinline__ void qle_pos(double (&d)[16], double (&e)[16], double& sn, double& cs, double& pp, double& g, bool& alive,
+                                        const bool live, const int l, const int m) {
+    if (live && alive && I >= l && I < m) {
+        const double f = sn * e[I], b = cs * e[I];
+        const double t = f * f + g * g;
+        if (t > 0.0) {
+            const double inv = rsqrt_full(t), r = t * inv;
+            e[I + 1] = I + 1 == m ? 0.0 : r;     // (e_m is zeroed at the end of a sweep)
+            sn = f * inv;
+            cs = g * inv;
+            const double gg = d[I + 1] - pp;
+            const double r2 = (d[I] - gg) * sn + 2.0 * cs * b;
+            pp = sn * r2;
+            d[I + 1] = gg + pp;
+            g = cs * r2 - b;
+            if (I == l) {                        // last position of the sweep
+                d[I] -= pp;
+                e[I] = g;
+            }
+        } else {                                 // r == 0 (underflow): tql2's recovery
+            d[I + 1] -= pp;
+            if (I + 1 == m) e[I + 1] = 0.0;
+            alive = false;
+        }
+    }
+    if constexpr (I > 0) qle_pos<I - 1>(d, e, sn, cs, pp, g, alive, live, l, m);
+}
+template <int J>
+__device__ __forceinline__ double qle_pick(const double (&a)[16], const int idx, const double acc) {
+    const double r = idx == J ? a[J] : acc;
+    if constexpr (J + 1 < 16) return qle_pick<J + 1>(a, idx, r);
+    else return r;
+}
+
+// de[j * nk + id] = (d_j, e_j) of matrix id  ->  eval[rank][id], ascending (the n real rows; padding rows rank last)
+__global__ __launch_bounds__(256) void k_tridiag_eigvals(const int n, const int64_t nk, const double2* __restrict__ de,
+                                                         double* __restrict__ eval, int* noconv_flag) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool has = id < nk;
+    const int64_t ic = has ? id : nk - 1;
+    double d[16], e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double2 v = de[(int64_t)j * nk + ic];
+        d[j] = v.x;
+        e[j] = v.y;
+    }
+    e[15] = 0.0;
+    int l = 0;
+    bool done = !has;
+    for (int iter = 0;; ++iter) {
+        int m = 15;
+        if (!done) {
+            unsigned negl = 0x8000u;
+#pragma unroll
+            for (int j = 0; j < 15; ++j)
+                negl |= fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1])) ? (1u << j) : 0u;
+            const unsigned open = ~negl & (0xffffu << l) & 0xffffu;
+            if (open == 0) {
+                done = true;
+            } else {
+                l = __builtin_ctz(open);
+                m = __builtin_ctz(negl & (0xffffu << l));
+            }
+        }
+        if (__all(done)) break;
+        if (iter >= TBK_QL_MAX_ITER) {
+            if (!done) atomicExch(noconv_flag, 1);
+            break;
+        }
+        double sn = 1.0, cs = 1.0, pp = 0.0, g = 0.0;
+        bool alive = true;
+        if (!done) {
+            const double dl = qle_pick<0>(d, l, 0.0), dl1 = qle_pick<0>(d, l + 1, 0.0);
+            const double el = qle_pick<0>(e, l, 1.0), dmm = qle_pick<0>(d, m, 0.0);
+            const double gs = (dl1 - dl) * (0.5 * __builtin_amdgcn_rcp(el));
+            const double r = __builtin_amdgcn_sqrt(fma(gs, gs, 1.0));
+            g = dmm - dl + el * __builtin_amdgcn_rcp(gs + copysign(r, gs));
+        }
+        qle_pos<14>(d, e, sn, cs, pp, g, alive, !done, l, m);
+    }
+    // stable ascending ranks among the n real entries, then one coalesced store per rank
+    int rk[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        int r = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) r += (b < n) && (d[b] < d[a] || (d[b] == d[a] && b < a)) ? 1 : 0;
+        rk[a] = r;
+    }
+    if (!has) return;
+    for (int r = 0; r < n; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v = (a < n && rk[a] == r) ? d[a] : v;
+        eval[(int64_t)r * nk + id] = v;
+    }
+}
+
 // MODE 0: k list, 1: regular mesh into a wf_array (+ min gaps), 2: supplied matrices
-template <int MODE, bool VEC>
+// STAGE 0: the whole solve.  STAGE 1 (eigenvalues only): stop after the tridiagonalisation, de[j * nk + id] = (d_j, e_j).
+template <int MODE, bool VEC, int STAGE = 0>
 __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G,
-                                                     int* noconv_flag) {
+                                                     int* noconv_flag, double2* __restrict__ de = nullptr) {
+    static_assert(STAGE == 0 || !VEC, "k_solve_ql16: the two-kernel form is the eigenvalue-only one");
     const int lane = threadIdx.x & 63;
     const int x = lane & 15;
     const int rowbase4 = (lane & 48) * 4;
@@ -257,6 +364,11 @@ __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const in
         if (VEC) z[15] = cmul(z[15], delta);
     }
     double dd = sel16<0>(a, x, cd{0.0, 0.0}).x;          // d_x = A[x][x]
+
+    if constexpr (STAGE == 1) {
+        if (live) de[(int64_t)x * nk + id] = double2{dd, x < 15 ? ee : 0.0};
+        return;
+    }
 
     // ---- 2. implicit QL; l = first row of the block being worked on, m = its last row
     int l = 0;
@@ -357,6 +469,26 @@ template <int MODE, bool VEC>
 static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G) {
     TBK_REQUIRE(nk * 16 < (int64_t)0x7fffffff * 256, TBK_EUNSUPPORTED, "too many k-points for one launch");
     const unsigned blocks = (unsigned)((nk * 16 + 255) / 256);
+    if constexpr (!VEC && MODE != 1) {
+        if (tbk_knobs().ql16_evonly != 0) {      // TBK_QL16_EVONLY=0: the single replicated kernel (A/B runs)
+            const size_t wbytes = (size_t)nk * 16 * sizeof(double2);
+            if (wbytes > ctx->work_bytes) {
+                TBK_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->work) TBK_HIP(hipFree(ctx->work));
+                ctx->work = nullptr;
+                ctx->work_bytes = 0;
+                hipError_t e = hipMalloc(&ctx->work, wbytes);
+                TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "tridiagonal workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
+                ctx->work_bytes = wbytes;
+            }
+            double2* de = (double2*)ctx->work;
+            hipLaunchKernelGGL((k_solve_ql16<MODE, false, 1>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev, de);
+            hipLaunchKernelGGL(k_tridiag_eigvals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, mv.nsta, nk,
+                               (const double2*)de, L.eval, ctx->flags_dev);
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
+    }
     hipLaunchKernelGGL((k_solve_ql16<MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
