@@ -486,6 +486,39 @@ __device__ __forceinline__ void ql_small(SmallMat<N>& M) {
     for (int j = 0; j < N; ++j) M.dg[j] = d[j];
 }
 
+// n = 3, 4 on meshes: bring the eigenpairs into ascending order in place with a sorting network (3 / 5 compare-exchanges
+// of an eigenvalue and its eigenvector column).  k_grid_rows stores band planes with static register indices, so picking
+// "the band of rank r" used to be a 4-way select of freshly multiplied candidates for every (rank, component): 640 of the
+// kernel's ~3400 instructions per 64 points; the network is ~200.  (Exactly equal eigenvalues -- Kramers pairs -- may end
+// up in either order within the pair: a gauge choice, but a fixed function of the matrix.)
+template <int N, int I, int J>
+__device__ __forceinline__ void cmpxchg_pair(SmallMat<N>& M) {
+    const bool sw = M.dg[I] > M.dg[J];
+    const double lo = sw ? M.dg[J] : M.dg[I], hi = sw ? M.dg[I] : M.dg[J];
+    M.dg[I] = lo;
+    M.dg[J] = hi;
+#pragma unroll
+    for (int o = 0; o < N; ++o) {
+        const cd a = M.v[o][I], b = M.v[o][J];
+        M.v[o][I] = cd{sw ? b.x : a.x, sw ? b.y : a.y};
+        M.v[o][J] = cd{sw ? a.x : b.x, sw ? a.y : b.y};
+    }
+}
+template <int N>
+__device__ __forceinline__ void sort_small(SmallMat<N>& M) {
+    if constexpr (N == 3) {
+        cmpxchg_pair<N, 0, 1>(M);
+        cmpxchg_pair<N, 1, 2>(M);
+        cmpxchg_pair<N, 0, 1>(M);
+    } else if constexpr (N == 4) {
+        cmpxchg_pair<N, 0, 1>(M);
+        cmpxchg_pair<N, 2, 3>(M);
+        cmpxchg_pair<N, 0, 2>(M);
+        cmpxchg_pair<N, 1, 3>(M);
+        cmpxchg_pair<N, 1, 2>(M);
+    }
+}
+
 // rank of each eigenvalue in ascending order (stable: ties keep index order)
 template <int N>
 __device__ __forceinline__ void ranks_small(const double (&ev)[N], int (&rk)[N], double (&sorted)[N]) {
@@ -838,17 +871,10 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
             init_vectors<N, true>(M);
             jacobi_small<N, true>(M);
         }
-        int rk[N];
         double sorted[N];
-        if constexpr (N <= 2) {                   // the closed forms come out ascending
+        if constexpr (N > 2) sort_small<N>(M);    // (N <= 2: the closed forms come out ascending)
 #pragma unroll
-            for (int b = 0; b < N; ++b) {
-                rk[b] = b;
-                sorted[b] = M.dg[b];
-            }
-        } else {
-            ranks_small<N>(M.dg, rk, sorted);
-        }
+        for (int b = 0; b < N; ++b) sorted[b] = M.dg[b];
 #pragma unroll
         for (int b = 0; b + 1 < N; ++b) gmin[b] = fmin(gmin[b], sorted[b + 1] - sorted[b]);
         // eigenvectors of H: D^+ v, periodic-image phases folded into fo
@@ -865,17 +891,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int o = 0; o < N; ++o) {
-                cd val{0.0, 0.0};
-                if constexpr (N <= 2) {
-                    val = cmul(M.v[o][r], fo[o]);
-                } else {
-#pragma unroll
-                    for (int b = 0; b < N; ++b) {  // band with rank r (static register select)
-                        const cd cand = cmul(M.v[o][b], fo[o]);
-                        val.x = rk[b] == r ? cand.x : val.x;
-                        val.y = rk[b] == r ? cand.y : val.y;
-                    }
-                }
+                const cd val = cmul(M.v[o][r], fo[o]);
                 stage[wslot[o]] = val;
             }
             asm volatile("" ::: "memory");
