@@ -123,6 +123,9 @@ int tbk_wfs_free(tbk_wfs* wfs);
 int tbk_wfs_upload(tbk_wfs* wfs, const double* host_c128);
 int tbk_wfs_download(tbk_wfs* wfs, double* host_c128);
 int tbk_wfs_device_ptr(tbk_wfs* wfs, void** ptr_dev, int64_t* bytes);
+/* wf_array.choose_states (pythtb.py:2568-2608) on the device: dst (same mesh and ncomp, nsta_arr = nb) receives the
+ * states bands[0..nb) of src.  Band planes are contiguous in HBM, so this is nb device-to-device copies.            */
+int tbk_wfs_copy_bands(tbk_wfs* dst, tbk_wfs* src, const int32_t* bands, int nb);
 /* wf_array.__getitem__/__setitem__ (pythtb.py:2644-2672) on a resident array: copy the states of
  * npoints mesh points (row-major mesh indices) to/from host[npoints][nsta_arr][ncomp] c128 without
  * moving the rest of the array.                                                              */

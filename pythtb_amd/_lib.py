@@ -66,6 +66,7 @@ SIGNATURES = {
     "tbk_wfs_free": (_i, [_p]),
     "tbk_wfs_upload": (_i, [_p, _dp]),
     "tbk_wfs_download": (_i, [_p, _dp]),
+    "tbk_wfs_copy_bands": (_i, [_p, _p, _ip, _i]),
     "tbk_wfs_device_ptr": (_i, [_p, _pp, C.POINTER(C.c_int64)]),
     "tbk_wfs_download_points": (_i, [_p, C.POINTER(C.c_int64), _i64, _dp]),
     "tbk_wfs_upload_points": (_i, [_p, C.POINTER(C.c_int64), _i64, _dp]),

@@ -836,6 +836,27 @@ extern "C" int tbk_ctx_transfer_stats(tbk_ctx* c, int64_t* h2d_bytes, int64_t* d
     return TBK_OK;
 }
 
+// wf_array.choose_states (pythtb.py:2568-2608) between two resident arrays of the same mesh: band planes are contiguous on
+// the device, so a subset of the states is nb device-to-device copies -- nothing crosses PCIe.
+extern "C" int tbk_wfs_copy_bands(tbk_wfs* dst, tbk_wfs* src, const int32_t* bands, int nb) {
+    TBK_REQUIRE(dst && src && bands && nb >= 1, TBK_EINVAL, "tbk_wfs_copy_bands: bad argument");
+    TBK_REQUIRE(dst->ctx == src->ctx, TBK_EINVAL, "tbk_wfs_copy_bands: arrays live on different contexts");
+    const WfsView &d = dst->view, &s = src->view;
+    TBK_REQUIRE(d.npts == s.npts && d.ncomp == s.ncomp && d.dim_arr == s.dim_arr && d.nsta == nb, TBK_EINVAL,
+                "tbk_wfs_copy_bands: destination must hold %d states on the same mesh", nb);
+    for (int i = 0; i < d.dim_arr; ++i) TBK_REQUIRE(d.mesh[i] == s.mesh[i], TBK_EINVAL, "tbk_wfs_copy_bands: mesh mismatch");
+    tbk_ctx* ctx = src->ctx;
+    TBK_HIP(hipSetDevice(ctx->device));
+    const size_t plane = (size_t)s.npts * s.ncomp * sizeof(cd);
+    for (int b = 0; b < nb; ++b) {
+        TBK_REQUIRE(bands[b] >= 0 && bands[b] < s.nsta, TBK_EINVAL, "tbk_wfs_copy_bands: state %d outside the %d stored", bands[b], s.nsta);
+        TBK_HIP(hipMemcpyAsync((unsigned char*)d.data + (size_t)b * plane, (const unsigned char*)s.data + (size_t)bands[b] * plane, plane,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    TBK_HIP(hipStreamSynchronize(ctx->stream));
+    return TBK_OK;
+}
+
 extern "C" int tbk_wfs_device_ptr(tbk_wfs* w, void** p, int64_t* bytes) {
     TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_device_ptr: null wfs");
     if (p) *p = w->view.data;

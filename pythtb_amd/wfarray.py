@@ -277,25 +277,53 @@ class wf_array(object):
                 key = key[0]
         self[key] = evec
 
+    def _clone_meta(self):
+        """A wf_array with this one's model, mesh and bookkeeping but no storage (deepcopy would first download a
+        resident array -- 69.5 GB for BASELINE configs[4] -- only to throw the copy away)."""
+        new = wf_array.__new__(wf_array)
+        for k, v in self.__dict__.items():
+            if k in ("_host", "_dev", "_dev_shape"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v)
+        new._host = None
+        new._host_valid = False
+        new._host_exported = False
+        new._dev = None
+        new._dev_shape = None
+        new._dev_valid = False
+        return new
+
     def choose_states(self, subset):
-        """New wf_array holding a subset of the states (pythtb.py:2568-2608)."""
+        """New wf_array holding a subset of the states (pythtb.py:2568-2608).  On a resident array the chosen band
+        planes are copied device to device; nothing crosses PCIe."""
         subset = np.array(subset, dtype=int)
         if subset.ndim != 1:
             raise Exception("\n\nParameter subset must be a one-dimensional array.")
         if self._dim_arr > 4:
             raise Exception("\n\n_dim_array too large.")
-        new = copy.deepcopy(self)
+        new = self._clone_meta()
         new._nsta_arr = subset.shape[0]
-        new._wfs = np.take(self._host_array(), subset, axis=self._dim_arr)
+        dev_current = self._dev_valid and self._dev is not None and not (self._host_exported and self._host_valid)
+        if dev_current and subset.size >= 1:
+            if np.any(subset < -self._nsta_arr) or np.any(subset >= self._nsta_arr):
+                raise IndexError("index out of bounds in choose_states")      # np.take's error class in the reference
+            sub32 = np.ascontiguousarray(subset % self._nsta_arr, dtype=np.int32)
+            h = new._dev_handle(new._shape())
+            _lib.check(_lib.lib.tbk_wfs_copy_bands(h, self._dev, _lib.iptr(sub32), len(sub32)))
+            new._dev_valid = True
+        else:
+            new._wfs = np.take(self._host_array(), subset, axis=self._dim_arr)
+            new._host_exported = False
         return new
 
     def empty_like(self, nsta_arr=None):
         """Same-shaped uninitialised wf_array, optionally with another number of states
         (pythtb.py:2610-2642)."""
-        new = copy.deepcopy(self)
+        new = self._clone_meta()
         if nsta_arr is not None:
             new._nsta_arr = nsta_arr
         new._wfs = np.empty(new._shape(), dtype=complex)
+        new._host_exported = False
         return new
 
     def _check_key(self, key):

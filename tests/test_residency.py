@@ -200,3 +200,27 @@ def test_singular_link_matrix_is_reported_not_returned(tb):
     w[1] = e                                   # repaired: a trivial loop, all eigenphases zero; the sticky flag was cleared
     got = w.berry_phase([0, 1, 2], berry_evals=True, contin=False)
     assert np.max(np.abs(got)) < 1e-12
+
+
+def test_choose_states_copies_band_planes_on_the_device(tb):
+    """pythtb.py:2568-2608 on a resident array: the subset is made of device-to-device plane copies (no PCIe), equals
+    np.take on the host copy, and Berry calls on it equal the occ-list form on the parent."""
+    m = hp.kane_mele(tb.tb_model, "odd")
+    w = tb.wf_array(m, [301, 97])
+    w.solve_on_grid([-0.5, -0.5])
+    stats(tb, reset=True)
+    sub = w.choose_states([1, 0])
+    low = w.choose_states([0, 1])
+    up = w.choose_states([3, -2])                      # negative indices as np.take allows
+    assert stats(tb)["h2d_calls"] == 0 and stats(tb)["d2h_calls"] == 0
+    assert sub._nsta_arr == 2 and sub._mesh_arr.tolist() == [301, 97]
+    host = w.to_host()
+    assert np.array_equal(sub.to_host(), np.take(host, [1, 0], axis=2))
+    assert np.array_equal(up.to_host(), np.take(host, [3, -2], axis=2))
+    assert np.array_equal(low.berry_phase([0, 1], 0, contin=False, berry_evals=True),
+                          w.berry_phase([0, 1], 0, contin=False, berry_evals=True))
+    assert abs(low.berry_flux("All") - w.berry_flux([0, 1])) < 1e-12
+    e = w.empty_like(nsta_arr=3)
+    assert e._wfs.shape == (301, 97, 3, 2, 2) and e._nsta_arr == 3
+    with pytest.raises(IndexError):
+        w.choose_states([4])
