@@ -915,15 +915,12 @@ extern "C" int tbk_berry_flux_result(tbk_wfs* w, double* totals, double* plaq) {
     TBK_REQUIRE(w && totals, TBK_EINVAL, "tbk_berry_flux_result: null argument");
     TBK_REQUIRE(w->flux_nslices > 0, TBK_EINVAL, "tbk_berry_flux_result: no flux launch pending");
     tbk_ctx* ctx = w->ctx;
-    TBK_HIP(hipMemcpyAsync(totals, w->flux_totals_dev, w->flux_nslices * sizeof(double), hipMemcpyDeviceToHost,
-                           ctx->stream));
     if (plaq) {
         TBK_REQUIRE(w->flux_plaq_n > 0, TBK_EINVAL, "tbk_berry_flux_result: plaquettes were not requested");
         TBK_HIP(hipMemcpyAsync(plaq, w->flux_plaq_dev, w->flux_plaq_n * sizeof(double), hipMemcpyDeviceToHost,
                                ctx->stream));
     }
-    TBK_HIP(hipStreamSynchronize(ctx->stream));
-    return TBK_OK;
+    return tbk_small_d2h(ctx, totals, w->flux_totals_dev, w->flux_nslices * sizeof(double));
 }
 
 extern "C" int tbk_berry_flux(tbk_wfs* w, const int32_t* occ, int nocc, int dir0, int dir1, double* totals,

@@ -97,6 +97,7 @@ extern "C" int tbk_ctx_create(int device, tbk_ctx** out) {
     TBK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     TBK_HIP(hipEventCreate(&c->timer0));
     TBK_HIP(hipEventCreate(&c->timer1));
+    if (hipHostMalloc(&c->pinned, 64 * 1024, hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;   // (optional: falls back to plain copies)
     TBK_HIP(hipMalloc((void**)&c->flags_dev, 64 * sizeof(int)));
     TBK_HIP(hipMemsetAsync(c->flags_dev, 0, 64 * sizeof(int), c->stream));
     TBK_HIP(hipStreamSynchronize(c->stream));
@@ -116,6 +117,7 @@ extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->scratch) hipFree(c->scratch);
     if (c->flags_dev) hipFree(c->flags_dev);
+    if (c->pinned) hipHostFree(c->pinned);
     if (c->work) hipFree(c->work);
     hipEventDestroy(c->timer0);
     hipEventDestroy(c->timer1);
@@ -137,6 +139,19 @@ extern "C" int tbk_ctx_device_info(tbk_ctx* c, char* name, int cap, int* cus, in
     if (name && cap > 0) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
     if (cus) *cus = prop.multiProcessorCount;
     if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
+    return TBK_OK;
+}
+
+int tbk_small_d2h(tbk_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+    if (bytes == 0) return TBK_OK;
+    if (bytes > 64 * 1024 || !c->pinned) {
+        TBK_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        TBK_HIP(hipStreamSynchronize(c->stream));
+        return TBK_OK;
+    }
+    TBK_HIP(hipMemcpyAsync(c->pinned, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    TBK_HIP(hipStreamSynchronize(c->stream));
+    memcpy(dst, c->pinned, bytes);
     return TBK_OK;
 }
 

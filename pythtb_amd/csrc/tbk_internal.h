@@ -123,6 +123,7 @@ struct tbk_ctx {
     // scratch reused across calls (grown on demand, stream-ordered use only)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    void* pinned = nullptr;    // 64 KiB of pinned host memory for small results
     int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
     void* work = nullptr;      // workspace of the workgroup-per-matrix eigen-solver (n > 64)
     size_t work_bytes = 0;
@@ -135,6 +136,9 @@ struct tbk_ctx {
 };
 
 int tbk_ctx_scratch(tbk_ctx* ctx, size_t bytes, void** out);
+// small device-to-host result (min gaps, flux totals, status words): through a pinned staging buffer -- an async copy into
+// pageable memory is staged by the runtime and cost ~10 us more per call on the Python-API path -- then stream sync
+int tbk_small_d2h(tbk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
 
 // RAII bracket recording HIP events around one kernel launch when profiling.
 struct ProfScope {

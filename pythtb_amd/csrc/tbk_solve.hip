@@ -1315,18 +1315,31 @@ __global__ __launch_bounds__(256) void k_gen_ham(const ModelView mv, const int64
     }
 }
 
-// min over the per-tile partial gaps of k_grid_rows: one workgroup per band pair
-__global__ __launch_bounds__(256) void k_gap_part_reduce(const double* __restrict__ part, const int64_t ntiles, const int ng,
-                                                         double* __restrict__ out) {
+// min over the per-tile partial gaps of k_grid_rows: one 1024-thread workgroup per band pair, four loads in flight per thread
+__global__ __launch_bounds__(1024) void k_gap_part_reduce(const double* __restrict__ part, const int64_t ntiles, const int ng,
+                                                          double* __restrict__ out) {
     const int b = blockIdx.x;
-    double g = INFINITY;
-    for (int64_t t = threadIdx.x; t < ntiles; t += 256) g = fmin(g, part[t * ng + b]);
+    double g0 = INFINITY, g1 = INFINITY, g2 = INFINITY, g3 = INFINITY;
+    int64_t t = threadIdx.x;
+    for (; t + 3 * 1024 < ntiles; t += 4 * 1024) {
+        g0 = fmin(g0, part[t * ng + b]);
+        g1 = fmin(g1, part[(t + 1024) * ng + b]);
+        g2 = fmin(g2, part[(t + 2048) * ng + b]);
+        g3 = fmin(g3, part[(t + 3072) * ng + b]);
+    }
+    for (; t < ntiles; t += 1024) g0 = fmin(g0, part[t * ng + b]);
+    double g = fmin(fmin(g0, g1), fmin(g2, g3));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) g = fmin(g, __shfl_xor(g, off));
-    __shared__ double red[4];
+    __shared__ double red[16];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = g;
     __syncthreads();
-    if (threadIdx.x == 0) out[b] = fmax(fmin(fmin(red[0], red[1]), fmin(red[2], red[3])), 0.0);
+    if (threadIdx.x == 0) {
+        double m = red[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = fmin(m, red[i]);
+        out[b] = fmax(m, 0.0);
+    }
 }
 
 __global__ void k_arm_gaps(unsigned long long* p, const int n) {
@@ -1826,11 +1839,11 @@ extern "C" int tbk_wfs_solve_grid_result(tbk_wfs* w, double* min_gaps) {
         int rc = tbk_ctx_scratch(ctx, 256 + (size_t)w->gaps_n * sizeof(double), &base);
         if (rc) return rc;
         double* out_dev = (double*)((unsigned char*)base + 256);
-        hipLaunchKernelGGL(k_gap_part_reduce, dim3(w->gaps_n), dim3(256), 0, ctx->stream, w->gap_part_dev, w->gap_part_n,
+        hipLaunchKernelGGL(k_gap_part_reduce, dim3(w->gaps_n), dim3(1024), 0, ctx->stream, w->gap_part_dev, w->gap_part_n,
                            w->gaps_n, out_dev);
         TBK_HIP(hipGetLastError());
-        TBK_HIP(hipMemcpyAsync(min_gaps, out_dev, (size_t)w->gaps_n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        rc = tbk_small_d2h(ctx, min_gaps, out_dev, (size_t)w->gaps_n * sizeof(double));
+        if (rc) return rc;
         return check_noconv(ctx, w->view.nsta);
     }
     const size_t half = (size_t)TBK_GAP_SHARDS * w->view.ncomp;
