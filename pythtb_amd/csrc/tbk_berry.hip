@@ -650,13 +650,19 @@ __global__ __launch_bounds__(1024) void k_flux_reduce(const double* __restrict__
         s3 += p[i + 3072];
     }
     for (; i < bps; i += 1024) s0 += p[i];
-    __shared__ double red[1024];
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
+    // fixed-shape tree: xor-butterfly inside each wavefront (the same bits in every lane), then the 16 wavefront sums in
+    // index order -- two barriers instead of the ten of an LDS tree over 1024 entries
+    double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
-    for (int w = 512; w > 0; w >>= 1) {
-        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    __shared__ double red[16];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t += red[i];
+        red[0] = t;
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = red[0];
 }
