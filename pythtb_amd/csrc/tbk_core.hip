@@ -33,6 +33,7 @@ static void knobs_parse() {
     geti("TBK_ROW16", k.use_row16);
     geti("TBK_QL16", k.use_ql16);
     geti("TBK_QL16_EVONLY", k.ql16_evonly);
+    getl("TBK_QL16_MIN", k.ql16_min);
     getl("TBK_FEW_MAX", k.few_max);
     geti("TBK_FEW_WARM", k.few_warm);
     geti("TBK_FEW_NT", k.few_nt);

@@ -37,6 +37,7 @@ struct TbkKnobs {
     int use_reg = 1;            // TBK_REG           0: n = 5..8 through the wavefront kernel
     int use_row16 = 1;          // TBK_ROW16         0: no DPP-row Jacobi kernel
     int use_ql16 = 1;           // TBK_QL16          0: n = 9..16 through the Jacobi kernels
+    long long ql16_min = -1;    // TBK_QL16_MIN      batches of at most this many matrices stay on the workgroup-per-matrix Jacobi (default 8 x CUs)
     int ql16_evonly = 1;        // TBK_QL16_EVONLY   0: eigenvalue-only n = 9..16 lists through the single replicated kernel instead of tridiagonalise + lane-per-matrix QL
     long long few_max = -1;     // TBK_FEW_MAX       largest n < 22 batch that gets a workgroup per matrix
     int few_warm = 1;           // TBK_FEW_WARM      0: workgroup solver always starts cold

@@ -1405,9 +1405,15 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // with vectors; at n = 12 and below the LDS kernel wins).  Mesh solves keep the warm-started LDS kernel
     // (a fine mesh needs ~3 sweeps there).  Needs the R-grouped table unless the matrices are supplied.
     // n = 9..16: the direct solver (Householder + implicit QL in registers, tbk_solve_ql16.inl) on meshes, k lists and
-    // supplied matrices alike; it needs the R-grouped table unless the matrices are supplied, and a batch that fills
-    // the chip with 16-lane rows (a handful of matrices is latency-bound: the workgroup-per-matrix Jacobi below)
-    if (n >= 9 && n <= 16 && use_ql16 && (MODE == 2 || mv.nR > 0) && nk_eff > (int64_t)ctx->cus * 8)
+    // supplied matrices alike; it needs the R-grouped table unless the matrices are supplied.  Batches that cannot fill
+    // the chip (a k path, one finite piece) stay on the workgroup-per-matrix JACOBI below although the direct solver is
+    // also faster there (0.05-0.10 ms against 0.07-0.21 ms for 8..2048 matrices, profiles/ql16_small_batches.py): Jacobi
+    // resolves nearly degenerate pairs of weakly coupled copies (splitting ~1e-12) with high RELATIVE accuracy, and the
+    // reference's model-equivalence test (tests/test_tbmodel/test_different_modes.py stage c: position expectations of
+    // the eigenstates of a finite piece, three embeddings whose H differ by one ulp) depends on exactly that.
+    // TBK_QL16_MIN=<count>: batches of at most that many matrices stay on Jacobi (default 8 x CUs; 0 = none).
+    const int64_t ql16_min = K.ql16_min >= 0 ? K.ql16_min : (int64_t)ctx->cus * 8;
+    if (n >= 9 && n <= 16 && use_ql16 && (MODE == 2 || mv.nR > 0) && nk_eff > ql16_min)
         return launch_ql16<MODE, VEC>(ctx, mv, nk, L, G);
     if constexpr (MODE != 1) {
         // (eigenvalues only: already from n = 13, where the LDS kernel takes ~9-10 ms for the same 262144 k)

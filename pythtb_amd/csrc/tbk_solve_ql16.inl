@@ -470,7 +470,9 @@ static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
     TBK_REQUIRE(nk * 16 < (int64_t)0x7fffffff * 256, TBK_EUNSUPPORTED, "too many k-points for one launch");
     const unsigned blocks = (unsigned)((nk * 16 + 255) / 256);
     if constexpr (!VEC && MODE != 1) {
-        if (tbk_knobs().ql16_evonly != 0) {      // TBK_QL16_EVONLY=0: the single replicated kernel (A/B runs)
+        // (from ~8 k matrices on: below that the second kernel's one-matrix-per-lane QL is a single under-filled wavefront
+        // and its latency exceeds what the replication costs; TBK_QL16_EVONLY=0: always the single replicated kernel)
+        if (tbk_knobs().ql16_evonly != 0 && nk >= 8192) {
             const size_t wbytes = (size_t)nk * 16 * sizeof(double2);
             if (wbytes > ctx->work_bytes) {
                 TBK_HIP(hipStreamSynchronize(ctx->stream));
