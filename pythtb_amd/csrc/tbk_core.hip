@@ -32,6 +32,10 @@ static void knobs_parse() {
     geti("TBK_REG", k.use_reg);
     geti("TBK_ROW16", k.use_row16);
     geti("TBK_QL16", k.use_ql16);
+    geti("TBK_QLW", k.use_qlw);
+    getl("TBK_QLW_MIN", k.qlw_min);
+    geti("TBK_QLW_NT", k.qlw_nt);
+    geti("TBK_QLW_WS_MB", k.qlw_ws_mb);
     geti("TBK_QL16_EVONLY", k.ql16_evonly);
     getl("TBK_QL16_MIN", k.ql16_min);
     getl("TBK_FEW_MAX", k.few_max);

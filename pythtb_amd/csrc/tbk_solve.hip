@@ -923,6 +923,67 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
 }
 
 // ---------------------------------------------------------------------------
+// S(k) of one point (or the supplied matrix, MODE 2) into the LDS matrix A[n][ld], by the NT threads of a
+// workgroup; `ph` is scratch for max(nR, 1) phases.  The last writes are NOT followed by a barrier.
+// ---------------------------------------------------------------------------
+template <int MODE, int NT>
+__device__ __forceinline__ void assemble_lds(const ModelView& mv, const ListArgs& L, const int64_t id, const double (&kk)[4],
+                                             cd* __restrict__ A, const int ld, cd* __restrict__ ph, const int lane) {
+    const int n = mv.nsta;
+    if constexpr (MODE == 2) {
+        const cd* h = L.ham + id * (int64_t)n * n;
+        for (int e = lane; e < n * n; e += NT) {
+            const int a = e / n, b = e - a * n;
+            // use the upper triangle, mirror it (the reference's eigh reads one triangle)
+            cd v = a <= b ? h[a * n + b] : cconj(h[b * n + a]);
+            if (a == b) v.y = 0.0;
+            A[a * ld + b] = v;
+        }
+    } else {
+        cd z[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
+        if (mv.nR > 0) {
+            // dense model: S_slot = sum_R U_R[slot] e^{2 pi i k.R}.  One lane per phase, then every
+            // slot is nR independent, coalesced coefficient loads (the table stays in L2)
+            for (int r = lane; r < mv.nR; r += NT) ph[r] = phase_of_R(z, mv.rvec[r]);
+            __syncthreads();
+            for (int slot = lane; slot < mv.nslot; slot += NT) {
+                const int ab = mv.slot_ab[slot];
+                const int a = ab & 0xffff, b = ab >> 16;
+                const cd* u = mv.rblock + slot;
+                cd acc{0.0, 0.0};
+#pragma unroll 4
+                for (int r = 0; r < mv.nR; ++r) cfma(acc, u[(size_t)r * mv.nslot], ph[r]);
+                if (a == b) {
+                    A[a * ld + a] = cd{acc.x, 0.0};
+                } else {
+                    A[a * ld + b] = acc;
+                    A[b * ld + a] = cconj(acc);
+                }
+            }
+            __syncthreads();   // phases consumed before the caller reuses `ph`
+        } else {
+            // sparse model (ribbons, slabs): clear A, then walk the non-empty slots only
+            for (int e = lane; e < n * ld; e += NT) A[e] = cd{0.0, 0.0};
+            __syncthreads();
+            for (int i = lane; i < mv.nnz; i += NT) {
+                const int4 s = mv.nz[i];
+                const int a = s.x & 0xffff, b = s.x >> 16;
+                cd acc{0.0, 0.0};
+                for (int t = s.y; t < s.z; ++t) cfma(acc, mv.term_amp[t], phase_of_R(z, mv.term_R[t]));
+                if (a == b) {
+                    A[a * ld + a] = cd{acc.x, 0.0};
+                } else {
+                    A[a * ld + b] = acc;
+                    A[b * ld + a] = cconj(acc);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // nsta > 4: one wavefront per matrix, A and V^T in LDS.
 // Row stride n+1 (one c128 of padding) keeps both row and column walks of the
 // 16-byte elements on distinct LDS banks.
@@ -1022,57 +1083,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
         }
         __syncthreads();  // previous matrix fully written out before LDS is reused
         // ---- assemble S(k) (or load the supplied matrix) into A, V^T = I
-        if constexpr (MODE == 2) {
-            const cd* h = L.ham + id * (int64_t)n * n;
-            for (int e = lane; e < n * n; e += NT) {
-                const int a = e / n, b = e - a * n;
-                // use the upper triangle, mirror it (the reference's eigh reads one triangle)
-                cd v = a <= b ? h[a * n + b] : cconj(h[b * n + a]);
-                if (a == b) v.y = 0.0;
-                S.A[a * ld + b] = v;
-            }
-        } else {
-            cd z[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
-            if (mv.nR > 0) {
-                // dense model: S_slot = sum_R U_R[slot] e^{2 pi i k.R}.  One lane per phase, then every
-                // slot is nR independent, coalesced coefficient loads (the table stays in L2)
-                for (int r = lane; r < mv.nR; r += NT) S.eo[r] = phase_of_R(z, mv.rvec[r]);
-                __syncthreads();
-                for (int slot = lane; slot < mv.nslot; slot += NT) {
-                    const int ab = mv.slot_ab[slot];
-                    const int a = ab & 0xffff, b = ab >> 16;
-                    const cd* u = mv.rblock + slot;
-                    cd acc{0.0, 0.0};
-#pragma unroll 4
-                    for (int r = 0; r < mv.nR; ++r) cfma(acc, u[(size_t)r * mv.nslot], S.eo[r]);
-                    if (a == b) {
-                        S.A[a * ld + a] = cd{acc.x, 0.0};
-                    } else {
-                        S.A[a * ld + b] = acc;
-                        S.A[b * ld + a] = cconj(acc);
-                    }
-                }
-                __syncthreads();   // phases consumed before eo is rewritten below
-            } else {
-                // sparse model (ribbons, slabs): clear A, then walk the non-empty slots only
-                for (int e = lane; e < n * ld; e += NT) S.A[e] = cd{0.0, 0.0};
-                __syncthreads();
-                for (int i = lane; i < mv.nnz; i += NT) {
-                    const int4 s = mv.nz[i];
-                    const int a = s.x & 0xffff, b = s.x >> 16;
-                    cd acc{0.0, 0.0};
-                    for (int t = s.y; t < s.z; ++t) cfma(acc, mv.term_amp[t], phase_of_R(z, mv.term_R[t]));
-                    if (a == b) {
-                        S.A[a * ld + a] = cd{acc.x, 0.0};
-                    } else {
-                        S.A[a * ld + b] = acc;
-                        S.A[b * ld + a] = cconj(acc);
-                    }
-                }
-            }
-        }
+        assemble_lds<MODE, NT>(mv, L, id, kk, S.A, ld, S.eo, lane);
         if (cold) {
             if (walker)
                 for (int a = i0; a < n; a += istep) S.Vt[a * ld + c0] = cd{a == c0 ? 1.0 : 0.0, 0.0};
@@ -1350,6 +1361,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 #include "tbk_solve_reg.inl"   // n = 5..8: register-resident cyclic Jacobi, 1/2/4 lanes per matrix
 #include "tbk_solve_row16.inl" // n = 15, 16 on lists: one DPP row of 16 lanes per matrix, rows of A in registers
 #include "tbk_solve_ql16.inl"  // n = 9..16: Householder + implicit QL in registers, one DPP row of 16 lanes per matrix
+#include "tbk_solve_qlw.inl"   // n = 17..64, large batches: Householder in LDS, lane-per-matrix QL, rotation replay
 #include "tbk_solve_blk.inl"   // batches of wide matrices: block Jacobi, 16x16 subproblems through k_solve_row16
 
 // ---------------------------------------------------------------------------
@@ -1415,6 +1427,10 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     const int64_t ql16_min = K.ql16_min >= 0 ? K.ql16_min : (int64_t)ctx->cus * 8;
     if (n >= 9 && n <= 16 && use_ql16 && (MODE == 2 || mv.nR > 0) && nk_eff > ql16_min)
         return launch_ql16<MODE, VEC>(ctx, mv, nk, L, G);
+    // n = 17..64, batches that fill the chip: the three-kernel tridiagonal path (tbk_solve_qlw.inl); smaller batches stay
+    // on Jacobi for the same reason as above.  TBK_QLW=0 / TBK_QLW_MIN=<count>.
+    const int64_t qlw_min = K.qlw_min >= 0 ? K.qlw_min : (int64_t)ctx->cus * 8;
+    if (n >= 17 && n <= 64 && K.use_qlw != 0 && nk_eff > qlw_min) return launch_qlw<MODE, VEC>(ctx, mv, n, nk, L, G);
     if constexpr (MODE != 1) {
         // (eigenvalues only: already from n = 13, where the LDS kernel takes ~9-10 ms for the same 262144 k)
         if ((n >= 15 || (!VEC && n >= 13)) && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0))

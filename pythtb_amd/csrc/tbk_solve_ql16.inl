@@ -143,7 +143,10 @@ __device__ __forceinline__ void ql16_pos(Ql16State& S, cd (&z)[16], double& dd, 
                 z[I] = cd{S.c * zi.x - S.s * zj.x, S.c * zi.y - S.s * zj.y};
             }
         } else {   // r == 0 (underflow): tql2's recovery -- d[i+1] -= p, e[m] = 0, start the block over
-            if (x == I + 1) dd -= S.p;
+            if (x == I + 1) {
+                dd -= S.p;
+                ee = 0.0;                              // (e_{i+1} = r = 0)
+            }
             S.alive = false;
         }
     }
@@ -185,7 +188,7 @@ __device__ __forceinline__ void qle_pos(double (&d)[16], double (&e)[16], double
             }
         } else {                                 // r == 0 (underflow): tql2's recovery
             d[I + 1] -= pp;
-            if (I + 1 == m) e[I + 1] = 0.0;
+            e[I + 1] = 0.0;                          // (e_{i+1} = r = 0)
             alive = false;
         }
     }

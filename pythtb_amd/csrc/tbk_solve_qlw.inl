@@ -1,0 +1,538 @@
+// tbk_solve_qlw.inl -- included by tbk_solve.hip (after tbk_solve_ql16.inl, whose row sums it uses).
+//
+// n = 17..64 states per k, large batches: the DIRECT Hermitian eigen-solver (what LAPACK's zhetrd + zsteqr/zungtr
+// do for the reference's numpy.linalg.eigh / eigvalsh, pythtb.py:939-947) as three kernels, because its three parts
+// parallelise differently:
+//
+//  1. k_tridiag_lds      one workgroup per matrix, A in LDS.  Householder reflections H_k = I - beta u u^+ bring A to a
+//                        (complex) tridiagonal form; u_k is kept where LAPACK keeps it, in the dead column k below the
+//                        diagonal.  With eigenvectors wanted the unitary Z = H_0 ... H_{n-3} D (D: the diagonal unitary
+//                        that makes the subdiagonal real) is then accumulated BACKWARDS, IN PLACE of A (each H_k only
+//                        touches the trailing block it was built from: n^3/3 work instead of n^3/2, and no second
+//                        matrix in LDS) and written to the output array, band slot b = column b.
+//                        O(n^3) work, n^2-way parallel, LDS-bandwidth bound.
+//  2. k_tridiag_ql_lanes the implicit-shift QL iteration on (d, e) is a SEQUENTIAL scalar recurrence (~n^2 plane
+//                        rotations, each a dozen dependent fp64 operations): one LANE per matrix, d and e in LDS laid
+//                        out [j][lane] (conflict-free whatever j each lane is at), all lanes of a wavefront stepping
+//                        through the same positions under EXEC masks.  It writes the sorted eigenvalues (or the mesh's
+//                        minimum gaps), the sorting permutation and -- with eigenvectors wanted -- the rotation
+//                        sequence (c, s) of every sweep into a workspace.
+//  3. k_ql_backtransform one workgroup per matrix: Z back into LDS, thread = (row, real | imaginary part) replays the
+//                        recorded rotations on its row (rows are independent, the rotations real), then the columns
+//                        leave in ascending order of their eigenvalue.
+//
+// The cyclic Jacobi kernels these replace do 7-9 sweeps of n(n-1)/2 rotations over A and V (~80 n^3 flops, all of it
+// LDS traffic); this path is ~(16/3 + 8/3 + 6) n^3.  Every point is solved on its own: periodic images, halo rows and
+// shard windows are bit-identical by construction.  Batches are processed in chunks so that the rotation workspace
+// stays below ~1.5 GiB.
+
+template <int RW>
+__device__ __forceinline__ double rw_allsum(double v) {   // sum over the RW (32 | 64) lanes x of a strip, same bits in every lane
+    v = row_allsum(v);
+    v += __shfl_xor(v, 16);
+    if constexpr (RW == 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
+    double2* de;           // [n][nchunk]      (d_j, e_j)
+    double2* rot;          // [nchunk][cap]    (c, s) in the order they were applied
+    unsigned* swp;         // [nchunk][scap]   one word per sweep: first position | rotations << 8
+    int* nsw;              // [nchunk]
+    unsigned char* perm;   // [n][nchunk]      perm[r][id] = column holding the r-th smallest eigenvalue
+    int64_t cap;
+    int scap;
+};
+
+static size_t qlw_lds1_bytes(int n, int nR, int rw, int nt) {
+    const int ld = n | 1, hs = nt / rw;
+    size_t b = (size_t)n * ld * sizeof(cd);                       // A / Z
+    b += (size_t)(2 * rw + rw + 2 * hs * rw) * sizeof(cd);        // ubuf (x2), qbuf, pbuf (x2)
+    b += (size_t)(std::max(n, nR) + 2 * n) * sizeof(cd);          // eo / phases, dphase, tsub
+    b += (size_t)2 * n * sizeof(double);                          // tau, eb
+    return (b + 15) & ~(size_t)15;
+}
+
+// MODE 0: k list, 1: regular mesh into a wf_array, 2: supplied matrices.  Block b works on matrix id0 + b of the batch
+// (chunk-local index b).
+template <int MODE, bool VEC, int RW, int NT>
+__global__ __launch_bounds__(NT) void k_tridiag_lds(const ModelView mv, const int64_t nk, const ListArgs L, const GridArgs G,
+                                                     const int64_t id0, const int64_t nchunk, double2* __restrict__ de) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int HS = NT / RW;
+    const int n = mv.nsta, ld = n | 1;
+    const int tid = threadIdx.x, x = tid & (RW - 1), h = tid / RW;
+    cd* A = (cd*)lds_raw;
+    cd* ubuf = A + n * ld;                 // [2][RW]
+    cd* qbuf = ubuf + 2 * RW;              // [RW]
+    cd* pbuf = qbuf + RW;                  // [2][HS][RW]
+    cd* eo = pbuf + 2 * HS * RW;           // [max(n, nR)]
+    cd* dphase = eo + (n > mv.nR ? n : mv.nR);
+    cd* tsub = dphase + n;
+    double* tau = (double*)(tsub + n);
+    double* eb = tau + n;
+    const int64_t idc = blockIdx.x, id = id0 + idc;
+
+    double kk[4] = {0.0, 0.0, 0.0, 0.0};
+    bool wrap[4] = {false, false, false, false};
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (d < mv.dim_k) kk[d] = L.k[id * mv.dim_k + d];
+    } else if constexpr (MODE == 1) {
+        grid_point(G, id, kk, wrap);
+    }
+    assemble_lds<MODE, NT>(mv, L, id, kk, A, ld, eo, tid);
+    __syncthreads();
+    if (VEC && tid < n) {
+        cd f{1.0, 0.0};
+        if constexpr (MODE != 2) f = cconj(expi2pi(kdot(kk, mv.orb[tid])));
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (wrap[d]) f = cmul(f, G.pbc[d * n + tid]);
+        }
+        eo[tid] = f;
+    }
+
+    // ---- 1. reflections k = 0 .. n-3.  Thread (x, h): row x, columns c = k+1+h, k+1+h+HS, ...
+    for (int k = 0; k + 2 < n; ++k) {
+        const bool below = x > k && x < n;
+        const cd colx = below ? A[x * ld + k] : cd{0.0, 0.0};
+        const double sigma = rw_allsum<RW>(cabs2(colx));     // |column below the diagonal|^2
+        const cd alpha = A[(k + 1) * ld + k];
+        const double absa2 = cabs2(alpha);
+        cd tK = alpha;
+        double beta = 0.0;
+        if (sigma > absa2) {   // (uniform) something to annihilate below the subdiagonal
+            const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
+            double absa = 0.0;
+            cd ph{1.0, 0.0};
+            if (absa2 > 0.0) {
+                const double inv_a = rsqrt_full(absa2);
+                absa = absa2 * inv_a;
+                ph = cd{alpha.x * inv_a, alpha.y * inv_a};
+            }
+            // u = column + phase * norm * e_{k+1};  H maps the column onto -phase * norm * e_{k+1}
+            const cd u = x == k + 1 ? cd{ph.x * (absa + nrm), ph.y * (absa + nrm)} : colx;
+            beta = 1.0 / (nrm * (nrm + absa));               // 2 / (u^+ u)
+            tK = cd{-ph.x * nrm, -ph.y * nrm};
+            if (h == 0) ubuf[x] = u;
+            __syncthreads();
+            cd p{0.0, 0.0};
+            if (below)
+                for (int c = k + 1 + h; c < n; c += HS) cfma(p, A[x * ld + c], ubuf[c]);
+            pbuf[h * RW + x] = p;
+            __syncthreads();
+            cd ps{0.0, 0.0};
+#pragma unroll
+            for (int hh = 0; hh < HS; ++hh) {
+                const cd t = pbuf[hh * RW + x];
+                ps.x += t.x;
+                ps.y += t.y;
+            }
+            ps = cd{ps.x * beta, ps.y * beta};
+            // kappa = beta/2 u^+ p  (real: u^+ A u of a Hermitian A)
+            const double kappa = 0.5 * beta * rw_allsum<RW>(u.x * ps.x + u.y * ps.y);
+            const cd q = below ? cd{ps.x - kappa * u.x, ps.y - kappa * u.y} : cd{0.0, 0.0};
+            if (h == 0) {
+                qbuf[x] = q;
+                if (below) A[x * ld + k] = u;                // the reflector stays in its column (LAPACK's convention)
+            }
+            __syncthreads();
+            if (below)
+                for (int c = k + 1 + h; c < n; c += HS) {    // A[x][c] -= u_x conj(q_c) + q_x conj(u_c)
+                    const cd uc = ubuf[c], qc = qbuf[c];
+                    cd a = A[x * ld + c];
+                    a.x -= (u.x * qc.x + u.y * qc.y) + (q.x * uc.x + q.y * uc.y);
+                    a.y -= (u.y * qc.x - u.x * qc.y) + (q.y * uc.x - q.x * uc.y);
+                    A[x * ld + c] = a;
+                }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            tau[k] = beta;
+            tsub[k] = tK;
+        }
+    }
+    if (tid == 0) {
+        if (n >= 2) tsub[n - 2] = A[(n - 1) * ld + (n - 2)];   // never reflected
+        if (n >= 2) tau[n - 2] = 0.0;
+    }
+    __syncthreads();
+    // subdiagonal moduli and the phases D_{k+1} = D_k t_k / |t_k|
+    if (tid < n) {
+        double mag = 0.0;
+        cd f{1.0, 0.0};
+        if (tid + 1 < n) {
+            const cd t = tsub[tid];
+            const double t2 = cabs2(t);
+            if (t2 > 0.0) {
+                const double inv = rsqrt_full(t2);
+                mag = t2 * inv;
+                f = cd{t.x * inv, t.y * inv};
+            }
+        }
+        eb[tid] = mag;
+        tsub[tid] = f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cd delta{1.0, 0.0};
+        dphase[0] = delta;
+        for (int k = 0; k + 1 < n; ++k) {
+            delta = cmul(delta, tsub[k]);
+            dphase[k + 1] = delta;
+        }
+    }
+    if (tid < n) de[(int64_t)tid * nchunk + idc] = double2{A[tid * ld + tid].x, eb[tid]};
+    if constexpr (!VEC) return;
+    __syncthreads();
+
+    // ---- 2. Z = H_0 (H_1 ( ... (H_{n-3} D))) in place: before step k the block [k+2.., k+2..] holds the product so far;
+    // row and column k+1 join it as D's entry, then H_k acts from the left on rows k+1.. (its reflector sits in column k,
+    // which the block has not reached yet).  Thread (c, h): column c = x, rows r = k+1+h, k+1+h+HS, ...
+    if (tid == 0) A[(n - 1) * ld + (n - 1)] = dphase[n - 1];
+    for (int k = n - 2; k >= 0; --k) {
+        const int par = k & 1;
+        cd* ub = ubuf + par * RW;
+        cd* pb = pbuf + par * HS * RW;
+        const double beta = tau[k];
+        // new row / column k+1 of the block; the reflector of step k into ubuf
+        if (h == 0 && x > k && x < n) ub[x] = A[x * ld + k];
+        if (h == 1 % HS && x > k + 1 && x < n) A[(k + 1) * ld + x] = cd{0.0, 0.0};
+        __syncthreads();   // (column k+1 below the diagonal held the reflector of step k+1: consumed one step ago)
+        if (h == 0 && x > k + 1 && x < n) A[x * ld + (k + 1)] = cd{0.0, 0.0};
+        if (tid == 0) A[(k + 1) * ld + (k + 1)] = dphase[k + 1];
+        __syncthreads();
+        if (beta != 0.0) {   // (uniform)
+            const bool col = x > k && x < n;
+            cd t{0.0, 0.0};
+            if (col)
+                for (int r = k + 1 + h; r < n; r += HS) cfmac(t, ub[r], A[r * ld + x]);   // t_c += conj(u_r) Z[r][c]
+            pb[h * RW + x] = t;
+            __syncthreads();
+            cd ts{0.0, 0.0};
+#pragma unroll
+            for (int hh = 0; hh < HS; ++hh) {
+                const cd v = pb[hh * RW + x];
+                ts.x += v.x;
+                ts.y += v.y;
+            }
+            ts = cd{ts.x * beta, ts.y * beta};
+            if (col)
+                for (int r = k + 1 + h; r < n; r += HS) {    // Z[r][c] -= u_r (beta t_c)
+                    const cd ur = ub[r];
+                    cd z = A[r * ld + x];
+                    z.x -= ur.x * ts.x - ur.y * ts.y;
+                    z.y -= ur.x * ts.y + ur.y * ts.x;
+                    A[r * ld + x] = z;
+                }
+        }
+    }
+    __syncthreads();
+    if (h == 0 && x > 0 && x < n) A[x * ld] = cd{0.0, 0.0};          // column 0 held the reflector of step 0
+    if (h == 1 % HS && x > 0 && x < n) A[x] = cd{0.0, 0.0};
+    if (tid == 0) A[0] = cd{1.0, 0.0};
+    __syncthreads();
+    // rows carry the orbital phase (and periodic-image phases) from here on: the rotations of step 3 act on columns
+    for (int e = tid; e < n * n; e += NT) {
+        const int b = e / n, o = e - b * n;
+        const cd val = cmul(A[o * ld + b], eo[o]);
+        if constexpr (MODE == 1) wf_at(G.wv, b, id)[o] = val;
+        else L.evec[((int64_t)b * nk + id) * n + o] = val;
+    }
+}
+
+// ---- one lane per matrix: implicit-shift QL (EISPACK tql2 recurrences) on (d, e)
+template <int MODE, bool REC>
+__global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
+                                                         const QlwWork W, double* __restrict__ eval, const GridArgs G,
+                                                         int* flags) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double* D = (double*)lds_raw;          // [n][64]
+    double* E = D + n * 64;                // [n][64]
+    const int lane = threadIdx.x;
+    const int64_t idc = (int64_t)blockIdx.x * 64 + lane;
+    const bool has = idc < nchunk;
+    const int64_t ic = has ? idc : nchunk - 1;
+    for (int j = 0; j < n; ++j) {
+        const double2 v = W.de[(int64_t)j * nchunk + ic];
+        D[j * 64 + lane] = v.x;
+        E[j * 64 + lane] = j + 1 < n ? v.y : 0.0;
+    }
+    double2* rot = W.rot + ic * W.cap;
+    unsigned* swp = W.swp + ic * W.scap;
+    int64_t seq = 0;
+    int isw = 0;
+    bool overflow = false;
+    int l = 0;
+    bool done = !has;
+    const int max_iter = 30 * n;
+    const unsigned long long top = 1ull << (n - 1);
+    for (int iter = 0;; ++iter) {
+        // negligible couplings: |e_j| <= eps (|d_j| + |d_j+1|)   (e_{n-1} = 0: always)
+        int m = n - 1;
+        if (!done) {
+            unsigned long long negl = top;
+            double dj = D[l * 64 + lane];
+            for (int j = l; j + 1 < n; ++j) {
+                const double dn = D[(j + 1) * 64 + lane];
+                if (fabs(E[j * 64 + lane]) <= 2.220446049250313e-16 * (fabs(dj) + fabs(dn))) negl |= 1ull << j;
+                dj = dn;
+            }
+            const unsigned long long from_l = ~0ull << l;
+            const unsigned long long open = ~negl & from_l & (top - 1);
+            if (open == 0) {
+                done = true;
+            } else {
+                l = __builtin_ctzll(open);
+                m = __builtin_ctzll(negl & (~0ull << l));
+            }
+        }
+        if (__all(done)) break;
+        if (iter >= max_iter) {
+            if (!done) atomicExch(flags, 1);
+            break;
+        }
+        double sn = 1.0, cs = 1.0, pp = 0.0, g = 0.0;
+        bool alive = !done;
+        if (!done) {
+            // Wilkinson-type shift from the leading 2 x 2 of the block (only the speed of convergence depends on its
+            // accuracy: hardware reciprocal / square root estimates are good enough)
+            const double dl = D[l * 64 + lane], dl1 = D[(l + 1) * 64 + lane], el = E[l * 64 + lane], dm = D[m * 64 + lane];
+            const double gs = (dl1 - dl) * (0.5 * __builtin_amdgcn_rcp(el));
+            const double r = __builtin_amdgcn_sqrt(fma(gs, gs, 1.0));
+            g = dm - dl + el * __builtin_amdgcn_rcp(gs + copysign(r, gs));
+        }
+        // the wavefront walks i = max(m) - 1 .. min(l); a lane takes part inside its own block [l, m)
+        int hi = done ? 0 : m, lo = done ? n : l;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            hi = max(hi, __shfl_xor(hi, o));
+            lo = min(lo, __shfl_xor(lo, o));
+        }
+        int cnt = 0;
+        for (int i = hi - 1; i >= lo; --i) {
+            if (alive && i >= l && i < m) {
+                const double ei = E[i * 64 + lane], di = D[i * 64 + lane], di1 = D[(i + 1) * 64 + lane];
+                const double f = sn * ei, b = cs * ei;
+                const double t = f * f + g * g;
+                if (t > 0.0) {
+                    const double inv = rsqrt_full(t), r = t * inv;
+                    E[(i + 1) * 64 + lane] = r;
+                    sn = f * inv;
+                    cs = g * inv;
+                    const double gg = di1 - pp;
+                    const double r2 = (di - gg) * sn + 2.0 * cs * b;
+                    pp = sn * r2;
+                    D[(i + 1) * 64 + lane] = gg + pp;
+                    g = cs * r2 - b;
+                    if (REC) {
+                        if (seq + cnt < W.cap) rot[seq + cnt] = double2{cs, sn};
+                        else overflow = true;
+                    }
+                    ++cnt;
+                } else {                                 // r == 0 (underflow): tql2's recovery
+                    D[(i + 1) * 64 + lane] = di1 - pp;
+                    E[(i + 1) * 64 + lane] = 0.0;          // (e_{i+1} = r = 0)
+                    alive = false;
+                }
+            }
+        }
+        if (!done) {
+            if (alive) {
+                D[l * 64 + lane] -= pp;
+                E[l * 64 + lane] = g;
+            }
+            E[m * 64 + lane] = 0.0;
+            if (REC) {
+                if (isw < W.scap) swp[isw] = (unsigned)(m - 1) | ((unsigned)cnt << 8);
+                else overflow = true;
+                ++isw;
+                seq += cnt;
+            }
+        }
+    }
+    if (REC) {
+        if (has) W.nsw[idc] = isw < W.scap ? isw : W.scap;
+        if (overflow) atomicExch(flags + 2, 1);
+    }
+    // stable ascending ranks; E is free now: E[r] <- the column of rank r (as a double)
+    for (int a = 0; a < n; ++a) {
+        const double da = D[a * 64 + lane];
+        int r = 0;
+        for (int b = 0; b < n; ++b) {
+            const double db = D[b * 64 + lane];
+            r += (db < da || (db == da && b < a)) ? 1 : 0;
+        }
+        E[r * 64 + lane] = (double)a;
+    }
+    double prev = 0.0;
+    for (int r = 0; r < n; ++r) {
+        const int a = (int)E[r * 64 + lane];
+        const double v = D[a * 64 + lane];
+        if (REC && has) W.perm[(int64_t)r * nchunk + idc] = (unsigned char)a;
+        if constexpr (MODE == 1) {
+            if (r > 0) {
+                double gap = has ? v - prev : INFINITY;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) gap = fmin(gap, __shfl_xor(gap, o));
+                if (lane == 0) {
+                    unsigned long long* slot = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * n + (r - 1);
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(fmax(gap, 0.0));
+                    if (bits < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, bits);
+                }
+            }
+            prev = v;
+        } else {
+            if (has) eval[(int64_t)r * nk + id0 + idc] = v;
+        }
+    }
+}
+
+// ---- one workgroup per matrix: replay the rotations on the rows of Z, leave in eigenvalue order
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
+                                                          const QlwWork W, cd* __restrict__ evec, const WfsView wv) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    cd* Z = (cd*)lds_raw;
+    double* Zr = (double*)lds_raw;
+    const int ld = n | 1;
+    const int tid = threadIdx.x;
+    const int64_t idc = blockIdx.x, id = id0 + idc;
+    for (int e = tid; e < n * n; e += NT) {
+        const int b = e / n, o = e - b * n;
+        cd v;
+        if constexpr (MODE == 1) v = wf_at(wv, b, id)[o];
+        else v = evec[((int64_t)b * nk + id) * n + o];
+        Z[o * ld + b] = v;
+    }
+    __syncthreads();
+    const int x = tid >> 1, part = tid & 1;
+    if (x < n) {
+        const double2* __restrict__ rot = W.rot + idc * W.cap;
+        const unsigned* __restrict__ swp = W.swp + idc * W.scap;
+        const int nsw = W.nsw[idc];
+        double* row = Zr + (size_t)x * ld * 2 + part;      // element i of the row: row[2 i]
+        int64_t seq = 0;
+        for (int s = 0; s < nsw; ++s) {
+            const unsigned desc = swp[s];
+            const int ihi = (int)(desc & 0xffu), cnt = (int)(desc >> 8);
+            if (cnt == 0) continue;
+            double z = row[2 * (ihi + 1)];
+            int j = 0;
+            for (; j + 4 <= cnt; j += 4) {
+                const int i = ihi - j;
+                const double2 r0 = rot[seq + j], r1 = rot[seq + j + 1], r2 = rot[seq + j + 2], r3 = rot[seq + j + 3];
+                const double z0 = row[2 * i], z1 = row[2 * (i - 1)], z2 = row[2 * (i - 2)], z3 = row[2 * (i - 3)];
+                row[2 * (i + 1)] = r0.y * z0 + r0.x * z;
+                z = r0.x * z0 - r0.y * z;
+                row[2 * i] = r1.y * z1 + r1.x * z;
+                z = r1.x * z1 - r1.y * z;
+                row[2 * (i - 1)] = r2.y * z2 + r2.x * z;
+                z = r2.x * z2 - r2.y * z;
+                row[2 * (i - 2)] = r3.y * z3 + r3.x * z;
+                z = r3.x * z3 - r3.y * z;
+            }
+            for (; j < cnt; ++j) {
+                const int i = ihi - j;
+                const double2 r = rot[seq + j];
+                const double zi = row[2 * i];
+                row[2 * (i + 1)] = r.y * zi + r.x * z;
+                z = r.x * zi - r.y * z;
+            }
+            row[2 * (ihi - cnt + 1)] = z;
+            seq += cnt;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NT) {
+        const int rb = e / n, o = e - rb * n;
+        const int a = W.perm[(int64_t)rb * nchunk + idc];
+        const cd v = Z[o * ld + a];
+        if constexpr (MODE == 1) wf_at(wv, rb, id)[o] = v;
+        else evec[((int64_t)rb * nk + id) * n + o] = v;
+    }
+}
+
+template <int MODE, bool VEC>
+static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L, const GridArgs& G) {
+    const TbkKnobs& K = tbk_knobs();
+    const int64_t cap = VEC ? (int64_t)3 * n * n + 64 : 0;
+    const int scap = VEC ? 8 * n : 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + n;
+    const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 1536) << 20;
+    int64_t chunk = std::max<int64_t>(1024, (int64_t)(budget / per));
+    chunk = std::min<int64_t>(chunk, nk);
+    const size_t wbytes = al((size_t)chunk * n * sizeof(double2)) + al((size_t)chunk * cap * sizeof(double2)) +
+                          al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n) + 1024;
+    if (wbytes > ctx->work_bytes) {
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->work) TBK_HIP(hipFree(ctx->work));
+        ctx->work = nullptr;
+        ctx->work_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->work, wbytes);
+        TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "tridiagonal-path workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
+        ctx->work_bytes = wbytes;
+    }
+    QlwWork W{};
+    unsigned char* p = (unsigned char*)ctx->work;
+    W.de = (double2*)p;
+    p += al((size_t)chunk * n * sizeof(double2));
+    W.rot = (double2*)p;
+    p += al((size_t)chunk * cap * sizeof(double2));
+    W.swp = (unsigned*)p;
+    p += al((size_t)chunk * scap * sizeof(unsigned));
+    W.nsw = (int*)p;
+    p += al((size_t)chunk * sizeof(int));
+    W.perm = p;
+    W.cap = cap;
+    W.scap = scap;
+
+    const int rw = n <= 32 ? 32 : 64;
+    int nt = rw == 32 ? 128 : 256;
+    if (K.qlw_nt > 0) nt = K.qlw_nt >= 512 ? 512 : (K.qlw_nt >= 256 ? 256 : (K.qlw_nt >= 128 ? 128 : 64));
+    if (rw == 64 && nt < 128) nt = 128;
+    if (rw == 32 && nt > 256) nt = 256;
+    const size_t lds1 = qlw_lds1_bytes(n, MODE == 2 ? 0 : mv.nR, rw, nt);
+    TBK_REQUIRE(lds1 <= 160 * 1024, TBK_EUNSUPPORTED, "nsta=%d with %d lattice vectors needs %zu bytes of LDS", n, mv.nR, lds1);
+    const size_t lds2 = (size_t)2 * n * 64 * sizeof(double);
+    const size_t lds3 = (size_t)n * (n | 1) * sizeof(cd);
+    const void* f1 = nullptr;
+#define TBK_QLW_K1(RW_, NT_)                                                                                                    \
+    if (rw == RW_ && nt == NT_) {                                                                                               \
+        f1 = (const void*)k_tridiag_lds<MODE, VEC, RW_, NT_>;                                                                   \
+    }
+    TBK_QLW_K1(32, 64) TBK_QLW_K1(32, 128) TBK_QLW_K1(32, 256) TBK_QLW_K1(64, 128) TBK_QLW_K1(64, 256) TBK_QLW_K1(64, 512)
+#undef TBK_QLW_K1
+    TBK_REQUIRE(f1, TBK_EINVAL, "launch_qlw: no kernel for %d rows x %d threads", rw, nt);
+    if (lds1 > 64 * 1024) TBK_HIP(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds2 > 64 * 1024)
+        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_ql_lanes<MODE, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (VEC && lds3 > 64 * 1024) {
+        TBK_HIP(hipFuncSetAttribute((const void*)k_ql_backtransform<MODE, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TBK_HIP(hipFuncSetAttribute((const void*)k_ql_backtransform<MODE, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    cd* evec = MODE == 1 ? nullptr : L.evec;
+    for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
+        const int64_t nc = std::min<int64_t>(chunk, nk - id0);
+#define TBK_QLW_K1(RW_, NT_)                                                                                                    \
+    if (rw == RW_ && nt == NT_)                                                                                                 \
+        hipLaunchKernelGGL((k_tridiag_lds<MODE, VEC, RW_, NT_>), dim3((unsigned)nc), dim3(NT_), lds1, ctx->stream, mv, nk, L, G, id0, nc, W.de);
+        TBK_QLW_K1(32, 64) TBK_QLW_K1(32, 128) TBK_QLW_K1(32, 256) TBK_QLW_K1(64, 128) TBK_QLW_K1(64, 256) TBK_QLW_K1(64, 512)
+#undef TBK_QLW_K1
+        hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0, nc,
+                           W, L.eval, G, ctx->flags_dev);
+        if (VEC) {
+            if (rw == 32)
+                hipLaunchKernelGGL((k_ql_backtransform<MODE, 64>), dim3((unsigned)nc), dim3(64), lds3, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+            else
+                hipLaunchKernelGGL((k_ql_backtransform<MODE, 128>), dim3((unsigned)nc), dim3(128), lds3, ctx->stream, n, nk, id0, nc, W, evec,
+                                   G.wv);
+        }
+        TBK_HIP(hipGetLastError());
+    }
+    return TBK_OK;
+}
