@@ -17,8 +17,10 @@
 //                        through the same positions under EXEC masks.  It writes the sorted eigenvalues (or the mesh's
 //                        minimum gaps), the sorting permutation and -- with eigenvectors wanted -- the rotation
 //                        sequence (c, s) of every sweep into a workspace.
-//  3. k_ql_backtransform one workgroup per matrix: Z back into LDS, thread = (row, real | imaginary part) replays the
-//                        recorded rotations on its row (rows are independent, the rotations real), then the columns
+//  3. k_ql_backtransform thread = (row of Z, real | imaginary part): the rotations are real and act on columns, so the
+//                        2n real rows are independent.  A thread keeps its row in REGISTERS (static indices: the
+//                        positions of a sweep are unrolled and skipped by wave-uniform branches), the (c, s) of a
+//                        sweep arrive through scalar loads, eight positions per load; no LDS, no barriers.  Columns
 //                        leave in ascending order of their eigenvalue.
 //
 // The cyclic Jacobi kernels these replace do 7-9 sweeps of n(n-1)/2 rotations over A and V (~80 n^3 flops, all of it
@@ -39,7 +41,7 @@ struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
     double2* rot;          // [nchunk][cap]    (c, s) in the order they were applied
     unsigned* swp;         // [nchunk][scap]   one word per sweep: first position | rotations << 8
     int* nsw;              // [nchunk]
-    unsigned char* perm;   // [n][nchunk]      perm[r][id] = column holding the r-th smallest eigenvalue
+    int* rank;             // [n][nchunk]      rank[b][id] = ascending rank of the eigenvalue of column b
     int64_t cap;
     int scap;
 };
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
     for (int r = 0; r < n; ++r) {
         const int a = (int)E[r * 64 + lane];
         const double v = D[a * 64 + lane];
-        if (REC && has) W.perm[(int64_t)r * nchunk + idc] = (unsigned char)a;
+        if (REC && has) W.rank[(int64_t)a * nchunk + idc] = r;
         if constexpr (MODE == 1) {
             if (r > 0) {
                 double gap = has ? v - prev : INFINITY;
@@ -391,7 +393,14 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
     }
 }
 
-// ---- one workgroup per matrix: replay the rotations on the rows of Z, leave in eigenvalue order
+// ---- replay the rotations on the rows of Z, leave in eigenvalue order.  Block = one matrix, Z in LDS, thread = (row x,
+// real | imaginary part).  rot holds, sweep after sweep, the rotations of positions ihi, ihi-1, ..., ihi-cnt+1 in that
+// order; the stream comes from HBM, so it passes through a small LDS ring that is refilled NT entries at a time, the next
+// refill already in flight (in a register per thread) while the current entries are applied.
+// (Tried: the rows in REGISTERS with the positions of a sweep unrolled -- wave-uniform branches, or a jump into the chain
+// at the sweep's first position -- and the (c, s) through scalar loads or the ring: 3.2-7.2 ms for 8192 x n=64 against
+// 9.2 ms for the first LDS form; the compiler spills the scalar (c, s) sets or copies the row at every merge point.)
+#define TBK_QLW_RING 256   // entries (4 KB); a power of two, at least 2 NT
 template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
                                                           const QlwWork W, cd* __restrict__ evec, const WfsView wv) {
@@ -399,8 +408,16 @@ __global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int6
     cd* Z = (cd*)lds_raw;
     double* Zr = (double*)lds_raw;
     const int ld = n | 1;
+    double2* ring = (double2*)(Z + n * ld);             // [TBK_QLW_RING]
+    unsigned* swl = (unsigned*)(ring + TBK_QLW_RING);   // [scap] the sweep words of this matrix
     const int tid = threadIdx.x;
     const int64_t idc = blockIdx.x, id = id0 + idc;
+    const double2* __restrict__ rot = W.rot + idc * W.cap;
+    const int cap = (int)W.cap;
+    const int nsw = W.nsw[idc];
+    int filled = 0;
+    double2 pre = tid < cap ? rot[tid] : double2{1.0, 0.0};   // the first refill, in flight while Z is loaded
+    for (int s = tid; s < nsw; s += NT) swl[s] = W.swp[idc * W.scap + s];
     for (int e = tid; e < n * n; e += NT) {
         const int b = e / n, o = e - b * n;
         cd v;
@@ -408,51 +425,88 @@ __global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int6
         else v = evec[((int64_t)b * nk + id) * n + o];
         Z[o * ld + b] = v;
     }
-    __syncthreads();
     const int x = tid >> 1, part = tid & 1;
-    if (x < n) {
-        const double2* __restrict__ rot = W.rot + idc * W.cap;
-        const unsigned* __restrict__ swp = W.swp + idc * W.scap;
-        const int nsw = W.nsw[idc];
-        double* row = Zr + (size_t)x * ld * 2 + part;      // element i of the row: row[2 i]
-        int64_t seq = 0;
-        for (int s = 0; s < nsw; ++s) {
-            const unsigned desc = swp[s];
+    const bool rowok = x < n;
+    double* row = Zr + (size_t)(rowok ? x : 0) * ld * 2 + part;      // element i of the row: row[2 i]
+    int seq = 0, s = 0;
+    while (s < nsw) {
+        if (filled + NT <= seq + TBK_QLW_RING && filled < cap) {   // (uniform) room for the refill that is in flight
+            ring[(filled + tid) & (TBK_QLW_RING - 1)] = pre;
+            filled += NT;
+            pre = filled + tid < cap ? rot[filled + tid] : double2{1.0, 0.0};
+        }
+        __syncthreads();
+        while (s < nsw) {
+            const unsigned desc = (unsigned)__builtin_amdgcn_readfirstlane((int)swl[s]);
             const int ihi = (int)(desc & 0xffu), cnt = (int)(desc >> 8);
+            if (seq + cnt > filled) {
+                if (filled >= cap) s = nsw;   // the recording overflowed (flagged by the QL kernel): give up
+                break;
+            }
+            ++s;
             if (cnt == 0) continue;
-            double z = row[2 * (ihi + 1)];
-            int j = 0;
-            for (; j + 4 <= cnt; j += 4) {
-                const int i = ihi - j;
-                const double2 r0 = rot[seq + j], r1 = rot[seq + j + 1], r2 = rot[seq + j + 2], r3 = rot[seq + j + 3];
-                const double z0 = row[2 * i], z1 = row[2 * (i - 1)], z2 = row[2 * (i - 2)], z3 = row[2 * (i - 3)];
-                row[2 * (i + 1)] = r0.y * z0 + r0.x * z;
-                z = r0.x * z0 - r0.y * z;
-                row[2 * i] = r1.y * z1 + r1.x * z;
-                z = r1.x * z1 - r1.y * z;
-                row[2 * (i - 1)] = r2.y * z2 + r2.x * z;
-                z = r2.x * z2 - r2.y * z;
-                row[2 * (i - 2)] = r3.y * z3 + r3.x * z;
-                z = r3.x * z3 - r3.y * z;
+            if (rowok) {
+                // z_{i+1}' = s z_i + c z,  z' = c z_i - s z  with z carried down the sweep: the products with z_i do not
+                // depend on the carry (one dependent fma per rotation), and the next group of four positions is loaded
+                // before this one is stored (the LDS addresses differ, which the compiler cannot know)
+                double z = row[2 * (ihi + 1)];
+                int j = 0;
+                double2 r0, r1, r2, r3;
+                double z0, z1, z2, z3;
+                if (cnt >= 4) {
+                    r0 = ring[seq & (TBK_QLW_RING - 1)], r1 = ring[(seq + 1) & (TBK_QLW_RING - 1)];
+                    r2 = ring[(seq + 2) & (TBK_QLW_RING - 1)], r3 = ring[(seq + 3) & (TBK_QLW_RING - 1)];
+                    z0 = row[2 * ihi], z1 = row[2 * (ihi - 1)], z2 = row[2 * (ihi - 2)], z3 = row[2 * (ihi - 3)];
+                }
+                // (all LDS reads so far complete before the loop: otherwise the wait-count pass assumes at the loop header
+                // that they may still be pending and makes every iteration wait for the prefetch it has just issued)
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                for (; j + 4 <= cnt; j += 4) {
+                    const int i = ihi - j, e = seq + j + 4;
+                    double2 n0, n1, n2, n3;
+                    double y0, y1, y2, y3;
+                    if (j + 8 <= cnt) {
+                        n0 = ring[e & (TBK_QLW_RING - 1)], n1 = ring[(e + 1) & (TBK_QLW_RING - 1)];
+                        n2 = ring[(e + 2) & (TBK_QLW_RING - 1)], n3 = ring[(e + 3) & (TBK_QLW_RING - 1)];
+                        y0 = row[2 * (i - 4)], y1 = row[2 * (i - 5)], y2 = row[2 * (i - 6)], y3 = row[2 * (i - 7)];
+                    }
+                    const double a0 = r0.x * z0, b0 = r0.y * z0, a1 = r1.x * z1, b1 = r1.y * z1;
+                    const double a2 = r2.x * z2, b2 = r2.y * z2, a3 = r3.x * z3, b3 = r3.y * z3;
+                    const double o0 = fma(r0.x, z, b0);
+                    z = fma(-r0.y, z, a0);
+                    const double o1 = fma(r1.x, z, b1);
+                    z = fma(-r1.y, z, a1);
+                    const double o2 = fma(r2.x, z, b2);
+                    z = fma(-r2.y, z, a2);
+                    const double o3 = fma(r3.x, z, b3);
+                    z = fma(-r3.y, z, a3);
+                    row[2 * (i + 1)] = o0;
+                    row[2 * i] = o1;
+                    row[2 * (i - 1)] = o2;
+                    row[2 * (i - 2)] = o3;
+                    r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+                    z0 = y0, z1 = y1, z2 = y2, z3 = y3;
+                }
+                for (; j < cnt; ++j) {
+                    const int i = ihi - j;
+                    const double2 r = ring[(seq + j) & (TBK_QLW_RING - 1)];
+                    const double zi = row[2 * i];
+                    row[2 * (i + 1)] = fma(r.x, z, r.y * zi);
+                    z = fma(-r.y, z, r.x * zi);
+                }
+                row[2 * (ihi - cnt + 1)] = z;
             }
-            for (; j < cnt; ++j) {
-                const int i = ihi - j;
-                const double2 r = rot[seq + j];
-                const double zi = row[2 * i];
-                row[2 * (i + 1)] = r.y * zi + r.x * z;
-                z = r.x * zi - r.y * z;
-            }
-            row[2 * (ihi - cnt + 1)] = z;
             seq += cnt;
         }
+        __syncthreads();
     }
     __syncthreads();
     for (int e = tid; e < n * n; e += NT) {
-        const int rb = e / n, o = e - rb * n;
-        const int a = W.perm[(int64_t)rb * nchunk + idc];
-        const cd v = Z[o * ld + a];
-        if constexpr (MODE == 1) wf_at(wv, rb, id)[o] = v;
-        else evec[((int64_t)rb * nk + id) * n + o] = v;
+        const int b = e / n, o = e - b * n;
+        const int r = W.rank[(int64_t)b * nchunk + idc];
+        const cd v = Z[o * ld + b];
+        if constexpr (MODE == 1) wf_at(wv, r, id)[o] = v;
+        else evec[((int64_t)r * nk + id) * n + o] = v;
     }
 }
 
@@ -462,12 +516,12 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     const int64_t cap = VEC ? (int64_t)3 * n * n + 64 : 0;
     const int scap = VEC ? 8 * n : 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + n;
+    const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + (size_t)n * sizeof(int);
     const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 1536) << 20;
     int64_t chunk = std::max<int64_t>(1024, (int64_t)(budget / per));
     chunk = std::min<int64_t>(chunk, nk);
-    const size_t wbytes = al((size_t)chunk * n * sizeof(double2)) + al((size_t)chunk * cap * sizeof(double2)) +
-                          al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n) + 1024;
+    const size_t wbytes = al((size_t)chunk * n * sizeof(double2)) + 256 + al((size_t)chunk * cap * sizeof(double2)) +
+                          al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n * sizeof(int)) + 1024;
     if (wbytes > ctx->work_bytes) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->work) TBK_HIP(hipFree(ctx->work));
@@ -481,13 +535,14 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     unsigned char* p = (unsigned char*)ctx->work;
     W.de = (double2*)p;
     p += al((size_t)chunk * n * sizeof(double2));
+    p += 256;                                  // (the back-transform's eight-entry loads may start before a sweep's first entry)
     W.rot = (double2*)p;
     p += al((size_t)chunk * cap * sizeof(double2));
     W.swp = (unsigned*)p;
     p += al((size_t)chunk * scap * sizeof(unsigned));
     W.nsw = (int*)p;
     p += al((size_t)chunk * sizeof(int));
-    W.perm = p;
+    W.rank = (int*)p;
     W.cap = cap;
     W.scap = scap;
 
@@ -499,7 +554,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     const size_t lds1 = qlw_lds1_bytes(n, MODE == 2 ? 0 : mv.nR, rw, nt);
     TBK_REQUIRE(lds1 <= 160 * 1024, TBK_EUNSUPPORTED, "nsta=%d with %d lattice vectors needs %zu bytes of LDS", n, mv.nR, lds1);
     const size_t lds2 = (size_t)2 * n * 64 * sizeof(double);
-    const size_t lds3 = (size_t)n * (n | 1) * sizeof(cd);
+    const size_t lds3 = (size_t)n * (n | 1) * sizeof(cd) + TBK_QLW_RING * sizeof(double2) + (size_t)scap * sizeof(unsigned);
     const void* f1 = nullptr;
 #define TBK_QLW_K1(RW_, NT_)                                                                                                    \
     if (rw == RW_ && nt == NT_) {                                                                                               \
