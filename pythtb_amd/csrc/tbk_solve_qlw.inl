@@ -397,9 +397,14 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
 // real | imaginary part).  rot holds, sweep after sweep, the rotations of positions ihi, ihi-1, ..., ihi-cnt+1 in that
 // order; the stream comes from HBM, so it passes through a small LDS ring that is refilled NT entries at a time, the next
 // refill already in flight (in a register per thread) while the current entries are applied.
-// (Tried: the rows in REGISTERS with the positions of a sweep unrolled -- wave-uniform branches, or a jump into the chain
-// at the sweep's first position -- and the (c, s) through scalar loads or the ring: 3.2-7.2 ms for 8192 x n=64 against
-// 9.2 ms for the first LDS form; the compiler spills the scalar (c, s) sets or copies the row at every merge point.)
+// Two matrices of n = 64 fit the LDS of a CU, i.e. one wavefront per SIMD: the kernel is bound by the issue latency of one
+// wavefront's dependent instructions (PMC: ~21 instructions per rotation, ~7 cycles each; profiles/qlw_pmc.sh).
+// Tried: the rows in REGISTERS (no LDS limit, 3 wavefronts per SIMD) with the positions of a sweep unrolled -- skipped by
+// wave-uniform branches per position or per group of four (sweeps recorded padded to whole groups), by EXEC-masked groups,
+// by a jump into the chain at the sweep's first position, or not skipped at all (sweeps padded to the full range, straight-
+// line code), rotations as tied-operand inline asm, (c, s) through scalar loads or the ring.  Best 3.2 ms for 8192 x n=64
+// (this form: 4.2 ms): in every variant the register allocator splits the row's live ranges around the unrolled regions
+// (256 VGPRs + AGPR copies + hundreds of moves for a 64-register row), or spills it under an occupancy bound.
 #define TBK_QLW_RING 256   // entries (4 KB); a power of two, at least 2 NT
 template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
@@ -446,46 +451,22 @@ __global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int6
             ++s;
             if (cnt == 0) continue;
             if (rowok) {
-                // z_{i+1}' = s z_i + c z,  z' = c z_i - s z  with z carried down the sweep: the products with z_i do not
-                // depend on the carry (one dependent fma per rotation), and the next group of four positions is loaded
-                // before this one is stored (the LDS addresses differ, which the compiler cannot know)
+                // z_{i+1}' = s z_i + c z,  z' = c z_i - s z  with z carried down the sweep
                 double z = row[2 * (ihi + 1)];
                 int j = 0;
-                double2 r0, r1, r2, r3;
-                double z0, z1, z2, z3;
-                if (cnt >= 4) {
-                    r0 = ring[seq & (TBK_QLW_RING - 1)], r1 = ring[(seq + 1) & (TBK_QLW_RING - 1)];
-                    r2 = ring[(seq + 2) & (TBK_QLW_RING - 1)], r3 = ring[(seq + 3) & (TBK_QLW_RING - 1)];
-                    z0 = row[2 * ihi], z1 = row[2 * (ihi - 1)], z2 = row[2 * (ihi - 2)], z3 = row[2 * (ihi - 3)];
-                }
-                // (all LDS reads so far complete before the loop: otherwise the wait-count pass assumes at the loop header
-                // that they may still be pending and makes every iteration wait for the prefetch it has just issued)
-                __builtin_amdgcn_s_waitcnt(0xc07f);
                 for (; j + 4 <= cnt; j += 4) {
-                    const int i = ihi - j, e = seq + j + 4;
-                    double2 n0, n1, n2, n3;
-                    double y0, y1, y2, y3;
-                    if (j + 8 <= cnt) {
-                        n0 = ring[e & (TBK_QLW_RING - 1)], n1 = ring[(e + 1) & (TBK_QLW_RING - 1)];
-                        n2 = ring[(e + 2) & (TBK_QLW_RING - 1)], n3 = ring[(e + 3) & (TBK_QLW_RING - 1)];
-                        y0 = row[2 * (i - 4)], y1 = row[2 * (i - 5)], y2 = row[2 * (i - 6)], y3 = row[2 * (i - 7)];
-                    }
-                    const double a0 = r0.x * z0, b0 = r0.y * z0, a1 = r1.x * z1, b1 = r1.y * z1;
-                    const double a2 = r2.x * z2, b2 = r2.y * z2, a3 = r3.x * z3, b3 = r3.y * z3;
-                    const double o0 = fma(r0.x, z, b0);
-                    z = fma(-r0.y, z, a0);
-                    const double o1 = fma(r1.x, z, b1);
-                    z = fma(-r1.y, z, a1);
-                    const double o2 = fma(r2.x, z, b2);
-                    z = fma(-r2.y, z, a2);
-                    const double o3 = fma(r3.x, z, b3);
-                    z = fma(-r3.y, z, a3);
-                    row[2 * (i + 1)] = o0;
-                    row[2 * i] = o1;
-                    row[2 * (i - 1)] = o2;
-                    row[2 * (i - 2)] = o3;
-                    r0 = n0, r1 = n1, r2 = n2, r3 = n3;
-                    z0 = y0, z1 = y1, z2 = y2, z3 = y3;
+                    const int i = ihi - j, e = seq + j;
+                    const double2 r0 = ring[e & (TBK_QLW_RING - 1)], r1 = ring[(e + 1) & (TBK_QLW_RING - 1)];
+                    const double2 r2 = ring[(e + 2) & (TBK_QLW_RING - 1)], r3 = ring[(e + 3) & (TBK_QLW_RING - 1)];
+                    const double z0 = row[2 * i], z1 = row[2 * (i - 1)], z2 = row[2 * (i - 2)], z3 = row[2 * (i - 3)];
+                    row[2 * (i + 1)] = fma(r0.x, z, r0.y * z0);
+                    z = fma(-r0.y, z, r0.x * z0);
+                    row[2 * i] = fma(r1.x, z, r1.y * z1);
+                    z = fma(-r1.y, z, r1.x * z1);
+                    row[2 * (i - 1)] = fma(r2.x, z, r2.y * z2);
+                    z = fma(-r2.y, z, r2.x * z2);
+                    row[2 * (i - 2)] = fma(r3.x, z, r3.y * z3);
+                    z = fma(-r3.y, z, r3.x * z3);
                 }
                 for (; j < cnt; ++j) {
                     const int i = ihi - j;
