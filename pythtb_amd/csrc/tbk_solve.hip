@@ -333,11 +333,14 @@ __device__ __forceinline__ void ql_small(SmallMat<N>& M) {
     for (int K = 0; K + 1 < N; ++K) {
         cd tK = a[K + 1][K];
         if (K + 2 < N) {                       // a reflection annihilates rows K+2.. of column K
-            double sigma = 0.0;
+            // (the decision is taken on the part to be annihilated ALONE, like LAPACK's zlarfg: compared through the sum
+            // with |a_{K+1,K}|^2, entries below ~1e-8 of it would be dropped -- an eigenvalue error of up to their size)
+            double rest = 0.0;
 #pragma unroll
-            for (int r = K + 1; r < N; ++r) sigma += cabs2(a[r][K]);
+            for (int r = K + 2; r < N; ++r) rest += cabs2(a[r][K]);
             const double absa2 = cabs2(tK);
-            if (sigma > absa2) {
+            const double sigma = rest + absa2;
+            if (rest > 0.0) {
                 const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
                 double absa = 0.0;
                 cd ph{1.0, 0.0};
@@ -1571,11 +1574,16 @@ static int launch_solve(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, bo
 
 static int check_noconv(tbk_ctx* ctx, int n) {
     if (n <= 4) return TBK_OK;
-    int flag = 0;
-    TBK_HIP(hipMemcpyAsync(&flag, ctx->flags_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    int flag[4] = {0, 0, 0, 0};   // 0: no convergence, 1: (Berry path) singular link, 2: the QL rotation record overflowed
+    TBK_HIP(hipMemcpyAsync(flag, ctx->flags_dev, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
-    if (flag) TBK_HIP(hipMemsetAsync(ctx->flags_dev, 0, sizeof(int), ctx->stream));
-    TBK_REQUIRE(flag == 0, TBK_ENOCONV, "Jacobi eigen-solver did not converge in %d sweeps", TBK_JACOBI_MAX_SWEEPS);
+    if (flag[0]) TBK_HIP(hipMemsetAsync(ctx->flags_dev, 0, sizeof(int), ctx->stream));
+    if (flag[2]) TBK_HIP(hipMemsetAsync(ctx->flags_dev + 2, 0, sizeof(int), ctx->stream));
+    TBK_REQUIRE(flag[0] == 0, TBK_ENOCONV, "eigen-solver did not converge (Jacobi: %d sweeps; QL: 30 shifts per eigenvalue)",
+                TBK_JACOBI_MAX_SWEEPS);
+    TBK_REQUIRE(flag[2] == 0, TBK_ENOCONV,
+                "eigen-solver: a matrix needed more than 3 n^2 QL rotations (4 x the usual); eigenvectors were not "
+                "completed -- rerun with TBK_QLW=0 (Jacobi kernels)");
     return TBK_OK;
 }
 

@@ -77,13 +77,15 @@ template <int K, bool VEC>
 __device__ __forceinline__ cd ql16_house(cd (&a)[16], cd (&z)[16], const int x) {
     const bool below = x > K;
     const cd xk = below ? a[K] : cd{0.0, 0.0};
-    const double sigma = row_allsum(cabs2(xk));          // |column below the diagonal|^2
+    // |rows > K+1 of the column|^2: a reflection is needed iff this is non-zero.  (Decided on this part ALONE, like LAPACK's
+    // zlarfg: through the sum with |alpha|^2, entries below ~1e-8 |alpha| would be dropped -- an eigenvalue error of up to
+    // their size; met on ribbon Hamiltonians near k = 0, whose imaginary parts are that small.)
+    const double rest = row_allsum(x > K + 1 ? cabs2(xk) : 0.0);
     const cd alpha = rowbcast_c<K + 1>(a[K]);            // A[K+1][K]
     const double absa2 = cabs2(alpha);
+    const double sigma = rest + absa2;                   // |column below the diagonal|^2
     cd tK{0.0, 0.0};
-    // nothing below the subdiagonal and a real non-negative... any subdiagonal: a reflection is only needed to
-    // annihilate rows > K+1; with sigma == |alpha|^2 the column is already in place
-    if (sigma > absa2) {                                 // row-uniform
+    if (rest > 0.0) {                                    // row-uniform
         const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
         double absa = 0.0;
         cd ph{1.0, 0.0};

@@ -26,7 +26,7 @@
 // The cyclic Jacobi kernels these replace do 7-9 sweeps of n(n-1)/2 rotations over A and V (~80 n^3 flops, all of it
 // LDS traffic); this path is ~(16/3 + 8/3 + 6) n^3.  Every point is solved on its own: periodic images, halo rows and
 // shard windows are bit-identical by construction.  Batches are processed in chunks so that the rotation workspace
-// stays below ~1.5 GiB.
+// stays below ~4 GiB.
 
 template <int RW>
 __device__ __forceinline__ double rw_allsum(double v) {   // sum over the RW (32 | 64) lanes x of a strip, same bits in every lane
@@ -101,12 +101,15 @@ __global__ __launch_bounds__(NT) void k_tridiag_lds(const ModelView mv, const in
     for (int k = 0; k + 2 < n; ++k) {
         const bool below = x > k && x < n;
         const cd colx = below ? A[x * ld + k] : cd{0.0, 0.0};
-        const double sigma = rw_allsum<RW>(cabs2(colx));     // |column below the diagonal|^2
+        // |rows > k+1 of the column|^2: a reflection is needed iff this is non-zero (decided on this part alone, like LAPACK's
+        // zlarfg: through the sum with |alpha|^2 entries below ~1e-8 |alpha| would be dropped)
+        const double rest = rw_allsum<RW>(x > k + 1 ? cabs2(colx) : 0.0);
         const cd alpha = A[(k + 1) * ld + k];
         const double absa2 = cabs2(alpha);
+        const double sigma = rest + absa2;                   // |column below the diagonal|^2
         cd tK = alpha;
         double beta = 0.0;
-        if (sigma > absa2) {   // (uniform) something to annihilate below the subdiagonal
+        if (rest > 0.0) {      // (uniform) something to annihilate below the subdiagonal
             const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
             double absa = 0.0;
             cd ph{1.0, 0.0};
@@ -498,9 +501,10 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     const int scap = VEC ? 8 * n : 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + (size_t)n * sizeof(int);
-    const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 1536) << 20;
+    const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 4096) << 20;
     int64_t chunk = std::max<int64_t>(1024, (int64_t)(budget / per));
     chunk = std::min<int64_t>(chunk, nk);
+    chunk = (nk + (nk + chunk - 1) / chunk - 1) / ((nk + chunk - 1) / chunk);   // equal chunks (the QL kernel's time hardly depends on the count)
     const size_t wbytes = al((size_t)chunk * n * sizeof(double2)) + 256 + al((size_t)chunk * cap * sizeof(double2)) +
                           al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n * sizeof(int)) + 1024;
     if (wbytes > ctx->work_bytes) {

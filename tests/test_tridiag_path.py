@@ -1,0 +1,208 @@
+"""n = 17..64 states per k, large batches: the three-kernel tridiagonal path (pythtb_amd/csrc/tbk_solve_qlw.inl --
+Householder reduction in LDS, lane-per-matrix implicit QL, rotation replay) that stands in for the reference's
+numpy.linalg.eigh / eigvalsh per k-point (pythtb.py:939-947).  The dispatcher only takes it above 8 x CUs matrices;
+TBK_QLW_MIN=0 sends small batches through it too, so that the oracle (a per-k Python loop) can follow.
+
+Checked: supplied matrices against numpy (eigenvalues, residuals, orthonormality; random, zero, degenerate, already
+tridiagonal, decoupled blocks, sizes on both sides of the 32- and 48-row kernels), models on k lists and meshes against
+the oracle, batches cut into several workspace chunks, ragged last wavefronts, and that windows of a mesh reproduce
+the whole mesh bit for bit."""
+import numpy as np
+import pytest
+
+import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tb():
+    import pythtb_amd
+    return pythtb_amd
+
+
+def _eigh_batch(h, vectors=True):
+    from pythtb_amd import _lib
+    lib, ctx = _lib.lib, _lib.default_context()
+    nk, n = h.shape[0], h.shape[1]
+    hh = np.ascontiguousarray(h, dtype=complex)
+    ev = np.zeros((n, nk))
+    vec = np.zeros((n, nk, n), dtype=complex) if vectors else None
+    _lib.check(lib.tbk_eigh_batch(ctx.handle, n, _lib.dptr(hh.view(float)), nk, _lib.dptr(ev),
+                                  _lib.dptr(vec.view(float)) if vectors else None))
+    return ev, vec
+
+
+def _special(n, rng):
+    out = [np.zeros((n, n), dtype=complex),
+           np.diag(np.arange(n) % 3).astype(complex),                                   # degenerate, already diagonal
+           np.kron(np.eye(n // 2 + 1), [[0, 1], [1, 0]])[:n, :n].astype(complex),       # repeated +-1
+           (np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)).astype(complex),  # already tridiagonal
+           np.diag(np.full(n - 2, 1j), 2) + np.diag(np.full(n - 2, -1j), -2),           # two decoupled chains
+           np.identity(n, dtype=complex) * 3.5]
+    a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    out.append(1e-9 * (a + a.conj().T) + np.diag(np.repeat([1.0, 2.0], [n // 2, n - n // 2])))   # two tight clusters
+    out.append(1e6 * (a + a.conj().T))                                                   # large scale
+    blk = np.zeros((n, n), dtype=complex)                                                # block diagonal: early deflation
+    blk[:n // 3, :n // 3] = (a + a.conj().T)[:n // 3, :n // 3]
+    blk[n // 3:, n // 3:] = (a + a.conj().T)[n // 3:, n // 3:]
+    out.append(blk)
+    return out
+
+
+@pytest.mark.parametrize("n", [17, 23, 31, 32, 33, 40, 47, 48, 49, 63, 64])
+def test_supplied_matrices_against_numpy(n):
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(100 + n)
+    nk = 130                                                   # two full wavefronts of the QL kernel and a ragged third
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    sp = _special(n, rng)
+    h[3:3 + len(sp)] = sp
+    with _lib.knob("TBK_QLW_MIN", 0):
+        ev, vec = _eigh_batch(h)
+        ev_only, _ = _eigh_batch(h, vectors=False)
+    with _lib.knob("TBK_QLW", 0):
+        ev_jac, _ = _eigh_batch(h, vectors=False)
+    ref = np.linalg.eigvalsh(h).T
+    scale = np.maximum(np.max(np.abs(ref), axis=0), 1.0)
+    assert np.max(np.abs(ev - ref) / scale) < 5e-14
+    assert np.array_equal(ev, ev_only)                         # the same reduction and the same QL in both forms
+    assert np.max(np.abs(ev_jac - ref) / scale) < 5e-13
+    V = vec.transpose(1, 0, 2)                                 # [k][band][component]
+    for i in range(nk):
+        s = scale[i]
+        assert np.max(np.abs(h[i] @ V[i].T - V[i].T * ev[:, i])) < 2e-13 * s * n
+        assert np.max(np.abs(V[i].conj() @ V[i].T - np.identity(n))) < 1e-13 * n
+
+
+def test_chunked_batches_equal_one_batch():
+    """A workspace budget of 1 MiB cuts 2600 matrices of n = 24 into three chunks (the smallest chunk is 1024)."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(7)
+    n, nk = 24, 2600
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    with _lib.knob("TBK_QLW_MIN", 0):
+        ev1, v1 = _eigh_batch(h)
+        with _lib.knob("TBK_QLW_WS_MB", 1):
+            ev3, v3 = _eigh_batch(h)
+            e3, _ = _eigh_batch(h, vectors=False)
+    assert np.array_equal(ev1, ev3) and np.array_equal(v1, v3) and np.array_equal(ev1, e3)
+    assert np.max(np.abs(ev1 - np.linalg.eigvalsh(h).T)) < 2e-13
+
+
+def _ribbon(tb, width):
+    """Haldane ribbon: `width` cells along a2, periodic along a1 (examples/haldane_fin.py builds the same cut)."""
+    m = hp.haldane(tb.tb_model, delta=0.2)
+    return hp.quiet(m.cut_piece, width, 1, glue_edgs=False)
+
+
+@pytest.mark.parametrize("width", [10, 17, 26])                # n = 20, 34, 52: sparse models (no R-grouped table)
+def test_ribbon_on_a_k_list_against_oracle(tb, width):
+    from oracle import tb_oracle as orc
+    from pythtb_amd import _lib
+    m = _ribbon(tb, width)
+    n = 2 * width
+    k = np.linspace(-0.5, 0.5, 67)
+    with _lib.knob("TBK_QLW_MIN", 0):
+        ev, vec = m.solve_all(k, eig_vectors=True)
+        ev_only = m.solve_all(k)
+    oev = orc.solve_all(m, [[x] for x in k])
+    assert np.max(np.abs(ev - oev)) < 1e-12
+    assert np.array_equal(ev, ev_only)
+    for i in range(0, len(k), 5):
+        H = m._gen_ham([k[i]])
+        V = vec[:, i, :]
+        assert np.max(np.abs(H @ V.T - V.T * ev[:, i])) < 1e-12
+        assert np.max(np.abs(V.conj() @ V.T - np.identity(n))) < 1e-13 * n
+
+
+def test_dense_model_on_a_mesh_against_oracle(tb):
+    """A dense 3-D model of 24 orbitals (R-grouped table) through solve_on_grid: minimum gaps and Berry phases of the
+    lower half of the bands against the oracle's per-k loop (pythtb.py:2499-2511, :3002-3025)."""
+    from oracle import tb_oracle as orc
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(5)
+    norb = 24
+    m = hp.quiet(tb.tb_model, 3, 3, np.identity(3), rng.random((norb, 3)))
+    m.set_onsite(np.where(np.arange(norb) < norb // 2, -2.5, 2.5) + 0.2 * rng.standard_normal(norb))
+    for R in ([0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]):
+        for i in range(norb):
+            for j in range(norb):
+                if R == [0, 0, 0] and j <= i:
+                    continue
+                m.set_hop(0.08 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, R)
+    mesh, start = [5, 6, 9], [0.1, -0.2, 0.05]
+    with _lib.knob("TBK_QLW_MIN", 0):
+        w = tb.wf_array(m, mesh)
+        gaps = w.solve_on_grid(start)
+        ph = w.berry_phase(range(norb // 2), 2, contin=False)
+        fl = w.berry_flux(range(norb // 2), dirs=[0, 1])
+    owfs, ogaps = orc.solve_on_grid(m, mesh, start, vectorised=True)
+    assert np.max(np.abs(gaps - ogaps)) < 1e-12
+    assert ogaps[norb // 2 - 1] > 0.5
+    oph = orc.berry_phase(owfs, 3, list(range(norb // 2)), 2, contin=False)
+    d = np.angle(np.exp(1j * (np.asarray(ph) - np.asarray(oph))))
+    assert np.max(np.abs(d)) < 1e-9
+    ofl = orc.berry_flux(owfs, 3, list(range(norb // 2)), dirs=[0, 1], vectorised=True)
+    assert np.max(np.abs(np.asarray(fl) - np.asarray(ofl))) < 1e-9
+
+
+def test_windows_reproduce_the_whole_mesh(tb):
+    """Every point is solved on its own: shard windows are bit-identical to the unsharded array."""
+    from pythtb_amd import _lib, shard
+    m = hp.quiet(hp.haldane(tb.tb_model, delta=0.3).make_supercell, [[3, 0], [0, 3]])   # 18 orbitals, 2-D
+    mesh, start = [13, 9], [-0.5, -0.5]
+    with _lib.knob("TBK_QLW_MIN", 0):
+        full = tb.wf_array(m, mesh)
+        gaps = full.solve_on_grid(start)
+        host = full.to_host().copy()
+        gmins = []
+        for r in range(3):
+            row0, nrows = shard.split_rows(mesh[0], 3, r)
+            w = tb.wf_array(m, [nrows, mesh[1]])
+            gmins.append(w.solve_on_grid_window(start, [row0, 0], mesh))
+            assert np.array_equal(w.to_host(), host[row0:row0 + nrows])
+    assert np.array_equal(np.min(gmins, axis=0), gaps)
+    # periodic images: last row / column = first times the orbital phase (pythtb.py:2733-2736)
+    ph0 = np.exp(-2j * np.pi * m._orb[:, 0])
+    assert np.max(np.abs(host[-1, 3] - host[0, 3] * ph0)) < 1e-15
+
+
+def test_large_batch_takes_the_path_by_default(tb):
+    """Above 8 x CUs matrices no knob is needed: 4096 k-points of a 20-orbital ribbon, against LAPACK on H(k)."""
+    m = _ribbon(tb, 10)
+    k = np.linspace(0.0, 1.0, 4096, endpoint=False)
+    ev = m.solve_all(k)
+    for i in (0, 1, 777, 4095):
+        assert np.max(np.abs(ev[:, i] - np.linalg.eigvalsh(m._gen_ham([k[i]])))) < 1e-12
+    # the bulk gap of the ribbon closes only through the two edge bands
+    assert ev.shape == (20, 4096)
+
+
+@pytest.mark.parametrize("n", [3, 4, 9, 12, 16, 20, 40])
+def test_small_entries_below_the_subdiagonal_are_not_dropped(n):
+    """A strong tridiagonal part plus couplings 1e-9 of it everywhere else (ribbon Hamiltonians near k = 0 look like that:
+    real hoppings, imaginary parts ~ k).  The Householder step must decide "nothing to annihilate" on the entries below
+    the subdiagonal alone (LAPACK zlarfg); deciding through their sum with the subdiagonal entry loses everything below
+    1e-8 of it and shifts eigenvalues by up to 1e-9 (seen on a 20-orbital Haldane ribbon at k = 0.001: 4e-10)."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(40 + n)
+    nk = 192
+    t = rng.uniform(1.0, 2.0, (nk, n - 1))
+    h = np.zeros((nk, n, n), dtype=complex)
+    for i in range(nk):
+        h[i] = np.diag(rng.standard_normal(n)) + np.diag(t[i], 1) + np.diag(t[i], -1)
+    x = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    x = x + x.conj().transpose(0, 2, 1)
+    for scale in (1e-9, 1e-12):
+        hs = h + scale * x
+        with _lib.knob("TBK_QLW_MIN", 0), _lib.knob("TBK_QL16_MIN", 0):
+            ev, vec = _eigh_batch(hs)
+            ev_only, _ = _eigh_batch(hs, vectors=False)
+        ref = np.linalg.eigvalsh(hs).T
+        assert np.max(np.abs(ev - ref)) < 1e-13 * n
+        assert np.max(np.abs(ev_only - ref)) < 1e-13 * n
+        V = vec.transpose(1, 0, 2)
+        assert max(np.max(np.abs(hs[i] @ V[i].T - V[i].T * ev[:, i])) for i in range(nk)) < 1e-13 * n
