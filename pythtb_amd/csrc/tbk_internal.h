@@ -41,7 +41,7 @@ struct TbkKnobs {
     int use_qlw = 1;            // TBK_QLW           0: n = 17..64 through the Jacobi kernels whatever the batch size
     long long qlw_min = -1;     // TBK_QLW_MIN       batches of at most this many matrices stay on the Jacobi kernels (default 8 x CUs)
     int qlw_nt = -1;            // TBK_QLW_NT        threads per matrix of the tridiagonalisation kernel (64 | 128 | 256 | 512)
-    int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal path in MiB (default 1536)
+    int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal path in MiB (default 4096)
     int ql16_evonly = 1;        // TBK_QL16_EVONLY   0: eigenvalue-only n = 9..16 lists through the single replicated kernel instead of tridiagonalise + lane-per-matrix QL
     long long few_max = -1;     // TBK_FEW_MAX       largest n < 22 batch that gets a workgroup per matrix
     int few_warm = 1;           // TBK_FEW_WARM      0: workgroup solver always starts cold
