@@ -130,9 +130,12 @@ def single_gpu(which, reps):
         t_solve = timed(ctx, lambda: _lib.check(lib.tbk_wfs_solve_grid_async(hw, hm, _lib.dptr(start), _lib.dptr(pbc.view(float)), 0, mesh[0])), max(1, reps // 2))
         occ32 = np.arange(8, dtype=np.int32)
         phases = np.zeros(65 * 65)
-        t0 = time.perf_counter()
-        _lib.check(lib.tbk_berry_phase(hw, _lib.iptr(occ32), 8, 2, 0, _lib.dptr(phases)))
-        t_phase = time.perf_counter() - t0
+        _lib.check(lib.tbk_berry_phase(hw, _lib.iptr(occ32), 8, 2, 0, _lib.dptr(phases)))   # (first call: workspace allocation)
+        t_phase = 1e9
+        for _ in range(max(1, reps // 2)):
+            t0 = time.perf_counter()
+            _lib.check(lib.tbk_berry_phase(hw, _lib.iptr(occ32), 8, 2, 0, _lib.dptr(phases)))
+            t_phase = min(t_phase, time.perf_counter() - t0)
         out.append({"config": "E: cubic16 (888 hops) 64^3 sub-mesh", "nk": nk, "solve_grid_ms": t_solve,
                     "kpts_per_s": nk / t_solve * 1e3, "berry_phase_8band_call_ms": t_phase * 1e3,
                     "links_per_s": 65 * 65 * 64 / t_phase})
