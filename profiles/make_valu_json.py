@@ -10,6 +10,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
 SOURCES = [
+    ("k_grid_rows<2,1>", "r02g/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r02g/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r02gcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r02gcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_solve_ql16<1,true>", "r02gcfg/pmc_per_dispatch.json", "k_solve_ql16<1,true,0>", 65 ** 3),
     ("k_grid_rows<2,1>", "r02f/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
     ("k_flux_rows<1,2>", "r02f/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
     ("k_grid_rows<4,1>", "r02fcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
