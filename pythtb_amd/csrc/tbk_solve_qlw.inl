@@ -36,6 +36,14 @@ __device__ __forceinline__ double rw_allsum(double v) {   // sum over the RW (32
     return v;
 }
 
+// lanes of ONE wavefront exchanging data through LDS: its LDS operations execute in order; this only keeps the compiler from
+// moving accesses across the exchange
+__device__ __forceinline__ void qlw_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
     double2* de;           // [n][nchunk]      (d_j, e_j)
     double2* rot;          // [nchunk][cap]    (c, s) in the order they were applied
@@ -49,7 +57,8 @@ struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
 static size_t qlw_lds1_bytes(int n, int nR, int rw, int nt) {
     const int ld = n | 1, hs = nt / rw;
     size_t b = (size_t)n * ld * sizeof(cd);                       // A / Z
-    b += (size_t)(2 * rw + rw + 2 * hs * rw) * sizeof(cd);        // ubuf (x2), qbuf, pbuf (x2)
+    const int nw = nt / 64;
+    b += (size_t)(nw * rw + rw + hs * rw) * sizeof(cd);           // ubuf (a private copy per wavefront), qbuf, pbuf
     b += (size_t)(std::max(n, nR) + 2 * n) * sizeof(cd);          // eo / phases, dphase, tsub
     b += (size_t)2 * n * sizeof(double);                          // tau, eb
     return (b + 15) & ~(size_t)15;
@@ -65,10 +74,16 @@ __global__ __launch_bounds__(NT) void k_tridiag_lds(const ModelView mv, const in
     const int n = mv.nsta, ld = n | 1;
     const int tid = threadIdx.x, x = tid & (RW - 1), h = tid / RW;
     cd* A = (cd*)lds_raw;
-    cd* ubuf = A + n * ld;                 // [2][RW]
-    cd* qbuf = ubuf + 2 * RW;              // [RW]
-    cd* pbuf = qbuf + RW;                  // [2][HS][RW]
-    cd* eo = pbuf + 2 * HS * RW;           // [max(n, nR)]
+    // Every wavefront holds all RW rows (once or twice), so u is computed by each wavefront for itself and passed between
+    // its lanes through a PRIVATE LDS copy: a wavefront's LDS operations execute in order, no workgroup barrier.  (q the same
+    // way would save another barrier per reflection but costs the LDS that lets two 64 x 64 matrices share a CU: slower.)
+    constexpr int NW = NT / 64;
+    const int wv = tid >> 6;
+    const bool first = (tid & 63) < RW;    // the lanes of a wavefront that write its private copy
+    cd* ubuf = A + n * ld + wv * RW;       // [NW][RW]
+    cd* qbuf = A + n * ld + NW * RW;       // [RW]
+    cd* pbuf = qbuf + RW;                  // [HS][RW]
+    cd* eo = pbuf + HS * RW;               // [max(n, nR)]
     cd* dphase = eo + (n > mv.nR ? n : mv.nR);
     cd* tsub = dphase + n;
     double* tau = (double*)(tsub + n);
@@ -122,17 +137,18 @@ __global__ __launch_bounds__(NT) void k_tridiag_lds(const ModelView mv, const in
             const cd u = x == k + 1 ? cd{ph.x * (absa + nrm), ph.y * (absa + nrm)} : colx;
             beta = 1.0 / (nrm * (nrm + absa));               // 2 / (u^+ u)
             tK = cd{-ph.x * nrm, -ph.y * nrm};
-            if (h == 0) ubuf[x] = u;
-            __syncthreads();
+            if (first) ubuf[x] = u;
+            qlw_wave_sync();
             cd p{0.0, 0.0};
             if (below)
                 for (int c = k + 1 + h; c < n; c += HS) cfma(p, A[x * ld + c], ubuf[c]);
-            pbuf[h * RW + x] = p;
+            cd* pb = pbuf;
+            pb[h * RW + x] = p;
             __syncthreads();
             cd ps{0.0, 0.0};
 #pragma unroll
             for (int hh = 0; hh < HS; ++hh) {
-                const cd t = pbuf[hh * RW + x];
+                const cd t = pb[hh * RW + x];
                 ps.x += t.x;
                 ps.y += t.y;
             }
@@ -199,14 +215,13 @@ __global__ __launch_bounds__(NT) void k_tridiag_lds(const ModelView mv, const in
     // which the block has not reached yet).  Thread (c, h): column c = x, rows r = k+1+h, k+1+h+HS, ...
     if (tid == 0) A[(n - 1) * ld + (n - 1)] = dphase[n - 1];
     for (int k = n - 2; k >= 0; --k) {
-        const int par = k & 1;
-        cd* ub = ubuf + par * RW;
-        cd* pb = pbuf + par * HS * RW;
+        cd* ub = ubuf;                       // (private to the wavefront)
+        cd* pb = pbuf;
         const double beta = tau[k];
-        // new row / column k+1 of the block; the reflector of step k into ubuf
-        if (h == 0 && x > k && x < n) ub[x] = A[x * ld + k];
+        // the reflector of step k, for this wavefront; the new row / column k+1 of the block (nobody reads these places
+        // before the barrier: column k+1 below the diagonal held the reflector of step k+1, consumed one step ago)
+        if (first && x > k && x < n) ub[x] = A[x * ld + k];
         if (h == 1 % HS && x > k + 1 && x < n) A[(k + 1) * ld + x] = cd{0.0, 0.0};
-        __syncthreads();   // (column k+1 below the diagonal held the reflector of step k+1: consumed one step ago)
         if (h == 0 && x > k + 1 && x < n) A[x * ld + (k + 1)] = cd{0.0, 0.0};
         if (tid == 0) A[(k + 1) * ld + (k + 1)] = dphase[k + 1];
         __syncthreads();
