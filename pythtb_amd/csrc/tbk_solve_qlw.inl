@@ -290,19 +290,24 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
     bool done = !has;
     const int max_iter = 30 * n;
     const unsigned long long top = 1ull << (n - 1);
+    // negligible couplings: bit j of `negl` <=> |e_j| <= eps (|d_j| + |d_j+1|)   (e_{n-1} = 0: always).  Scanned once; a sweep
+    // over [l, m) changes e_l .. e_{m-1} and d_l .. d_m only, and those bits are renewed as the new values appear.
+    const double eps = 2.220446049250313e-16;
+    unsigned long long negl = top;
+    auto rescan = [&]() {
+        negl = top;
+        double dj = D[lane];
+        for (int j = 0; j + 1 < n; ++j) {
+            const double dn = D[(j + 1) * 64 + lane];
+            if (fabs(E[j * 64 + lane]) <= eps * (fabs(dj) + fabs(dn))) negl |= 1ull << j;
+            dj = dn;
+        }
+    };
+    rescan();
     for (int iter = 0;; ++iter) {
-        // negligible couplings: |e_j| <= eps (|d_j| + |d_j+1|)   (e_{n-1} = 0: always)
         int m = n - 1;
         if (!done) {
-            unsigned long long negl = top;
-            double dj = D[l * 64 + lane];
-            for (int j = l; j + 1 < n; ++j) {
-                const double dn = D[(j + 1) * 64 + lane];
-                if (fabs(E[j * 64 + lane]) <= 2.220446049250313e-16 * (fabs(dj) + fabs(dn))) negl |= 1ull << j;
-                dj = dn;
-            }
-            const unsigned long long from_l = ~0ull << l;
-            const unsigned long long open = ~negl & from_l & (top - 1);
+            const unsigned long long open = ~negl & (~0ull << l) & (top - 1);
             if (open == 0) {
                 done = true;
             } else {
@@ -326,16 +331,25 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
             g = dm - dl + el * __builtin_amdgcn_rcp(gs + copysign(r, gs));
         }
         // the wavefront walks i = max(m) - 1 .. min(l); a lane takes part inside its own block [l, m)
-        int hi = done ? 0 : m, lo = done ? n : l;
+        int hi = done ? 1 : m, lo = done ? n - 1 : l;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             hi = max(hi, __shfl_xor(hi, o));
             lo = min(lo, __shfl_xor(lo, o));
         }
         int cnt = 0;
+        // e_i, d_i of the position are loaded one position ahead; d_{i+1} as it was BEFORE the sweep is the d_i of the
+        // position above (position i+1 wrote d_{i+2})
+        double e_cur = E[(hi - 1) * 64 + lane], d_cur = D[(hi - 1) * 64 + lane], d_up = D[hi * 64 + lane];
+        double d_new_up = 0.0;                            // the NEW d_{i+2} while position i is worked on
         for (int i = hi - 1; i >= lo; --i) {
+            double e_nx = 0.0, d_nx = 0.0;
+            if (i > lo) {
+                e_nx = E[(i - 1) * 64 + lane];
+                d_nx = D[(i - 1) * 64 + lane];
+            }
             if (alive && i >= l && i < m) {
-                const double ei = E[i * 64 + lane], di = D[i * 64 + lane], di1 = D[(i + 1) * 64 + lane];
+                const double ei = e_cur, di = d_cur, di1 = d_up;
                 const double f = sn * ei, b = cs * ei;
                 const double t = f * f + g * g;
                 if (t > 0.0) {
@@ -346,8 +360,14 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
                     const double gg = di1 - pp;
                     const double r2 = (di - gg) * sn + 2.0 * cs * b;
                     pp = sn * r2;
-                    D[(i + 1) * 64 + lane] = gg + pp;
+                    const double dn = gg + pp;
+                    D[(i + 1) * 64 + lane] = dn;
                     g = cs * r2 - b;
+                    if (i + 1 < m) {                      // bit i+1: e_{i+1} = r, d_{i+1} = dn, d_{i+2} = d_new_up, all final
+                        const unsigned long long bit = 1ull << (i + 1);
+                        negl = r <= eps * (fabs(dn) + fabs(d_new_up)) ? negl | bit : negl & ~bit;
+                    }
+                    d_new_up = dn;
                     if (REC) {
                         if (seq + cnt < W.cap) rot[seq + cnt] = double2{cs, sn};
                         else overflow = true;
@@ -359,11 +379,20 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
                     alive = false;
                 }
             }
+            d_up = d_cur;
+            e_cur = e_nx;
+            d_cur = d_nx;
         }
+        bool again = false;
         if (!done) {
             if (alive) {
-                D[l * 64 + lane] -= pp;
+                const double dl = D[l * 64 + lane] - pp;
+                D[l * 64 + lane] = dl;
                 E[l * 64 + lane] = g;
+                const unsigned long long bit = 1ull << l;  // bit l: e_l = g, d_l = dl, d_{l+1} = d_new_up
+                negl = fabs(g) <= eps * (fabs(dl) + fabs(d_new_up)) ? negl | bit : negl & ~bit;
+            } else {
+                again = true;                            // (underflow stop: renew every bit)
             }
             E[m * 64 + lane] = 0.0;
             if (REC) {
@@ -372,6 +401,11 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
                 ++isw;
                 seq += cnt;
             }
+        }
+        if (__any(again)) {
+            const unsigned long long keep = negl;
+            rescan();
+            if (!again) negl = keep;
         }
     }
     if (REC) {
