@@ -206,3 +206,20 @@ def test_small_entries_below_the_subdiagonal_are_not_dropped(n):
         assert np.max(np.abs(ev_only - ref)) < 1e-13 * n
         V = vec.transpose(1, 0, 2)
         assert max(np.max(np.abs(hs[i] @ V[i].T - V[i].T * ev[:, i])) for i in range(nk)) < 1e-13 * n
+
+
+def test_chunked_mesh_equals_one_batch(tb):
+    """solve_on_grid of a ribbon on 2601 k-points in three workspace chunks: the same array and gaps as in one."""
+    from pythtb_amd import _lib
+    m = _ribbon(tb, 10)
+    with _lib.knob("TBK_QLW_MIN", 0):
+        w1 = tb.wf_array(m, [2601])
+        g1 = w1.solve_on_grid([0.0])
+        a1 = w1.to_host().copy()
+        with _lib.knob("TBK_QLW_WS_MB", 1):
+            w3 = tb.wf_array(m, [2601])
+            g3 = w3.solve_on_grid([0.0])
+            a3 = w3.to_host()
+    assert np.array_equal(g1, g3) and np.array_equal(a1, a3)
+    ev = m.solve_all(np.linspace(0.0, 1.0, 2601)[:-1])
+    assert np.max(np.abs(np.min(ev[1:] - ev[:-1], axis=1) - g1)) < 1e-12
