@@ -36,6 +36,7 @@ static void knobs_parse() {
     getl("TBK_QLW_MIN", k.qlw_min);
     geti("TBK_QLW_NT", k.qlw_nt);
     geti("TBK_QLW_WS_MB", k.qlw_ws_mb);
+    getl("TBK_QLW_CAP", k.qlw_cap);
     geti("TBK_QL16_EVONLY", k.ql16_evonly);
     getl("TBK_QL16_MIN", k.ql16_min);
     getl("TBK_FEW_MAX", k.few_max);

@@ -41,6 +41,7 @@ struct TbkKnobs {
     int use_qlw = 1;            // TBK_QLW           0: n = 17..64 through the Jacobi kernels whatever the batch size
     long long qlw_min = -1;     // TBK_QLW_MIN       batches of at most this many matrices stay on the Jacobi kernels (default 8 x CUs)
     int qlw_nt = -1;            // TBK_QLW_NT        threads per matrix of the tridiagonalisation kernel (64 | 128 | 256 | 512)
+    long long qlw_cap = -1;     // TBK_QLW_CAP       tests: rotations recorded per matrix (default 3 n^2 + 64)
     int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal path in MiB (default 4096)
     int ql16_evonly = 1;        // TBK_QL16_EVONLY   0: eigenvalue-only n = 9..16 lists through the single replicated kernel instead of tridiagonalise + lane-per-matrix QL
     long long few_max = -1;     // TBK_FEW_MAX       largest n < 22 batch that gets a workgroup per matrix
@@ -118,6 +119,7 @@ struct ProfAgg {
 struct tbk_ctx {
     int device = 0;
     int cus = 0;
+    bool qlw_off = false;  // set while a solve is repeated on the Jacobi kernels (the QL rotation record overflowed)
     hipStream_t stream = nullptr;
     hipEvent_t timer0 = nullptr, timer1 = nullptr;
     int prof_period = 0;   // 0 off, 1 bracket every launch, N bracket every Nth launch
@@ -222,6 +224,11 @@ struct tbk_wfs {
     double* gap_part_dev = nullptr;          // per-tile minima of the row kernel (n <= 4), [ntiles][n-1]
     int64_t gap_part_cap = 0, gap_part_n = 0; // gap_part_n > 0: the last solve wrote partials, not shards
     cd* pbc_dev = nullptr;                   // [TBK_MAX_DIM][nsta]
+    // the last solve_grid launch, kept so that tbk_wfs_solve_grid_result can repeat it on other kernels
+    struct tbk_model* last_model = nullptr;
+    double last_start[TBK_MAX_DIM] = {0.0, 0.0, 0.0, 0.0};
+    int64_t last_off[TBK_MAX_DIM] = {0, 0, 0, 0}, last_gmesh[TBK_MAX_DIM] = {1, 1, 1, 1};
+    std::vector<double> last_pbc;
     // per-axis phase tables of the regular mesh (rebuilt only when their inputs change)
     cd* tab_dev = nullptr;                   // z[d][i] then f[d][i][n]
     int64_t tab_cap = 0;

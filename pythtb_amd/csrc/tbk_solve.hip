@@ -1433,7 +1433,7 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // n = 17..64, batches that fill the chip: the three-kernel tridiagonal path (tbk_solve_qlw.inl); smaller batches stay
     // on Jacobi for the same reason as above.  TBK_QLW=0 / TBK_QLW_MIN=<count>.
     const int64_t qlw_min = K.qlw_min >= 0 ? K.qlw_min : (int64_t)ctx->cus * 8;
-    if (n >= 17 && n <= 64 && K.use_qlw != 0 && nk_eff > qlw_min) return launch_qlw<MODE, VEC>(ctx, mv, n, nk, L, G);
+    if (n >= 17 && n <= 64 && K.use_qlw != 0 && !ctx->qlw_off && nk_eff > qlw_min) return launch_qlw<MODE, VEC>(ctx, mv, n, nk, L, G);
     if constexpr (MODE != 1) {
         // (eigenvalues only: already from n = 13, where the LDS kernel takes ~9-10 ms for the same 262144 k)
         if ((n >= 15 || (!VEC && n >= 13)) && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0))
@@ -1572,7 +1572,10 @@ static int launch_solve(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, bo
     return vec ? launch_wave<MODE, true>(ctx, mv, n, nk, L, G) : launch_wave<MODE, false>(ctx, mv, n, nk, L, G);
 }
 
-static int check_noconv(tbk_ctx* ctx, int n) {
+// TBK_ERETRY_JACOBI (internal): the QL rotation record of the n = 17..64 path overflowed; callers that still have their
+// inputs repeat the solve with ctx->qlw_off set, the others report TBK_ENOCONV.
+#define TBK_ERETRY_JACOBI (-1000)
+static int check_noconv(tbk_ctx* ctx, int n, bool can_retry = false) {
     if (n <= 4) return TBK_OK;
     int flag[4] = {0, 0, 0, 0};   // 0: no convergence, 1: (Berry path) singular link, 2: the QL rotation record overflowed
     TBK_HIP(hipMemcpyAsync(flag, ctx->flags_dev, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
@@ -1581,6 +1584,7 @@ static int check_noconv(tbk_ctx* ctx, int n) {
     if (flag[2]) TBK_HIP(hipMemsetAsync(ctx->flags_dev + 2, 0, sizeof(int), ctx->stream));
     TBK_REQUIRE(flag[0] == 0, TBK_ENOCONV, "eigen-solver did not converge (Jacobi: %d sweeps; QL: 30 shifts per eigenvalue)",
                 TBK_JACOBI_MAX_SWEEPS);
+    if (flag[2] && can_retry && !ctx->qlw_off) return TBK_ERETRY_JACOBI;
     TBK_REQUIRE(flag[2] == 0, TBK_ENOCONV,
                 "eigen-solver: a matrix needed more than 3 n^2 QL rotations (4 x the usual); eigenvectors were not "
                 "completed -- rerun with TBK_QLW=0 (Jacobi kernels)");
@@ -1617,12 +1621,17 @@ extern "C" int tbk_solve_list(tbk_model* m, const double* k, int64_t nk, double*
         TBK_REQUIRE(k, TBK_EINVAL, "tbk_solve_list: null k");
         TBK_HIP(hipMemcpyAsync(k_dev, k, kb, hipMemcpyHostToDevice, ctx->stream));
     }
-    rc = tbk_solve_list_dev(m, k_dev, nk, e_dev, v_dev);
+    for (int attempt = 0;; ++attempt) {
+        rc = tbk_solve_list_dev(m, k_dev, nk, e_dev, v_dev);
+        if (rc == TBK_OK) rc = check_noconv(ctx, n, attempt == 0);
+        ctx->qlw_off = rc == TBK_ERETRY_JACOBI;      // (the inputs are still on the device: once more on the Jacobi kernels)
+        if (rc != TBK_ERETRY_JACOBI) break;
+    }
     if (rc) return rc;
     TBK_HIP(hipMemcpyAsync(eval, e_dev, eb, hipMemcpyDeviceToHost, ctx->stream));
     if (evec) TBK_HIP(hipMemcpyAsync(evec, v_dev, vb, hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
-    return check_noconv(ctx, n);
+    return TBK_OK;
 }
 
 extern "C" int tbk_eigh_batch(tbk_ctx* ctx, int n, const double* ham, int64_t nk, double* eval,
@@ -1648,12 +1657,17 @@ extern "C" int tbk_eigh_batch(tbk_ctx* ctx, int n, const double* ham, int64_t nk
     mv.nspin = 1;
     mv.nslot = n * (n + 1) / 2;
     ListArgs L{nullptr, h_dev, e_dev, v_dev};
-    rc = launch_solve<2>(ctx, mv, n, nk, evec != nullptr, L, "eigh_batch");
+    for (int attempt = 0;; ++attempt) {
+        rc = launch_solve<2>(ctx, mv, n, nk, evec != nullptr, L, "eigh_batch");
+        if (rc == TBK_OK) rc = check_noconv(ctx, n, attempt == 0);
+        ctx->qlw_off = rc == TBK_ERETRY_JACOBI;
+        if (rc != TBK_ERETRY_JACOBI) break;
+    }
     if (rc) return rc;
     TBK_HIP(hipMemcpyAsync(eval, e_dev, eb, hipMemcpyDeviceToHost, ctx->stream));
     if (evec) TBK_HIP(hipMemcpyAsync(evec, v_dev, vb, hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
-    return check_noconv(ctx, n);
+    return TBK_OK;
 }
 
 // device-to-device form used by other translation units (position operator path)
@@ -1732,6 +1746,15 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
     TBK_HIP(hipSetDevice(ctx->device));
     const int n = m->nsta;
     const int D = v.dim_arr;
+    if (!ctx->qlw_off) {   // (kept for tbk_wfs_solve_grid_result, which may have to repeat this launch)
+        w->last_model = m;
+        for (int d = 0; d < TBK_MAX_DIM; ++d) {
+            w->last_start[d] = d < D ? start_k[d] : 0.0;
+            w->last_off[d] = d < D ? offset[d] : 0;
+            w->last_gmesh[d] = d < D ? global_mesh[d] : 1;
+        }
+        w->last_pbc.assign(pbc_phase, pbc_phase + (size_t)D * n * 2);
+    }
     GridArgs G{};
     G.wv = v;
     for (int d = 0; d < TBK_MAX_DIM; ++d) {
@@ -1861,8 +1884,7 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
     return launch_wave<1, true>(ctx, m->view, n, v.npts, L, G);
 }
 
-extern "C" int tbk_wfs_solve_grid_result(tbk_wfs* w, double* min_gaps) {
-    TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_solve_grid_result: null wfs");
+static int solve_grid_result_once(tbk_wfs* w, double* min_gaps, bool can_retry) {
     tbk_ctx* ctx = w->ctx;
     if (w->gap_part_n > 0 && w->gaps_n > 0 && min_gaps) {   // the row kernel left per-tile minima
         void* base = nullptr;
@@ -1890,7 +1912,20 @@ extern "C" int tbk_wfs_solve_grid_result(tbk_wfs* w, double* min_gaps) {
             memcpy(&min_gaps[b], &best, sizeof(double));
         }
     }
-    return check_noconv(ctx, w->view.nsta);
+    return check_noconv(ctx, w->view.nsta, can_retry);
+}
+
+extern "C" int tbk_wfs_solve_grid_result(tbk_wfs* w, double* min_gaps) {
+    TBK_REQUIRE(w, TBK_EINVAL, "tbk_wfs_solve_grid_result: null wfs");
+    int rc = solve_grid_result_once(w, min_gaps, w->last_model != nullptr);
+    if (rc == TBK_ERETRY_JACOBI) {   // the QL rotation record overflowed: the same launch again on the Jacobi kernels
+        tbk_ctx* ctx = w->ctx;
+        ctx->qlw_off = true;
+        rc = tbk_wfs_solve_window_async(w, w->last_model, w->last_start, w->last_pbc.data(), w->last_off, w->last_gmesh);
+        if (rc == TBK_OK) rc = solve_grid_result_once(w, min_gaps, false);
+        ctx->qlw_off = false;
+    }
+    return rc;
 }
 
 extern "C" int tbk_wfs_solve_grid(tbk_wfs* w, tbk_model* m, const double* start_k,

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int6
 template <int MODE, bool VEC>
 static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L, const GridArgs& G) {
     const TbkKnobs& K = tbk_knobs();
-    const int64_t cap = VEC ? (int64_t)3 * n * n + 64 : 0;
+    const int64_t cap = VEC ? (K.qlw_cap > 0 ? (int64_t)K.qlw_cap : (int64_t)3 * n * n + 64) : 0;   // rotations recorded per matrix (~1.2 n^2 are typical)
     const int scap = VEC ? 8 * n : 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + (size_t)n * sizeof(int);

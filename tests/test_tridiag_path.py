@@ -223,3 +223,32 @@ def test_chunked_mesh_equals_one_batch(tb):
     assert np.array_equal(g1, g3) and np.array_equal(a1, a3)
     ev = m.solve_all(np.linspace(0.0, 1.0, 2601)[:-1])
     assert np.max(np.abs(np.min(ev[1:] - ev[:-1], axis=1) - g1)) < 1e-12
+
+
+def test_rotation_record_overflow_falls_back_to_jacobi(tb):
+    """The QL kernel records at most 3 n^2 rotations per matrix (4 x the usual count).  If a matrix needs more, the call is
+    repeated on the Jacobi kernels; TBK_QLW_CAP=64 provokes that for every matrix here."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(12)
+    n, nk = 24, 70
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    m = _ribbon(tb, 10)
+    k = np.linspace(-0.5, 0.5, 33)
+    with _lib.knob("TBK_QLW_MIN", 0), _lib.knob("TBK_QLW_CAP", 64):
+        ev, vec = _eigh_batch(h)
+        mev, mvec = m.solve_all(k, eig_vectors=True)
+        w = tb.wf_array(m, [41])
+        gaps = w.solve_on_grid([0.0])
+        host = w.to_host()
+    with _lib.knob("TBK_QLW", 0):
+        ev_j, vec_j = _eigh_batch(h)
+        w2 = tb.wf_array(m, [41])
+        gaps_j = w2.solve_on_grid([0.0])
+    assert np.array_equal(ev, ev_j) and np.array_equal(vec, vec_j)          # literally the Jacobi kernels' output
+    assert np.array_equal(gaps, gaps_j) and np.array_equal(host, w2.to_host())
+    assert np.max(np.abs(ev - np.linalg.eigvalsh(h).T)) < 1e-12
+    for i in (0, 16, 32):
+        H = m._gen_ham([k[i]])
+        V = mvec[:, i, :]
+        assert np.max(np.abs(H @ V.T - V.T * mev[:, i])) < 1e-12
