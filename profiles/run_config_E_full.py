@@ -11,7 +11,7 @@ with contextlib.redirect_stdout(io.StringIO()):
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 257
 mesh=[N,N,N]
 t0=time.perf_counter()
-hw,pbc=grid_handle(ctx, model, mesh)
+hw,pbc=grid_handle(_lib, lib, ctx, model, mesh)
 print("alloc GB", N**3*256*16/1e9, "s", time.perf_counter()-t0, flush=True)
 hm=model._device_model(); start=np.zeros(3)
 for rep in range(2):

@@ -38,6 +38,8 @@ static void knobs_parse() {
     geti("TBK_QLW_WS_MB", k.qlw_ws_mb);
     getl("TBK_QLW_CAP", k.qlw_cap);
     geti("TBK_QL16_EVONLY", k.ql16_evonly);
+    geti("TBK_QL16_SPLIT", k.ql16_split);
+    getl("TBK_QL16_SPLIT_MIN", k.ql16_split_min);
     getl("TBK_QL16_MIN", k.ql16_min);
     getl("TBK_FEW_MAX", k.few_max);
     geti("TBK_FEW_WARM", k.few_warm);

@@ -43,6 +43,8 @@ struct TbkKnobs {
     int qlw_nt = -1;            // TBK_QLW_NT        threads per matrix of the tridiagonalisation kernel (64 | 128 | 256 | 512)
     long long qlw_cap = -1;     // TBK_QLW_CAP       tests: rotations recorded per matrix (default 3 n^2 + 64)
     int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal path in MiB (default 4096)
+    int ql16_split = 1;         // TBK_QL16_SPLIT    0: n = 9..16 with eigenvectors in the single kernel instead of three (tridiagonalise | lane-per-matrix QL, recorded | replay)
+    long long ql16_split_min = -1;  // TBK_QL16_SPLIT_MIN  smallest batch that takes the three-kernel form (default 8192)
     int ql16_evonly = 1;        // TBK_QL16_EVONLY   0: eigenvalue-only n = 9..16 lists through the single replicated kernel instead of tridiagonalise + lane-per-matrix QL
     long long few_max = -1;     // TBK_FEW_MAX       largest n < 22 batch that gets a workgroup per matrix
     int few_warm = 1;           // TBK_FEW_WARM      0: workgroup solver always starts cold

@@ -1429,7 +1429,7 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // TBK_QL16_MIN=<count>: batches of at most that many matrices stay on Jacobi (default 8 x CUs; 0 = none).
     const int64_t ql16_min = K.ql16_min >= 0 ? K.ql16_min : (int64_t)ctx->cus * 8;
     if (n >= 9 && n <= 16 && use_ql16 && (MODE == 2 || mv.nR > 0) && nk_eff > ql16_min)
-        return launch_ql16<MODE, VEC>(ctx, mv, nk, L, G);
+        return launch_ql16<MODE, VEC>(ctx, mv, nk, L, G, nk_eff);
     // n = 17..64, batches that fill the chip: the three-kernel tridiagonal path (tbk_solve_qlw.inl); smaller batches stay
     // on Jacobi for the same reason as above.  TBK_QLW=0 / TBK_QLW_MIN=<count>.
     const int64_t qlw_min = K.qlw_min >= 0 ? K.qlw_min : (int64_t)ctx->cus * 8;

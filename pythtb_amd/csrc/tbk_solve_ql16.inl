@@ -168,9 +168,11 @@ __device__ __forceinline__ void ql16_bcast_ev(const double dd, double (&ev)[16])
 // is two kernels: k_solve_ql16<.., false, 1> stops after the tridiagonalisation and leaves (d_j, e_j) in a workspace laid out
 // [j][matrix]; k_tridiag_eigvals then gives every LANE one matrix -- static register indices, nothing replicated, coalesced
 // loads and stores -- ~0.4 k wave-instructions per matrix.
-template <int I>
+// REC: the rotation of position I goes to rot[I * stride]; lstop = lowest position rotated so far
+template <int I, bool REC = false>
 __device__ __forceinline__ void qle_pos(double (&d)[16], double (&e)[16], double& sn, double& cs, double& pp, double& g, bool& alive,
-                                        const bool live, const int l, const int m) {
+                                        const bool live, const int l, const int m, double2* __restrict__ rot = nullptr,
+                                        int* lstop = nullptr, const int64_t stride = 0) {
     if (live && alive && I >= l && I < m) {
         const double f = sn * e[I], b = cs * e[I];
         const double t = f * f + g * g;
@@ -188,13 +190,17 @@ __device__ __forceinline__ void qle_pos(double (&d)[16], double (&e)[16], double
                 d[I] -= pp;
                 e[I] = g;
             }
+            if constexpr (REC) {
+                rot[(int64_t)I * stride] = double2{cs, sn};
+                *lstop = I;
+            }
         } else {                                 // r == 0 (underflow): tql2's recovery
             d[I + 1] -= pp;
             e[I + 1] = 0.0;                          // (e_{i+1} = r = 0)
             alive = false;
         }
     }
-    if constexpr (I > 0) qle_pos<I - 1>(d, e, sn, cs, pp, g, alive, live, l, m);
+    if constexpr (I > 0) qle_pos<I - 1, REC>(d, e, sn, cs, pp, g, alive, live, l, m, rot, lstop, stride);
 }
 template <int J>
 __device__ __forceinline__ double qle_pick(const double (&a)[16], const int idx, const double acc) {
@@ -268,18 +274,202 @@ __global__ __launch_bounds__(256) void k_tridiag_eigvals(const int n, const int6
     }
 }
 
+// ---- with eigenvectors, three-kernel form (TBK_QL16_SPLIT): the rotation recurrence replicated over the 16 lanes of a matrix
+// is ~60 % of k_solve_ql16's instructions.  Here it runs ONCE per matrix -- one lane per matrix, like k_tridiag_eigvals --
+// and leaves the rotations of every sweep in a record; k_ql16_replay then applies them to the rows of Z with the 16 lanes of
+// a matrix (no recurrence, one coalesced load of the sweep's rotations per iteration).
+// The record is laid out [sweep][position][matrix]: the lanes of the QL kernel (consecutive matrices, in step through sweeps
+// and positions) write consecutive 16-byte entries, and the four matrices of a replay wavefront share each 64-byte sector
+// they read.  Only the entries of positions a sweep rotated are ever touched.
+struct Ql16Rec {
+    double2* rot;      // [scap][16][nc]  (c, s) of sweep it at position i
+    unsigned* swp;     // [scap][nc]      per sweep: lowest position rotated | m << 8   (rotations m-1 .. lowest)
+    int* nit;          // [nc]
+    signed char* rank; // [16][nc]        ascending rank of column b (padding columns rank last)
+    int scap;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ql16_lanes(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
+                                                    const double2* __restrict__ de, double* __restrict__ eval, const GridArgs G,
+                                                    const Ql16Rec R, int* flags) {
+    const int64_t idc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool has = idc < nc;
+    const int64_t ic = has ? idc : nc - 1;
+    double d[16], e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double2 v = de[(int64_t)j * nc + ic];
+        d[j] = v.x;
+        e[j] = v.y;
+    }
+    e[15] = 0.0;
+    int it = 0;
+    bool overflow = false;
+    int l = 0;
+    bool done = !has;
+    for (int iter = 0;; ++iter) {
+        int m = 15;
+        if (!done) {
+            unsigned negl = 0x8000u;
+#pragma unroll
+            for (int j = 0; j < 15; ++j)
+                negl |= fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1])) ? (1u << j) : 0u;
+            const unsigned open = ~negl & (0xffffu << l) & 0xffffu;
+            if (open == 0) {
+                done = true;
+            } else {
+                l = __builtin_ctz(open);
+                m = __builtin_ctz(negl & (0xffffu << l));
+            }
+        }
+        if (__all(done)) break;
+        if (iter >= TBK_QL_MAX_ITER) {
+            if (!done) atomicExch(flags, 1);
+            break;
+        }
+        double sn = 1.0, cs = 1.0, pp = 0.0, g = 0.0;
+        bool alive = true;
+        if (!done) {
+            const double dl = qle_pick<0>(d, l, 0.0), dl1 = qle_pick<0>(d, l + 1, 0.0);
+            const double el = qle_pick<0>(e, l, 1.0), dmm = qle_pick<0>(d, m, 0.0);
+            const double gs = (dl1 - dl) * (0.5 * __builtin_amdgcn_rcp(el));
+            const double r = __builtin_amdgcn_sqrt(fma(gs, gs, 1.0));
+            g = dmm - dl + el * __builtin_amdgcn_rcp(gs + copysign(r, gs));
+        }
+        // (a sweep that would not fit the record is not written at all: the lane flags the overflow and goes on unrecorded)
+        const bool fits = it < R.scap;   // (a sweep that does not fit is not recorded: the lane flags the overflow and goes on)
+        int lstop = m;
+        qle_pos<14, true>(d, e, sn, cs, pp, g, alive, !done && fits, l, m, R.rot + (int64_t)it * 16 * nc + ic, &lstop, nc);
+        if (!done && !fits) {
+            overflow = true;
+            qle_pos<14, false>(d, e, sn, cs, pp, g, alive, true, l, m);
+        }
+        if (!done && fits) {
+            R.swp[(int64_t)it * nc + ic] = (unsigned)lstop | ((unsigned)m << 8);
+            ++it;
+        }
+    }
+    if (has) R.nit[idc] = it;
+    if (overflow) atomicExch(flags + 2, 1);
+    // stable ascending ranks among the n real entries (padding columns rank last, in place)
+    double prev = 0.0;
+    int rk[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        int r = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const bool before = a < n ? (b < n && (d[b] < d[a] || (d[b] == d[a] && b < a))) : (b < n || b < a);
+            r += before ? 1 : 0;
+        }
+        rk[a] = r;
+        if (has) R.rank[(int64_t)a * nc + idc] = (signed char)r;
+    }
+    for (int r = 0; r < n; ++r) {
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v = (a < n && rk[a] == r) ? d[a] : v;
+        if constexpr (MODE == 1) {
+            if (r > 0) {
+                double gap = has ? v - prev : INFINITY;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) gap = fmin(gap, __shfl_xor(gap, o));
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long* slot = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * n + (r - 1);
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(fmax(gap, 0.0));
+                    if (bits < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, bits);
+                }
+            }
+            prev = v;
+        } else {
+            if (has) eval[(int64_t)r * nk + id0 + idc] = v;
+        }
+    }
+}
+
+// position I of a recorded sweep over [lo, m): lane x of the matrix loaded the rotation of position x into `mine`
+template <int I>
+__device__ __forceinline__ void ql16_replay_pos(cd (&z)[16], const double2 mine, const bool on, const int lo, const int m) {
+    const double c = rowbcast_d<I>(mine.x), s = rowbcast_d<I>(mine.y);
+    if (on && I >= lo && I < m) {
+        const cd zi = z[I], zj = z[I + 1];
+        z[I + 1] = cd{s * zi.x + c * zj.x, s * zi.y + c * zj.y};
+        z[I] = cd{c * zi.x - s * zj.x, c * zi.y - s * zj.y};
+    }
+    if constexpr (I > 0) ql16_replay_pos<I - 1>(z, mine, on, lo, m);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ql16_replay(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
+                                                      const Ql16Rec R, cd* __restrict__ evec, const WfsView wv) {
+    const int lane = threadIdx.x & 63;
+    const int x = lane & 15;
+    const int64_t idc0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = idc0 < nc;
+    const int64_t idc = live ? idc0 : nc - 1, id = id0 + idc;
+    const bool real_row = x < n;
+    const int xr = real_row ? x : n - 1;
+    cd z[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int bb = b < n ? b : n - 1;
+        if constexpr (MODE == 1) z[b] = wf_at(wv, bb, id)[xr];
+        else z[b] = evec[((int64_t)bb * nk + id) * n + xr];
+    }
+    const double2* __restrict__ rot = R.rot + idc;     // entry (it, i): rot[(it * 16 + i) * nc]
+    const unsigned* __restrict__ swp = R.swp + idc;    // sweep it: swp[it * nc]
+    const int nit = live ? R.nit[idc] : 0;
+    int nmax = nit;
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    // the sweep word and this lane's rotation of the NEXT sweep are loaded while the current one is applied
+    unsigned w_nx = nit > 0 ? swp[0] : 0u;
+    double2 r_nx{1.0, 0.0};
+    {
+        const int lo = (int)(w_nx & 0xffu), m = (int)(w_nx >> 8);
+        if (nit > 0 && x >= lo && x < m) r_nx = rot[(int64_t)x * nc];
+    }
+    for (int it = 0; it < nmax; ++it) {
+        const bool on = it < nit;
+        const unsigned w = w_nx;
+        const double2 mine = r_nx;
+        const int lo = (int)(w & 0xffu), m = (int)(w >> 8);
+        if (it + 1 < nit) {
+            w_nx = swp[(int64_t)(it + 1) * nc];
+            const int lo2 = (int)(w_nx & 0xffu), m2 = (int)(w_nx >> 8);
+            r_nx = (x >= lo2 && x < m2) ? rot[((int64_t)(it + 1) * 16 + x) * nc] : double2{1.0, 0.0};
+        }
+        ql16_replay_pos<14>(z, mine, on, lo, m);
+    }
+    if (!live || !real_row) return;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        if (b < n) {
+            const int r = R.rank[(int64_t)b * nc + idc];
+            if constexpr (MODE == 1) wf_at(wv, r, id)[x] = z[b];
+            else evec[((int64_t)r * nk + id) * n + x] = z[b];
+        }
+    }
+}
+
 // MODE 0: k list, 1: regular mesh into a wf_array (+ min gaps), 2: supplied matrices
-// STAGE 0: the whole solve.  STAGE 1 (eigenvalues only): stop after the tridiagonalisation, de[j * nk + id] = (d_j, e_j).
+// STAGE 0: the whole solve.  STAGE 1 (eigenvalues only): stop after the tridiagonalisation, de[j * nc + (id - id0)] = (d_j, e_j).
+// STAGE 2 (with eigenvectors, three-kernel form): the same, and Z = H_0 ... H_13 D goes to the output array in column order
+// (band slot b = column b) for k_ql16_replay.  The launch covers the matrices [id0, id0 + nc) of the batch of nk.
 template <int MODE, bool VEC, int STAGE = 0>
 __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G,
-                                                     int* noconv_flag, double2* __restrict__ de = nullptr) {
-    static_assert(STAGE == 0 || !VEC, "k_solve_ql16: the two-kernel form is the eigenvalue-only one");
+                                                     int* noconv_flag, double2* __restrict__ de = nullptr, const int64_t id0 = 0,
+                                                     const int64_t nc = 0) {
+    static_assert(STAGE != 1 || !VEC, "k_solve_ql16: stage 1 is the eigenvalue-only form");
+    static_assert(STAGE != 2 || VEC, "k_solve_ql16: stage 2 is the eigenvector form");
     const int lane = threadIdx.x & 63;
     const int x = lane & 15;
     const int rowbase4 = (lane & 48) * 4;
-    const int64_t mat = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const bool live = mat < nk;
-    const int64_t id = live ? mat : nk - 1;   // idle tail rows shadow the last point
+    const int64_t mat = id0 + (((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4);
+    const int64_t nend = STAGE == 0 ? nk : id0 + nc;
+    const bool live = mat < nend;
+    const int64_t id = live ? mat : nend - 1;   // idle tail rows shadow the last point
     const int n = mv.nsta;
     const bool real_row = x < n;
     double kk[4] = {0.0, 0.0, 0.0, 0.0};
@@ -370,8 +560,27 @@ __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const in
     }
     double dd = sel16<0>(a, x, cd{0.0, 0.0}).x;          // d_x = A[x][x]
 
-    if constexpr (STAGE == 1) {
-        if (live) de[(int64_t)x * nk + id] = double2{dd, x < 15 ? ee : 0.0};
+    if constexpr (STAGE != 0) {
+        if (live) de[(int64_t)x * nc + (id - id0)] = double2{dd, x < 15 ? ee : 0.0};
+        if constexpr (STAGE == 2) {
+            if (live && real_row) {
+                cd f{1.0, 0.0};
+                if constexpr (MODE != 2) f = cconj(expi2pi(kdot(kk, mv.orb[x])));
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (wrap[d]) f = cmul(f, G.pbc[d * n + x]);
+                }
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    if (b < n) {
+                        const cd val = cmul(z[b], f);
+                        if constexpr (MODE == 1) wf_at(G.wv, b, id)[x] = val;
+                        else Lst.evec[((int64_t)b * nk + id) * n + x] = val;
+                    }
+                }
+            }
+        }
         return;
     }
 
@@ -471,7 +680,7 @@ __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const in
 }
 
 template <int MODE, bool VEC>
-static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G) {
+static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G, int64_t nk_eff) {
     TBK_REQUIRE(nk * 16 < (int64_t)0x7fffffff * 256, TBK_EUNSUPPORTED, "too many k-points for one launch");
     const unsigned blocks = (unsigned)((nk * 16 + 255) / 256);
     if constexpr (!VEC && MODE != 1) {
@@ -489,9 +698,58 @@ static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
                 ctx->work_bytes = wbytes;
             }
             double2* de = (double2*)ctx->work;
-            hipLaunchKernelGGL((k_solve_ql16<MODE, false, 1>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev, de);
+            hipLaunchKernelGGL((k_solve_ql16<MODE, false, 1>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev, de,
+                               (int64_t)0, nk);
             hipLaunchKernelGGL(k_tridiag_eigvals, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, mv.nsta, nk,
                                (const double2*)de, L.eval, ctx->flags_dev);
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
+    }
+    if constexpr (VEC) {
+        // three-kernel form (TBK_QL16_SPLIT): tridiagonalise + Z | one lane per matrix: QL, recording | replay on the rows of Z
+        const TbkKnobs& K = tbk_knobs();
+        // (decided on the size of the GLOBAL mesh: every window of an array takes the same route)
+        if (K.ql16_split != 0 && !ctx->qlw_off && nk_eff >= (K.ql16_split_min >= 0 ? K.ql16_split_min : 8192)) {
+            const int scap = 64;   // sweeps recorded per matrix (~35 are typical at n = 16; LAPACK gives up at 480)
+            auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+            const size_t per = 16 * sizeof(double2) + (size_t)scap * 16 * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + 16;
+            const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 4096) << 20;
+            int64_t chunk = std::max<int64_t>(4096, (int64_t)(budget / per));
+            chunk = std::min<int64_t>(chunk, nk);
+            chunk = (nk + (nk + chunk - 1) / chunk - 1) / ((nk + chunk - 1) / chunk);
+            const size_t wbytes = al((size_t)chunk * 16 * sizeof(double2)) + al((size_t)chunk * scap * 16 * sizeof(double2)) +
+                                  al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * 16) + 1024;
+            if (wbytes > ctx->work_bytes) {
+                TBK_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->work) TBK_HIP(hipFree(ctx->work));
+                ctx->work = nullptr;
+                ctx->work_bytes = 0;
+                hipError_t e = hipMalloc(&ctx->work, wbytes);
+                TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "QL record workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
+                ctx->work_bytes = wbytes;
+            }
+            unsigned char* p = (unsigned char*)ctx->work;
+            double2* de = (double2*)p;
+            p += al((size_t)chunk * 16 * sizeof(double2));
+            Ql16Rec R{};
+            R.rot = (double2*)p;
+            p += al((size_t)chunk * scap * 16 * sizeof(double2));
+            R.swp = (unsigned*)p;
+            p += al((size_t)chunk * scap * sizeof(unsigned));
+            R.nit = (int*)p;
+            p += al((size_t)chunk * sizeof(int));
+            R.rank = (signed char*)p;
+            R.scap = scap;
+            cd* evec = MODE == 1 ? nullptr : L.evec;
+            for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
+                const int64_t nc = std::min<int64_t>(chunk, nk - id0);
+                const unsigned b16 = (unsigned)((nc * 16 + 255) / 256);
+                hipLaunchKernelGGL((k_solve_ql16<MODE, true, 2>), dim3(b16), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev, de, id0, nc);
+                hipLaunchKernelGGL((k_ql16_lanes<MODE>), dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc,
+                                   (const double2*)de, L.eval, G, R, ctx->flags_dev);
+                hipLaunchKernelGGL((k_ql16_replay<MODE>), dim3(b16), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, R, evec, G.wv);
+            }
             TBK_HIP(hipGetLastError());
             return TBK_OK;
         }
