@@ -711,7 +711,9 @@ static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
         const TbkKnobs& K = tbk_knobs();
         // (decided on the size of the GLOBAL mesh: every window of an array takes the same route)
         if (K.ql16_split != 0 && !ctx->qlw_off && nk_eff >= (K.ql16_split_min >= 0 ? K.ql16_split_min : 8192)) {
-            const int scap = 64;   // sweeps recorded per matrix (~35 are typical at n = 16; LAPACK gives up at 480)
+            // sweeps recorded per matrix (~35 are typical at n = 16; LAPACK gives up at 480).  A matrix that needs more makes the
+            // caller repeat the batch on the single kernel (TBK_QLW_CAP: tests provoke that)
+            const int scap = K.qlw_cap > 0 ? (int)std::max<long long>(1, std::min<long long>(64, K.qlw_cap / 16)) : 64;
             auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
             const size_t per = 16 * sizeof(double2) + (size_t)scap * 16 * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + 16;
             const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 4096) << 20;

@@ -252,3 +252,25 @@ def test_rotation_record_overflow_falls_back_to_jacobi(tb):
         H = m._gen_ham([k[i]])
         V = mvec[:, i, :]
         assert np.max(np.abs(H @ V.T - V.T * mev[:, i])) < 1e-12
+
+
+def test_sweep_record_overflow_of_the_16_lane_form_falls_back(tb):
+    """n = 9..16 with eigenvectors: the three-kernel form records at most 64 sweeps per matrix; TBK_QLW_CAP=64 leaves room
+    for four, every matrix overflows and the batch is repeated on the single kernel -- the same bits as with TBK_QL16_SPLIT=0."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(21)
+    n, nk = 14, 300
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    with _lib.knob("TBK_QL16_MIN", 0), _lib.knob("TBK_QL16_SPLIT_MIN", 0):
+        ev3, v3 = _eigh_batch(h)                                   # three kernels
+        with _lib.knob("TBK_QLW_CAP", 64):
+            ev_f, v_f = _eigh_batch(h)                             # overflow -> repeated on the single kernel
+        with _lib.knob("TBK_QL16_SPLIT", 0):
+            ev1, v1 = _eigh_batch(h)                               # single kernel
+    assert np.array_equal(ev_f, ev1) and np.array_equal(v_f, v1)
+    ref = np.linalg.eigvalsh(h).T
+    assert np.max(np.abs(ev3 - ref)) < 1e-13 and np.max(np.abs(ev1 - ref)) < 1e-13
+    V = v3.transpose(1, 0, 2)
+    assert max(np.max(np.abs(h[i] @ V[i].T - V[i].T * ev3[:, i])) for i in range(nk)) < 1e-13
+    assert max(np.max(np.abs(V[i].conj() @ V[i].T - np.identity(n))) for i in range(nk)) < 1e-13
