@@ -9,7 +9,12 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
+# (a key "a+b+c" sums the per-dispatch counts of several kernels that each cover the same points)
 SOURCES = [
+    ("k_grid_rows<4,1>", "r02hcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r02hcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    # the 65^3 mesh of the collection goes through the three kernels in two chunks
+    ("k_solve_ql16<1,true>", "r02hcfg/pmc_per_dispatch.json", "k_solve_ql16<1,true,2>+k_ql16_lanes<1>+k_ql16_replay<1>", 65 ** 3 // 2),
     ("k_grid_rows<2,1>", "r02g/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
     ("k_flux_rows<1,2>", "r02g/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
     ("k_grid_rows<4,1>", "r02gcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
@@ -43,10 +48,12 @@ for name, rel, key, points in SOURCES:
     path = os.path.join(HERE, rel)
     if not os.path.exists(path):
         continue
-    rec = json.load(open(path)).get(key)
-    if not rec or "SQ_INSTS_VALU" not in rec:
+    table = json.load(open(path))
+    recs = [table.get(k) for k in key.split("+")]
+    if any(not r or "SQ_INSTS_VALU" not in r for r in recs):
         continue
-    out[name] = {"kernel": key, "source": "profiles/" + rel, "SQ_INSTS_VALU_per_dispatch": rec["SQ_INSTS_VALU"],
-                 "mesh_points_per_dispatch": points, "valu_wave_insts_per_point": rec["SQ_INSTS_VALU"] / points}
+    insts = sum(r["SQ_INSTS_VALU"] for r in recs)
+    out[name] = {"kernel": key, "source": "profiles/" + rel, "SQ_INSTS_VALU_per_dispatch": insts,
+                 "mesh_points_per_dispatch": points, "valu_wave_insts_per_point": insts / points}
 json.dump(out, open(os.path.join(HERE, "valu.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))
