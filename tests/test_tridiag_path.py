@@ -274,3 +274,31 @@ def test_sweep_record_overflow_of_the_16_lane_form_falls_back(tb):
     V = v3.transpose(1, 0, 2)
     assert max(np.max(np.abs(h[i] @ V[i].T - V[i].T * ev3[:, i])) for i in range(nk)) < 1e-13
     assert max(np.max(np.abs(V[i].conj() @ V[i].T - np.identity(n))) for i in range(nk)) < 1e-13
+
+
+def test_three_kernel_16_lane_form_on_a_mesh(tb):
+    """cubic16 on a small 3-D mesh forced through tridiagonalise | lane-per-matrix QL | replay: gaps and Berry phases against
+    the oracle, the single kernel's eigenvalue gaps, and bit-identical shard windows (the route is decided on the global mesh)."""
+    from oracle import tb_oracle as orc
+    from pythtb_amd import _lib, shard
+    m = hp.cubic16(tb.tb_model)
+    mesh, start = [7, 6, 9], [0.05, -0.1, 0.2]
+    with _lib.knob("TBK_QL16_MIN", 0), _lib.knob("TBK_QL16_SPLIT_MIN", 0):
+        w = tb.wf_array(m, mesh)
+        gaps = w.solve_on_grid(start)
+        host = w.to_host().copy()
+        ph = w.berry_phase(range(8), 2, contin=False)
+        for r in range(2):
+            row0, nrows = shard.split_rows(mesh[0], 2, r)
+            ww = tb.wf_array(m, [nrows, mesh[1], mesh[2]])
+            ww.solve_on_grid_window(start, [row0, 0, 0], mesh)
+            assert np.array_equal(ww.to_host(), host[row0:row0 + nrows])
+        with _lib.knob("TBK_QL16_SPLIT", 0):
+            w1 = tb.wf_array(m, mesh)
+            gaps1 = w1.solve_on_grid(start)
+    owfs, ogaps = orc.solve_on_grid(m, mesh, start, vectorised=True)
+    assert np.max(np.abs(gaps - ogaps)) < 1e-12 and np.max(np.abs(gaps1 - ogaps)) < 1e-12
+    oph = orc.berry_phase(owfs, 3, list(range(8)), 2, contin=False)
+    assert np.max(np.abs(np.angle(np.exp(1j * (np.asarray(ph) - np.asarray(oph)))))) < 1e-9
+    V = host.reshape(-1, 16, 16)
+    assert max(np.max(np.abs(v.conj() @ v.T - np.identity(16))) for v in V) < 1e-13
