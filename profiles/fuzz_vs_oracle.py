@@ -42,8 +42,15 @@ for case in range(ncase):
     nhop = int(norb * norb * (1.5 if dense else 0.3)) + 2
     rmax = int(rng.integers(1, 3))
     m = hp.random_model(tb.tb_model, norb, dim_k, nspin, int(rng.integers(0, 10 ** 6)), nhop=nhop, rmax=rmax)
+    # FUZZ_IMAG_SCALE / FUZZ_K_SCALE: nearly real Hamiltonians (imaginary parts of the hoppings scaled down, k close to 0) --
+    # the structure that exposed the Householder "nothing to annihilate" test of the direct solvers
+    imag_scale = float(os.environ.get("FUZZ_IMAG_SCALE", "1"))
+    if imag_scale != 1.0:
+        for hop in m._hoppings:
+            hop[0] = np.real(hop[0]) + 1j * imag_scale * np.imag(hop[0])
     nk_max = int(os.environ.get("FUZZ_NK", "40"))
     k = rng.uniform(-0.7, 0.7, size=(int(rng.integers(max(1, nk_max // 2), nk_max)) if nk_max > 100 else int(rng.integers(1, nk_max)), dim_k))
+    k = k * float(os.environ.get("FUZZ_K_SCALE", "1"))
     ev, vec = m.solve_all(k, eig_vectors=True)
     ev_only = m.solve_all(k)
     ref = orc.solve_all_vec(m, k)
