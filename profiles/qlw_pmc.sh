@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/qlw_pmc_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         nm = re.sub(r'\(.*', '', r['Kernel_Name'])
-        if 'tridiag' in nm or 'backtransform' in nm:
+        if 'tridiag' in nm or 'backtransform' in nm or 'replay' in nm:
             agg[nm][r['Counter_Name']].append(float(r['Counter_Value']))
 for nm in sorted(agg):
     print(nm)

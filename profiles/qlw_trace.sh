@@ -15,6 +15,6 @@ f = sorted(glob.glob('gpurun_out/qlw_prof/*/*_kernel_trace.csv'))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 for r in rows:
     nm = r['Kernel_Name']
-    if 'tridiag' in nm or 'backtransform' in nm:
+    if 'tridiag' in nm or 'backtransform' in nm or 'replay' in nm:
         print(re.sub(r'\(.*', '', nm)[:60], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, 'grid', r.get('Grid_Size_X', r.get('Grid_Size')), 'vgpr', r.get('VGPR_Count'))
 PY

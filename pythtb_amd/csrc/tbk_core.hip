@@ -35,6 +35,7 @@ static void knobs_parse() {
     geti("TBK_QLW", k.use_qlw);
     getl("TBK_QLW_MIN", k.qlw_min);
     geti("TBK_QLW_NT", k.qlw_nt);
+    geti("TBK_QLW_REPLAY_REG", k.qlw_replay_reg);
     geti("TBK_QLW_WS_MB", k.qlw_ws_mb);
     getl("TBK_QLW_CAP", k.qlw_cap);
     geti("TBK_QL16_EVONLY", k.ql16_evonly);

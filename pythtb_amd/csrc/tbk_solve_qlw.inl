@@ -543,6 +543,155 @@ __global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int6
     }
 }
 
+// ---- the replay with the rows of Z in REGISTERS, n <= 32 (TBK_QLW_REPLAY_REG): the form k_ql16_replay has -- 32 lanes per
+// matrix, lane = row, z[NMAX] complex with static indices, EVERY position of the range unrolled and taken or not under a
+// per-lane predicate (EXEC-masked, in place).  The lane that sits on position x loads that sweep's rotation; the others get
+// it through a 1 KB LDS exchange (a DPP row broadcast spans 16 lanes only).  Twice the positions of the LDS form are
+// visited (a sweep covers [l, m) of 0..n-2), but there is no Z in LDS, so occupancy is set by the registers.
+template <int I, int NMAX>
+__device__ __forceinline__ void qlw_replay_pos(cd (&z)[NMAX], const double2* __restrict__ xg, const bool on, const int ilo, const int ihi) {
+    const double2 r = xg[I];
+    if (on && I >= ilo && I <= ihi) {
+        const cd zi = z[I], zj = z[I + 1];
+        z[I + 1] = cd{r.y * zi.x + r.x * zj.x, r.y * zi.y + r.x * zj.y};
+        z[I] = cd{r.x * zi.x - r.y * zj.x, r.x * zi.y - r.y * zj.y};
+    }
+    if constexpr (I > 0) qlw_replay_pos<I - 1, NMAX>(z, xg, on, ilo, ihi);
+}
+
+template <int MODE, int NMAX>
+__global__ __launch_bounds__(256) void k_ql_replay_reg(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
+                                                        const QlwWork W, cd* __restrict__ evec, const WfsView wv) {
+    __shared__ double2 xch[4][2][32];
+    const int lane = threadIdx.x & 63, x = lane & 31;
+    double2* xg = xch[threadIdx.x >> 6][lane >> 5];
+    const int64_t idc0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const bool live = idc0 < nchunk;
+    const int64_t idc = live ? idc0 : nchunk - 1, id = id0 + idc;
+    const bool real_row = x < n;
+    const int xr = real_row ? x : n - 1;
+    cd z[NMAX];
+#pragma unroll
+    for (int b = 0; b < NMAX; ++b) {
+        const int bb = b < n ? b : n - 1;
+        if constexpr (MODE == 1) z[b] = wf_at(wv, bb, id)[xr];
+        else z[b] = evec[((int64_t)bb * nk + id) * n + xr];
+    }
+    const double2* __restrict__ rot = W.rot + idc * W.cap;
+    const unsigned* __restrict__ swp = W.swp + idc * W.scap;
+    const int nsw = live ? W.nsw[idc] : 0;
+    int nmax = nsw;
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    int seq = 0;
+    // the sweep word and this lane's rotation of the NEXT sweep are loaded while the current one is applied
+    unsigned w_nx = nsw > 0 ? swp[0] : 0u;
+    double2 r_nx{1.0, 0.0};
+    {
+        const int ihi = (int)(w_nx & 0xffu), cnt = (int)(w_nx >> 8);
+        if (nsw > 0 && x <= ihi && x > ihi - cnt) r_nx = rot[ihi - x];
+    }
+    for (int s = 0; s < nmax; ++s) {
+        const bool on = s < nsw;
+        const unsigned w = w_nx;
+        const double2 mine = r_nx;
+        const int ihi = (int)(w & 0xffu), cnt = on ? (int)(w >> 8) : 0, ilo = ihi - cnt + 1;
+        seq += cnt;
+        if (s + 1 < nsw) {
+            w_nx = swp[s + 1];
+            const int ihi2 = (int)(w_nx & 0xffu), cnt2 = (int)(w_nx >> 8);
+            r_nx = (x <= ihi2 && x > ihi2 - cnt2) ? rot[seq + (ihi2 - x)] : double2{1.0, 0.0};
+        }
+        xg[x] = mine;
+        qlw_wave_sync();
+        qlw_replay_pos<NMAX - 2, NMAX>(z, xg, on && cnt > 0, ilo, ihi);
+        qlw_wave_sync();
+    }
+    if (!live || !real_row) return;
+#pragma unroll
+    for (int b = 0; b < NMAX; ++b) {
+        if (b < n) {
+            const int r = W.rank[(int64_t)b * nchunk + idc];
+            if constexpr (MODE == 1) wf_at(wv, r, id)[x] = z[b];
+            else evec[((int64_t)r * nk + id) * n + x] = z[b];
+        }
+    }
+}
+
+// ---- the same for n = 33..64: one matrix per 128-thread block, wavefront 0 holds the real parts of the 64 rows and wavefront 1
+// the imaginary parts (the rotations are real), z[NMAX] doubles per lane; each wavefront loads the sweep's rotations for
+// itself.  The sweep word is loaded through an address the compiler cannot prove uniform: as a wave-uniform value the
+// per-position tests become scalar branches, and at their merge points the register allocator copies the row (see above).
+template <int I, int NMAX, int LOW = 0>
+__device__ __forceinline__ void qlw_replay_pos_re(double (&z)[NMAX], const double2* __restrict__ xg, const int ilo, const int ihi) {
+    const double2 r = xg[I];
+    if (I >= ilo && I <= ihi) {
+        const double zi = z[I], zj = z[I + 1];
+        z[I + 1] = r.y * zi + r.x * zj;
+        z[I] = r.x * zi - r.y * zj;
+    }
+    if constexpr (I > LOW) qlw_replay_pos_re<I - 1, NMAX, LOW>(z, xg, ilo, ihi);
+}
+
+template <int MODE, int NMAX>
+__global__ __launch_bounds__(128) void k_ql_replay_reg64(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
+                                                          const QlwWork W, cd* __restrict__ evec, const WfsView wv) {
+    __shared__ double2 xch[2][64];
+    const int x = threadIdx.x & 63, part = threadIdx.x >> 6;
+    double2* xg = xch[part];
+    const int64_t idc = blockIdx.x, id = id0 + idc;
+    const bool real_row = x < n;
+    const int xr = real_row ? x : n - 1;
+    double z[NMAX];
+#pragma unroll
+    for (int b = 0; b < NMAX; ++b) {
+        const int bb = b < n ? b : n - 1;
+        const double* src;
+        if constexpr (MODE == 1) src = (const double*)(wf_at(wv, bb, id) + xr);
+        else src = (const double*)(evec + ((int64_t)bb * nk + id) * n + xr);
+        z[b] = src[part];
+    }
+    int lane0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));          // (0 in every lane; opaque)
+    const double2* __restrict__ rot = W.rot + idc * W.cap;
+    const unsigned* __restrict__ swp = W.swp + idc * W.scap + lane0;
+    const int nsw = W.nsw[idc];
+    int seq = 0;
+    unsigned w_nx = nsw > 0 ? swp[0] : 0u;
+    double2 r_nx{1.0, 0.0};
+    {
+        const int ihi = (int)(w_nx & 0xffu), cnt = (int)(w_nx >> 8);
+        if (nsw > 0 && x <= ihi && x > ihi - cnt) r_nx = rot[ihi - x];
+    }
+    for (int s = 0; s < nsw; ++s) {
+        const unsigned w = w_nx;
+        const double2 mine = r_nx;
+        const int ihi = (int)(w & 0xffu), cnt = (int)(w >> 8), ilo = ihi - cnt + 1;
+        seq += __builtin_amdgcn_readfirstlane(cnt);
+        if (s + 1 < nsw) {
+            w_nx = swp[s + 1];
+            const int ihi2 = (int)(w_nx & 0xffu), cnt2 = (int)(w_nx >> 8);
+            r_nx = (x <= ihi2 && x > ihi2 - cnt2) ? rot[seq + (ihi2 - x)] : double2{1.0, 0.0};
+        }
+        xg[x] = mine;
+        qlw_wave_sync();
+        // (tried: l only grows during the QL iteration, so late sweeps could run a half-range variant -- chosen by a
+        // wave-uniform branch, which again makes the allocator split the row: 256 VGPRs instead of 166)
+        qlw_replay_pos_re<NMAX - 2, NMAX>(z, xg, ilo, ihi);
+        qlw_wave_sync();
+    }
+    if (!real_row) return;
+#pragma unroll
+    for (int b = 0; b < NMAX; ++b) {
+        if (b < n) {
+            const int r = W.rank[(int64_t)b * nchunk + idc];
+            double* dst;
+            if constexpr (MODE == 1) dst = (double*)(wf_at(wv, r, id) + x);
+            else dst = (double*)(evec + ((int64_t)r * nk + id) * n + x);
+            dst[part] = z[b];
+        }
+    }
+}
+
 template <int MODE, bool VEC>
 static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L, const GridArgs& G) {
     const TbkKnobs& K = tbk_knobs();
@@ -615,7 +764,22 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0, nc,
                            W, L.eval, G, ctx->flags_dev);
         if (VEC) {
-            if (rw == 32)
+            if (rw == 32 && K.qlw_replay_reg != 0) {
+                const unsigned b32 = (unsigned)((nc * 32 + 255) / 256);
+                if (n <= 24)
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                else
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+            } else if (rw == 64 && K.qlw_replay_reg != 0 && n >= 40) {   // (33..39: the 40-row form wastes more than it gains)
+                if (n <= 40)
+                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 40>), dim3((unsigned)nc), dim3(128), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                else if (n <= 48)
+                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 48>), dim3((unsigned)nc), dim3(128), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                else if (n <= 56)
+                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 56>), dim3((unsigned)nc), dim3(128), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                else
+                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 64>), dim3((unsigned)nc), dim3(128), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+            } else if (rw == 32)
                 hipLaunchKernelGGL((k_ql_backtransform<MODE, 64>), dim3((unsigned)nc), dim3(64), lds3, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
             else
                 hipLaunchKernelGGL((k_ql_backtransform<MODE, 128>), dim3((unsigned)nc), dim3(128), lds3, ctx->stream, n, nk, id0, nc, W, evec,
