@@ -17,10 +17,11 @@
 //                        through the same positions under EXEC masks.  It writes the sorted eigenvalues (or the mesh's
 //                        minimum gaps), the sorting permutation and -- with eigenvectors wanted -- the rotation
 //                        sequence (c, s) of every sweep into a workspace.
-//  3. k_ql_backtransform thread = (row of Z, real | imaginary part): the rotations are real and act on columns, so the
-//                        2n real rows are independent.  A thread keeps its row in REGISTERS (static indices: the
-//                        positions of a sweep are unrolled and skipped by wave-uniform branches), the (c, s) of a
-//                        sweep arrive through scalar loads, eight positions per load; no LDS, no barriers.  Columns
+//  3. k_ql_replay_reg / k_ql_replay_reg64 / k_ql_backtransform: the recorded rotations are replayed on Z.  They are real
+//                        and act on columns, so the 2n real rows are independent.  A lane keeps its row in REGISTERS
+//                        (static indices: every position of the range unrolled, taken or not under a per-lane
+//                        predicate) -- 32 lanes per matrix up to n = 32, one wavefront per part (real | imaginary)
+//                        from n = 40; n = 33..39 keep Z in LDS with dynamic positions (k_ql_backtransform).  Columns
 //                        leave in ascending order of their eigenvalue.
 //
 // The cyclic Jacobi kernels these replace do 7-9 sweeps of n(n-1)/2 rotations over A and V (~80 n^3 flops, all of it
@@ -451,12 +452,12 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
 // refill already in flight (in a register per thread) while the current entries are applied.
 // Two matrices of n = 64 fit the LDS of a CU, i.e. one wavefront per SIMD: the kernel is bound by the issue latency of one
 // wavefront's dependent instructions (PMC: ~21 instructions per rotation, ~7 cycles each; profiles/qlw_pmc.sh).
-// Tried: the rows in REGISTERS (no LDS limit, 3 wavefronts per SIMD) with the positions of a sweep unrolled -- skipped by
-// wave-uniform branches per position or per group of four (sweeps recorded padded to whole groups), by EXEC-masked groups,
-// by a jump into the chain at the sweep's first position, or not skipped at all (sweeps padded to the full range, straight-
-// line code), rotations as tied-operand inline asm, (c, s) through scalar loads or the ring.  Best 3.2 ms for 8192 x n=64
-// (this form: 4.2 ms): in every variant the register allocator splits the row's live ranges around the unrolled regions
-// (256 VGPRs + AGPR copies + hundreds of moves for a 64-register row), or spills it under an occupancy bound.
+// The register-resident kernels below (k_ql_replay_reg*) are the default outside n = 33..39.  What does NOT work for them is
+// any WAVE-UNIFORM way of skipping the positions a sweep does not touch -- scalar branches per position or per group of four
+// (sweeps recorded padded to whole groups), a jump into the unrolled chain at the sweep's first position, one if / else per
+// sweep between range variants, or sweeps padded to the full range as straight-line code under an occupancy bound: the
+// register allocator then splits the row's live ranges around the regions (256 VGPRs + AGPR copies + hundreds of moves for a
+// 64-register row, or spills).  Per-lane predicates (EXEC-masked, in place) compile to exactly the row plus temporaries.
 #define TBK_QLW_RING 256   // entries (4 KB); a power of two, at least 2 NT
 template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void k_ql_backtransform(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
