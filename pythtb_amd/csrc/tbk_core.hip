@@ -33,6 +33,7 @@ static void knobs_parse() {
     geti("TBK_ROW16", k.use_row16);
     geti("TBK_QL16", k.use_ql16);
     geti("TBK_QLW", k.use_qlw);
+    geti("TBK_TRIG", k.use_trig);
     getl("TBK_QLW_MIN", k.qlw_min);
     geti("TBK_QLW_NT", k.qlw_nt);
     geti("TBK_QLW_REPLAY_REG", k.qlw_replay_reg);

@@ -1365,6 +1365,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 #include "tbk_solve_row16.inl" // n = 15, 16 on lists: one DPP row of 16 lanes per matrix, rows of A in registers
 #include "tbk_solve_ql16.inl"  // n = 9..16: Householder + implicit QL in registers, one DPP row of 16 lanes per matrix
 #include "tbk_solve_qlw.inl"   // n = 17..64, large batches: Householder in LDS, lane-per-matrix QL, rotation replay
+#include "tbk_solve_trig.inl"  // eigenvalues only, n = 65..1024: Householder with A in L2, then one thread per eigenvalue (bisection)
 #include "tbk_solve_blk.inl"   // batches of wide matrices: block Jacobi, 16x16 subproblems through k_solve_row16
 
 // ---------------------------------------------------------------------------
@@ -1402,6 +1403,15 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // Larger batches of 65..256 states (ms; workgroup solver with 1024 threads | whole chip): eigenvalues only 512 x n=128
     // 97 | 81, 256 x n=200 261 | 196, 256 x n=256 648 | 333 (the whole-chip solver skips V then); with vectors 109 | 145,
     // 277 | 335, 670 | 648.
+    // Eigenvalues only (band structures of ribbons and slabs), n = 65..1024: tridiagonalise, then bisection (tbk_solve_trig.inl).
+    // One workgroup per matrix streams its matrix ~n/3 times from L2: fine for batches and for single matrices up to ~512
+    // (one CU draws ~150 GB/s); few larger ones stay on the whole-chip Jacobi rounds.  TBK_TRIG=0 disables.
+    if constexpr (MODE != 1 && !VEC) {
+        // (measured, profiles/trig_probe.py: a matrix costs 18 / 32 / 57 / 138 / 266 ms at n = 400 / 512 / 600 / 800 / 1024 whatever
+        // the batch -- one CU per matrix -- against 19 / 27 / 39 ms for ONE matrix on the whole-chip Jacobi rounds; TBK_TRIG=2 forces)
+        const bool pays = n <= 400 || (n <= 512 && nk >= 2) || (n <= 800 && nk >= 3) || nk >= 6;
+        if (n > 64 && n <= 1024 && K.use_trig != 0 && (pays || K.use_trig == 2)) return launch_trig<MODE>(ctx, mv, n, nk, L);
+    }
     if (n > 64) {
         // Block Jacobi (tbk_solve_blk.inl) makes n/8 - 1 passes over A and V per sweep instead of n - 1, but every pass
         // costs three launches and the latency of a 16x16 sub-solve (~0.19 ms x n in total): it wins once the batch

@@ -1,0 +1,224 @@
+// tbk_solve_trig.inl -- included by tbk_solve.hip.
+//
+// EIGENVALUES ONLY, n = 65..1024 states per k (ribbon and slab band structures: solve_all(k_path) without eigenvectors,
+// pythtb.py:939 numpy.linalg.eigvalsh per k): the direct method where the Jacobi solvers (tbk_solve_big.inl,
+// tbk_solve_blk.inl) spend 7-9 sweeps of n^2/2 rotations on a result that needs no eigenvectors.
+//
+//  1. k_tridiag_glb   one 1024-thread workgroup per matrix, A in a global workspace (it stays in L2 / the last-level cache
+//                     for the sizes this path takes), u, p, q in LDS.  Householder step k: the column below the diagonal
+//                     is read as the conjugate of row k (contiguous), p = A u and the rank-2 update A -= u q^+ + q u^+ run
+//                     one wavefront per row with the lanes along the columns (coalesced), the whole trailing block is
+//                     kept Hermitian (both triangles updated).  (16/3) n^3 flops, 48 n^3 / 3 bytes of L2 traffic per matrix.
+//  2. k_tridiag_bisect one thread per EIGENVALUE: bisection on the Sturm count of the real symmetric tridiagonal (d, e)
+//                     (LAPACK dstebz's recurrence).  The QL iteration of the smaller sizes is a sequential chain of ~n^2
+//                     rotations per matrix -- 11 ms at n = 300 whatever the batch -- whereas all n bisections of a matrix
+//                     run side by side: 64 halvings x n recurrence steps each, d and e^2 broadcast from LDS.  Eigenvalue j
+//                     is the j-th smallest by construction, so nothing is sorted.
+//
+// Every matrix is solved on its own.  Eigenvectors (and mesh solves, which always want them) keep the Jacobi kernels.
+
+#define TBK_TRIG_NT 1024
+
+// sum over the workgroup, the same bits in every thread (fixed order); red: 16 doubles of LDS; two barriers
+__device__ __forceinline__ double trig_block_sum(double v, double* red, const int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();   // (red may still be read from the previous call)
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < TBK_TRIG_NT / 64; ++w) s += red[w];
+    return s;
+}
+
+// MODE 0: k list, 2: supplied matrices.  Block b works on matrix id0 + b; work holds nc matrices of n x n.
+template <int MODE>
+__global__ __launch_bounds__(TBK_TRIG_NT) void k_tridiag_glb(const ModelView mv, const int64_t nk, const ListArgs L, const int64_t id0,
+                                                              const int64_t nc, cd* __restrict__ work, double2* __restrict__ de) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int n = mv.nsta, ld = n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = TBK_TRIG_NT / 64;
+    cd* ub = (cd*)lds_raw;                    // [n]
+    cd* pb = ub + n;                          // [n]
+    cd* qb = pb + n;                          // [n]
+    cd* ph = qb + n;                          // [max(nR, 1)] assembly phases
+    double* eb = (double*)(ph + (mv.nR > 1 ? mv.nR : 1));   // [n]
+    double* red = eb + n;                     // [16]
+    cd* shr = (cd*)(red + 16);                // [2]: alpha
+    const int64_t idc = blockIdx.x, id = id0 + idc;
+    cd* A = work + (size_t)idc * n * ld;
+
+    double kk[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (d < mv.dim_k) kk[d] = L.k[id * mv.dim_k + d];
+    }
+    assemble_lds<MODE, TBK_TRIG_NT>(mv, L, id, kk, A, ld, ph, tid);
+    __syncthreads();
+
+    const int x = tid;                        // this thread's row in the per-row steps (n <= 1024)
+    for (int k = 0; k + 2 < n; ++k) {
+        // the column below the diagonal = conj(row k to the right of it): contiguous
+        const bool below = x > k && x < n;
+        cd colx{0.0, 0.0};
+        if (below) colx = cconj(A[(size_t)k * ld + x]);
+        if (x == k + 1) shr[0] = colx;
+        const double rest = trig_block_sum(x > k + 1 && x < n ? cabs2(colx) : 0.0, red, tid);   // (its barriers publish shr[0])
+        const cd alpha = shr[0];
+        const double absa2 = cabs2(alpha);
+        double mag = sqrt(absa2);             // |t_k| when nothing is reflected
+        if (rest > 0.0) {                     // (uniform) decided on the part to be annihilated alone (LAPACK zlarfg)
+            const double sigma = rest + absa2;
+            const double nrm = sqrt(sigma);
+            double absa = 0.0;
+            cd phs{1.0, 0.0};
+            if (absa2 > 0.0) {
+                absa = sqrt(absa2);
+                phs = cd{alpha.x / absa, alpha.y / absa};
+            }
+            const cd u = x == k + 1 ? cd{phs.x * (absa + nrm), phs.y * (absa + nrm)} : colx;
+            const double beta = 1.0 / (nrm * (nrm + absa));
+            mag = nrm;                        // t_k = -phase * nrm
+            if (x < n) ub[x] = u;
+            __syncthreads();
+            // p = beta A u over the trailing block: one wavefront per row, lanes along the columns
+            for (int r = k + 1 + wv; r < n; r += NW) {
+                const cd* row = A + (size_t)r * ld;
+                cd acc{0.0, 0.0};
+                for (int c = k + 1 + lane; c < n; c += 64) cfma(acc, row[c], ub[c]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    acc.x += __shfl_xor(acc.x, o);
+                    acc.y += __shfl_xor(acc.y, o);
+                }
+                if (lane == 0) pb[r] = cd{acc.x * beta, acc.y * beta};
+            }
+            __syncthreads();
+            const cd p = below ? pb[x] : cd{0.0, 0.0};
+            const double kappa = 0.5 * beta * trig_block_sum(u.x * p.x + u.y * p.y, red, tid);   // beta/2 u^+ p (real)
+            if (below) qb[x] = cd{p.x - kappa * u.x, p.y - kappa * u.y};
+            __syncthreads();
+            // A -= u q^+ + q u^+ on the trailing block (both triangles: row k+1 is the next step's column)
+            for (int r = k + 1 + wv; r < n; r += NW) {
+                cd* row = A + (size_t)r * ld;
+                const cd ur = ub[r], qr = qb[r];
+                for (int c = k + 1 + lane; c < n; c += 64) {
+                    const cd uc = ub[c], qc = qb[c];
+                    cd a = row[c];
+                    a.x -= (ur.x * qc.x + ur.y * qc.y) + (qr.x * uc.x + qr.y * uc.y);
+                    a.y -= (ur.y * qc.x - ur.x * qc.y) + (qr.y * uc.x - qr.x * uc.y);
+                    row[c] = a;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) eb[k] = mag;            // e_k = |t_k| (a diagonal unitary makes the subdiagonal real and non-negative)
+    }
+    if (tid == 0) {
+        if (n >= 2) {
+            const cd t = A[(size_t)(n - 2) * ld + (n - 1)];
+            eb[n - 2] = sqrt(cabs2(t));
+        }
+        eb[n - 1] = 0.0;
+    }
+    __syncthreads();
+    if (tid < n) de[(int64_t)idc * n + tid] = double2{A[(size_t)tid * ld + tid].x, eb[tid]};
+}
+
+// de[idc][j] = (d_j, e_j)  ->  eval[j][id] ascending.  One block of NT threads per matrix, thread j <-> eigenvalue j (+ NT, ...).
+__global__ __launch_bounds__(256) void k_tridiag_bisect(const int n, const int64_t nk, const int64_t id0, const double2* __restrict__ de,
+                                                        double* __restrict__ eval) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double2* T = (double2*)lds_raw;           // [n] (d_j, e_{j-1}^2)   (e_{-1} = 0)
+    double* red = (double*)(T + n);           // [8]
+    const int tid = threadIdx.x;
+    const int64_t idc = blockIdx.x, id = id0 + idc;
+    const double2* src = de + idc * n;
+    double glo = INFINITY, ghi = -INFINITY, emax = 0.0;
+    for (int j = tid; j < n; j += 256) {
+        const double2 v = src[j];
+        const double em = j > 0 ? src[j - 1].y : 0.0;
+        T[j] = double2{v.x, em * em};
+        const double rad = em + v.y;          // Gershgorin: |e_{j-1}| + |e_j|   (e_{n-1} = 0)
+        glo = fmin(glo, v.x - rad);
+        ghi = fmax(ghi, v.x + rad);
+        emax = fmax(emax, v.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        glo = fmin(glo, __shfl_xor(glo, o));
+        ghi = fmax(ghi, __shfl_xor(ghi, o));
+    }
+    if ((tid & 63) == 0) {
+        red[2 * (tid >> 6)] = glo;
+        red[2 * (tid >> 6) + 1] = ghi;
+    }
+    __syncthreads();
+    glo = fmin(fmin(red[0], red[2]), fmin(red[4], red[6]));
+    ghi = fmax(fmax(red[1], red[3]), fmax(red[5], red[7]));
+    const double span = fmax(fabs(glo), fabs(ghi));
+    const double pivmin = 2.2250738585072014e-308 * fmax(1.0, span * span);   // safe minimum pivot (dstebz)
+    glo -= 2.220446049250313e-16 * span * n + pivmin;
+    ghi += 2.220446049250313e-16 * span * n + pivmin;
+    for (int j = tid; j < n; j += 256) {
+        // eigenvalue j (0-based): the smallest x with count(x) > j, count(x) = number of eigenvalues below x
+        double lo = glo, hi = ghi;
+        for (int it = 0; it < 120; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (mid <= lo || mid >= hi) break;                 // the interval is down to neighbouring doubles
+            int cnt = 0;
+            double q = 1.0;
+            for (int i = 0; i < n; ++i) {
+                const double2 t = T[i];
+                q = t.x - mid - t.y / q;                       // (t.y = 0 at i = 0)
+                if (fabs(q) < pivmin) q = -pivmin;
+                cnt += q < 0.0 ? 1 : 0;
+            }
+            if (cnt > j) hi = mid;
+            else lo = mid;
+            if (hi - lo <= 2.0 * 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
+        }
+        eval[(int64_t)j * nk + id] = 0.5 * (lo + hi);
+    }
+}
+
+template <int MODE>
+static int launch_trig(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L) {
+    static_assert(MODE != 1, "launch_trig: eigenvalues only, k lists and supplied matrices");
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t per = al((size_t)n * n * sizeof(cd)) + al((size_t)n * sizeof(double2));
+    size_t free_b = 0, total_b = 0;
+    TBK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = std::max<size_t>(per, std::min<size_t>((size_t)4 << 30, (free_b + ctx->work_bytes) / 2));
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nk, (int64_t)(budget / per)));
+    chunk = (nk + (nk + chunk - 1) / chunk - 1) / ((nk + chunk - 1) / chunk);
+    const size_t wbytes = (size_t)chunk * per + 256;
+    if (wbytes > ctx->work_bytes) {
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->work) TBK_HIP(hipFree(ctx->work));
+        ctx->work = nullptr;
+        ctx->work_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->work, wbytes);
+        TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "tridiagonalisation workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
+        ctx->work_bytes = wbytes;
+    }
+    cd* work = (cd*)ctx->work;
+    double2* de = (double2*)((unsigned char*)ctx->work + (size_t)chunk * al((size_t)n * n * sizeof(cd)));
+    const int nR = MODE == 2 ? 0 : mv.nR;
+    const size_t lds1 = ((size_t)3 * n + std::max(nR, 1) + 2) * sizeof(cd) + ((size_t)n + 16) * sizeof(double);
+    TBK_REQUIRE(lds1 <= 160 * 1024, TBK_EUNSUPPORTED, "nsta=%d with %d lattice vectors needs %zu bytes of LDS", n, nR, lds1);
+    if (lds1 > 64 * 1024)
+        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_glb<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t lds2 = (size_t)n * sizeof(double2) + 8 * sizeof(double);
+    for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
+        const int64_t nc = std::min<int64_t>(chunk, nk - id0);
+        // (the workspace stride is n x n complex, rounded: keep the kernels' own stride n * n -- chunks are packed)
+        hipLaunchKernelGGL((k_tridiag_glb<MODE>), dim3((unsigned)nc), dim3(TBK_TRIG_NT), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
+        hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(256), lds2, ctx->stream, n, nk, id0, (const double2*)de, L.eval);
+        TBK_HIP(hipGetLastError());
+    }
+    return TBK_OK;
+}

@@ -302,3 +302,40 @@ def test_three_kernel_16_lane_form_on_a_mesh(tb):
     assert np.max(np.abs(np.angle(np.exp(1j * (np.asarray(ph) - np.asarray(oph)))))) < 1e-9
     V = host.reshape(-1, 16, 16)
     assert max(np.max(np.abs(v.conj() @ v.T - np.identity(16))) for v in V) < 1e-13
+
+
+@pytest.mark.parametrize("n,nk", [(65, 6), (100, 5), (137, 4), (256, 3), (300, 2), (513, 2)])
+def test_eigenvalues_only_above_64_states(n, nk):
+    """Eigenvalue-only solves of 65..1024 states: Householder tridiagonalisation with the matrix in L2, then one thread per
+    eigenvalue bisecting on the Sturm count (tbk_solve_trig.inl) -- against numpy.linalg.eigvalsh and the Jacobi solvers."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(500 + n)
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    if nk >= 4:
+        h[1] = np.diag(np.arange(n) % 5).astype(complex)                                   # degenerate, diagonal
+        h[2] = np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)                   # already tridiagonal
+        h[3] = 0.0
+    ev, _ = _eigh_batch(h, vectors=False)
+    ref = np.linalg.eigvalsh(h).T
+    scale = max(1.0, np.max(np.abs(ref)))
+    assert np.max(np.abs(ev - ref)) < 1e-13 * scale
+    assert np.all(np.diff(ev, axis=0) >= 0.0)
+    with _lib.knob("TBK_TRIG", 0):
+        ev_j, _ = _eigh_batch(h, vectors=False)
+    assert np.max(np.abs(ev_j - ref)) < 5e-12 * scale
+
+
+def test_wide_ribbon_band_structure_against_oracle(tb):
+    """solve_all without eigenvectors on a Haldane ribbon of 45 cells (90 states, a sparse model): the reference's
+    band-structure call (pythtb.py:955-1079 with eig_vectors=False)."""
+    from oracle import tb_oracle as orc
+    m = _ribbon(tb, 45)
+    k = np.linspace(0.0, 1.0, 41)
+    ev = m.solve_all(k)
+    oev = orc.solve_all(m, [[x] for x in k])
+    assert ev.shape == (90, 41)
+    assert np.max(np.abs(ev - oev)) < 1e-12
+    # near k = 0 the imaginary parts of H(k) are tiny (the case that needs LAPACK's zlarfg decision)
+    kz = np.array([0.0, 1e-3, 2.44140625e-4])
+    assert np.max(np.abs(m.solve_all(kz) - orc.solve_all(m, [[x] for x in kz]))) < 1e-12
