@@ -1364,8 +1364,8 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 #include "tbk_solve_reg.inl"   // n = 5..8: register-resident cyclic Jacobi, 1/2/4 lanes per matrix
 #include "tbk_solve_row16.inl" // n = 15, 16 on lists: one DPP row of 16 lanes per matrix, rows of A in registers
 #include "tbk_solve_ql16.inl"  // n = 9..16: Householder + implicit QL in registers, one DPP row of 16 lanes per matrix
-#include "tbk_solve_qlw.inl"   // n = 17..64, large batches: Householder in LDS, lane-per-matrix QL, rotation replay
 #include "tbk_solve_trig.inl"  // eigenvalues only, n = 65..1024: Householder with A in L2, then one thread per eigenvalue (bisection)
+#include "tbk_solve_qlw.inl"   // n = 17..64, large batches: Householder in LDS, lane-per-matrix QL, rotation replay
 #include "tbk_solve_blk.inl"   // batches of wide matrices: block Jacobi, 16x16 subproblems through k_solve_row16
 
 // ---------------------------------------------------------------------------
@@ -1443,7 +1443,9 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // n = 17..64, batches that fill the chip: the three-kernel tridiagonal path (tbk_solve_qlw.inl); smaller batches stay
     // on Jacobi for the same reason as above.  TBK_QLW=0 / TBK_QLW_MIN=<count>.
     const int64_t qlw_min = K.qlw_min >= 0 ? K.qlw_min : (int64_t)ctx->cus * 8;
-    if (n >= 17 && n <= 64 && K.use_qlw != 0 && !ctx->qlw_off && nk_eff > qlw_min) return launch_qlw<MODE, VEC>(ctx, mv, n, nk, L, G);
+    // (eigenvalues alone carry no such caveat: lists and supplied matrices of any count take the tridiagonal path)
+    if (n >= 17 && n <= 64 && K.use_qlw != 0 && !ctx->qlw_off && (nk_eff > qlw_min || (!VEC && MODE != 1 && K.qlw_min < 0)))
+        return launch_qlw<MODE, VEC>(ctx, mv, n, nk, L, G);
     if constexpr (MODE != 1) {
         // (eigenvalues only: already from n = 13, where the LDS kernel takes ~9-10 ms for the same 262144 k)
         if ((n >= 15 || (!VEC && n >= 13)) && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0))

@@ -762,8 +762,16 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         hipLaunchKernelGGL((k_tridiag_lds<MODE, VEC, RW_, NT_>), dim3((unsigned)nc), dim3(NT_), lds1, ctx->stream, mv, nk, L, G, id0, nc, W.de);
         TBK_QLW_K1(32, 64) TBK_QLW_K1(32, 128) TBK_QLW_K1(32, 256) TBK_QLW_K1(64, 128) TBK_QLW_K1(64, 256) TBK_QLW_K1(64, 512)
 #undef TBK_QLW_K1
-        hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0, nc,
-                           W, L.eval, G, ctx->flags_dev);
+        // eigenvalues only, batches that leave the lane-per-matrix QL kernel a few wavefronts of pure latency: one thread per
+        // EIGENVALUE instead (bisection, tbk_solve_trig.inl); TBK_QLW_BISECT=0 | 1 forces either
+        bool bisect = false;
+        if constexpr (!VEC && MODE != 1) bisect = K.qlw_bisect >= 0 ? K.qlw_bisect == 1 : nc < (int64_t)ctx->cus * 16;
+        if (bisect)
+            hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(64), (size_t)n * sizeof(double2) + 8 * sizeof(double), ctx->stream, n,
+                               nk, id0, (const double2*)W.de, L.eval, (int64_t)1, nc);
+        else
+            hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0,
+                               nc, W, L.eval, G, ctx->flags_dev);
         if (VEC) {
             if (rw == 32 && K.qlw_replay_reg != 0) {
                 const unsigned b32 = (unsigned)((nc * 32 + 255) / 256);

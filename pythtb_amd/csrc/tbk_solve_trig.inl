@@ -128,19 +128,20 @@ __global__ __launch_bounds__(TBK_TRIG_NT) void k_tridiag_glb(const ModelView mv,
     if (tid < n) de[(int64_t)idc * n + tid] = double2{A[(size_t)tid * ld + tid].x, eb[tid]};
 }
 
-// de[idc][j] = (d_j, e_j)  ->  eval[j][id] ascending.  One block of NT threads per matrix, thread j <-> eigenvalue j (+ NT, ...).
+// (d_j, e_j) of matrix idc at de[idc * si + j * sj]  ->  eval[j][id] ascending.  One block per matrix, thread j <-> eigenvalue j (+ 256, ...).
 __global__ __launch_bounds__(256) void k_tridiag_bisect(const int n, const int64_t nk, const int64_t id0, const double2* __restrict__ de,
-                                                        double* __restrict__ eval) {
+                                                        double* __restrict__ eval, const int64_t si, const int64_t sj) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double2* T = (double2*)lds_raw;           // [n] (d_j, e_{j-1}^2)   (e_{-1} = 0)
     double* red = (double*)(T + n);           // [8]
     const int tid = threadIdx.x;
     const int64_t idc = blockIdx.x, id = id0 + idc;
-    const double2* src = de + idc * n;
+    const double2* src = de + idc * si;
     double glo = INFINITY, ghi = -INFINITY, emax = 0.0;
-    for (int j = tid; j < n; j += 256) {
-        const double2 v = src[j];
-        const double em = j > 0 ? src[j - 1].y : 0.0;
+    const int nt = blockDim.x;                // 64 | 256
+    for (int j = tid; j < n; j += nt) {
+        const double2 v = src[j * sj];
+        const double em = j > 0 ? src[(j - 1) * sj].y : 0.0;
         T[j] = double2{v.x, em * em};
         const double rad = em + v.y;          // Gershgorin: |e_{j-1}| + |e_j|   (e_{n-1} = 0)
         glo = fmin(glo, v.x - rad);
@@ -157,13 +158,17 @@ __global__ __launch_bounds__(256) void k_tridiag_bisect(const int n, const int64
         red[2 * (tid >> 6) + 1] = ghi;
     }
     __syncthreads();
-    glo = fmin(fmin(red[0], red[2]), fmin(red[4], red[6]));
-    ghi = fmax(fmax(red[1], red[3]), fmax(red[5], red[7]));
+    glo = red[0];
+    ghi = red[1];
+    for (int w = 1; w < (nt >> 6); ++w) {
+        glo = fmin(glo, red[2 * w]);
+        ghi = fmax(ghi, red[2 * w + 1]);
+    }
     const double span = fmax(fabs(glo), fabs(ghi));
     const double pivmin = 2.2250738585072014e-308 * fmax(1.0, span * span);   // safe minimum pivot (dstebz)
     glo -= 2.220446049250313e-16 * span * n + pivmin;
     ghi += 2.220446049250313e-16 * span * n + pivmin;
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += nt) {
         // eigenvalue j (0-based): the smallest x with count(x) > j, count(x) = number of eigenvalues below x
         double lo = glo, hi = ghi;
         for (int it = 0; it < 120; ++it) {
@@ -217,7 +222,8 @@ static int launch_trig(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
         // (the workspace stride is n x n complex, rounded: keep the kernels' own stride n * n -- chunks are packed)
         hipLaunchKernelGGL((k_tridiag_glb<MODE>), dim3((unsigned)nc), dim3(TBK_TRIG_NT), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
-        hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(256), lds2, ctx->stream, n, nk, id0, (const double2*)de, L.eval);
+        hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(256), lds2, ctx->stream, n, nk, id0, (const double2*)de, L.eval,
+                           (int64_t)n, (int64_t)1);
         TBK_HIP(hipGetLastError());
     }
     return TBK_OK;

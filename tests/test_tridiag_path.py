@@ -61,13 +61,16 @@ def test_supplied_matrices_against_numpy(n):
     h[3:3 + len(sp)] = sp
     with _lib.knob("TBK_QLW_MIN", 0):
         ev, vec = _eigh_batch(h)
-        ev_only, _ = _eigh_batch(h, vectors=False)
+        with _lib.knob("TBK_QLW_BISECT", 0):
+            ev_only, _ = _eigh_batch(h, vectors=False)         # tridiagonalise + lane-per-matrix QL
+        ev_bis, _ = _eigh_batch(h, vectors=False)              # small batch: tridiagonalise + bisection
     with _lib.knob("TBK_QLW", 0):
         ev_jac, _ = _eigh_batch(h, vectors=False)
     ref = np.linalg.eigvalsh(h).T
     scale = np.maximum(np.max(np.abs(ref), axis=0), 1.0)
     assert np.max(np.abs(ev - ref) / scale) < 5e-14
     assert np.array_equal(ev, ev_only)                         # the same reduction and the same QL in both forms
+    assert np.max(np.abs(ev_bis - ref) / scale) < 5e-14 and np.all(np.diff(ev_bis, axis=0) >= 0.0)
     assert np.max(np.abs(ev_jac - ref) / scale) < 5e-13
     V = vec.transpose(1, 0, 2)                                 # [k][band][component]
     for i in range(nk):
@@ -85,7 +88,7 @@ def test_chunked_batches_equal_one_batch():
     h = h + h.conj().transpose(0, 2, 1)
     with _lib.knob("TBK_QLW_MIN", 0):
         ev1, v1 = _eigh_batch(h)
-        with _lib.knob("TBK_QLW_WS_MB", 1):
+        with _lib.knob("TBK_QLW_WS_MB", 1), _lib.knob("TBK_QLW_BISECT", 0):
             ev3, v3 = _eigh_batch(h)
             e3, _ = _eigh_batch(h, vectors=False)
     assert np.array_equal(ev1, ev3) and np.array_equal(v1, v3) and np.array_equal(ev1, e3)
@@ -107,9 +110,11 @@ def test_ribbon_on_a_k_list_against_oracle(tb, width):
     k = np.linspace(-0.5, 0.5, 67)
     with _lib.knob("TBK_QLW_MIN", 0):
         ev, vec = m.solve_all(k, eig_vectors=True)
-        ev_only = m.solve_all(k)
+        with _lib.knob("TBK_QLW_BISECT", 0):
+            ev_only = m.solve_all(k)
+    ev_bis = m.solve_all(k)                                    # the default route of a short eigenvalue-only list: bisection
     oev = orc.solve_all(m, [[x] for x in k])
-    assert np.max(np.abs(ev - oev)) < 1e-12
+    assert np.max(np.abs(ev - oev)) < 1e-12 and np.max(np.abs(ev_bis - oev)) < 1e-12
     assert np.array_equal(ev, ev_only)
     for i in range(0, len(k), 5):
         H = m._gen_ham([k[i]])
