@@ -1438,7 +1438,8 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // the eigenstates of a finite piece, three embeddings whose H differ by one ulp) depends on exactly that.
     // TBK_QL16_MIN=<count>: batches of at most that many matrices stay on Jacobi (default 8 x CUs; 0 = none).
     const int64_t ql16_min = K.ql16_min >= 0 ? K.ql16_min : (int64_t)ctx->cus * 8;
-    if (n >= 9 && n <= 16 && use_ql16 && (MODE == 2 || mv.nR > 0) && nk_eff > ql16_min)
+    // (eigenvalues alone carry no such caveat: lists and supplied matrices of any count take the direct solver)
+    if (n >= 9 && n <= 16 && use_ql16 && (MODE == 2 || mv.nR > 0) && (nk_eff > ql16_min || (!VEC && MODE != 1 && K.ql16_min < 0)))
         return launch_ql16<MODE, VEC>(ctx, mv, nk, L, G, nk_eff);
     // n = 17..64, batches that fill the chip: the three-kernel tridiagonal path (tbk_solve_qlw.inl); smaller batches stay
     // on Jacobi for the same reason as above.  TBK_QLW=0 / TBK_QLW_MIN=<count>.
