@@ -1408,8 +1408,9 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     // (one CU draws ~150 GB/s); few larger ones stay on the whole-chip Jacobi rounds.  TBK_TRIG=0 disables.
     if constexpr (MODE != 1 && !VEC) {
         // (measured, profiles/trig_probe.py: a matrix costs 18 / 32 / 57 / 138 / 266 ms at n = 400 / 512 / 600 / 800 / 1024 whatever
-        // the batch -- one CU per matrix -- against 19 / 27 / 39 ms for ONE matrix on the whole-chip Jacobi rounds; TBK_TRIG=2 forces)
-        const bool pays = n <= 400 || (n <= 512 && nk >= 2) || (n <= 800 && nk >= 3) || nk >= 6;
+        // the batch -- one CU per matrix -- against 19 / 27-100 / 39 ms for ONE matrix on the whole-chip Jacobi rounds, whose
+        // per-sweep host read-backs make single runs vary by 4 x; TBK_TRIG=2 forces)
+        const bool pays = n <= 512 || (n <= 800 && nk >= 2) || nk >= 6;
         if (n > 64 && n <= 1024 && K.use_trig != 0 && (pays || K.use_trig == 2)) return launch_trig<MODE>(ctx, mv, n, nk, L);
     }
     if (n > 64) {
