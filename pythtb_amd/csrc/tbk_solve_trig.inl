@@ -21,8 +21,9 @@
 
 // sum over the workgroup, the same bits in every thread (fixed order); red: 16 doubles of LDS; two barriers
 __device__ __forceinline__ double trig_block_sum(double v, double* red, const int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = row_allsum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     __syncthreads();   // (red may still be read from the previous call)
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
@@ -33,11 +34,13 @@ __device__ __forceinline__ double trig_block_sum(double v, double* red, const in
 }
 
 // MODE 0: k list, 2: supplied matrices.  Block b works on matrix id0 + b; work holds nc matrices of n x n.
-template <int MODE>
+// ALDS: the matrix fits the LDS of a CU next to the vectors (n <= 96): the same steps on an LDS-resident A -- a row costs
+// ~0.1 us of latency instead of ~1 us from L2, and the small sizes are all latency.
+template <int MODE, bool ALDS>
 __global__ __launch_bounds__(TBK_TRIG_NT) void k_tridiag_glb(const ModelView mv, const int64_t nk, const ListArgs L, const int64_t id0,
                                                               const int64_t nc, cd* __restrict__ work, double2* __restrict__ de) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int n = mv.nsta, ld = n;
+    const int n = mv.nsta, ld = ALDS ? (n | 1) : n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = TBK_TRIG_NT / 64;
     cd* ub = (cd*)lds_raw;                    // [n]
@@ -46,9 +49,9 @@ __global__ __launch_bounds__(TBK_TRIG_NT) void k_tridiag_glb(const ModelView mv,
     cd* ph = qb + n;                          // [max(nR, 1)] assembly phases
     double* eb = (double*)(ph + (mv.nR > 1 ? mv.nR : 1));   // [n]
     double* red = eb + n;                     // [16]
-    cd* shr = (cd*)(red + 16);                // [2]: alpha
+    cd* shr = (cd*)(red + 16 + (n & 1));      // [2]: alpha (16-byte aligned)
     const int64_t idc = blockIdx.x, id = id0 + idc;
-    cd* A = work + (size_t)idc * n * ld;
+    cd* A = ALDS ? shr + 2 : work + (size_t)idc * n * ld;
 
     double kk[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (MODE == 0) {
@@ -89,11 +92,12 @@ __global__ __launch_bounds__(TBK_TRIG_NT) void k_tridiag_glb(const ModelView mv,
                 const cd* row = A + (size_t)r * ld;
                 cd acc{0.0, 0.0};
                 for (int c = k + 1 + lane; c < n; c += 64) cfma(acc, row[c], ub[c]);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    acc.x += __shfl_xor(acc.x, o);
-                    acc.y += __shfl_xor(acc.y, o);
-                }
+                acc.x = row_allsum(acc.x);                     // (DPP within rows of 16 lanes, then two cross-row steps)
+                acc.y = row_allsum(acc.y);
+                acc.x += __shfl_xor(acc.x, 16);
+                acc.y += __shfl_xor(acc.y, 16);
+                acc.x += __shfl_xor(acc.x, 32);
+                acc.y += __shfl_xor(acc.y, 32);
                 if (lane == 0) pb[r] = cd{acc.x * beta, acc.y * beta};
             }
             __syncthreads();
@@ -213,15 +217,23 @@ static int launch_trig(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     cd* work = (cd*)ctx->work;
     double2* de = (double2*)((unsigned char*)ctx->work + (size_t)chunk * al((size_t)n * n * sizeof(cd)));
     const int nR = MODE == 2 ? 0 : mv.nR;
-    const size_t lds1 = ((size_t)3 * n + std::max(nR, 1) + 2) * sizeof(cd) + ((size_t)n + 16) * sizeof(double);
+    const size_t lds_vec = ((size_t)3 * n + std::max(nR, 1) + 2) * sizeof(cd) + (((size_t)n + 16 + 1) & ~(size_t)1) * sizeof(double);
+    const size_t lds_a = (size_t)n * (n | 1) * sizeof(cd);
+    const bool alds = lds_vec + lds_a <= 160 * 1024 && tbk_knobs().use_trig != 3;   // (TBK_TRIG=3: A in L2 at every size)
+    const size_t lds1 = lds_vec + (alds ? lds_a : 0);
     TBK_REQUIRE(lds1 <= 160 * 1024, TBK_EUNSUPPORTED, "nsta=%d with %d lattice vectors needs %zu bytes of LDS", n, nR, lds1);
-    if (lds1 > 64 * 1024)
-        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_glb<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds1 > 64 * 1024) {
+        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_glb<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_glb<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     const size_t lds2 = (size_t)n * sizeof(double2) + 8 * sizeof(double);
     for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
         // (the workspace stride is n x n complex, rounded: keep the kernels' own stride n * n -- chunks are packed)
-        hipLaunchKernelGGL((k_tridiag_glb<MODE>), dim3((unsigned)nc), dim3(TBK_TRIG_NT), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
+        if (alds)
+            hipLaunchKernelGGL((k_tridiag_glb<MODE, true>), dim3((unsigned)nc), dim3(TBK_TRIG_NT), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
+        else
+            hipLaunchKernelGGL((k_tridiag_glb<MODE, false>), dim3((unsigned)nc), dim3(TBK_TRIG_NT), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
         hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(256), lds2, ctx->stream, n, nk, id0, (const double2*)de, L.eval,
                            (int64_t)n, (int64_t)1);
         TBK_HIP(hipGetLastError());
