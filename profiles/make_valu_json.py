@@ -15,6 +15,8 @@ SOURCES = [
     ("k_flux_rows<2,4>", "r02hcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
     # the 65^3 mesh of the collection goes through the three kernels in two chunks
     ("k_solve_ql16<1,true>", "r02hcfg/pmc_per_dispatch.json", "k_solve_ql16<1,true,2>+k_ql16_lanes<1>+k_ql16_replay<1>", 65 ** 3 // 2),
+    ("k_grid_rows<2,1>", "r02i/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r02i/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
     ("k_grid_rows<2,1>", "r02g/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
     ("k_flux_rows<1,2>", "r02g/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
     ("k_grid_rows<4,1>", "r02gcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
