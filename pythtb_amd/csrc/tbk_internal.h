@@ -38,6 +38,7 @@ struct TbkKnobs {
     int use_row16 = 1;          // TBK_ROW16         0: no DPP-row Jacobi kernel
     int use_ql16 = 1;           // TBK_QL16          0: n = 9..16 through the Jacobi kernels
     long long ql16_min = -1;    // TBK_QL16_MIN      batches of at most this many matrices stay on the workgroup-per-matrix Jacobi (default 8 x CUs)
+    int trig_nt = -1;           // TBK_TRIG_NT       threads per matrix of the L2 Householder kernel (256 | 512 | 1024; at least n)
     int use_trig = 1;           // TBK_TRIG          0: eigenvalue-only n = 65..1024 through the Jacobi solvers instead of tridiagonalise + bisection
     int use_qlw = 1;            // TBK_QLW           0: n = 17..64 through the Jacobi kernels whatever the batch size
     long long qlw_min = -1;     // TBK_QLW_MIN       batches of at most this many matrices stay on the Jacobi kernels (default 8 x CUs)

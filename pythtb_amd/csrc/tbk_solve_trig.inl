@@ -17,9 +17,8 @@
 //
 // Every matrix is solved on its own.  Eigenvectors (and mesh solves, which always want them) keep the Jacobi kernels.
 
-#define TBK_TRIG_NT 1024
-
-// sum over the workgroup, the same bits in every thread (fixed order); red: 16 doubles of LDS; two barriers
+// sum over the workgroup of NT threads, the same bits in every thread (fixed order); red: 16 doubles of LDS; two barriers
+template <int NT>
 __device__ __forceinline__ double trig_block_sum(double v, double* red, const int tid) {
     v = row_allsum(v);
     v += __shfl_xor(v, 16);
@@ -29,20 +28,20 @@ __device__ __forceinline__ double trig_block_sum(double v, double* red, const in
     __syncthreads();
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < TBK_TRIG_NT / 64; ++w) s += red[w];
+    for (int w = 0; w < NT / 64; ++w) s += red[w];
     return s;
 }
 
 // MODE 0: k list, 2: supplied matrices.  Block b works on matrix id0 + b; work holds nc matrices of n x n.
 // ALDS: the matrix fits the LDS of a CU next to the vectors (n <= 96): the same steps on an LDS-resident A -- a row costs
 // ~0.1 us of latency instead of ~1 us from L2, and the small sizes are all latency.
-template <int MODE, bool ALDS>
-__global__ __launch_bounds__(TBK_TRIG_NT) void k_tridiag_glb(const ModelView mv, const int64_t nk, const ListArgs L, const int64_t id0,
+template <int MODE, bool ALDS, int NT>
+__global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const int64_t nk, const ListArgs L, const int64_t id0,
                                                               const int64_t nc, cd* __restrict__ work, double2* __restrict__ de) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int n = mv.nsta, ld = ALDS ? (n | 1) : n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int NW = TBK_TRIG_NT / 64;
+    constexpr int NW = NT / 64;
     cd* ub = (cd*)lds_raw;                    // [n]
     cd* pb = ub + n;                          // [n]
     cd* qb = pb + n;                          // [n]
@@ -59,17 +58,17 @@ __global__ __launch_bounds__(TBK_TRIG_NT) void k_tridiag_glb(const ModelView mv,
         for (int d = 0; d < 4; ++d)
             if (d < mv.dim_k) kk[d] = L.k[id * mv.dim_k + d];
     }
-    assemble_lds<MODE, TBK_TRIG_NT>(mv, L, id, kk, A, ld, ph, tid);
+    assemble_lds<MODE, NT>(mv, L, id, kk, A, ld, ph, tid);
     __syncthreads();
 
-    const int x = tid;                        // this thread's row in the per-row steps (n <= 1024)
+    const int x = tid;                        // this thread's row in the per-row steps (n <= NT)
     for (int k = 0; k + 2 < n; ++k) {
         // the column below the diagonal = conj(row k to the right of it): contiguous
         const bool below = x > k && x < n;
         cd colx{0.0, 0.0};
         if (below) colx = cconj(A[(size_t)k * ld + x]);
         if (x == k + 1) shr[0] = colx;
-        const double rest = trig_block_sum(x > k + 1 && x < n ? cabs2(colx) : 0.0, red, tid);   // (its barriers publish shr[0])
+        const double rest = trig_block_sum<NT>(x > k + 1 && x < n ? cabs2(colx) : 0.0, red, tid);   // (its barriers publish shr[0])
         const cd alpha = shr[0];
         const double absa2 = cabs2(alpha);
         double mag = sqrt(absa2);             // |t_k| when nothing is reflected
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(TBK_TRIG_NT) void k_tridiag_glb(const ModelView mv,
             }
             __syncthreads();
             const cd p = below ? pb[x] : cd{0.0, 0.0};
-            const double kappa = 0.5 * beta * trig_block_sum(u.x * p.x + u.y * p.y, red, tid);   // beta/2 u^+ p (real)
+            const double kappa = 0.5 * beta * trig_block_sum<NT>(u.x * p.x + u.y * p.y, red, tid);   // beta/2 u^+ p (real)
             if (below) qb[x] = cd{p.x - kappa * u.x, p.y - kappa * u.y};
             __syncthreads();
             // A -= u q^+ + q u^+ on the trailing block (both triangles: row k+1 is the next step's column)
@@ -222,18 +221,29 @@ static int launch_trig(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     const bool alds = lds_vec + lds_a <= 160 * 1024 && tbk_knobs().use_trig != 3;   // (TBK_TRIG=3: A in L2 at every size)
     const size_t lds1 = lds_vec + (alds ? lds_a : 0);
     TBK_REQUIRE(lds1 <= 160 * 1024, TBK_EUNSUPPORTED, "nsta=%d with %d lattice vectors needs %zu bytes of LDS", n, nR, lds1);
-    if (lds1 > 64 * 1024) {
-        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_glb<MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_glb<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // threads per matrix: a row per thread in the per-row steps, so at least n.  Measured (ms, 256 / 512 / 1024 threads): 512 x n=96
+    // 2.50 / 2.11 / 2.19, 512 x n=128 4.59 / 4.18 / 4.27, 256 x n=200 11.2 / 7.96 / 7.31, 128 x n=256 20.3 / 12.5 / 9.1
+    // (TBK_TRIG_NT forces 256 | 512 | 1024)
+    int nt = n <= 160 ? 512 : 1024;
+    if (tbk_knobs().trig_nt > 0) {
+        const int want = tbk_knobs().trig_nt >= 1024 ? 1024 : (tbk_knobs().trig_nt >= 512 ? 512 : 256);
+        nt = std::max(want, n <= 256 ? 256 : (n <= 512 ? 512 : 1024));
     }
+    const void* f1 = nullptr;
+#define TBK_TRIG_K1(AL_, NT_) \
+    if (alds == AL_ && nt == NT_) f1 = (const void*)k_tridiag_glb<MODE, AL_, NT_>;
+    TBK_TRIG_K1(false, 256) TBK_TRIG_K1(false, 512) TBK_TRIG_K1(false, 1024) TBK_TRIG_K1(true, 256) TBK_TRIG_K1(true, 512) TBK_TRIG_K1(true, 1024)
+#undef TBK_TRIG_K1
+    if (lds1 > 64 * 1024) TBK_HIP(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t lds2 = (size_t)n * sizeof(double2) + 8 * sizeof(double);
     for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
         // (the workspace stride is n x n complex, rounded: keep the kernels' own stride n * n -- chunks are packed)
-        if (alds)
-            hipLaunchKernelGGL((k_tridiag_glb<MODE, true>), dim3((unsigned)nc), dim3(TBK_TRIG_NT), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
-        else
-            hipLaunchKernelGGL((k_tridiag_glb<MODE, false>), dim3((unsigned)nc), dim3(TBK_TRIG_NT), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
+#define TBK_TRIG_K1(AL_, NT_)            \
+    if (alds == AL_ && nt == NT_)        \
+        hipLaunchKernelGGL((k_tridiag_glb<MODE, AL_, NT_>), dim3((unsigned)nc), dim3(NT_), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
+        TBK_TRIG_K1(false, 256) TBK_TRIG_K1(false, 512) TBK_TRIG_K1(false, 1024) TBK_TRIG_K1(true, 256) TBK_TRIG_K1(true, 512) TBK_TRIG_K1(true, 1024)
+#undef TBK_TRIG_K1
         hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(256), lds2, ctx->stream, n, nk, id0, (const double2*)de, L.eval,
                            (int64_t)n, (int64_t)1);
         TBK_HIP(hipGetLastError());
