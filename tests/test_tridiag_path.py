@@ -344,3 +344,24 @@ def test_wide_ribbon_band_structure_against_oracle(tb):
     # near k = 0 the imaginary parts of H(k) are tiny (the case that needs LAPACK's zlarfg decision)
     kz = np.array([0.0, 1e-3, 2.44140625e-4])
     assert np.max(np.abs(m.solve_all(kz) - orc.solve_all(m, [[x] for x in kz]))) < 1e-12
+
+
+def test_spinful_ribbon_band_structure_against_oracle(tb):
+    """A Kane-Mele ribbon of 20 cells (nspin = 2: 80 states, 2 x 2 blocks in the tables) through the eigenvalue-only path, and
+    one of 8 cells (32 states) through the tridiagonal path with eigenvectors."""
+    from oracle import tb_oracle as orc
+    from pythtb_amd import _lib
+    km = hp.kane_mele(tb.tb_model, "odd")
+    wide = hp.quiet(km.cut_piece, 20, 1, glue_edgs=False)
+    k = np.linspace(0.0, 1.0, 23)
+    ev = wide.solve_all(k)
+    assert ev.shape == (80, 23)
+    assert np.max(np.abs(ev - orc.solve_all(wide, [[x] for x in k]))) < 1e-12
+    narrow = hp.quiet(km.cut_piece, 8, 1, glue_edgs=False)
+    with _lib.knob("TBK_QLW_MIN", 0):
+        ev2, vec2 = narrow.solve_all(k, eig_vectors=True)
+    assert np.max(np.abs(ev2 - orc.solve_all(narrow, [[x] for x in k]))) < 1e-12
+    for i in (0, 7, 22):
+        H = narrow._gen_ham([k[i]]).reshape(32, 32)
+        V = vec2[:, i].reshape(32, 32)
+        assert np.max(np.abs(H @ V.T - V.T * ev2[:, i])) < 1e-12
