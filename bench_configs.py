@@ -2,7 +2,7 @@
 """Secondary measurements: the other BASELINE.json configs (device-resident timings from HIP events on the
 library's stream; not the driver's headline line -- that is bench.py).  One JSON object per config.
 
-    python bench_configs.py [B] [C] [D] [E] [--reps 5]                 one GPU
+    python bench_configs.py [B] [C] [D] [E] [R] [--reps 5]             one GPU (R: ribbons / mid-size meshes, not in BASELINE.json)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench_configs.py --gpus N [D] [E] [--side 257]               N GPUs, one process each
 
@@ -144,6 +144,40 @@ def single_gpu(which, reps):
                     "kpts_per_s": nk / t_solve * 1e3, "berry_phase_8band_call_ms": t_phase * 1e3,
                     "links_per_s": 65 * 65 * 64 / t_phase})
         _lib.check(lib.tbk_wfs_free(hw))
+    if "R" in which:
+        # (not a BASELINE config) the widening rows of SURVEY.md 8f-2: ribbon band structures and a mid-size mesh solve, to keep
+        # the direct paths for 17..1024 states under measurement.  Wall-clock of the Python calls, PCIe included.
+        def wall(fn, r=3):
+            fn()
+            best = 1e9
+            for _ in range(r):
+                t0 = time.perf_counter()
+                fn()
+                best = min(best, time.perf_counter() - t0)
+            return best * 1e3
+        res = {"config": "R: ribbons / mid-size meshes (not in BASELINE.json)"}
+        with contextlib.redirect_stdout(io.StringIO()):
+            hal = hp.haldane(tb.tb_model, 0.2)
+            rib = {w: hal.cut_piece(w, 1, glue_edgs=False) for w in (20, 64, 150)}
+        k = np.linspace(0.0, 1.0, 512, endpoint=False)
+        for w, m in rib.items():
+            res["ribbon_n%d_512k_eigenvalues_ms" % (2 * w)] = wall(lambda m=m: m.solve_all(k))
+        res["ribbon_n40_512k_with_vectors_ms"] = wall(lambda: rib[20].solve_all(k, eig_vectors=True))
+        rng = np.random.default_rng(5)
+        norb = 24
+        with contextlib.redirect_stdout(io.StringIO()):
+            m24 = tb.tb_model(3, 3, np.identity(3), rng.random((norb, 3)))
+        m24.set_onsite(np.where(np.arange(norb) < norb // 2, -2.5, 2.5))
+        for Rv in ([0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]):
+            for i in range(norb):
+                for j in range(norb):
+                    if Rv == [0, 0, 0] and j <= i:
+                        continue
+                    m24.set_hop(0.08 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, Rv)
+        w24 = tb.wf_array(m24, [33, 33, 33])
+        res["dense24_32cubed_solve_on_grid_ms"] = wall(lambda: w24.solve_on_grid([0.0, 0.0, 0.0]))
+        res["dense24_kpts_per_s"] = 32 ** 3 / res["dense24_32cubed_solve_on_grid_ms"] * 1e3
+        out.append(res)
     for o in out:
         print(json.dumps(o))
 
