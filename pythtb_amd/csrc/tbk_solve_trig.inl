@@ -6,9 +6,11 @@
 //
 //  1. k_tridiag_glb   one 1024-thread workgroup per matrix, A in a global workspace (it stays in L2 / the last-level cache
 //                     for the sizes this path takes), u, p, q in LDS.  Householder step k: the column below the diagonal
-//                     is read as the conjugate of row k (contiguous), p = A u and the rank-2 update A -= u q^+ + q u^+ run
-//                     one wavefront per row with the lanes along the columns (coalesced), the whole trailing block is
-//                     kept Hermitian (both triangles updated).  (16/3) n^3 flops, 48 n^3 / 3 bytes of L2 traffic per matrix.
+//                     is read as the conjugate of row k (contiguous); the rank-2 update A -= u q^+ + q u^+ of step k and
+//                     the product p = A u of step k+1 share ONE pass over the trailing block (the next reflector only needs
+//                     the updated column k+1, which is formed ahead from row k+1): every element is read once and written
+//                     once per step, one wavefront per row with the lanes along the columns, both triangles kept.
+//                     (16/3) n^3 flops, 32 n^3 / 3 bytes of L2 traffic per matrix.
 //  2. k_tridiag_bisect one thread per EIGENVALUE: bisection on the Sturm count of the real symmetric tridiagonal (d, e)
 //                     (LAPACK dstebz's recurrence).  The QL iteration of the smaller sizes is a sequential chain of ~n^2
 //                     rotations per matrix -- 11 ms at n = 300 whatever the batch -- whereas all n bisections of a matrix
@@ -42,9 +44,11 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
     const int n = mv.nsta, ld = ALDS ? (n | 1) : n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     constexpr int NW = NT / 64;
-    cd* ub = (cd*)lds_raw;                    // [n]
-    cd* pb = ub + n;                          // [n]
-    cd* qb = pb + n;                          // [n]
+    cd* ub = (cd*)lds_raw;                    // [n]   u of the current step
+    cd* pb = ub + n;                          // [n]   p = beta A u of the current step
+    cd* ub2 = pb + n;                         // [n]   the next step's
+    cd* pb2 = ub2 + n;                        // [n]
+    cd* qb = pb2 + n;                         // [n]
     cd* ph = qb + n;                          // [max(nR, 1)] assembly phases
     double* eb = (double*)(ph + (mv.nR > 1 ? mv.nR : 1));   // [n]
     double* red = eb + n;                     // [16]
@@ -62,63 +66,125 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
     __syncthreads();
 
     const int x = tid;                        // this thread's row in the per-row steps (n <= NT)
-    for (int k = 0; k + 2 < n; ++k) {
-        // the column below the diagonal = conj(row k to the right of it): contiguous
-        const bool below = x > k && x < n;
-        cd colx{0.0, 0.0};
-        if (below) colx = cconj(A[(size_t)k * ld + x]);
+    // The reflector of a step: from the column below the diagonal (colx: this thread's entry, 0 outside) to u_x, beta and
+    // |t_k|; reflect = something to annihilate (decided on the annihilated part alone, LAPACK zlarfg).  Uniform results.
+    struct Refl {
+        cd u;
+        double beta, mag;
+        bool on;
+    };
+    auto reflector = [&](const cd colx, const int k) {
         if (x == k + 1) shr[0] = colx;
         const double rest = trig_block_sum<NT>(x > k + 1 && x < n ? cabs2(colx) : 0.0, red, tid);   // (its barriers publish shr[0])
         const cd alpha = shr[0];
         const double absa2 = cabs2(alpha);
-        double mag = sqrt(absa2);             // |t_k| when nothing is reflected
-        if (rest > 0.0) {                     // (uniform) decided on the part to be annihilated alone (LAPACK zlarfg)
-            const double sigma = rest + absa2;
-            const double nrm = sqrt(sigma);
+        Refl R{cd{0.0, 0.0}, 0.0, sqrt(absa2), rest > 0.0};
+        if (R.on) {
+            const double nrm = sqrt(rest + absa2);
             double absa = 0.0;
             cd phs{1.0, 0.0};
             if (absa2 > 0.0) {
                 absa = sqrt(absa2);
                 phs = cd{alpha.x / absa, alpha.y / absa};
             }
-            const cd u = x == k + 1 ? cd{phs.x * (absa + nrm), phs.y * (absa + nrm)} : colx;
-            const double beta = 1.0 / (nrm * (nrm + absa));
-            mag = nrm;                        // t_k = -phase * nrm
-            if (x < n) ub[x] = u;
+            R.u = x == k + 1 ? cd{phs.x * (absa + nrm), phs.y * (absa + nrm)} : colx;   // u = column + phase * norm * e_{k+1}
+            R.beta = 1.0 / (nrm * (nrm + absa));
+            R.mag = nrm;                                                               // t_k = -phase * nrm
+        }
+        return R;
+    };
+    // step 0: its reflector and p = beta A u by a pass of their own; every later step gets both from the previous step's pass
+    Refl cur;
+    {
+        cd colx{0.0, 0.0};
+        if (x > 0 && x < n) colx = cconj(A[x]);          // column 0 below the diagonal = conj(row 0): contiguous
+        cur = reflector(colx, 0);
+        if (cur.on) {
+            if (x < n) ub[x] = cur.u;
             __syncthreads();
-            // p = beta A u over the trailing block: one wavefront per row, lanes along the columns
-            for (int r = k + 1 + wv; r < n; r += NW) {
+            for (int r = 1 + wv; r < n; r += NW) {
                 const cd* row = A + (size_t)r * ld;
                 cd acc{0.0, 0.0};
-                for (int c = k + 1 + lane; c < n; c += 64) cfma(acc, row[c], ub[c]);
-                acc.x = row_allsum(acc.x);                     // (DPP within rows of 16 lanes, then two cross-row steps)
+                for (int c = 1 + lane; c < n; c += 64) cfma(acc, row[c], ub[c]);
+                acc.x = row_allsum(acc.x);
                 acc.y = row_allsum(acc.y);
                 acc.x += __shfl_xor(acc.x, 16);
                 acc.y += __shfl_xor(acc.y, 16);
                 acc.x += __shfl_xor(acc.x, 32);
                 acc.y += __shfl_xor(acc.y, 32);
-                if (lane == 0) pb[r] = cd{acc.x * beta, acc.y * beta};
+                if (lane == 0) pb[r] = cd{acc.x * cur.beta, acc.y * cur.beta};
             }
-            __syncthreads();
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k + 2 < n; ++k) {
+        const bool below = x > k && x < n;
+        cd q{0.0, 0.0};
+        if (cur.on) {                             // (uniform)
             const cd p = below ? pb[x] : cd{0.0, 0.0};
-            const double kappa = 0.5 * beta * trig_block_sum<NT>(u.x * p.x + u.y * p.y, red, tid);   // beta/2 u^+ p (real)
-            if (below) qb[x] = cd{p.x - kappa * u.x, p.y - kappa * u.y};
-            __syncthreads();
-            // A -= u q^+ + q u^+ on the trailing block (both triangles: row k+1 is the next step's column)
-            for (int r = k + 1 + wv; r < n; r += NW) {
-                cd* row = A + (size_t)r * ld;
-                const cd ur = ub[r], qr = qb[r];
-                for (int c = k + 1 + lane; c < n; c += 64) {
-                    const cd uc = ub[c], qc = qb[c];
-                    cd a = row[c];
-                    a.x -= (ur.x * qc.x + ur.y * qc.y) + (qr.x * uc.x + qr.y * uc.y);
-                    a.y -= (ur.y * qc.x - ur.x * qc.y) + (qr.y * uc.x - qr.x * uc.y);
-                    row[c] = a;
-                }
+            const double kappa = 0.5 * cur.beta * trig_block_sum<NT>(cur.u.x * p.x + cur.u.y * p.y, red, tid);   // beta/2 u^+ p (real)
+            if (below) {
+                q = cd{p.x - kappa * cur.u.x, p.y - kappa * cur.u.y};
+                qb[x] = q;
             }
             __syncthreads();
         }
-        if (tid == 0) eb[k] = mag;            // e_k = |t_k| (a diagonal unitary makes the subdiagonal real and non-negative)
+        // the NEXT step's reflector: column k+1 below the diagonal as it will be after this step's update,
+        // conj(A[k+1][x] - (u_{k+1} conj(q_x) + q_{k+1} conj(u_x)))  (row k+1: contiguous)
+        Refl nxt{cd{0.0, 0.0}, 0.0, 0.0, false};
+        const bool more = k + 3 < n;
+        if (more) {
+            cd colx{0.0, 0.0};
+            if (x > k + 1 && x < n) {
+                cd a = A[(size_t)(k + 1) * ld + x];
+                if (cur.on) {
+                    const cd u1 = ub[k + 1], q1 = qb[k + 1];
+                    a.x -= (u1.x * q.x + u1.y * q.y) + (q1.x * cur.u.x + q1.y * cur.u.y);
+                    a.y -= (u1.y * q.x - u1.x * q.y) + (q1.y * cur.u.x - q1.x * cur.u.y);
+                }
+                colx = cconj(a);
+            }
+            nxt = reflector(colx, k + 1);
+            if (nxt.on && x < n) ub2[x] = nxt.u;
+        }
+        __syncthreads();
+        // ONE pass over the trailing block: A -= u q^+ + q u^+ (both triangles kept) and, on the fly, the next step's
+        // p' = beta' A_new u' over rows and columns >= k+2 -- every element is read once and written once per step
+        if (cur.on || nxt.on) {
+            for (int r = k + 1 + wv; r < n; r += NW) {
+                cd* row = A + (size_t)r * ld;
+                const cd ur = cur.on ? ub[r] : cd{0.0, 0.0}, qr = cur.on ? qb[r] : cd{0.0, 0.0};
+                cd acc{0.0, 0.0};
+                for (int c = k + 1 + lane; c < n; c += 64) {
+                    cd a = row[c];
+                    if (cur.on) {
+                        const cd uc = ub[c], qc = qb[c];
+                        a.x -= (ur.x * qc.x + ur.y * qc.y) + (qr.x * uc.x + qr.y * uc.y);
+                        a.y -= (ur.y * qc.x - ur.x * qc.y) + (qr.y * uc.x - qr.x * uc.y);
+                        row[c] = a;
+                    }
+                    if (nxt.on && c > k + 1) cfma(acc, a, ub2[c]);
+                }
+                if (nxt.on && r > k + 1) {        // (wave-uniform)
+                    acc.x = row_allsum(acc.x);
+                    acc.y = row_allsum(acc.y);
+                    acc.x += __shfl_xor(acc.x, 16);
+                    acc.y += __shfl_xor(acc.y, 16);
+                    acc.x += __shfl_xor(acc.x, 32);
+                    acc.y += __shfl_xor(acc.y, 32);
+                    if (lane == 0) pb2[r] = cd{acc.x * nxt.beta, acc.y * nxt.beta};
+                }
+            }
+        }
+        if (tid == 0) eb[k] = cur.mag;            // e_k = |t_k| (a diagonal unitary makes the subdiagonal real and non-negative)
+        __syncthreads();
+        cd* t = ub;
+        ub = ub2;
+        ub2 = t;
+        t = pb;
+        pb = pb2;
+        pb2 = t;
+        cur = nxt;
     }
     if (tid == 0) {
         if (n >= 2) {
@@ -216,7 +282,7 @@ static int launch_trig(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     cd* work = (cd*)ctx->work;
     double2* de = (double2*)((unsigned char*)ctx->work + (size_t)chunk * al((size_t)n * n * sizeof(cd)));
     const int nR = MODE == 2 ? 0 : mv.nR;
-    const size_t lds_vec = ((size_t)3 * n + std::max(nR, 1) + 2) * sizeof(cd) + (((size_t)n + 16 + 1) & ~(size_t)1) * sizeof(double);
+    const size_t lds_vec = ((size_t)5 * n + std::max(nR, 1) + 2) * sizeof(cd) + (((size_t)n + 16 + 1) & ~(size_t)1) * sizeof(double);
     const size_t lds_a = (size_t)n * (n | 1) * sizeof(cd);
     const bool alds = lds_vec + lds_a <= 160 * 1024 && tbk_knobs().use_trig != 3;   // (TBK_TRIG=3: A in L2 at every size)
     const size_t lds1 = lds_vec + (alds ? lds_a : 0);
