@@ -3,18 +3,20 @@
 library's stream; not the driver's headline line -- that is bench.py).  One JSON object per config.
 
     python bench_configs.py [B] [C] [D] [E] [R] [--reps 5]             one GPU (R: ribbons / mid-size meshes, not in BASELINE.json)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench_configs.py --gpus N [D] [E] [--side 257]               N GPUs, one process each
+    python bench_configs.py --gpus N [B] [D] [E] [--side 257]           N GPUs, one process each (starts its own ranks; the
+                                                                        same under torch.distributed.run --nproc-per-node N)
 
-Multi-GPU legs (BASELINE configs[3] and [4]; drivers in pythtb_amd/multi.py):
+Multi-GPU legs (BASELINE configs[1], [3] and [4]; drivers in pythtb_amd/multi.py):
+  B  Haldane solve_all on the 1024^2 k list: contiguous chunks of the list, ONE all-gather-v of the eigenvalues into the
+     band-major (2, nk) array (also E's solve_all leg: (16, 256^3), 268 MB contributed per rank).
   D  Kane-Mele wf_array([4097,513]): the 513 Wilson loops along axis 0 are sharded along axis 1 (65 + 7 x 64 for
      8 ranks); every rank solves its own window of the global mesh and the (513, 2) eigenphase array is assembled by
      ONE all-gather-v.
   E  cubic16 wf_array([257]*3): slabs along axis 0 with a recomputed halo plane, berry_phase(range(8), dir=2) per slab,
      the (257, 257) phase array and the min gaps assembled by the gather.
-The gather runs through gloo for the reported numbers and once more through tbk_comm_allgatherv_f64 (RCCL over xGMI)
-under a watchdog; `gather` says which of them agreed.  Time per config = max over ranks of the device-resident
-compute (solve + Berry kernels), the gather reported separately.
+The RCCL communicator is brought up first and the gathers of the reported runs are tbk_comm_allgatherv[_rows]_f64 (RCCL over
+xGMI); every RCCL call runs under a time limit, gloo is the labelled fallback (exit status 4).  Time per config = max over
+ranks of one pass including its gather.
 """
 import contextlib
 import ctypes as C
@@ -22,7 +24,6 @@ import io
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -183,88 +184,138 @@ def single_gpu(which, reps):
 
 
 def multi_gpu(which, side):
-    """Launched under torch.distributed.run: rendezvous (gloo) BEFORE anything touches the GPU."""
+    """One process per GPU (started by main() through pythtb_amd/launch.py, or by torch.distributed.run): gloo rendezvous
+    BEFORE anything touches the GPU, then the RCCL communicator, then the legs.  The gathers inside the drivers of
+    pythtb_amd/multi.py -- the path's one collective each -- run through RCCL (tbk_comm_allgatherv[_rows]_f64); gloo is the
+    labelled fallback, and then the exit status is 4."""
+    import datetime
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
     import pythtb_amd as tb
     from pythtb_amd import _lib, multi
     import helpers as hp
-    lib = _lib.lib
     ctx = _lib.default_context()                              # device = LOCAL_RANK
+    limit = float(os.environ.get("TBK_BENCH_RCCL_TIMEOUT", "120"))
     gloo = multi.GlooComm(dist)
+    comm, err, hung = multi.rccl_bring_up(ctx, dist, rank, world, limit)
+    status = 0
+    if comm is None:
+        sys.stderr.write("[bench_configs] rank %d: RCCL communicator unavailable (%s); gathers go through gloo\n" % (rank, err))
+        comm, gather, status = gloo, "gloo (FALLBACK: rccl %s)" % err, 4
+    else:
+        gather = "rccl all-gather-v (tbk_comm_allgatherv[_rows]_f64, RCCL over xGMI)"
+    lines = []
 
-    def run(tag, fn):
-        """fn(comm) -> (array, gaps).  Timed with the gloo gather; then once more with the RCCL gather as a check."""
-        fn(gloo)                                              # warm-up (allocations, table builds)
-        ctx.sync()
-        dist.barrier()
-        t0 = time.perf_counter()
-        arr, gaps = fn(gloo)
-        ctx.sync()
-        t1 = time.perf_counter()
-        tmax = gloo.allgatherv(np.array([t1 - t0]), [1] * world).max()
-        return arr, gaps, float(tmax)
+    def finish(code):
+        if rank == 0:
+            for ln in lines:
+                print(json.dumps(ln), flush=True)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(code)
 
-    results = []
+    def run(fn):
+        """fn(comm) -> result.  One warm-up (allocations, table builds), one timed pass between barriers; every pass under a
+        time limit, and the ranks agree on the outcome before going on (a rank that failed must not leave the others in a
+        collective).  Returns (result, max-over-ranks seconds) or None."""
+        out = None
+        for timed_pass in (False, True):
+            ctx.sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            ok, val, h = multi.call_with_timeout(lambda: fn(comm), 10 * limit)
+            ctx.sync() if ok else None
+            t1 = time.perf_counter()
+            if h:                                             # stuck inside a collective: report what is known and leave
+                lines.append({"error": "a leg did not return within %g s" % (10 * limit), "gather": gather})
+                finish(3)
+            if not multi.agree(dist, ok):
+                if not ok:
+                    sys.stderr.write("[bench_configs] rank %d: %s\n" % (rank, val))
+                return None
+            out = (val, t1 - t0)
+        tmax = float(gloo.allgatherv(np.array([out[1]]), [1] * world).max())
+        return out[0], tmax
+
+    if "B" in which:
+        m = hp.haldane(tb.tb_model, 0.2)
+        k = m.k_uniform_mesh([1024, 1024])
+        nk = len(k)
+        r = run(lambda c: multi.solve_all_sharded(m, k, c, rank, world))
+        if r is None:
+            lines.append({"config": "configs[1]", "error": "solve_all_sharded failed", "gather": gather})
+            status = status or 6
+        else:
+            ev, t = r
+            samp = np.arange(0, nk, 4099)
+            same = bool(np.array_equal(ev[:, samp], m.solve_all(k[samp])))
+            ln = {"config": "configs[1]: Haldane (delta 0.2) solve_all(k_uniform_mesh([1024,1024])), k list cut into %d chunks, ONE "
+                            "all-gather-v of eval (2, nk) band-major" % world,
+                  "n_gpus": world, "kpts": nk, "seconds_max_over_ranks_incl_upload_gather_download": t, "kpts_per_s": nk / t,
+                  "chunks": [e - b for b, e in multi.plan_list(nk, world)], "gathered_bytes_per_rank": 8 * 2 * nk,
+                  "check": {"sum": float(ev.sum()), "min": float(ev.min()), "max": float(ev.max()),
+                            "sampled_columns_equal_unsharded": same}, "gather": gather}
+            if hasattr(comm, "allgatherv_rows_dev"):
+                r2 = run(lambda c: multi.solve_all_mesh_sharded(m, [1024, 1024], c, rank, world))
+                if r2 is not None:
+                    ln["k_generated_on_device_seconds"] = r2[1]
+                    ln["k_generated_on_device_equal"] = bool(np.array_equal(r2[0], ev))
+            lines.append(ln)
     if "D" in which:
         m = hp.kane_mele(tb.tb_model, "odd")
         mesh = [4097, 513]
-        arr, gaps, t = run("D", lambda comm: multi.wilson_loops_sharded(tb.wf_array, m, mesh, [-0.5, -0.5], [0, 1], comm, rank, world))
-        results.append(("D", arr, {"config": "configs[3]: Kane-Mele wf_array([4097,513]), 513 Wilson loops (2 bands) sharded over %d GPUs" % world,
-                                   "n_gpus": world, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": 4096 * 512 / t,
-                                   "strings_per_rank": [p[2] - p[1] for p in multi.plan_strings(mesh, 0, world)],
-                                   "checksum": float(np.sum(np.cos(arr)))}))
+        r = run(lambda c: multi.wilson_loops_sharded(tb.wf_array, m, mesh, [-0.5, -0.5], [0, 1], c, rank, world))
+        if r is None:
+            lines.append({"config": "configs[3]", "error": "wilson_loops_sharded failed", "gather": gather})
+            status = status or 6
+        else:
+            (arr, gaps), t = r
+            lines.append({"config": "configs[3]: Kane-Mele wf_array([4097,513]), 513 Wilson loops (2 bands) sharded over %d GPUs" % world,
+                          "n_gpus": world, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": 4096 * 512 / t,
+                          "strings_per_rank": [p[2] - p[1] for p in multi.plan_strings(mesh, 0, world)],
+                          "checksum": float(np.sum(np.cos(arr))), "gather": gather})
     if "E" in which:
         with contextlib.redirect_stdout(io.StringIO()):
             m = hp.cubic16(tb.tb_model)
         mesh = [side, side, side]
-        arr, gaps, t = run("E", lambda comm: multi.mesh_phases_sharded(tb.wf_array, m, mesh, [0.0, 0.0, 0.0], list(range(8)), comm, rank, world))
-        results.append(("E", arr, {"config": "configs[4]: cubic16 wf_array([%d]*3), solve_on_grid + berry_phase(range(8), dir=2), axis-0 slabs over %d GPUs" % (side, world),
-                                   "n_gpus": world, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": (side - 1) ** 3 / t,
-                                   "planes_per_rank": [p[2] for p in multi.plan_slabs(side, world)],
-                                   "gap78": float(gaps[7]), "checksum": float(np.sum(np.cos(arr)))}))
-    # ---- the same gathers through RCCL, checked against the gloo results; a communicator that never comes up must not
-    # hang the job: the watchdog prints what is already known and exits with status 3
-    lines = [dict(r[2], gather="gloo") for r in results]
-
-    def give_up():
-        try:
-            if rank == 0:
-                for ln in lines:
-                    print(json.dumps(dict(ln, gather="gloo (rccl all-gather-v timed out)")), flush=True)
-        finally:
-            os._exit(3)
-    dog = threading.Timer(float(os.environ.get("TBK_BENCH_RCCL_TIMEOUT", "120")), give_up)
-    dog.daemon = True
-    dog.start()
-    gather = "gloo (rccl unavailable)"
-    try:
-        box = [None]
-        if rank == 0:
-            uid = (C.c_ubyte * 128)()
-            _lib.check(lib.tbk_comm_unique_id(uid))
-            box[0] = bytes(uid)
-        dist.broadcast_object_list(box, src=0)
-        rccl = multi.RcclComm(ctx, box[0], world, rank)
-        same = True
-        for tag, arr, _ in results:
-            flat = np.asarray(arr, dtype=float).reshape(-1)
-            counts = [len(x) for x in np.array_split(np.arange(flat.size), world)]
-            got = rccl.allgatherv(flat[sum(counts[:rank]):sum(counts[:rank + 1])], counts)   # uneven blocks of the known result
-            same = same and np.array_equal(got, flat)
-        rccl.close()
-        import torch
-        flag = torch.tensor([1 if same else 0], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        gather = "rccl all-gather-v (equal to the gloo gather)" if bool(flag.item()) else "gloo (rccl result differs)"
-    except Exception as e:
-        sys.stderr.write("[bench_configs] rank %d: RCCL gather unavailable (%s)\n" % (rank, " ".join(str(e).split())))
-    dog.cancel()
+        r = run(lambda c: multi.mesh_phases_sharded(tb.wf_array, m, mesh, [0.0, 0.0, 0.0], list(range(8)), c, rank, world))
+        if r is None:
+            lines.append({"config": "configs[4]", "error": "mesh_phases_sharded failed", "gather": gather})
+            status = status or 6
+        else:
+            (arr, gaps), t = r
+            lines.append({"config": "configs[4]: cubic16 wf_array([%d]*3), solve_on_grid + berry_phase(range(8), dir=2), axis-0 slabs over %d GPUs" % (side, world),
+                          "n_gpus": world, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": (side - 1) ** 3 / t,
+                          "planes_per_rank": [p[2] for p in multi.plan_slabs(side, world)],
+                          "gap78": float(gaps[7]), "checksum": float(np.sum(np.cos(arr))), "gather": gather})
+        if hasattr(comm, "allgatherv_rows_dev"):
+            # the solve_all leg of configs[4]: eigenvalues of the (side-1)^3 uniform mesh, k generated per rank on the device,
+            # ONE rows all-gather-v of eval (16, nk) -- 268 MB contributed per rank at 256^3 over 8 GPUs (SURVEY.md 8e)
+            msz = [side - 1] * 3
+            nk = (side - 1) ** 3
+            r = run(lambda c: multi.solve_all_mesh_sharded(m, msz, c, rank, world, download=False))
+            if r is None:
+                lines.append({"config": "configs[4] solve_all", "error": "solve_all_mesh_sharded failed", "gather": gather})
+                status = status or 6
+            else:
+                ends, t = r
+                ref = m.solve_all(np.array([[0.0, 0.0, 0.0], [(side - 2.0) / (side - 1.0)] * 3]))
+                lines.append({"config": "configs[4] solve_all leg: cubic16 eigenvalues on k_uniform_mesh([%d]*3), k chunks over %d GPUs, ONE "
+                                        "rows all-gather-v of eval (16, nk)" % (side - 1, world),
+                              "n_gpus": world, "kpts": nk, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": nk / t,
+                              "gathered_bytes_per_rank": 8 * 16 * nk,
+                              "first_and_last_columns_equal_unsharded": bool(np.array_equal(ends, ref)), "gather": gather})
+    dist.barrier()
+    if hasattr(comm, "close") and not hung:
+        comm.close()
     if rank == 0:
         for ln in lines:
-            print(json.dumps(dict(ln, gather=gather)), flush=True)
-    dist.barrier()
+            print(json.dumps(ln), flush=True)
+    if hung or status:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(status or 3)
     dist.destroy_process_group()
 
 
@@ -280,10 +331,15 @@ def main():
             skip.add(flags[flags.index(name) + 1])
     which = [a for a in args if a not in skip] or None
     gpus = opt("--gpus", int(os.environ.get("WORLD_SIZE", "1")))
-    if gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        if int(os.environ.get("WORLD_SIZE", "1")) != gpus:
-            sys.exit("bench_configs.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (gpus, gpus))
-        multi_gpu(which or ["D", "E"], opt("--side", 257))
+    if "WORLD_SIZE" not in os.environ and gpus > 1:
+        # plain `python bench_configs.py --gpus N ...`: start the N ranks (this process has made no GPU call)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_tbk_launch", os.path.join(_ROOT, "pythtb_amd", "launch.py"))
+        launch = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(launch)
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        multi_gpu(which or ["B", "D", "E"], opt("--side", 257))
     else:
         single_gpu(which or ["B", "C", "D", "E"], opt("--reps", 5))
 

@@ -206,6 +206,9 @@ int tbk_wfs_position_hwf(tbk_wfs* wfs, const int64_t* point_index, int64_t npoin
  * tb_model.k_uniform_mesh (pythtb.py:1792-1861): k_dev[prod(mesh)][dim_k], point
  * (i_0,..) row-major = (i_0/N_0, ...); dim_k 1..3 like the reference.                  */
 int tbk_k_uniform_mesh_dev(tbk_ctx* ctx, int dim_k, const int32_t* mesh, double* k_dev);
+/* points [first, first+count) of that list only: the chunk one rank of a k-sharded solve_all owns  */
+int tbk_k_uniform_mesh_range_dev(tbk_ctx* ctx, int dim_k, const int32_t* mesh, int64_t first,
+                                 int64_t count, double* k_dev);
 /* interpolation step of tb_model.k_path (pythtb.py:1978-1996): nodes[n_nodes][dim_k] and
  * node_index[n_nodes] (0 .. nk-1, increasing; both computed on the host, :1926-1976)
  * -> k_dev[nk][dim_k], bit-equal to the reference's k_vec.                             */
@@ -237,6 +240,14 @@ int tbk_comm_allgather_f64(tbk_ctx* ctx, const double* send_dev, double* recv_de
  * entries and count must equal counts[own rank].  One grouped ncclSend/ncclRecv exchange.                  */
 int tbk_comm_allgatherv_f64(tbk_ctx* ctx, const double* send_dev, int64_t count, double* recv_dev,
                             const int64_t* counts, const int64_t* displs);
+/* the eigenvalue gather of a sharded solve_all (ret_eval (nsta, nkp) band-major, pythtb.py:1040,1053-1067): rank r
+ * holds send_dev[nrows][counts[r]] -- its contiguous chunk of the k list for every band -- and every rank receives
+ * recv_dev[nrows][row_stride] with that chunk of row b at b*row_stride + displs[r].  Same single grouped exchange,
+ * nrows messages per pair of ranks, so the result lands band-major with no relayout pass (config E: 16 messages of
+ * 16.8 MB per pair).                                                                                              */
+int tbk_comm_allgatherv_rows_f64(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count,
+                                 double* recv_dev, const int64_t* counts, const int64_t* displs,
+                                 int64_t row_stride);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,7 @@ SIGNATURES = {
     "tbk_position_hwf": (_i, [_p, _dp, _i64, _i, _i, _dp, _dp, _dp, _dp, _i]),
     "tbk_wfs_position_hwf": (_i, [_p, C.POINTER(C.c_int64), _i64, _ip, _i, _dp, _dp, _dp, _dp, _i]),
     "tbk_k_uniform_mesh_dev": (_i, [_p, _i, _ip, _p]),
+    "tbk_k_uniform_mesh_range_dev": (_i, [_p, _i, _ip, _i64, _i64, _p]),
     "tbk_k_path_dev": (_i, [_p, _i, _i, _dp, _ip, _i64, _p]),
     "tbk_solve_mesh": (_i, [_p, _ip, _dp, _dp]),
     "tbk_dos_mesh": (_i, [_p, _ip, _i, _dp, C.POINTER(C.c_int64), _dp, _dp]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "tbk_comm_destroy": (_i, [_p]),
     "tbk_comm_allgather_f64": (_i, [_p, _p, _p, _i64]),
     "tbk_comm_allgatherv_f64": (_i, [_p, _p, _i64, _p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "tbk_comm_allgatherv_rows_f64": (_i, [_p, _p, _i64, _i64, _p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i64]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -108,30 +108,50 @@ extern "C" int tbk_comm_allgather_f64(tbk_ctx* ctx, const double* send_dev, doub
     return TBK_OK;
 }
 
-// Ranks contribute different counts (513 strings over 8 ranks, slabs of 257 planes): one grouped exchange in which
-// every rank sends its block to every rank and receives block r at displs[r] -- the standard all-gather-v on
-// point-to-point links, which is what xGMI is.  counts / displs are host arrays of nranks entries (in doubles).
-extern "C" int tbk_comm_allgatherv_f64(tbk_ctx* ctx, const double* send_dev, int64_t count, double* recv_dev,
-                                       const int64_t* counts, const int64_t* displs) {
-    TBK_REQUIRE(ctx && ctx->comm, TBK_ECOMM, "tbk_comm_allgatherv_f64: communicator not initialised");
-    TBK_REQUIRE(recv_dev && counts && displs && count >= 0 && (send_dev || count == 0), TBK_EINVAL,
-                "tbk_comm_allgatherv_f64: bad argument");
+// Ranks contribute different counts (513 strings over 8 ranks, slabs of 257 planes, k lists that do not divide): one
+// grouped exchange in which every rank sends its block to every rank and receives block r at displs[r] -- the standard
+// all-gather-v on point-to-point links, which is what xGMI is.  counts / displs are host arrays of nranks entries (in
+// doubles).  The ROWS form gathers a band-major array in place: rank r holds send[nrows][counts[r]] (its k-chunk of
+// eval[band][k], pythtb.py:1040,1053-1067) and every rank receives recv[nrows][row_stride] with rank r's piece of row b
+// at b*row_stride + displs[r] -- nrows messages per pair of ranks inside the same group, no relayout pass afterwards.
+static int allgatherv_rows(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count, double* recv_dev,
+                           const int64_t* counts, const int64_t* displs, int64_t row_stride, const char* who) {
+    TBK_REQUIRE(ctx && ctx->comm, TBK_ECOMM, "%s: communicator not initialised", who);
+    TBK_REQUIRE(recv_dev && counts && displs && count >= 0 && nrows >= 1 && (send_dev || count == 0), TBK_EINVAL,
+                "%s: bad argument", who);
     TBK_REQUIRE(g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end, TBK_ECOMM,
                 "librccl.so lacks ncclSend/ncclRecv/ncclGroupStart/ncclGroupEnd");
     TBK_REQUIRE(ctx->comm_rank >= 0 && ctx->comm_rank < ctx->comm_nranks && counts[ctx->comm_rank] == count, TBK_EINVAL,
-                "tbk_comm_allgatherv_f64: counts[rank] (%lld) != count (%lld)",
+                "%s: counts[rank] (%lld) != count (%lld)", who,
                 (long long)(ctx->comm_rank >= 0 && ctx->comm_rank < ctx->comm_nranks ? counts[ctx->comm_rank] : -1), (long long)count);
+    for (int r = 0; r < ctx->comm_nranks; ++r)
+        TBK_REQUIRE(counts[r] >= 0 && displs[r] >= 0 && (nrows == 1 || displs[r] + counts[r] <= row_stride), TBK_EINVAL,
+                    "%s: block %d (displacement %lld, count %lld) does not fit a row of %lld", who, r, (long long)displs[r],
+                    (long long)counts[r], (long long)row_stride);
     const int nccl_float64 = 8;  // ncclDouble
     int nrc = g_rccl.group_start();
     TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclGroupStart: %s", nccl_msg(nrc));
-    for (int r = 0; r < ctx->comm_nranks && nrc == 0; ++r) {
-        if (count > 0) nrc = g_rccl.send(const_cast<double*>(send_dev), (size_t)count, nccl_float64, r, ctx->comm, ctx->stream);
-        if (nrc == 0 && counts[r] > 0)
-            nrc = g_rccl.recv(recv_dev + displs[r], (size_t)counts[r], nccl_float64, r, ctx->comm, ctx->stream);
-    }
+    for (int64_t b = 0; b < nrows && nrc == 0; ++b)
+        for (int r = 0; r < ctx->comm_nranks && nrc == 0; ++r) {
+            if (count > 0)
+                nrc = g_rccl.send(const_cast<double*>(send_dev) + b * count, (size_t)count, nccl_float64, r, ctx->comm, ctx->stream);
+            if (nrc == 0 && counts[r] > 0)
+                nrc = g_rccl.recv(recv_dev + b * row_stride + displs[r], (size_t)counts[r], nccl_float64, r, ctx->comm, ctx->stream);
+        }
     const int erc = g_rccl.group_end();
     TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclSend/ncclRecv: %s", nccl_msg(nrc));
     TBK_REQUIRE(erc == 0, TBK_ECOMM, "ncclGroupEnd: %s", nccl_msg(erc));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
     return TBK_OK;
+}
+
+extern "C" int tbk_comm_allgatherv_f64(tbk_ctx* ctx, const double* send_dev, int64_t count, double* recv_dev,
+                                       const int64_t* counts, const int64_t* displs) {
+    return allgatherv_rows(ctx, send_dev, 1, count, recv_dev, counts, displs, 0, "tbk_comm_allgatherv_f64");
+}
+
+extern "C" int tbk_comm_allgatherv_rows_f64(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count,
+                                            double* recv_dev, const int64_t* counts, const int64_t* displs,
+                                            int64_t row_stride) {
+    return allgatherv_rows(ctx, send_dev, nrows, count, recv_dev, counts, displs, row_stride, "tbk_comm_allgatherv_rows_f64");
 }

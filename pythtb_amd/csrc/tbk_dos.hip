@@ -12,11 +12,12 @@
 #include "tbk_internal.h"
 
 // k[idx] = (i_0/N_0, ..., i_{d-1}/N_{d-1}),  idx row-major, last index fastest (pythtb.py:1828-1859)
-__global__ __launch_bounds__(256) void k_gen_mesh(const int d, const int n0, const int n1, const int n2, const int64_t nk,
-                                                  double* __restrict__ k) {
+// (k[0] is point `first` of the mesh: a rank of a sharded solve_all generates only its chunk of the list)
+__global__ __launch_bounds__(256) void k_gen_mesh(const int d, const int n0, const int n1, const int n2, const int64_t first,
+                                                  const int64_t nk, double* __restrict__ k) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= nk) return;
-    int64_t rem = idx;
+    int64_t rem = first + idx;
     int i2 = 0, i1 = 0;
     if (d >= 3) {
         i2 = (int)(rem % n2);
@@ -109,20 +110,32 @@ __global__ __launch_bounds__(256) void k_hist(const double* __restrict__ eval, c
         if (h[b]) atomicAdd(&counts[(int64_t)band * nbins + b], (unsigned long long)h[b]);
 }
 
-extern "C" int tbk_k_uniform_mesh_dev(tbk_ctx* ctx, int dim_k, const int32_t* mesh, double* k_dev) {
-    TBK_REQUIRE(ctx && mesh && k_dev, TBK_EINVAL, "tbk_k_uniform_mesh_dev: null argument");
+extern "C" int tbk_k_uniform_mesh_range_dev(tbk_ctx* ctx, int dim_k, const int32_t* mesh, int64_t first, int64_t count,
+                                            double* k_dev) {
+    TBK_REQUIRE(ctx && mesh && (k_dev || count == 0), TBK_EINVAL, "tbk_k_uniform_mesh_dev: null argument");
     TBK_REQUIRE(dim_k >= 1 && dim_k <= 3, TBK_EINVAL, "tbk_k_uniform_mesh_dev: dim_k=%d (the reference supports 1..3)", dim_k);
     int64_t nk = 1;
     for (int d = 0; d < dim_k; ++d) {
         TBK_REQUIRE(mesh[d] >= 1, TBK_EINVAL, "tbk_k_uniform_mesh_dev: mesh[%d]=%d", d, mesh[d]);
         nk *= mesh[d];
     }
+    TBK_REQUIRE(first >= 0 && count >= 0 && first + count <= nk, TBK_EINVAL,
+                "tbk_k_uniform_mesh_range_dev: points [%lld, %lld) of a mesh of %lld", (long long)first,
+                (long long)(first + count), (long long)nk);
+    if (count == 0) return TBK_OK;
     TBK_HIP(hipSetDevice(ctx->device));
     ProfScope ps(ctx, "k_uniform_mesh");
-    hipLaunchKernelGGL(k_gen_mesh, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, dim_k, mesh[0],
-                       dim_k > 1 ? mesh[1] : 1, dim_k > 2 ? mesh[2] : 1, nk, k_dev);
+    hipLaunchKernelGGL(k_gen_mesh, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, dim_k, mesh[0],
+                       dim_k > 1 ? mesh[1] : 1, dim_k > 2 ? mesh[2] : 1, first, count, k_dev);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
+}
+
+extern "C" int tbk_k_uniform_mesh_dev(tbk_ctx* ctx, int dim_k, const int32_t* mesh, double* k_dev) {
+    TBK_REQUIRE(ctx && mesh && k_dev, TBK_EINVAL, "tbk_k_uniform_mesh_dev: null argument");
+    int64_t nk = 1;
+    for (int d = 0; d < dim_k && d < 3; ++d) nk *= mesh[d] > 0 ? mesh[d] : 0;
+    return tbk_k_uniform_mesh_range_dev(ctx, dim_k, mesh, 0, nk, k_dev);
 }
 
 extern "C" int tbk_k_path_dev(tbk_ctx* ctx, int dim_k, int n_nodes, const double* nodes, const int32_t* node_index,

@@ -1,4 +1,8 @@
-"""One-process-per-GPU drivers for the two multi-GPU configurations of BASELINE.json:
+"""One-process-per-GPU drivers for the multi-GPU configurations of BASELINE.json:
+
+* solve_all on a k list (configs[1], and the solve_all leg of configs[4]): contiguous chunks of the list
+  (reference loop: pythtb.py:1047), ONE gather of the eigenvalues into the band-major (nsta, nkp) array the
+  reference returns (pythtb.py:1040,1053-1067) -- `solve_all_sharded`, `solve_all_mesh_sharded`.
 
 * configs[3]: Kane-Mele wf_array([4097, 513]) -- Wilson-loop eigenphases of the 513 strings along axis 0
   (reference loop: pythtb.py:2987-2996).  Strings shard along axis 1; 513 strings over 8 ranks is an uneven
@@ -19,12 +23,15 @@ The drivers take the `wf_array` class to use, so the CPU test-suite can run them
 counts) with an oracle-backed stand-in where no GPU exists; the library itself never does that.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
 from . import shard
 
-__all__ = ["GlooComm", "RcclComm", "plan_strings", "plan_slabs", "wilson_loops_sharded", "mesh_phases_sharded"]
+__all__ = ["GlooComm", "RcclComm", "plan_strings", "plan_slabs", "plan_list", "wilson_loops_sharded",
+           "mesh_phases_sharded", "solve_all_sharded", "solve_all_mesh_sharded", "call_with_timeout", "agree",
+           "rccl_bring_up"]
 
 
 # ---------------------------------------------------------------------------------------------- plans
@@ -54,7 +61,16 @@ def plan_slabs(mesh0, world):
     return plans
 
 
+def plan_list(n_items, world):
+    """Per rank: (begin, end) of its contiguous chunk of a flat k list."""
+    return [shard.split_list(n_items, world, r) for r in range(world)]
+
+
 # ---------------------------------------------------------------------------------------------- communicators
+def _displs(counts):
+    return [int(x) for x in np.concatenate([[0], np.cumsum(counts)[:-1]])]
+
+
 class GlooComm(object):
     """torch.distributed process group (gloo) used as an all-gather-v of float64 host arrays."""
 
@@ -73,6 +89,18 @@ class GlooComm(object):
         buf = [torch.zeros(cap, dtype=torch.float64) for _ in range(self.world)]
         self.dist.all_gather(buf, torch.from_numpy(pad))
         return np.concatenate([b.numpy()[:c] for b, c in zip(buf, counts)])
+
+    def allgatherv_rows(self, mine, counts):
+        """mine (nrows, counts[rank]) on every rank -> (nrows, sum(counts)): rank r's columns at displs[r] (one collective)."""
+        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        nrows = mine.shape[0]
+        flat = self.allgatherv(mine.reshape(-1), [nrows * int(c) for c in counts])
+        out = np.empty((nrows, int(sum(counts))))
+        pos = 0
+        for c, d in zip(counts, _displs(counts)):
+            out[:, d:d + c] = flat[pos:pos + nrows * c].reshape(nrows, c)
+            pos += nrows * c
+        return out
 
 
 class RcclComm(object):
@@ -111,8 +139,119 @@ class RcclComm(object):
             lib.tbk_dev_free(ctx.handle, recv)
         return out
 
+    def allgatherv_rows_dev(self, send_dev, nrows, counts):
+        """send_dev: device pointer of this rank's (nrows, counts[rank]) doubles.  Returns the HOST array
+        (nrows, sum(counts)), assembled on the device by ONE grouped exchange (tbk_comm_allgatherv_rows_f64)."""
+        _lib, lib, ctx = self._lib, self.lib, self.ctx
+        total = int(sum(counts))
+        cnt = np.ascontiguousarray(counts, dtype=np.int64)
+        dsp = np.ascontiguousarray(_displs(counts), dtype=np.int64)
+        recv = C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, 8 * max(total * nrows, 1), C.byref(recv)))
+        try:
+            i64p = C.POINTER(C.c_int64)
+            _lib.check(lib.tbk_comm_allgatherv_rows_f64(ctx.handle, send_dev, nrows, int(counts[self.rank]), recv,
+                                                        cnt.ctypes.data_as(i64p), dsp.ctypes.data_as(i64p), total))
+            out = np.zeros((nrows, total))
+            if out.size:
+                _lib.check(lib.tbk_dev_download(ctx.handle, out.ctypes.data_as(C.c_void_p), recv, out.nbytes))
+        finally:
+            lib.tbk_dev_free(ctx.handle, recv)
+        return out
+
+    def allgatherv_rows(self, mine, counts):
+        _lib, lib, ctx = self._lib, self.lib, self.ctx
+        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        assert mine.ndim == 2 and mine.shape[1] == counts[self.rank]
+        send = C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, max(mine.nbytes, 8), C.byref(send)))
+        try:
+            if mine.size:
+                _lib.check(lib.tbk_dev_upload(ctx.handle, send, mine.ctypes.data_as(C.c_void_p), mine.nbytes))
+            return self.allgatherv_rows_dev(send, mine.shape[0], counts)
+        finally:
+            lib.tbk_dev_free(ctx.handle, send)
+
     def close(self):
         self._lib.check(self.lib.tbk_comm_destroy(self.ctx.handle))
+
+
+    def allgather(self, mine):
+        """Equal contributions: ncclAllGather proper (tbk_comm_allgather_f64).  Returns (world, len(mine))."""
+        _lib, lib, ctx = self._lib, self.lib, self.ctx
+        mine = np.ascontiguousarray(mine, dtype=np.float64).reshape(-1)
+        nb = 8 * mine.size
+        send, recv = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nb, C.byref(send)))
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nb * self.world, C.byref(recv)))
+        try:
+            _lib.check(lib.tbk_dev_upload(ctx.handle, send, mine.ctypes.data_as(C.c_void_p), nb))
+            _lib.check(lib.tbk_comm_allgather_f64(ctx.handle, send, recv, mine.size))
+            out = np.zeros((self.world, mine.size))
+            _lib.check(lib.tbk_dev_download(ctx.handle, out.ctypes.data_as(C.c_void_p), recv, out.nbytes))
+        finally:
+            lib.tbk_dev_free(ctx.handle, send)
+            lib.tbk_dev_free(ctx.handle, recv)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------- bring-up
+def call_with_timeout(fn, seconds):
+    """fn() on a worker thread (ctypes releases the GIL inside libtbk / RCCL) -> (ok, value or message, hung).
+    A call that never returns is left behind on its daemon thread and reported as hung: the caller carries on with
+    its fallback and must finish with os._exit (a stuck collective must not cost the measurement already made)."""
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except BaseException as e:                      # noqa: BLE001 (reported, not swallowed)
+            box["e"] = e
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return False, "no return within %g s" % seconds, True
+    if "e" in box:
+        return False, " ".join(str(box["e"]).split()), False
+    return True, box.get("v"), False
+
+
+def agree(dist, ok):
+    """Every rank takes the same branch: true only if `ok` everywhere (one gloo all-reduce of a flag)."""
+    import torch
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def rccl_bring_up(ctx, dist, rank, world, timeout=120.0):
+    """The RCCL communicator of a one-process-per-GPU run, brought up FIRST (before any measurement): rank 0 creates the
+    id, gloo hands it round, every rank joins on a worker thread with a time limit, and the ranks agree on the outcome.
+    Returns (RcclComm or None, message, hung)."""
+    from . import _lib
+    err, uid = "", None
+    if rank == 0:
+        try:
+            buf = (C.c_ubyte * 128)()
+            _lib.check(_lib.lib.tbk_comm_unique_id(buf))
+            uid = bytes(buf)
+        except Exception as e:                          # noqa: BLE001
+            err = "unique_id: %s" % " ".join(str(e).split())
+    box = [uid]
+    dist.broadcast_object_list(box, src=0)
+    ok, comm, hung = box[0] is not None, None, False
+    if ok:
+        ok, val, hung = call_with_timeout(lambda: RcclComm(ctx, box[0], world, rank), timeout)
+        if ok:
+            comm = val
+        else:
+            err = "init: %s" % val
+    elif not err:
+        err = "unique_id failed on rank 0"
+    if not agree(dist, ok):
+        return None, err or "another rank failed to join", hung
+    return comm, "", hung
 
 
 # ---------------------------------------------------------------------------------------------- drivers
@@ -151,8 +290,91 @@ def mesh_phases_sharded(wf_array_cls, model, mesh, start_k, occ, comm, rank, wor
     gaps = w.solve_on_grid_window(start_k, [row0, 0, 0], mesh)
     ph = np.asarray(w.berry_phase(occ, dir, contin=False))          # (nrows, N_other)
     other = mesh[2] if dir == 1 else mesh[1]
-    counts = [p[2] * other for p in plans]
-    allv = comm.allgatherv(ph[:own], counts).reshape(mesh[0], other)
+    # ONE collective: every rank's block is [its planes' phases | its min gaps]
     ng = len(gaps)
-    allg = comm.allgatherv(np.asarray(gaps, dtype=float), [ng] * world).reshape(world, ng).min(axis=0)
+    counts = [p[2] * other + ng for p in plans]
+    flat = comm.allgatherv(np.concatenate([np.asarray(ph[:own], dtype=float).reshape(-1), np.asarray(gaps, dtype=float)]), counts)
+    allv, allg, pos = np.empty((mesh[0], other)), np.full(ng, np.inf), 0
+    row = 0
+    for p, c in zip(plans, counts):
+        allv[row:row + p[2]] = flat[pos:pos + p[2] * other].reshape(p[2], other)
+        allg = np.minimum(allg, flat[pos + p[2] * other:pos + c])
+        row += p[2]
+        pos += c
     return allv, allg
+
+
+def solve_all_sharded(model, k_list, comm, rank, world, solve_chunk=None):
+    """tb_model.solve_all(k_list) (eigenvalues; pythtb.py:955-1067) with the k list cut into `world` contiguous
+    chunks: every rank solves its own chunk and ONE all-gather-v assembles ret_eval (nsta, nkp), band-major like
+    the reference's (pythtb.py:1040).  With an RcclComm everything between the k chunk's upload and the final
+    download stays on the device (tbk_solve_list_dev -> tbk_comm_allgatherv_rows_f64).  `solve_chunk(k) -> (nsta, nk)`
+    replaces the device solve in the CPU test-suite (an oracle-backed stand-in); the library never does that."""
+    k = np.asarray(k_list, dtype=float)
+    if k.ndim == 1:                                            # a flat list of scalar k for dim_k = 1 (pythtb.py:1036)
+        k = k.reshape(-1, 1)
+    k = np.ascontiguousarray(k)
+    nk = k.shape[0]
+    plans = plan_list(nk, world)
+    counts = [e - b for b, e in plans]
+    b, e = plans[rank]
+    if solve_chunk is not None or not hasattr(comm, "allgatherv_rows_dev"):
+        ev = (solve_chunk or model.solve_all)(k[b:e]) if e > b else np.zeros((model._nsta, 0))
+        return comm.allgatherv_rows(np.asarray(ev, dtype=float).reshape(model._nsta, e - b), counts)
+    from . import _lib
+    lib, ctx, n = _lib.lib, comm.ctx, model._nsta
+    hm = model._device_model()
+    kd, ed = C.c_void_p(), C.c_void_p()
+    mine = k[b:e]
+    _lib.check(lib.tbk_dev_alloc(ctx.handle, max(mine.nbytes, 8), C.byref(kd)))
+    _lib.check(lib.tbk_dev_alloc(ctx.handle, max(8 * n * (e - b), 8), C.byref(ed)))
+    try:
+        if e > b:
+            _lib.check(lib.tbk_dev_upload(ctx.handle, kd, mine.ctypes.data_as(C.c_void_p), mine.nbytes))
+            _lib.check(lib.tbk_solve_list_dev(hm, kd, e - b, ed, None))
+        return comm.allgatherv_rows_dev(ed, n, counts)
+    finally:
+        lib.tbk_dev_free(ctx.handle, kd)
+        lib.tbk_dev_free(ctx.handle, ed)
+
+
+def solve_all_mesh_sharded(model, mesh_size, comm, rank, world, download=True):
+    """solve_all(k_uniform_mesh(mesh_size)) (pythtb.py:1792-1861, :955-1067), k-sharded, with every rank generating its
+    chunk of the k list on the device (tbk_k_uniform_mesh_range_dev): nothing but the gathered eigenvalues leaves a GPU.
+    Needs an RcclComm.  Returns ret_eval (nsta, prod(mesh_size)); with download=False the gather still runs (it is what
+    is being measured) and only a (nsta, 2) array of every band's first and last eigenvalue comes back to the host."""
+    from . import _lib
+    lib, ctx, n = _lib.lib, comm.ctx, model._nsta
+    mesh = np.ascontiguousarray(mesh_size, dtype=np.int32).reshape(-1)
+    if mesh.size != model._dim_k:
+        raise Exception("\n\nmesh_size must have dim_k entries")
+    nk = int(np.prod(mesh.astype(np.int64)))
+    plans = plan_list(nk, world)
+    counts = [e - b for b, e in plans]
+    b, e = plans[rank]
+    hm = model._device_model()
+    kd, ed, recv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(lib.tbk_dev_alloc(ctx.handle, max(8 * model._dim_k * (e - b), 8), C.byref(kd)))
+    _lib.check(lib.tbk_dev_alloc(ctx.handle, max(8 * n * (e - b), 8), C.byref(ed)))
+    try:
+        _lib.check(lib.tbk_k_uniform_mesh_range_dev(ctx.handle, model._dim_k, _lib.iptr(mesh), b, e - b, kd))
+        if e > b:
+            _lib.check(lib.tbk_solve_list_dev(hm, kd, e - b, ed, None))
+        if download:
+            return comm.allgatherv_rows_dev(ed, n, counts)
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, 8 * n * nk, C.byref(recv)))
+        cnt = np.ascontiguousarray(counts, dtype=np.int64)
+        dsp = np.ascontiguousarray(_displs(counts), dtype=np.int64)
+        i64p = C.POINTER(C.c_int64)
+        _lib.check(lib.tbk_comm_allgatherv_rows_f64(ctx.handle, ed, n, e - b, recv, cnt.ctypes.data_as(i64p),
+                                                    dsp.ctypes.data_as(i64p), nk))
+        ends = np.zeros((n, 2))
+        for band in range(n):
+            for j, col in enumerate((0, nk - 1)):
+                _lib.check(lib.tbk_dev_download(ctx.handle, ends[band, j:j + 1].ctypes.data_as(C.c_void_p),
+                                                C.c_void_p(recv.value + 8 * (band * nk + col)), 8))
+        return ends
+    finally:
+        for ptr in (kd, ed, recv):
+            if ptr.value:
+                lib.tbk_dev_free(ctx.handle, ptr)

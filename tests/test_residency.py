@@ -156,6 +156,17 @@ def test_multi_gpu_drivers_single_rank_rccl_and_every_ranks_share(tb):
         # uneven blocks through the all-gather-v itself (one rank: its own block at displacement 0)
         x = np.arange(7, dtype=float)
         assert np.array_equal(rccl.allgatherv(x, [7]), x)
+        assert np.array_equal(rccl.allgather(x), x.reshape(1, 7))
+        # the eigenvalue gather of a sharded solve_all: band-major rows, device-resident from the k
+        # chunk's upload to the gathered array's download; and with the k list generated on the device
+        hal = hp.haldane(tb.tb_model, 0.2)
+        k = np.random.default_rng(8).random((1000, 2))
+        assert np.array_equal(multi.solve_all_sharded(hal, k, rccl, 0, 1), hal.solve_all(k))
+        assert np.array_equal(rccl.allgatherv_rows(np.arange(12.0).reshape(3, 4), [4]), np.arange(12.0).reshape(3, 4))
+        ev16 = multi.solve_all_mesh_sharded(m16, [6, 5, 7], rccl, 0, 1)
+        assert np.array_equal(ev16, m16.solve_all(m16.k_uniform_mesh([6, 5, 7])))
+        ends = multi.solve_all_mesh_sharded(m16, [6, 5, 7], rccl, 0, 1, download=False)
+        assert np.array_equal(ends, ev16[:, [0, -1]])
     finally:
         rccl.close()
 
@@ -179,8 +190,37 @@ def test_multi_gpu_drivers_single_rank_rccl_and_every_ranks_share(tb):
         for r in range(world):
             rec.rank = r
             multi.mesh_phases_sharded(tb.wf_array, m16, mesh3, start3, list(range(8)), rec, r, world)
-        assert np.array_equal(np.concatenate([rec.parts[r][0] for r in range(world)]).reshape(10, 9), ref3)
-        assert np.array_equal(np.min([rec.parts[r][1] for r in range(world)], axis=0), g3)
+        # ONE collective per rank: [its planes' phases | its min gaps]
+        assert all(len(rec.parts[r]) == 1 for r in range(world))
+        ng = len(g3)
+        assert np.array_equal(np.concatenate([rec.parts[r][0][:-ng] for r in range(world)]).reshape(10, 9), ref3)
+        assert np.array_equal(np.min([rec.parts[r][0][-ng:] for r in range(world)], axis=0), g3)
+
+    # every rank's chunk of a k list in turn (worlds 3 and 8, 1000 k-points: uneven), chunks of a device-generated mesh too
+    class RowRecorder(object):
+        def __init__(self):
+            self.parts = []
+        def allgatherv_rows(self, mine, counts):
+            self.parts.append(np.array(mine))
+            return np.zeros((mine.shape[0], int(sum(counts))))
+    hal = hp.haldane(tb.tb_model, 0.2)
+    k = np.random.default_rng(8).random((1000, 2))
+    ref_ev = hal.solve_all(k)
+    for world in (3, 8):
+        rec = RowRecorder()
+        for r in range(world):
+            multi.solve_all_sharded(hal, k, rec, r, world)
+        assert np.array_equal(np.concatenate(rec.parts, axis=1), ref_ev)
+    # (the ranged device generator against the host list)
+    mesh32 = np.array([6, 5, 7], dtype=np.int32)
+    kh = m16.k_uniform_mesh([6, 5, 7])
+    kd = C.c_void_p()
+    _lib.check(lib.tbk_dev_alloc(ctx.handle, 8 * 3 * 100, C.byref(kd)))
+    got = np.zeros((100, 3))
+    _lib.check(lib.tbk_k_uniform_mesh_range_dev(ctx.handle, 3, _lib.iptr(mesh32), 57, 100, kd))
+    _lib.check(lib.tbk_dev_download(ctx.handle, got.ctypes.data_as(C.c_void_p), kd, got.nbytes))
+    _lib.check(lib.tbk_dev_free(ctx.handle, kd))
+    assert np.array_equal(got, kh[57:157])
 
 
 def test_singular_link_matrix_is_reported_not_returned(tb):

@@ -179,9 +179,35 @@ class OracleWf(object):
         return orc.berry_phase(self.wfs, len(self.mesh), list(occ), dir, contin=contin, berry_evals=berry_evals)
 
 
+class Counting(multi.GlooComm):
+    '''counts the collectives a driver issues (north_star: ONE gather per driver)'''
+    calls = 0
+    def allgatherv(self, mine, counts):
+        Counting.calls += 1
+        return multi.GlooComm.allgatherv(self, mine, counts)
+
+
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-comm = multi.GlooComm(dist)
+comm = Counting(dist)
+# solve_all on a k list (configs[1] / the solve_all leg of configs[4]) in small: 11 k-points do not divide by 2 or 3
+hal = hp.haldane(tb.tb_model, 0.2)
+k11 = np.random.default_rng(3).random((11, 2))
+def per_k(model, n):
+    # one k at a time, so that the bits do not depend on how the list is cut
+    return lambda kk: np.concatenate([orc.solve_all_vec(model, kk[i:i + 1]) for i in range(len(kk))] + [np.zeros((n, 0))], axis=1)
+oracle_chunk = per_k(hal, 2)
+ev = multi.solve_all_sharded(hal, k11, comm, rank, world, solve_chunk=oracle_chunk)
+assert Counting.calls == 1, Counting.calls
+assert ev.shape == (2, 11) and ev.flags["C_CONTIGUOUS"] and np.array_equal(ev, oracle_chunk(k11))
+assert np.max(np.abs(ev - orc.solve_all_vec(hal, k11))) < 1e-13
+chunks = [e - b for b, e in multi.plan_list(11, world)]
+assert sum(chunks) == 11 and len(set(chunks)) > 1, chunks
+m3s = hp.random_model(tb.tb_model, 3, 3, 1, 5)                # more ranks than k-points: empty chunks
+k2 = np.random.default_rng(4).random((2, 3))
+oc3 = per_k(m3s, 3)
+assert np.array_equal(multi.solve_all_sharded(m3s, k2, comm, rank, world, solve_chunk=oc3), oc3(k2))
+Counting.calls = 0
 # configs[3] in small: Kane-Mele, 7 strings over `world` ranks (uneven for 2 and 3)
 km = hp.kane_mele(tb.tb_model, "odd")
 mesh, start = [9, 7], [-0.5, -0.5]
@@ -196,7 +222,9 @@ assert np.array_equal(got1, orc.berry_phase(full, 2, [2, 3], 0, contin=False))
 # configs[4] in small: a 3-orbital cubic model, slabs along axis 0 (5 plaquette rows over `world` ranks), strings along 2
 m3 = hp.random_model(tb.tb_model, 3, 3, 1, 11)
 mesh3, start3 = [6, 4, 5], [0.1, 0.2, 0.3]
+Counting.calls = 0
 ph, gaps = multi.mesh_phases_sharded(OracleWf, m3, mesh3, start3, [0, 1], comm, rank, world, dir=2)
+assert Counting.calls == 1, Counting.calls                    # phases and min gaps travel in one buffer
 full3, gaps3 = orc.solve_on_grid(m3, mesh3, start3, vectorised=True)
 assert ph.shape == (6, 4) and np.array_equal(ph, orc.berry_phase(full3, 3, [0, 1], 2, contin=False))
 assert np.max(np.abs(gaps - gaps3)) < 1e-12
