@@ -42,6 +42,8 @@ static void knobs_parse() {
     geti("TBK_QLW_WS_MB", k.qlw_ws_mb);
     getl("TBK_QLW_CAP", k.qlw_cap);
     geti("TBK_QL16_EVONLY", k.ql16_evonly);
+    geti("TBK_TW16", k.tw16);
+    if (const char* e = getenv("TBK_TW16_GAPTOL")) k.tw16_gaptol = atof(e);
     geti("TBK_QL16_SPLIT", k.ql16_split);
     getl("TBK_QL16_SPLIT_MIN", k.ql16_split_min);
     getl("TBK_QL16_MIN", k.ql16_min);

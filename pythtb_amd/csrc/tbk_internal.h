@@ -49,6 +49,8 @@ struct TbkKnobs {
     int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal path in MiB (default 4096)
     int ql16_split = 1;         // TBK_QL16_SPLIT    0: n = 9..16 with eigenvectors in the single kernel instead of three (tridiagonalise | lane-per-matrix QL, recorded | replay)
     long long ql16_split_min = -1;  // TBK_QL16_SPLIT_MIN  smallest batch that takes the three-kernel form (default 8192)
+    int tw16 = 1;               // TBK_TW16          0: n = 9..16 with eigenvectors through the QL-replay three-kernel form instead of twisted-factorisation vectors
+    double tw16_gaptol = 1e-5;  // TBK_TW16_GAPTOL   relative eigenvalue gap (of one unreduced block) below which a matrix is solved again by QL replay
     int ql16_evonly = 1;        // TBK_QL16_EVONLY   0: eigenvalue-only n = 9..16 lists through the single replicated kernel instead of tridiagonalise + lane-per-matrix QL
     long long few_max = -1;     // TBK_FEW_MAX       largest n < 22 batch that gets a workgroup per matrix
     int few_warm = 1;           // TBK_FEW_WARM      0: workgroup solver always starts cold

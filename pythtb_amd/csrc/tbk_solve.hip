@@ -1364,6 +1364,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 #include "tbk_solve_reg.inl"   // n = 5..8: register-resident cyclic Jacobi, 1/2/4 lanes per matrix
 #include "tbk_solve_row16.inl" // n = 15, 16 on lists: one DPP row of 16 lanes per matrix, rows of A in registers
 #include "tbk_solve_ql16.inl"  // n = 9..16: Householder + implicit QL in registers, one DPP row of 16 lanes per matrix
+#include "tbk_solve_tw16.inl"  // n = 9..16 with eigenvectors, large batches: tridiagonalise | eigenvalues | twisted-factorisation vectors (MFMA Newton-Schulz) + back-transformation
 #include "tbk_solve_trig.inl"  // eigenvalues only, n = 65..1024: Householder with A in L2, then one thread per eigenvalue (bisection)
 #include "tbk_solve_qlw.inl"   // n = 17..64, large batches: Householder in LDS, lane-per-matrix QL, rotation replay
 #include "tbk_solve_blk.inl"   // batches of wide matrices: block Jacobi, 16x16 subproblems through k_solve_row16

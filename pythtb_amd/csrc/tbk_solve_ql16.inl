@@ -289,13 +289,20 @@ struct Ql16Rec {
     int scap;
 };
 
+// LIST MODE (list != nullptr; tbk_solve_tw16.inl's fallback): the launch covers the *count matrices id0 + list[0 .. *count) of
+// the chunk (count is read on the device: the grid is sized for the whole chunk and the surplus blocks leave at once);
+// workspace entries are indexed by the position in the list; the mesh's minimum gaps have been taken already.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_ql16_lanes(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
                                                     const double2* __restrict__ de, double* __restrict__ eval, const GridArgs G,
-                                                    const Ql16Rec R, int* flags) {
+                                                    const Ql16Rec R, int* flags, const int* __restrict__ list = nullptr,
+                                                    const int* __restrict__ count = nullptr) {
     const int64_t idc = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool has = idc < nc;
-    const int64_t ic = has ? idc : nc - 1;
+    const int64_t nhave = list ? (int64_t)*count : nc;
+    if ((int64_t)blockIdx.x * 256 >= nhave) return;
+    const bool has = idc < nhave;
+    const int64_t ic = has ? idc : nhave - 1;
+    const int64_t mat_out = id0 + (list ? (int64_t)list[ic] : idc);
     double d[16], e[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(256) void k_ql16_lanes(const int n, const int64_t n
 #pragma unroll
         for (int a = 0; a < 16; ++a) v = (a < n && rk[a] == r) ? d[a] : v;
         if constexpr (MODE == 1) {
-            if (r > 0) {
+            if (r > 0 && list == nullptr) {
                 double gap = has ? v - prev : INFINITY;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) gap = fmin(gap, __shfl_xor(gap, o));
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256) void k_ql16_lanes(const int n, const int64_t n
             }
             prev = v;
         } else {
-            if (has) eval[(int64_t)r * nk + id0 + idc] = v;
+            if (has) eval[(int64_t)r * nk + mat_out] = v;
         }
     }
 }
@@ -402,12 +409,15 @@ __device__ __forceinline__ void ql16_replay_pos(cd (&z)[16], const double2 mine,
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_ql16_replay(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
-                                                      const Ql16Rec R, cd* __restrict__ evec, const WfsView wv) {
+                                                      const Ql16Rec R, cd* __restrict__ evec, const WfsView wv,
+                                                      const int* __restrict__ list = nullptr, const int* __restrict__ count = nullptr) {
     const int lane = threadIdx.x & 63;
     const int x = lane & 15;
     const int64_t idc0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const bool live = idc0 < nc;
-    const int64_t idc = live ? idc0 : nc - 1, id = id0 + idc;
+    const int64_t nhave = list ? (int64_t)*count : nc;
+    if ((int64_t)blockIdx.x * 16 >= nhave) return;
+    const bool live = idc0 < nhave;
+    const int64_t idc = live ? idc0 : nhave - 1, id = id0 + (list ? (int64_t)list[idc] : idc);
     const bool real_row = x < n;
     const int xr = real_row ? x : n - 1;
     cd z[16];
@@ -460,16 +470,29 @@ __global__ __launch_bounds__(256) void k_ql16_replay(const int n, const int64_t 
 template <int MODE, bool VEC, int STAGE = 0>
 __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G,
                                                      int* noconv_flag, double2* __restrict__ de = nullptr, const int64_t id0 = 0,
-                                                     const int64_t nc = 0) {
+                                                     const int64_t nc = 0, const int* __restrict__ list = nullptr,
+                                                     const int* __restrict__ count = nullptr) {
     static_assert(STAGE != 1 || !VEC, "k_solve_ql16: stage 1 is the eigenvalue-only form");
     static_assert(STAGE != 2 || VEC, "k_solve_ql16: stage 2 is the eigenvector form");
     const int lane = threadIdx.x & 63;
     const int x = lane & 15;
     const int rowbase4 = (lane & 48) * 4;
-    const int64_t mat = id0 + (((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4);
-    const int64_t nend = STAGE == 0 ? nk : id0 + nc;
-    const bool live = mat < nend;
-    const int64_t id = live ? mat : nend - 1;   // idle tail rows shadow the last point
+    int64_t wslot = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;   // workspace entry of this matrix (stages 1, 2)
+    bool live;
+    int64_t id;
+    if (list != nullptr) {                      // list mode (see k_ql16_lanes): the matrices id0 + list[0 .. *count)
+        const int64_t cnt = *count;
+        if ((int64_t)blockIdx.x * 16 >= cnt) return;
+        live = wslot < cnt;
+        wslot = live ? wslot : cnt - 1;
+        id = id0 + list[wslot];
+    } else {
+        const int64_t mat = id0 + wslot;
+        const int64_t nend = STAGE == 0 ? nk : id0 + nc;
+        live = mat < nend;
+        id = live ? mat : nend - 1;             // idle tail rows shadow the last point
+        wslot = id - id0;
+    }
     const int n = mv.nsta;
     const bool real_row = x < n;
     double kk[4] = {0.0, 0.0, 0.0, 0.0};
@@ -561,7 +584,7 @@ __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const in
     double dd = sel16<0>(a, x, cd{0.0, 0.0}).x;          // d_x = A[x][x]
 
     if constexpr (STAGE != 0) {
-        if (live) de[(int64_t)x * nc + (id - id0)] = double2{dd, x < 15 ? ee : 0.0};
+        if (live) de[(int64_t)x * nc + wslot] = double2{dd, x < 15 ? ee : 0.0};
         if constexpr (STAGE == 2) {
             if (live && real_row) {
                 cd f{1.0, 0.0};
@@ -679,6 +702,10 @@ __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const in
     }
 }
 
+// tbk_solve_tw16.inl: tridiagonalise | eigenvalues | twisted-factorisation eigenvectors + back-transformation
+template <int MODE>
+static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G);
+
 template <int MODE, bool VEC>
 static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G, int64_t nk_eff) {
     TBK_REQUIRE(nk * 16 < (int64_t)0x7fffffff * 256, TBK_EUNSUPPORTED, "too many k-points for one launch");
@@ -711,6 +738,7 @@ static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
         const TbkKnobs& K = tbk_knobs();
         // (decided on the size of the GLOBAL mesh: every window of an array takes the same route)
         if (K.ql16_split != 0 && !ctx->qlw_off && nk_eff >= (K.ql16_split_min >= 0 ? K.ql16_split_min : 8192)) {
+            if (K.tw16 != 0) return launch_tw16<MODE>(ctx, mv, nk, L, G);
             // sweeps recorded per matrix (~35 are typical at n = 16; LAPACK gives up at 480).  A matrix that needs more makes the
             // caller repeat the batch on the single kernel (TBK_QLW_CAP: tests provoke that)
             const int scap = K.qlw_cap > 0 ? (int)std::max<long long>(1, std::min<long long>(64, K.qlw_cap / 16)) : 64;
