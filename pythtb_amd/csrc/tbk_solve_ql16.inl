@@ -290,16 +290,14 @@ struct Ql16Rec {
 };
 
 // LIST MODE (list != nullptr; tbk_solve_tw16.inl's fallback): the launch covers the *count matrices id0 + list[0 .. *count) of
-// the chunk (count is read on the device: the grid is sized for the whole chunk and the surplus blocks leave at once);
-// workspace entries are indexed by the position in the list; the mesh's minimum gaps have been taken already.
+// the chunk.  count is read on the device, so the grid is a fixed small one whose blocks stride over the list (an empty
+// list costs a few idle blocks); workspace entries are indexed by the position in the list; the mesh's minimum gaps have
+// been taken already.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ql16_lanes(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
-                                                    const double2* __restrict__ de, double* __restrict__ eval, const GridArgs G,
-                                                    const Ql16Rec R, int* flags, const int* __restrict__ list = nullptr,
-                                                    const int* __restrict__ count = nullptr) {
-    const int64_t idc = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t nhave = list ? (int64_t)*count : nc;
-    if ((int64_t)blockIdx.x * 256 >= nhave) return;
+__device__ __forceinline__ void ql16_lanes_body(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
+                                                const double2* __restrict__ de, double* __restrict__ eval, const GridArgs& G,
+                                                const Ql16Rec& R, int* flags, const int* __restrict__ list, const int64_t nhave,
+                                                const int64_t idc) {
     const bool has = idc < nhave;
     const int64_t ic = has ? idc : nhave - 1;
     const int64_t mat_out = id0 + (list ? (int64_t)list[ic] : idc);
@@ -395,6 +393,20 @@ __global__ __launch_bounds__(256) void k_ql16_lanes(const int n, const int64_t n
     }
 }
 
+template <int MODE, bool LIST = false>
+__global__ __launch_bounds__(256) void k_ql16_lanes(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
+                                                    const double2* __restrict__ de, double* __restrict__ eval, const GridArgs G,
+                                                    const Ql16Rec R, int* flags, const int* __restrict__ list = nullptr,
+                                                    const int* __restrict__ count = nullptr) {
+    if constexpr (!LIST) {
+        ql16_lanes_body<MODE>(n, nk, id0, nc, de, eval, G, R, flags, nullptr, nc, (int64_t)blockIdx.x * 256 + threadIdx.x);
+        return;
+    }
+    const int64_t nhave = *count;
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < nhave; base += (int64_t)gridDim.x * 256)
+        ql16_lanes_body<MODE>(n, nk, id0, nc, de, eval, G, R, flags, list, nhave, base + threadIdx.x);
+}
+
 // position I of a recorded sweep over [lo, m): lane x of the matrix loaded the rotation of position x into `mine`
 template <int I>
 __device__ __forceinline__ void ql16_replay_pos(cd (&z)[16], const double2 mine, const bool on, const int lo, const int m) {
@@ -408,14 +420,11 @@ __device__ __forceinline__ void ql16_replay_pos(cd (&z)[16], const double2 mine,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ql16_replay(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
-                                                      const Ql16Rec R, cd* __restrict__ evec, const WfsView wv,
-                                                      const int* __restrict__ list = nullptr, const int* __restrict__ count = nullptr) {
+__device__ __forceinline__ void ql16_replay_body(const int n, const int64_t nk, const int64_t id0, const int64_t nc, const Ql16Rec& R,
+                                                 cd* __restrict__ evec, const WfsView& wv, const int* __restrict__ list,
+                                                 const int64_t nhave, const int64_t idc0) {
     const int lane = threadIdx.x & 63;
     const int x = lane & 15;
-    const int64_t idc0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const int64_t nhave = list ? (int64_t)*count : nc;
-    if ((int64_t)blockIdx.x * 16 >= nhave) return;
     const bool live = idc0 < nhave;
     const int64_t idc = live ? idc0 : nhave - 1, id = id0 + (list ? (int64_t)list[idc] : idc);
     const bool real_row = x < n;
@@ -463,36 +472,32 @@ __global__ __launch_bounds__(256) void k_ql16_replay(const int n, const int64_t 
     }
 }
 
+template <int MODE, bool LIST = false>
+__global__ __launch_bounds__(256) void k_ql16_replay(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
+                                                      const Ql16Rec R, cd* __restrict__ evec, const WfsView wv,
+                                                      const int* __restrict__ list = nullptr, const int* __restrict__ count = nullptr) {
+    if constexpr (!LIST) {
+        ql16_replay_body<MODE>(n, nk, id0, nc, R, evec, wv, nullptr, nc, ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4);
+        return;
+    }
+    const int64_t nhave = *count;
+    for (int64_t base = (int64_t)blockIdx.x * 16; base < nhave; base += (int64_t)gridDim.x * 16)
+        ql16_replay_body<MODE>(n, nk, id0, nc, R, evec, wv, list, nhave, base + (threadIdx.x >> 4));
+}
+
 // MODE 0: k list, 1: regular mesh into a wf_array (+ min gaps), 2: supplied matrices
 // STAGE 0: the whole solve.  STAGE 1 (eigenvalues only): stop after the tridiagonalisation, de[j * nc + (id - id0)] = (d_j, e_j).
 // STAGE 2 (with eigenvectors, three-kernel form): the same, and Z = H_0 ... H_13 D goes to the output array in column order
 // (band slot b = column b) for k_ql16_replay.  The launch covers the matrices [id0, id0 + nc) of the batch of nk.
-template <int MODE, bool VEC, int STAGE = 0>
-__global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G,
-                                                     int* noconv_flag, double2* __restrict__ de = nullptr, const int64_t id0 = 0,
-                                                     const int64_t nc = 0, const int* __restrict__ list = nullptr,
-                                                     const int* __restrict__ count = nullptr) {
+template <int MODE, bool VEC, int STAGE>
+__device__ __forceinline__ void ql16_solve_body(const ModelView& mv, const int64_t nk, const ListArgs& Lst, const GridArgs& G,
+                                                int* noconv_flag, double2* __restrict__ de, const int64_t id0, const int64_t nc,
+                                                const int64_t wslot, const bool live, const int64_t id) {
     static_assert(STAGE != 1 || !VEC, "k_solve_ql16: stage 1 is the eigenvalue-only form");
     static_assert(STAGE != 2 || VEC, "k_solve_ql16: stage 2 is the eigenvector form");
     const int lane = threadIdx.x & 63;
     const int x = lane & 15;
     const int rowbase4 = (lane & 48) * 4;
-    int64_t wslot = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;   // workspace entry of this matrix (stages 1, 2)
-    bool live;
-    int64_t id;
-    if (list != nullptr) {                      // list mode (see k_ql16_lanes): the matrices id0 + list[0 .. *count)
-        const int64_t cnt = *count;
-        if ((int64_t)blockIdx.x * 16 >= cnt) return;
-        live = wslot < cnt;
-        wslot = live ? wslot : cnt - 1;
-        id = id0 + list[wslot];
-    } else {
-        const int64_t mat = id0 + wslot;
-        const int64_t nend = STAGE == 0 ? nk : id0 + nc;
-        live = mat < nend;
-        id = live ? mat : nend - 1;             // idle tail rows shadow the last point
-        wslot = id - id0;
-    }
     const int n = mv.nsta;
     const bool real_row = x < n;
     double kk[4] = {0.0, 0.0, 0.0, 0.0};
@@ -699,6 +704,29 @@ __global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const in
                 }
             }
         }
+    }
+}
+
+template <int MODE, bool VEC, int STAGE = 0, bool LIST = false>
+__global__ __launch_bounds__(256) void k_solve_ql16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G,
+                                                     int* noconv_flag, double2* __restrict__ de = nullptr, const int64_t id0 = 0,
+                                                     const int64_t nc = 0, const int* __restrict__ list = nullptr,
+                                                     const int* __restrict__ count = nullptr) {
+    if constexpr (!LIST) {
+        const int64_t mat = id0 + (((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4);
+        const int64_t nend = STAGE == 0 ? nk : id0 + nc;
+        const bool live = mat < nend;
+        const int64_t id = live ? mat : nend - 1;   // idle tail rows shadow the last point
+        ql16_solve_body<MODE, VEC, STAGE>(mv, nk, Lst, G, noconv_flag, de, id0, nc, id - id0, live, id);
+        return;
+    }
+    // list mode (see k_ql16_lanes): the matrices id0 + list[0 .. *count), workspace entries by position in the list
+    const int64_t cnt = *count;
+    for (int64_t base = (int64_t)blockIdx.x * 16; base < cnt; base += (int64_t)gridDim.x * 16) {
+        const int64_t w0 = base + (threadIdx.x >> 4);
+        const bool live = w0 < cnt;
+        const int64_t w = live ? w0 : cnt - 1;
+        ql16_solve_body<MODE, VEC, STAGE>(mv, nk, Lst, G, noconv_flag, de, id0, nc, w, live, id0 + list[w]);
     }
 }
 

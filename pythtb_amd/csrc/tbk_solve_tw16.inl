@@ -138,20 +138,15 @@ __global__ __launch_bounds__(256) void k_tw16_tridiag(const ModelView mv, const 
             const int lo = x < c ? x : c, hi = x < c ? c : x;
             sidx[c] = real_row && c < n ? lo * n - lo * (lo - 1) / 2 + (hi - lo) : -1;
         }
-        for (int base = 0; base < mv.nR; base += 16) {
-            const int mine = base + x;
-            const cd ph = mine < mv.nR ? phase_of_R(zk, mv.rvec[mine]) : cd{0.0, 0.0};
-            cd phs[16];
-            row16_bcast_phase<0>(ph, phs);
+        // (every lane forms the phase of every lattice vector itself -- a few complex products with wave-uniform loop counts --
+        // instead of sixteen lanes forming one each and broadcasting them: the broadcast array cost 64 registers, the
+        // difference between two and three wavefronts per SIMD for this kernel)
+        for (int r = 0; r < mv.nR; ++r) {
+            const cd ph = phase_of_R(zk, mv.rvec[r]);
+            const cd* u = mv.rblock + (size_t)r * mv.nslot;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (base + j < mv.nR) {
-                    const cd* u = mv.rblock + (size_t)(base + j) * mv.nslot;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c)
-                        if (sidx[c] >= 0) cfma(a[c], u[sidx[c]], phs[j]);
-                }
-            }
+            for (int c = 0; c < 16; ++c)
+                if (sidx[c] >= 0) cfma(a[c], u[sidx[c]], ph);
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -197,7 +192,7 @@ __global__ __launch_bounds__(256) void k_tw16_tridiag(const ModelView mv, const 
 // ---- 2. eigenvalues of T, one lane per matrix.  lam[j * nc + slot] = eigenvalue left at position j;
 // meta[slot] = {ranks of positions 0..7 (4 bits each), of positions 8..15, split mask (bit i: e_i negligible in T), flagged}
 template <int MODE>
-__global__ __launch_bounds__(256) void k_tw16_eigvals(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
+__global__ __launch_bounds__(256, 3) void k_tw16_eigvals(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
                                                       const double2* __restrict__ de, double* __restrict__ eval, const GridArgs G,
                                                       double* __restrict__ lam, uint4* __restrict__ meta, int* __restrict__ list,
                                                       int* __restrict__ count, int* flags, const double gaptol) {
@@ -650,14 +645,16 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
             hipLaunchKernelGGL((k_tw16_vectors<MODE>), dim3(b16), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, mv, L, G, (const double2*)de,
                                (const double*)lam, (const uint4*)meta, (const cd*)refl, list, count);
         }
-        // the listed matrices once more, by QL with replayed rotations (grids sized for the chunk; surplus blocks leave at once)
+        // the listed matrices once more, by QL with replayed rotations: the count stays on the device, so these are small fixed
+        // grids whose blocks stride over the list (an empty list costs three launches of idle blocks)
         {
             ProfScope ps(ctx, "tw16_fallback");
-            hipLaunchKernelGGL((k_solve_ql16<MODE, true, 2>), dim3(b16), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev, de, id0, nc,
+            const unsigned f16 = std::min<unsigned>(b16, 4u * (unsigned)ctx->cus), f1 = std::min<unsigned>(b1, 4u * (unsigned)ctx->cus);
+            hipLaunchKernelGGL((k_solve_ql16<MODE, true, 2, true>), dim3(f16), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev, de, id0, nc,
                                (const int*)list, (const int*)count);
-            hipLaunchKernelGGL((k_ql16_lanes<MODE>), dim3(b1), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, (const double2*)de, L.eval, G, R,
+            hipLaunchKernelGGL((k_ql16_lanes<MODE, true>), dim3(f1), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, (const double2*)de, L.eval, G, R,
                                ctx->flags_dev, (const int*)list, (const int*)count);
-            hipLaunchKernelGGL((k_ql16_replay<MODE>), dim3(b16), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, R, evec, G.wv, (const int*)list,
+            hipLaunchKernelGGL((k_ql16_replay<MODE, true>), dim3(f16), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, R, evec, G.wv, (const int*)list,
                                (const int*)count);
         }
     }

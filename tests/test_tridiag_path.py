@@ -267,8 +267,8 @@ def test_sweep_record_overflow_of_the_16_lane_form_falls_back(tb):
     n, nk = 14, 300
     h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
     h = h + h.conj().transpose(0, 2, 1)
-    with _lib.knob("TBK_QL16_MIN", 0), _lib.knob("TBK_QL16_SPLIT_MIN", 0):
-        ev3, v3 = _eigh_batch(h)                                   # three kernels
+    with _lib.knob("TBK_QL16_MIN", 0), _lib.knob("TBK_QL16_SPLIT_MIN", 0), _lib.knob("TBK_TW16", 0):
+        ev3, v3 = _eigh_batch(h)                                   # three kernels (the QL-replay form)
         with _lib.knob("TBK_QLW_CAP", 64):
             ev_f, v_f = _eigh_batch(h)                             # overflow -> repeated on the single kernel
         with _lib.knob("TBK_QL16_SPLIT", 0):
@@ -281,14 +281,16 @@ def test_sweep_record_overflow_of_the_16_lane_form_falls_back(tb):
     assert max(np.max(np.abs(V[i].conj() @ V[i].T - np.identity(n))) for i in range(nk)) < 1e-13
 
 
-def test_three_kernel_16_lane_form_on_a_mesh(tb):
-    """cubic16 on a small 3-D mesh forced through tridiagonalise | lane-per-matrix QL | replay: gaps and Berry phases against
+@pytest.mark.parametrize("tw16", [0, 1])
+def test_three_kernel_16_lane_form_on_a_mesh(tb, tw16):
+    """cubic16 on a small 3-D mesh forced through the three-kernel forms -- tridiagonalise | lane-per-matrix QL | replay (tw16 = 0)
+    and tridiagonalise | eigenvalues | twisted-factorisation vectors (tw16 = 1, tbk_solve_tw16.inl): gaps and Berry phases against
     the oracle, the single kernel's eigenvalue gaps, and bit-identical shard windows (the route is decided on the global mesh)."""
     from oracle import tb_oracle as orc
     from pythtb_amd import _lib, shard
     m = hp.cubic16(tb.tb_model)
     mesh, start = [7, 6, 9], [0.05, -0.1, 0.2]
-    with _lib.knob("TBK_QL16_MIN", 0), _lib.knob("TBK_QL16_SPLIT_MIN", 0):
+    with _lib.knob("TBK_QL16_MIN", 0), _lib.knob("TBK_QL16_SPLIT_MIN", 0), _lib.knob("TBK_TW16", tw16):
         w = tb.wf_array(m, mesh)
         gaps = w.solve_on_grid(start)
         host = w.to_host().copy()

@@ -1,0 +1,181 @@
+"""n = 9..16 states with eigenvectors on chip-filling batches: tridiagonalise | eigenvalues | twisted-factorisation vectors +
+MFMA Newton-Schulz + back-transformation (pythtb_amd/csrc/tbk_solve_tw16.inl), the path config E's solve_on_grid takes.
+The reference runs numpy.linalg.eigh per matrix (pythtb.py:939-947): eigenvalues, residuals and orthonormality against it;
+the near-degenerate matrices the path hands to the QL-replay kernels; the bits of that fallback."""
+import numpy as np
+import pytest
+
+import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tb():
+    import pythtb_amd
+    return pythtb_amd
+
+
+def _eigh_batch(h):
+    from pythtb_amd import _lib
+    ctx = _lib.default_context()
+    nk, n, _ = h.shape
+    ev, vec = np.zeros((n, nk)), np.zeros((n, nk, n), dtype=complex)
+    hc = np.ascontiguousarray(h)
+    _lib.check(_lib.lib.tbk_eigh_batch(ctx.handle, n, _lib.dptr(hc.view(float)), nk, _lib.dptr(ev), _lib.dptr(vec.view(float))))
+    return ev, vec
+
+
+def _quality(h, ev, vec):
+    n, nk = ev.shape
+    V = vec.transpose(1, 0, 2)
+    ref = np.linalg.eigvalsh(h)
+    nrm = np.maximum(np.abs(ref).max(axis=1), 1e-300)
+    res = np.abs(np.einsum("kij,kbj->kbi", h, V) - V * ev.T[:, :, None]).reshape(nk, -1).max(axis=1) / nrm
+    orth = np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.eye(n)).reshape(nk, -1).max(axis=1)
+    return (np.abs(ev.T - ref).max(axis=1) / nrm).max(), res.max(), orth.max()
+
+
+def _forced():
+    """every size onto the twisted path: no Jacobi for small batches, three-kernel forms from the first matrix"""
+    import contextlib
+    from pythtb_amd import _lib
+    st = contextlib.ExitStack()
+    st.enter_context(_lib.knob("TBK_QL16_MIN", 0))
+    st.enter_context(_lib.knob("TBK_QL16_SPLIT_MIN", 0))
+    return st
+
+
+def special_matrices(n, rng):
+    """the structures the twisted factorisation has to survive"""
+    out = []
+    out.append(np.zeros((n, n), dtype=complex))                                       # zero matrix: T splits everywhere
+    out.append(np.diag(np.arange(n, dtype=float)).astype(complex))                   # diagonal
+    out.append(np.diag([1.0] * (n // 2) + [2.0] * (n - n // 2)).astype(complex))     # two exactly repeated levels
+    a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    a = a + a.conj().T
+    b = a.copy()
+    b[: n // 2, n // 2:] = 0
+    b[n // 2:, : n // 2] = 0
+    out.append(b)                                                                     # block diagonal
+    c = a.copy()
+    c[: n // 2, n // 2:] *= 1e-9
+    c[n // 2:, : n // 2] *= 1e-9
+    out.append(c)                                                                     # weakly coupled blocks
+    u = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0]
+    pairs = u @ np.diag(np.repeat(np.arange(n // 2 + 1, dtype=float), 2)[:n]) @ u.conj().T
+    out.append(0.5 * (pairs + pairs.conj().T))                                        # exact pairs (Kramers-like)
+    near = u @ np.diag(np.arange(n, dtype=float) + np.where(np.arange(n) % 2, 1e-7 - 1.0, 0.0)) @ u.conj().T
+    out.append(0.5 * (near + near.conj().T))                                          # pairs split by 1e-7
+    t = np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1)
+    out.append(t.astype(complex))                                                     # already tridiagonal (Toeplitz)
+    w = np.diag(np.abs(np.arange(n) - (n - 1) / 2.0)) + t                             # Wilkinson-like: pairs agreeing to many digits
+    out.append(w.astype(complex))
+    out.append((a * 1e-150))                                                          # tiny scale
+    out.append((a * 1e+120))                                                          # huge scale
+    return out
+
+
+@pytest.mark.parametrize("n", [9, 10, 12, 13, 15, 16])
+def test_supplied_matrices_against_lapack(tb, n):
+    rng = np.random.default_rng(100 + n)
+    nk = 3000
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    sp = special_matrices(n, rng)
+    h[:len(sp)] = np.array(sp)
+    with _forced():
+        ev, vec = _eigh_batch(h)
+        ev2, vec2 = _eigh_batch(h)
+    assert np.isfinite(vec).all()
+    assert np.array_equal(ev, ev2) and np.array_equal(vec, vec2)                      # run to run: the same bits
+    e_err, res, orth = _quality(h, ev, vec)
+    assert e_err < 1e-14 and res < 2e-14 and orth < 2e-14, (e_err, res, orth)
+    assert np.all(np.diff(ev, axis=0) >= 0.0)
+    # each special case on its own, so that one of them cannot hide behind the maximum
+    for i in range(len(sp)):
+        q = _quality(h[i:i + 1], ev[:, i:i + 1], vec[:, i:i + 1])
+        assert max(q) < 2e-14, (i, q)
+
+
+def test_every_matrix_listed_equals_the_ql_replay_form_bit_for_bit(tb):
+    """TBK_TW16_GAPTOL = 1e300 lists every matrix: the result is the QL-replay kernels' own (TBK_TW16=0), bit for bit; and a
+    threshold of 0 lists none but the residual failures -- exact pairs still come out orthonormal (their T splits)."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(7)
+    n, nk = 16, 2500
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    sp = special_matrices(n, rng)
+    h[:len(sp)] = np.array(sp)
+    with _forced():
+        with _lib.knob("TBK_TW16", 0):
+            ev0, v0 = _eigh_batch(h)
+        with _lib.knob("TBK_TW16_GAPTOL", "1e300"):
+            ev1, v1 = _eigh_batch(h)
+        ev2, v2 = _eigh_batch(h)
+    assert np.array_equal(ev0, ev1) and np.array_equal(v0, v1)
+    assert max(_quality(h, ev2, v2)) < 2e-14
+    # where the two forms differ they differ by rounding only (eigenvalues), and the unlisted vectors are not the replay's bits
+    assert np.max(np.abs(ev2 - ev0).max(axis=0) / np.maximum(np.abs(ev0).max(axis=0), 1e-300)) < 1e-13
+    assert not np.array_equal(v2[:, len(sp):], v0[:, len(sp):])
+
+
+def test_listed_matrices_overflowing_the_sweep_record_fall_back_to_the_single_kernel(tb):
+    """the fallback's rotation record holds TBK_QLW_CAP / 16 sweeps per listed matrix; when that overflows, the call is repeated
+    on the single kernel like the QL-replay form's own overflow (same bits as TBK_QL16_SPLIT=0)."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(21)
+    n, nk = 14, 300
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    with _forced():
+        with _lib.knob("TBK_TW16_GAPTOL", "1e300"), _lib.knob("TBK_QLW_CAP", 64):
+            ev_f, v_f = _eigh_batch(h)
+        with _lib.knob("TBK_QL16_SPLIT", 0):
+            ev1, v1 = _eigh_batch(h)
+    assert np.array_equal(ev_f, ev1) and np.array_equal(v_f, v1)
+
+
+def test_k_list_and_mesh_windows(tb):
+    """cubic16 (config E's model): solve_all with eigenvectors on a k list against numpy on _gen_ham's matrices, and
+    solve_on_grid windows of one global mesh -- every point is solved on its own, so windows repeat the full solve bit for bit."""
+    from pythtb_amd import _lib
+    m = hp.cubic16(tb.tb_model)
+    rng = np.random.default_rng(3)
+    k = rng.random((700, 3))
+    with _forced():
+        ev, vec = m.solve_all(k, eig_vectors=True)
+        mesh, start = [9, 7, 12], [0.1, -0.2, 0.05]
+        w = tb.wf_array(m, mesh)
+        gaps = w.solve_on_grid(start)
+        host = w.to_host().copy()
+        for off, sub in (([0, 0, 0], [4, 7, 12]), ([3, 2, 5], [6, 5, 7]), ([8, 6, 11], [1 + 0, 1 + 0, 1 + 0])):
+            sub = [max(2, s) for s in sub]
+            off = [min(o, mesh[d] - sub[d]) for d, o in enumerate(off)]
+            ww = tb.wf_array(m, sub)
+            ww.solve_on_grid_window(start, off, mesh)
+            sl = tuple(slice(o, o + s) for o, s in zip(off, sub))
+            assert np.array_equal(ww.to_host(), host[sl])
+    H = np.array([m._gen_ham(kk) for kk in k[::7]])
+    q = _quality(H, ev[:, ::7], vec[:, ::7, :])
+    assert max(q) < 2e-14, q
+    V = host.reshape(-1, 16, 16)
+    assert max(np.max(np.abs(v.conj() @ v.T - np.identity(16))) for v in V) < 1e-13
+    assert gaps.shape == (15,) and gaps[7] > 0.3
+
+
+def test_padded_sizes_on_a_mesh_against_the_oracle(tb):
+    """n = 11 (five padding rows): gaps and Berry phases of a random 11-orbital model against the oracle."""
+    from oracle import tb_oracle as orc
+    m = hp.random_model(tb.tb_model, 11, 2, 1, 31)
+    mesh, start = [13, 17], [0.0, 0.3]
+    with _forced():
+        w = tb.wf_array(m, mesh)
+        gaps = w.solve_on_grid(start)
+        ph = w.berry_phase(range(5), 1, contin=False)
+    owfs, ogaps = orc.solve_on_grid(m, mesh, start, vectorised=True)
+    assert np.max(np.abs(gaps - ogaps)) < 1e-12
+    oph = orc.berry_phase(owfs, 2, list(range(5)), 1, contin=False)
+    if np.min(ogaps[4]) > 1e-3:                       # (the occupied set must be separated for its phase to be defined)
+        assert np.max(np.abs(np.angle(np.exp(1j * (np.asarray(ph) - np.asarray(oph)))))) < 1e-9
