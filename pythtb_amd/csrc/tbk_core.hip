@@ -43,6 +43,7 @@ static void knobs_parse() {
     getl("TBK_QLW_CAP", k.qlw_cap);
     geti("TBK_QL16_EVONLY", k.ql16_evonly);
     geti("TBK_TW16", k.tw16);
+    geti("TBK_TW16_STREAMS", k.tw16_streams);
     if (const char* e = getenv("TBK_TW16_GAPTOL")) k.tw16_gaptol = atof(e);
     geti("TBK_QL16_SPLIT", k.ql16_split);
     getl("TBK_QL16_SPLIT_MIN", k.ql16_split_min);
@@ -135,6 +136,10 @@ extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
     if (c->work) hipFree(c->work);
     hipEventDestroy(c->timer0);
     hipEventDestroy(c->timer1);
+    for (int i = 0; i < 3; ++i)
+        if (c->side[i]) hipStreamDestroy(c->side[i]);
+    for (int i = 0; i < 4; ++i)
+        if (c->side_ev[i]) hipEventDestroy(c->side_ev[i]);
     hipStreamDestroy(c->stream);
     delete c;
     return TBK_OK;
@@ -246,7 +251,7 @@ static hipEvent_t prof_event(tbk_ctx* c) {
 }
 
 ProfScope::ProfScope(tbk_ctx* c, const char* n) : ctx(c), name(n) {
-    if (ctx->prof_period > 0 && (ctx->prof_tick++ % (unsigned)ctx->prof_period) == 0) {
+    if (ctx && ctx->prof_period > 0 && (ctx->prof_tick++ % (unsigned)ctx->prof_period) == 0) {   // (null ctx: no bracket)
         t0 = prof_event(ctx);
         t1 = prof_event(ctx);
         hipEventRecord(t0, ctx->stream);

@@ -49,6 +49,7 @@ struct TbkKnobs {
     int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal path in MiB (default 4096)
     int ql16_split = 1;         // TBK_QL16_SPLIT    0: n = 9..16 with eigenvectors in the single kernel instead of three (tridiagonalise | lane-per-matrix QL, recorded | replay)
     long long ql16_split_min = -1;  // TBK_QL16_SPLIT_MIN  smallest batch that takes the three-kernel form (default 8192)
+    int tw16_streams = -1;      // TBK_TW16_STREAMS  chunks of the twisted-factorisation path in flight at once, 1..3 (default 3; 1 = the context's own stream alone, with per-kernel brackets)
     int tw16 = 1;               // TBK_TW16          0: n = 9..16 with eigenvectors through the QL-replay three-kernel form instead of twisted-factorisation vectors
     double tw16_gaptol = 1e-5;  // TBK_TW16_GAPTOL   relative eigenvalue gap (of one unreduced block) below which a matrix is solved again by QL replay
     int ql16_evonly = 1;        // TBK_QL16_EVONLY   0: eigenvalue-only n = 9..16 lists through the single replicated kernel instead of tridiagonalise + lane-per-matrix QL
@@ -129,6 +130,10 @@ struct tbk_ctx {
     int cus = 0;
     bool qlw_off = false;  // set while a solve is repeated on the Jacobi kernels (the QL rotation record overflowed)
     hipStream_t stream = nullptr;
+    // side streams of the chunked n = 9..16 solve (tbk_solve_tw16.inl): chunks alternate between them so that one chunk's
+    // latency-bound eigenvalue kernel runs beside its neighbours' throughput-bound ones; created on first use
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0]: fork point on `stream`; [1..3]: each side stream's end
     hipEvent_t timer0 = nullptr, timer1 = nullptr;
     int prof_period = 0;   // 0 off, 1 bracket every launch, N bracket every Nth launch
     unsigned prof_tick = 0;

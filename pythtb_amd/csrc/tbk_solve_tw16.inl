@@ -38,27 +38,34 @@
 __host__ __device__ constexpr int tw16_off(const int K) { return 15 * K - K * (K - 1) / 2; }   // first element of u_K
 
 typedef double tw_d4 __attribute__((ext_vector_type(4)));
+// the LDS regions of these kernels are private to a wavefront, whose LDS operations execute in order: no barriers, no waits;
+// only the compiler has to keep the order (the views of a region differ in type)
+#define TW_LDS_ORDER() asm volatile("" ::: "memory")
 
-// ---- Householder step K on the rows of A alone; us = sqrt(beta) u_x of this lane (0 for x <= K or when nothing is reflected)
+// ---- Householder step K on the rows of A alone; us = sqrt(beta) u_x of this lane (0 for x <= K or when nothing is reflected).
+// u and q reach the other rows through LDS: every lane stores its element once (16 bytes) and reads the elements of the
+// columns c > K as 16-lane broadcasts -- 1 LDS read where a DPP row broadcast of a complex number takes 4 VALU moves
+// (960 of the kernel's 4.9 k instructions per wavefront were those moves).  lu / lq: this matrix's 16 slots; the region is
+// private to the wavefront and a wavefront's LDS operations execute in order, so there is no barrier anywhere.
 template <int K, int C>
-__device__ __forceinline__ void tw16_pass1(const cd (&a)[16], cd (&uc)[16], const cd u, cd& p) {
-    uc[C] = rowbcast_c<C>(u);
-    p.x = fma(a[C].x, uc[C].x, p.x);
-    p.x = fma(-a[C].y, uc[C].y, p.x);
-    p.y = fma(a[C].x, uc[C].y, p.y);
-    p.y = fma(a[C].y, uc[C].x, p.y);
-    if constexpr (C + 1 < 16) tw16_pass1<K, C + 1>(a, uc, u, p);
+__device__ __forceinline__ void tw16_pass1(const cd (&a)[16], const cd* __restrict__ lu, cd& p) {
+    const cd uc = lu[C];
+    p.x = fma(a[C].x, uc.x, p.x);
+    p.x = fma(-a[C].y, uc.y, p.x);
+    p.y = fma(a[C].x, uc.y, p.y);
+    p.y = fma(a[C].y, uc.x, p.y);
+    if constexpr (C + 1 < 16) tw16_pass1<K, C + 1>(a, lu, p);
 }
 template <int K, int C>
-__device__ __forceinline__ void tw16_pass2(cd (&a)[16], const cd (&uc)[16], const cd u, const cd q) {
-    const cd qc = rowbcast_c<C>(q);
+__device__ __forceinline__ void tw16_pass2(cd (&a)[16], const cd* __restrict__ lu, const cd* __restrict__ lq, const cd u, const cd q) {
+    const cd uc = lu[C], qc = lq[C];
     // A[x][c] -= u_x conj(q_c) + q_x conj(u_c)
-    a[C].x = fma(-u.x, qc.x, fma(-u.y, qc.y, fma(-q.x, uc[C].x, fma(-q.y, uc[C].y, a[C].x))));
-    a[C].y = fma(-u.y, qc.x, fma(u.x, qc.y, fma(-q.y, uc[C].x, fma(q.x, uc[C].y, a[C].y))));
-    if constexpr (C + 1 < 16) tw16_pass2<K, C + 1>(a, uc, u, q);
+    a[C].x = fma(-u.x, qc.x, fma(-u.y, qc.y, fma(-q.x, uc.x, fma(-q.y, uc.y, a[C].x))));
+    a[C].y = fma(-u.y, qc.x, fma(u.x, qc.y, fma(-q.y, uc.x, fma(q.x, uc.y, a[C].y))));
+    if constexpr (C + 1 < 16) tw16_pass2<K, C + 1>(a, lu, lq, u, q);
 }
 template <int K>
-__device__ __forceinline__ cd tw16_house(cd (&a)[16], const int x, cd& us) {
+__device__ __forceinline__ cd tw16_house(cd (&a)[16], const int x, cd& us, cd* __restrict__ lu, cd* __restrict__ lq) {
     const bool below = x > K;
     const cd xk = below ? a[K] : cd{0.0, 0.0};
     // (decided on the entries below the subdiagonal alone, like LAPACK's zlarfg: see ql16_house)
@@ -80,13 +87,17 @@ __device__ __forceinline__ cd tw16_house(cd (&a)[16], const int x, cd& us) {
         const cd u = x == K + 1 ? cd{ph.x * (absa + nrm), ph.y * (absa + nrm)} : xk;
         const double sb = rsqrt_full(nrm * (nrm + absa)), beta = sb * sb;   // beta = 2 / (u^+ u)
         tK = cd{-ph.x * nrm, -ph.y * nrm};
+        lu[x] = u;
+        TW_LDS_ORDER();
         cd p{0.0, 0.0};
-        cd uc[16];
-        tw16_pass1<K, K + 1>(a, uc, u, p);
+        tw16_pass1<K, K + 1>(a, lu, p);
         p = cd{p.x * beta, p.y * beta};
         const double kappa = 0.5 * beta * row_allsum(u.x * p.x + u.y * p.y);
         const cd q = below ? cd{fma(-kappa, u.x, p.x), fma(-kappa, u.y, p.y)} : cd{0.0, 0.0};
-        tw16_pass2<K, K + 1>(a, uc, u, q);
+        lq[x] = q;
+        TW_LDS_ORDER();
+        tw16_pass2<K, K + 1>(a, lu, lq, u, q);
+        TW_LDS_ORDER();
         us = cd{u.x * sb, u.y * sb};
     }
     return tK;
@@ -97,8 +108,13 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_tw16_tridiag(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G,
                                                       double2* __restrict__ de, cd* __restrict__ refl, const int64_t id0,
                                                       const int64_t nc) {
+    // per wavefront: u and q of its four matrices, 17 slots of 16 bytes per matrix (the four broadcasts of a read then fall
+    // on different banks)
+    __shared__ __attribute__((aligned(16))) cd lds_uq[4 * 2 * 4 * 17];
     const int lane = threadIdx.x & 63;
     const int x = lane & 15;
+    cd* const lu = lds_uq + ((threadIdx.x >> 6) * 2 * 4 + (lane >> 4)) * 17;
+    cd* const lq = lu + 4 * 17;
     const int64_t slot0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const bool live = slot0 < nc;
     const int64_t slot = live ? slot0 : nc - 1;          // idle tail rows shadow the last matrix
@@ -119,18 +135,25 @@ __global__ __launch_bounds__(256) void k_tw16_tridiag(const ModelView mv, const 
             }
         }
     } else {
-        double kk[4] = {0.0, 0.0, 0.0, 0.0};
-        bool wrap[4] = {false, false, false, false};
+        cd zk[4] = {cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}};
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int d = 0; d < 4; ++d)
-                if (d < mv.dim_k) kk[d] = Lst.k[id * mv.dim_k + d];
+                if (d < mv.dim_k) zk[d] = expi2pi(Lst.k[id * mv.dim_k + d]);
         } else {
-            grid_point(G, id, kk, wrap);
-        }
-        cd zk[4];
+            // exp(2 pi i k_d) of a mesh point: the per-axis tables (k_grid_tables: the same expression as grid_point + expi2pi,
+            // so the same bits whichever window the point is solved in)
+            int64_t rem = id;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) zk[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
+            for (int d = 3; d >= 0; --d) {
+                if (d < G.wv.dim_arr) {
+                    const int64_t md = G.wv.mesh[d];
+                    const int64_t qd = d > 0 ? rem / md : 0;
+                    zk[d] = G.tz[d][d > 0 ? rem - qd * md : rem];
+                    rem = qd;
+                }
+            }
+        }
         // S[x][c] = sum_R U_R[slot(min,max)] e^{2 pi i k.R}  (conjugated below the diagonal)
         int sidx[16];
 #pragma unroll
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(256) void k_tw16_tridiag(const ModelView mv, const 
 #define TBK_TW_HOUSE(KK)                                                          \
     {                                                                             \
         cd us;                                                                    \
-        const cd t = tw16_house<KK>(a, x, us);                                    \
+        const cd t = tw16_house<KK>(a, x, us, lu, lq);                            \
         step_phase(t, KK + 1);                                                    \
         if (live && x > KK) rec[tw16_off(KK) + x - KK - 1] = us;                  \
     }
@@ -316,14 +339,13 @@ __device__ __forceinline__ double tw_rcp(const double p) {
     return y;
 }
 #define TW_TINY 1e-290
-#define TW_LDS_ORDER() asm volatile("" ::: "memory")
 __device__ __forceinline__ double tw_guard(const double p) { return fabs(p) < TW_TINY ? -TW_TINY : p; }
 
 #define TW16_WAVE_LDS 9216   // bytes of LDS per wavefront: V of 4 matrices at a row stride of 18 doubles; the same region
                              // then stages the 4 reflector records (8704 B) and the output transposition (4 x 16 x 17 doubles)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_tw16_vectors(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
+__global__ __launch_bounds__(256, 3) void k_tw16_vectors(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
                                                       const ModelView mv, const ListArgs Lst, const GridArgs G,
                                                       const double2* __restrict__ de, const double* __restrict__ lam,
                                                       const uint4* __restrict__ meta, const cd* __restrict__ refl,
@@ -574,7 +596,21 @@ __global__ __launch_bounds__(256) void k_tw16_vectors(const int n, const int64_t
     }
 }
 
-// ---- host side: chunks of the batch through the three kernels, then the listed matrices through the QL-replay kernels
+// ---- host side: chunks of the batch through the three kernels, then the listed matrices through the QL-replay kernels.
+// Up to three chunks are in flight, each on a stream and a workspace of its own: the eigenvalue kernel is a dependent chain
+// per lane (2 wavefronts per SIMD's worth of work at 43 % of the VALU issue rate, profiles/r03*), the other two are
+// throughput kernels, and side by side they fill each other's gaps and tails.  The context's stream forks into the side
+// streams at entry and waits for all of them at exit, so to every caller this is still one stream-ordered launch.
+struct Tw16Work {
+    double2* de;
+    cd* refl;
+    double* lam;
+    uint4* meta;
+    int* list;
+    int* count;
+    Ql16Rec R;
+};
+
 template <int MODE>
 static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G) {
     const TbkKnobs& K = tbk_knobs();
@@ -585,16 +621,24 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
     // sweep words, sweep count and ranks (touched for listed matrices only)
     const size_t per_main = 16 * sizeof(double2) + TW16_REC * sizeof(cd) + 16 * sizeof(double) + sizeof(uint4) + sizeof(int);
     const size_t per_fb = (size_t)scap * 16 * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + 16;
-    const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 4096) << 20;
-    int64_t chunk = std::max<int64_t>(4096, (int64_t)(budget / (per_main + per_fb)));
-    chunk = std::min<int64_t>(chunk, nk);
-    chunk = (nk + (nk + chunk - 1) / chunk - 1) / ((nk + chunk - 1) / chunk);      // equal chunks
+    const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 8192) << 20;
+    int ns = K.tw16_streams >= 1 ? std::min(K.tw16_streams, 3) : 3;
+    // (per-kernel HIP-event brackets exist with TBK_TW16_STREAMS=1 only; otherwise the caller's bracket on the context's
+    // stream covers the fork and the join)
+    if (nk < 4 * 16384) ns = 1;
+    int64_t chunk = std::max<int64_t>(4096, (int64_t)(budget / ns / (per_main + per_fb)));
+    chunk = std::min<int64_t>(chunk, (nk + ns - 1) / ns);
+    {
+        const int64_t nch = (nk + chunk - 1) / chunk;
+        chunk = (nk + nch - 1) / nch;                                                // equal chunks
+    }
     chunk = (chunk + 3) & ~(int64_t)3;                                               // whole wavefronts of four matrices
     TBK_REQUIRE(chunk < (int64_t)0x7fffffff / 16, TBK_EUNSUPPORTED, "chunk of %lld matrices", (long long)chunk);
-    const size_t wbytes = al((size_t)chunk * 16 * sizeof(double2)) + al((size_t)chunk * TW16_REC * sizeof(cd)) +
-                          al((size_t)chunk * 16 * sizeof(double)) + al((size_t)chunk * sizeof(uint4)) + al((size_t)chunk * sizeof(int)) + 256 +
-                          al((size_t)chunk * scap * 16 * sizeof(double2)) + al((size_t)chunk * scap * sizeof(unsigned)) +
-                          al((size_t)chunk * sizeof(int)) + al((size_t)chunk * 16) + 1024;
+    const size_t wone = al((size_t)chunk * 16 * sizeof(double2)) + al((size_t)chunk * TW16_REC * sizeof(cd)) +
+                        al((size_t)chunk * 16 * sizeof(double)) + al((size_t)chunk * sizeof(uint4)) + al((size_t)chunk * sizeof(int)) + 256 +
+                        al((size_t)chunk * scap * 16 * sizeof(double2)) + al((size_t)chunk * scap * sizeof(unsigned)) +
+                        al((size_t)chunk * sizeof(int)) + al((size_t)chunk * 16) + 1024;
+    const size_t wbytes = wone * ns;
     if (wbytes > ctx->work_bytes) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->work) TBK_HIP(hipFree(ctx->work));
@@ -604,60 +648,84 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
         TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "tridiagonal workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
         ctx->work_bytes = wbytes;
     }
-    unsigned char* p = (unsigned char*)ctx->work;
-    double2* de = (double2*)p;
-    p += al((size_t)chunk * 16 * sizeof(double2));
-    cd* refl = (cd*)p;
-    p += al((size_t)chunk * TW16_REC * sizeof(cd));
-    double* lam = (double*)p;
-    p += al((size_t)chunk * 16 * sizeof(double));
-    uint4* meta = (uint4*)p;
-    p += al((size_t)chunk * sizeof(uint4));
-    int* list = (int*)p;
-    p += al((size_t)chunk * sizeof(int));
-    int* count = (int*)p;
-    p += 256;
-    Ql16Rec R{};
-    R.rot = (double2*)p;
-    p += al((size_t)chunk * scap * 16 * sizeof(double2));
-    R.swp = (unsigned*)p;
-    p += al((size_t)chunk * scap * sizeof(unsigned));
-    R.nit = (int*)p;
-    p += al((size_t)chunk * sizeof(int));
-    R.rank = (signed char*)p;
-    R.scap = scap;
+    Tw16Work W[3];
+    for (int s = 0; s < ns; ++s) {
+        unsigned char* p = (unsigned char*)ctx->work + (size_t)s * wone;
+        W[s].de = (double2*)p;
+        p += al((size_t)chunk * 16 * sizeof(double2));
+        W[s].refl = (cd*)p;
+        p += al((size_t)chunk * TW16_REC * sizeof(cd));
+        W[s].lam = (double*)p;
+        p += al((size_t)chunk * 16 * sizeof(double));
+        W[s].meta = (uint4*)p;
+        p += al((size_t)chunk * sizeof(uint4));
+        W[s].list = (int*)p;
+        p += al((size_t)chunk * sizeof(int));
+        W[s].count = (int*)p;
+        p += 256;
+        W[s].R = Ql16Rec{};
+        W[s].R.rot = (double2*)p;
+        p += al((size_t)chunk * scap * 16 * sizeof(double2));
+        W[s].R.swp = (unsigned*)p;
+        p += al((size_t)chunk * scap * sizeof(unsigned));
+        W[s].R.nit = (int*)p;
+        p += al((size_t)chunk * sizeof(int));
+        W[s].R.rank = (signed char*)p;
+        W[s].R.scap = scap;
+    }
+    hipStream_t st[3] = {ctx->stream, ctx->stream, ctx->stream};
+    if (ns > 1) {
+        if (!ctx->side_ev[0])
+            for (int i = 0; i < 4; ++i) TBK_HIP(hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming));
+        TBK_HIP(hipEventRecord(ctx->side_ev[0], ctx->stream));
+        for (int s = 0; s < ns; ++s) {
+            if (!ctx->side[s]) TBK_HIP(hipStreamCreateWithFlags(&ctx->side[s], hipStreamNonBlocking));
+            st[s] = ctx->side[s];
+            TBK_HIP(hipStreamWaitEvent(st[s], ctx->side_ev[0], 0));
+        }
+    }
     cd* evec = MODE == 1 ? nullptr : L.evec;
-    for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
+    int which = 0;
+    for (int64_t id0 = 0; id0 < nk; id0 += chunk, which = (which + 1) % ns) {
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
         const unsigned b16 = (unsigned)((nc * 16 + 255) / 256), b1 = (unsigned)((nc + 255) / 256);
-        TBK_HIP(hipMemsetAsync(count, 0, sizeof(int), ctx->stream));
+        const Tw16Work& w = W[which];
+        hipStream_t sq = st[which];
+        const bool brackets = ns == 1;
+        TBK_HIP(hipMemsetAsync(w.count, 0, sizeof(int), sq));
         {
-            ProfScope ps(ctx, "tw16_tridiag");
-            hipLaunchKernelGGL((k_tw16_tridiag<MODE>), dim3(b16), dim3(256), 0, ctx->stream, mv, nk, L, G, de, refl, id0, nc);
+            ProfScope ps(brackets ? ctx : nullptr, "tw16_tridiag");
+            hipLaunchKernelGGL((k_tw16_tridiag<MODE>), dim3(b16), dim3(256), 0, sq, mv, nk, L, G, w.de, w.refl, id0, nc);
         }
         {
-            ProfScope ps(ctx, "tw16_eigvals");
-            hipLaunchKernelGGL((k_tw16_eigvals<MODE>), dim3(b1), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, (const double2*)de, L.eval, G,
-                               lam, meta, list, count, ctx->flags_dev, K.tw16_gaptol);
+            ProfScope ps(brackets ? ctx : nullptr, "tw16_eigvals");
+            hipLaunchKernelGGL((k_tw16_eigvals<MODE>), dim3(b1), dim3(256), 0, sq, mv.nsta, nk, id0, nc, (const double2*)w.de, L.eval, G, w.lam,
+                               w.meta, w.list, w.count, ctx->flags_dev, K.tw16_gaptol);
         }
         {
-            ProfScope ps(ctx, "tw16_vectors");
-            hipLaunchKernelGGL((k_tw16_vectors<MODE>), dim3(b16), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, mv, L, G, (const double2*)de,
-                               (const double*)lam, (const uint4*)meta, (const cd*)refl, list, count);
+            ProfScope ps(brackets ? ctx : nullptr, "tw16_vectors");
+            hipLaunchKernelGGL((k_tw16_vectors<MODE>), dim3(b16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, mv, L, G, (const double2*)w.de,
+                               (const double*)w.lam, (const uint4*)w.meta, (const cd*)w.refl, w.list, w.count);
         }
         // the listed matrices once more, by QL with replayed rotations: the count stays on the device, so these are small fixed
         // grids whose blocks stride over the list (an empty list costs three launches of idle blocks)
         {
-            ProfScope ps(ctx, "tw16_fallback");
+            ProfScope ps(brackets ? ctx : nullptr, "tw16_fallback");
             const unsigned f16 = std::min<unsigned>(b16, 4u * (unsigned)ctx->cus), f1 = std::min<unsigned>(b1, 4u * (unsigned)ctx->cus);
-            hipLaunchKernelGGL((k_solve_ql16<MODE, true, 2, true>), dim3(f16), dim3(256), 0, ctx->stream, mv, nk, L, G, ctx->flags_dev, de, id0, nc,
-                               (const int*)list, (const int*)count);
-            hipLaunchKernelGGL((k_ql16_lanes<MODE, true>), dim3(f1), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, (const double2*)de, L.eval, G, R,
-                               ctx->flags_dev, (const int*)list, (const int*)count);
-            hipLaunchKernelGGL((k_ql16_replay<MODE, true>), dim3(f16), dim3(256), 0, ctx->stream, mv.nsta, nk, id0, nc, R, evec, G.wv, (const int*)list,
-                               (const int*)count);
+            hipLaunchKernelGGL((k_solve_ql16<MODE, true, 2, true>), dim3(f16), dim3(256), 0, sq, mv, nk, L, G, ctx->flags_dev, w.de, id0, nc,
+                               (const int*)w.list, (const int*)w.count);
+            hipLaunchKernelGGL((k_ql16_lanes<MODE, true>), dim3(f1), dim3(256), 0, sq, mv.nsta, nk, id0, nc, (const double2*)w.de, L.eval, G, w.R,
+                               ctx->flags_dev, (const int*)w.list, (const int*)w.count);
+            hipLaunchKernelGGL((k_ql16_replay<MODE, true>), dim3(f16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, w.R, evec, G.wv, (const int*)w.list,
+                               (const int*)w.count);
         }
     }
     TBK_HIP(hipGetLastError());
+    if (ns > 1) {
+        for (int s = 0; s < ns; ++s) {
+            TBK_HIP(hipEventRecord(ctx->side_ev[1 + s], st[s]));
+            TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_ev[1 + s], 0));
+        }
+    }
     return TBK_OK;
 }
