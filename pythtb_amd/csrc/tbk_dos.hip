@@ -192,7 +192,7 @@ static int mesh_solve_dev(tbk_model* m, const int32_t* mesh, bool vec, size_t ex
     *nk_out = nk;
     rc = tbk_k_uniform_mesh_dev(ctx, d, mesh, *k_dev);
     if (rc) return rc;
-    return tbk_solve_list_dev(m, *k_dev, nk, *e_dev, *v_dev);
+    return tbk_solve_list_dev_checked(m, *k_dev, nk, *e_dev, *v_dev);
 }
 
 extern "C" int tbk_solve_mesh(tbk_model* m, const int32_t* mesh, double* eval, double* evec) {
@@ -207,7 +207,7 @@ extern "C" int tbk_solve_mesh(tbk_model* m, const int32_t* mesh, double* eval, d
     TBK_HIP(hipMemcpyAsync(eval, e_dev, (size_t)nk * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (evec) TBK_HIP(hipMemcpyAsync(evec, v_dev, (size_t)nk * n * n * sizeof(cd), hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
-    return tbk_eigh_check(ctx, n);
+    return TBK_OK;
 }
 
 extern "C" int tbk_dos_mesh(tbk_model* m, const int32_t* mesh, int nbins, const double* edges, int64_t* counts,
@@ -262,5 +262,5 @@ extern "C" int tbk_dos_mesh(tbk_model* m, const int32_t* mesh, int nbins, const 
         if (band_min) band_min[b] = lo;
         if (band_max) band_max[b] = hi;
     }
-    return tbk_eigh_check(ctx, n);
+    return TBK_OK;
 }

@@ -261,3 +261,7 @@ struct tbk_wfs {
 int tbk_eigh_dev(tbk_ctx* ctx, int n, const cd* ham_dev, int64_t nk, double* eval_dev, cd* evec_dev,
                  const char* name);
 int tbk_eigh_check(tbk_ctx* ctx, int n);
+// solve + check in one (one host synchronisation); a rotation-record overflow of the direct solvers is repeated on the Jacobi
+// kernels instead of being reported (the inputs must still be on the device)
+int tbk_eigh_dev_checked(tbk_ctx* ctx, int n, const cd* ham_dev, int64_t nk, double* eval_dev, cd* evec_dev, const char* name);
+int tbk_solve_list_dev_checked(struct tbk_model* m, const double* k_dev, int64_t nk, double* eval_dev, double* evec_dev);

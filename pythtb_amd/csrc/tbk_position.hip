@@ -115,7 +115,7 @@ static int position_run(tbk_ctx* ctx, const double* host_evec, EvecSrc src, cons
     }
     if (xmat) TBK_HIP(hipMemcpyAsync(xmat, d_x, (size_t)nk * nsub * nsub * sizeof(cd), hipMemcpyDeviceToHost, ctx->stream));
     if (eig) {
-        rc = tbk_eigh_dev(ctx, nsub, d_x, nk, d_ev, d_vw, "position_eigh");
+        rc = tbk_eigh_dev_checked(ctx, nsub, d_x, nk, d_ev, d_vw, "position_eigh");
         if (rc) return rc;
         {
             ProfScope ps(ctx, "hwf_out");
@@ -128,7 +128,7 @@ static int position_run(tbk_ctx* ctx, const double* host_evec, EvecSrc src, cons
         if (hwf) TBK_HIP(hipMemcpyAsync(hwf, d_h, (size_t)nk * nsub * width * sizeof(cd), hipMemcpyDeviceToHost, ctx->stream));
     }
     TBK_HIP(hipStreamSynchronize(ctx->stream));
-    return eig ? tbk_eigh_check(ctx, nsub) : TBK_OK;
+    return TBK_OK;
 }
 
 extern "C" int tbk_position_hwf(tbk_ctx* ctx, const double* evec, int64_t nk, int nsub, int ncomp,

@@ -46,6 +46,7 @@ struct GridArgs {
     int64_t nchunks;
     int wnchunk;             // k_solve_wave: aligned chains per mesh row that touch the window
     int64_t wcfirst;         // ... and the global number of the first of them
+    int* flags;              // the context's sticky status words ([0]: an eigen-solver ran into its iteration cap)
     int seg;                 // chunks per wave tile (k_grid_rows)
     int tpr;                 // wave tiles per row
     int64_t ntiles;
@@ -59,9 +60,18 @@ struct ListArgs {
     const cd* ham;    // [nk][n][n] (eigh of supplied matrices) or null
     double* eval;     // [n][nk]
     cd* evec;         // [n][nk][n] or null
+    int* flags;       // the context's sticky status words ([0]: an eigen-solver ran into its iteration cap); null: not reported
     int natural;      // k_solve_row16 only: leave the eigenpairs in Jacobi's own order (column j grown out of e_j, so the
                       // eigenvector matrix stays as close to the identity as the rotations allow) instead of sorting
 };
+
+// "entry j (value o) comes before entry x (value mine)" in an ascending order that is TOTAL even with NaNs (they sort last,
+// ties by index): the ranks counted with it are a permutation whatever the input -- a NaN Hamiltonian must end in
+// TBK_ENOCONV, not in a scatter through a half-filled permutation array
+__device__ __forceinline__ bool tbk_before(const double o, const double mine, const int j, const int x) {
+    const bool on = o != o, mn = mine != mine;
+    return on ? (mn && j < x) : (mn || o < mine || (o == mine && j < x));
+}
 
 __device__ __forceinline__ cd expi2pi(double x) {
     double s, c;
@@ -241,12 +251,14 @@ struct Sweep {
 };
 
 template <int N, bool VEC>
-__device__ __forceinline__ void ql_small(SmallMat<N>& M);   // n = 3, 4: direct solver, defined below
+__device__ __forceinline__ bool ql_small(SmallMat<N>& M);   // n = 3, 4: direct solver, defined below
 
 template <int N, bool VEC>
-__device__ __forceinline__ void jacobi_small(SmallMat<N>& M) {
+// (returns false when the iteration ran into its cap -- NaN input, or a matrix LAPACK would give up on too: the reference's
+// np.linalg.eigh raises "Eigenvalues did not converge" there, pythtb.py:939,944; the kernels raise the sticky flag)
+__device__ __forceinline__ bool jacobi_small(SmallMat<N>& M) {
     if constexpr (N == 1) {
-        return;
+        return true;
     } else if constexpr (N == 2) {
         // closed form, already ascending: lambda = m -+ r, one sqrt and one rsqrt.
         //   delta >= 0: v- ~ (delta + r, -conj g)    delta < 0: v- ~ (g, delta - r)
@@ -278,10 +290,10 @@ __device__ __forceinline__ void jacobi_small(SmallMat<N>& M) {
         }
     } else {
 #ifndef TBK_SMALL_JACOBI
-        ql_small<N, VEC>(M);      // n = 3, 4: Householder + implicit QL (-DTBK_SMALL_JACOBI keeps the cyclic Jacobi for A/B runs)
-        return;
+        return ql_small<N, VEC>(M);      // n = 3, 4: Householder + implicit QL (-DTBK_SMALL_JACOBI keeps the cyclic Jacobi for A/B runs)
 #endif
-        for (int sweep = 0; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
+        int sweep = 0;
+        for (; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
             double off = 0.0, dia = 0.0;
 #pragma unroll
             for (int p = 0; p < N; ++p) {
@@ -292,7 +304,9 @@ __device__ __forceinline__ void jacobi_small(SmallMat<N>& M) {
             if (off <= 1.0e-32 * (dia + off)) break;
             Sweep<N, 0, 1, VEC>::run(M);
         }
+        return sweep < TBK_JACOBI_MAX_SWEEPS;
     }
+    return true;
 }
 
 // 1 / sqrt(t) to full double precision from the hardware estimate (relative error 5e-8 measured,
@@ -315,7 +329,7 @@ __device__ __forceinline__ double rsqrt_full(const double t) {
 // Every thread runs the same full-range sweep i = N-2 .. 0; a position takes part only inside the thread's
 // active block [l, m) (EXEC-masked), so register indices stay static while l and m are data.
 template <int N, bool VEC>
-__device__ __forceinline__ void ql_small(SmallMat<N>& M) {
+__device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
     static_assert(N == 3 || N == 4, "ql_small: n = 3, 4");
     cd a[N][N];
 #pragma unroll
@@ -410,7 +424,8 @@ __device__ __forceinline__ void ql_small(SmallMat<N>& M) {
     e[N - 1] = 0.0;
 
     int l = 0;
-    for (int iter = 0; iter < 30 * N; ++iter) {
+    int iter = 0;
+    for (; iter < 30 * N; ++iter) {
         // first coupling at or after l that is not negligible, then the end m of its block
         bool negl[N];
 #pragma unroll
@@ -487,6 +502,7 @@ __device__ __forceinline__ void ql_small(SmallMat<N>& M) {
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) M.dg[j] = d[j];
+    return iter < 30 * N;      // (LAPACK's limit: 30 shifts per eigenvalue)
 }
 
 // n = 3, 4 on meshes: bring the eigenpairs into ascending order in place with a sorting network (3 / 5 compare-exchanges
@@ -604,7 +620,11 @@ __global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const i
         assemble_small<N>(mv, z, M);
     }
     init_vectors<N, VEC>(M);
-    jacobi_small<N, VEC>(M);
+    if constexpr (N > 2) {
+        if (!jacobi_small<N, VEC>(M) && L.flags) L.flags[0] = 1;
+    } else {
+        jacobi_small<N, VEC>(M);
+    }
     int rk[N];
     double sorted[N];
     ranks_small<N>(M.dg, rk, sorted);
@@ -702,7 +722,11 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
     init_vectors<N, true>(M);
     if (TBK_ABLATE(G.ablate) != 2) {
         assemble_small<N>(mv, z, M);
-        jacobi_small<N, true>(M);
+        if constexpr (N > 2) {
+            if (!jacobi_small<N, true>(M) && G.flags) G.flags[0] = 1;
+        } else {
+            jacobi_small<N, true>(M);
+        }
     } else {
 #pragma unroll
         for (int a = 0; a < N; ++a) M.dg[a] = zl.x + a;
@@ -872,7 +896,11 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
                 }
             }
             init_vectors<N, true>(M);
-            jacobi_small<N, true>(M);
+            if constexpr (N > 2) {
+                if (!jacobi_small<N, true>(M) && G.flags) G.flags[0] = 1;
+            } else {
+                jacobi_small<N, true>(M);
+            }
         }
         double sorted[N];
         if constexpr (N > 2) sort_small<N>(M);    // (N <= 2: the closed forms come out ascending)
@@ -1254,10 +1282,7 @@ __global__ __launch_bounds__(NT) void k_solve_wave(const ModelView mv, const int
         if (lane < n) {
             const double mine = S.ev[lane];
             int r = 0;
-            for (int j = 0; j < n; ++j) {
-                const double o = S.ev[j];
-                r += (o < mine) || (o == mine && j < lane);
-            }
+            for (int j = 0; j < n; ++j) r += tbk_before(S.ev[j], mine, j, lane) ? 1 : 0;
             S.perm[r] = lane;
         }
         __syncthreads();
@@ -1583,15 +1608,18 @@ static int launch_solve(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, bo
     if (nk <= 0) return TBK_OK;
     ProfScope ps(ctx, name);
     GridArgs G{};
-    if (n <= 4) return vec ? launch_small<MODE, true>(ctx, mv, n, nk, L) : launch_small<MODE, false>(ctx, mv, n, nk, L);
-    return vec ? launch_wave<MODE, true>(ctx, mv, n, nk, L, G) : launch_wave<MODE, false>(ctx, mv, n, nk, L, G);
+    G.flags = ctx->flags_dev;
+    ListArgs Lf = L;
+    Lf.flags = ctx->flags_dev;
+    if (n <= 4) return vec ? launch_small<MODE, true>(ctx, mv, n, nk, Lf) : launch_small<MODE, false>(ctx, mv, n, nk, Lf);
+    return vec ? launch_wave<MODE, true>(ctx, mv, n, nk, Lf, G) : launch_wave<MODE, false>(ctx, mv, n, nk, Lf, G);
 }
 
 // TBK_ERETRY_JACOBI (internal): the QL rotation record of the n = 17..64 path overflowed; callers that still have their
 // inputs repeat the solve with ctx->qlw_off set, the others report TBK_ENOCONV.
 #define TBK_ERETRY_JACOBI (-1000)
 static int check_noconv(tbk_ctx* ctx, int n, bool can_retry = false) {
-    if (n <= 4) return TBK_OK;
+    if (n <= 2) return TBK_OK;   // (closed forms: nothing iterates)
     int flag[4] = {0, 0, 0, 0};   // 0: no convergence, 1: (Berry path) singular link, 2: the QL rotation record overflowed
     TBK_HIP(hipMemcpyAsync(flag, ctx->flags_dev, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1636,12 +1664,7 @@ extern "C" int tbk_solve_list(tbk_model* m, const double* k, int64_t nk, double*
         TBK_REQUIRE(k, TBK_EINVAL, "tbk_solve_list: null k");
         TBK_HIP(hipMemcpyAsync(k_dev, k, kb, hipMemcpyHostToDevice, ctx->stream));
     }
-    for (int attempt = 0;; ++attempt) {
-        rc = tbk_solve_list_dev(m, k_dev, nk, e_dev, v_dev);
-        if (rc == TBK_OK) rc = check_noconv(ctx, n, attempt == 0);
-        ctx->qlw_off = rc == TBK_ERETRY_JACOBI;      // (the inputs are still on the device: once more on the Jacobi kernels)
-        if (rc != TBK_ERETRY_JACOBI) break;
-    }
+    rc = tbk_solve_list_dev_checked(m, k_dev, nk, e_dev, v_dev);   // (the inputs stay on the device: a record overflow is repeated on Jacobi)
     if (rc) return rc;
     TBK_HIP(hipMemcpyAsync(eval, e_dev, eb, hipMemcpyDeviceToHost, ctx->stream));
     if (evec) TBK_HIP(hipMemcpyAsync(evec, v_dev, vb, hipMemcpyDeviceToHost, ctx->stream));
@@ -1667,17 +1690,7 @@ extern "C" int tbk_eigh_batch(tbk_ctx* ctx, int n, const double* ham, int64_t nk
     double* e_dev = (double*)(p + al(hb));
     cd* v_dev = evec ? (cd*)(p + al(hb) + al(eb)) : nullptr;
     TBK_HIP(hipMemcpyAsync(h_dev, ham, hb, hipMemcpyHostToDevice, ctx->stream));
-    ModelView mv{};
-    mv.nsta = n;
-    mv.nspin = 1;
-    mv.nslot = n * (n + 1) / 2;
-    ListArgs L{nullptr, h_dev, e_dev, v_dev};
-    for (int attempt = 0;; ++attempt) {
-        rc = launch_solve<2>(ctx, mv, n, nk, evec != nullptr, L, "eigh_batch");
-        if (rc == TBK_OK) rc = check_noconv(ctx, n, attempt == 0);
-        ctx->qlw_off = rc == TBK_ERETRY_JACOBI;
-        if (rc != TBK_ERETRY_JACOBI) break;
-    }
+    rc = tbk_eigh_dev_checked(ctx, n, h_dev, nk, e_dev, v_dev, "eigh_batch");
     if (rc) return rc;
     TBK_HIP(hipMemcpyAsync(eval, e_dev, eb, hipMemcpyDeviceToHost, ctx->stream));
     if (evec) TBK_HIP(hipMemcpyAsync(evec, v_dev, vb, hipMemcpyDeviceToHost, ctx->stream));
@@ -1697,6 +1710,30 @@ int tbk_eigh_dev(tbk_ctx* ctx, int n, const cd* ham_dev, int64_t nk, double* eva
 }
 
 int tbk_eigh_check(tbk_ctx* ctx, int n) { return check_noconv(ctx, n); }
+
+// The same two solves WITH their check (one host synchronisation), repeated once on the Jacobi kernels when a direct solver's
+// rotation record overflowed -- for every caller whose inputs are still on the device at that point (mesh solves on generated
+// k lists, the position operator's small eigenproblems): the one attempt loop instead of a hard TBK_ENOCONV.
+int tbk_eigh_dev_checked(tbk_ctx* ctx, int n, const cd* ham_dev, int64_t nk, double* eval_dev, cd* evec_dev, const char* name) {
+    int rc = TBK_OK;
+    for (int attempt = 0;; ++attempt) {
+        rc = tbk_eigh_dev(ctx, n, ham_dev, nk, eval_dev, evec_dev, name);
+        if (rc == TBK_OK) rc = check_noconv(ctx, n, attempt == 0);
+        ctx->qlw_off = rc == TBK_ERETRY_JACOBI;
+        if (rc != TBK_ERETRY_JACOBI) break;
+    }
+    return rc;
+}
+int tbk_solve_list_dev_checked(tbk_model* m, const double* k_dev, int64_t nk, double* eval_dev, double* evec_dev) {
+    int rc = TBK_OK;
+    for (int attempt = 0;; ++attempt) {
+        rc = tbk_solve_list_dev(m, k_dev, nk, eval_dev, evec_dev);
+        if (rc == TBK_OK) rc = check_noconv(m->ctx, m->nsta, attempt == 0);
+        m->ctx->qlw_off = rc == TBK_ERETRY_JACOBI;
+        if (rc != TBK_ERETRY_JACOBI) break;
+    }
+    return rc;
+}
 
 extern "C" int tbk_gen_ham(tbk_model* m, const double* k, int64_t nk, double* ham_out) {
     TBK_REQUIRE(m && ham_out && nk >= 0, TBK_EINVAL, "tbk_gen_ham: bad argument");
@@ -1778,6 +1815,7 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
         G.off[d] = d < D ? offset[d] : 0;
     }
     G.pbc = w->pbc_dev;
+    G.flags = ctx->flags_dev;
     // everything the per-axis tables depend on; rebuild them only when it changes
     std::vector<double> key;
     key.push_back((double)m->upload_id);

@@ -303,10 +303,7 @@ __global__ __launch_bounds__(256) void k_big_sort(const BigWs W, const int64_t b
     for (int x = threadIdx.x; x < ld; x += 256) {
         const double mine = ev[x];
         int r = 0;
-        for (int j = 0; j < ld; ++j) {
-            const double o = ev[j];
-            r += (o < mine) || (o == mine && j < x);
-        }
+        for (int j = 0; j < ld; ++j) r += tbk_before(ev[j], mine, j, x) ? 1 : 0;
         perm[r] = x;
         sorted[r] = mine;
     }

@@ -171,7 +171,7 @@ static int launch_blocked(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, 
     for (int64_t base = 0; base < nk; base += B) {
         const int nb = (int)std::min<int64_t>(B, nk - base);
         A.nsub = (int64_t)nb * npairs;
-        const ListArgs Ls{nullptr, A.S, A.sev, A.U, 1};
+        const ListArgs Ls{nullptr, A.S, A.sev, A.U, nullptr, 1};
         hipLaunchKernelGGL((k_big_init<MODE>), dim3(init_x, nb), dim3(256), 0, ctx->stream, mv, base, L, G, W, VEC ? 1 : 0);
         int par = 0;
         for (int sweep = 0; sweep <= TBK_JACOBI_MAX_SWEEPS; ++sweep) {

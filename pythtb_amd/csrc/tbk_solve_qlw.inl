@@ -410,7 +410,10 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
         }
     }
     if (REC) {
-        if (has) W.nsw[idc] = isw < W.scap ? isw : W.scap;
+        // (a matrix whose record overflowed is replayed as "no sweeps": its sweep words would otherwise send the register
+        // replay kernels past the end of the truncated record -- past the workspace for the last matrix of a chunk; the
+        // flag below makes the caller repeat the call on the Jacobi kernels anyway)
+        if (has) W.nsw[idc] = overflow ? 0 : (isw < W.scap ? isw : W.scap);
         if (overflow) atomicExch(flags + 2, 1);
     }
     // stable ascending ranks; E is free now: E[r] <- the column of rank r (as a double)
@@ -768,7 +771,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         if constexpr (!VEC && MODE != 1) bisect = K.qlw_bisect >= 0 ? K.qlw_bisect == 1 : nc < (int64_t)ctx->cus * 16;
         if (bisect)
             hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(64), (size_t)n * sizeof(double2) + 8 * sizeof(double), ctx->stream, n,
-                               nk, id0, (const double2*)W.de, L.eval, (int64_t)1, nc);
+                               nk, id0, (const double2*)W.de, L.eval, (int64_t)1, nc, ctx->flags_dev);
         else
             hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0,
                                nc, W, L.eval, G, ctx->flags_dev);

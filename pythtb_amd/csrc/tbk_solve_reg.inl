@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
 #pragma unroll
             for (int b = 0; b < N; ++b) M.v[i][b] = cd{sub + L * i == b ? 1.0 : 0.0, 0.0};
     }
-    for (int sweep = 0; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
+    int sweep = 0;
+    for (; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
         double off = 0.0, dia = 0.0;
 #pragma unroll
         for (int p = 0; p < N; ++p) {
@@ -174,6 +175,11 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
         }
         if (off <= 1.0e-32 * (dia + off)) break;
         SweepReg<N, NR, 0, 1, VEC>::run(M);
+    }
+    // (ran into the sweep cap: NaN input, or no convergence -- the reference's eigh raises there, pythtb.py:939,944)
+    if (sweep >= TBK_JACOBI_MAX_SWEEPS) {
+        int* fl = MODE == 1 ? G.flags : Lst.flags;
+        if (fl) fl[0] = 1;
     }
     int rk[N];
     double sorted[N];

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
 
 // (d_j, e_j) of matrix idc at de[idc * si + j * sj]  ->  eval[j][id] ascending.  One block per matrix, thread j <-> eigenvalue j (+ 256, ...).
 __global__ __launch_bounds__(256) void k_tridiag_bisect(const int n, const int64_t nk, const int64_t id0, const double2* __restrict__ de,
-                                                        double* __restrict__ eval, const int64_t si, const int64_t sj) {
+                                                        double* __restrict__ eval, const int64_t si, const int64_t sj, int* flags) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double2* T = (double2*)lds_raw;           // [n] (d_j, e_{j-1}^2)   (e_{-1} = 0)
     double* red = (double*)(T + n);           // [8]
@@ -212,6 +212,9 @@ __global__ __launch_bounds__(256) void k_tridiag_bisect(const int n, const int64
         const double2 v = src[j * sj];
         const double em = j > 0 ? src[(j - 1) * sj].y : 0.0;
         T[j] = double2{v.x, em * em};
+        // a NaN or an infinity in T (from the Hamiltonian: the reference's eigvalsh raises "Eigenvalues did not converge" on a
+        // NaN, pythtb.py:939): bisection always "converges", so say it here (fmin / fmax below would drop a NaN silently)
+        if (!(fabs(v.x) < INFINITY) || !(fabs(v.y) < INFINITY)) flags[0] = 1;
         const double rad = em + v.y;          // Gershgorin: |e_{j-1}| + |e_j|   (e_{n-1} = 0)
         glo = fmin(glo, v.x - rad);
         ghi = fmax(ghi, v.x + rad);
@@ -311,7 +314,7 @@ static int launch_trig(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         TBK_TRIG_K1(false, 256) TBK_TRIG_K1(false, 512) TBK_TRIG_K1(false, 1024) TBK_TRIG_K1(true, 256) TBK_TRIG_K1(true, 512) TBK_TRIG_K1(true, 1024)
 #undef TBK_TRIG_K1
         hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(256), lds2, ctx->stream, n, nk, id0, (const double2*)de, L.eval,
-                           (int64_t)n, (int64_t)1);
+                           (int64_t)n, (int64_t)1, ctx->flags_dev);
         TBK_HIP(hipGetLastError());
     }
     return TBK_OK;

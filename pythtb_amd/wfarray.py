@@ -424,9 +424,11 @@ class wf_array(object):
                 key = key[0]
         self._check_key(key)
         if self._dev_valid and self._dev is not None and not (self._host_exported and self._host_valid):
-            if np.any(occ < 0) or np.any(occ >= self._nsta_arr):
+            # (the reference indexes _wfs[key][occ] with NumPy: negative state indices count from the end, whichever copy
+            # of the array happens to be current)
+            if np.any(occ < -self._nsta_arr) or np.any(occ >= self._nsta_arr):
                 raise IndexError("state index outside the range!")
-            return None, (self._dev, [self._flat_index(key)], occ, None)
+            return None, (self._dev, [self._flat_index(key)], occ % self._nsta_arr, None)
         return self._host_array()[key if self._dim_arr == 1 else tuple(key)][occ], None
 
     def position_matrix(self, key, occ, dir):
@@ -454,8 +456,9 @@ class wf_array(object):
         Returns hwfc[mesh..., nocc] (and hwf[mesh..., nocc, x]) -- the loop the reference's examples
         write around position_hwf (e.g. examples/cubic_slab_hwf.py)."""
         occ = self._occ_list(occ)
-        if np.any(occ < 0) or np.any(occ >= self._nsta_arr):
+        if np.any(occ < -self._nsta_arr) or np.any(occ >= self._nsta_arr):
             raise IndexError("state index outside the range!")
+        occ = occ % self._nsta_arr
         mesh = tuple(int(x) for x in self._mesh_arr)
         h = self._ensure_dev()
         res = self._model.position_hwf(None, dir, hwf_evec, basis, (h, None, occ, int(np.prod(mesh))))

@@ -724,6 +724,13 @@ def test_wide_models_workgroup_kernel(tb):
     assert np.max(np.abs(m.solve_all(k) - ref)) < 1e-12 * scale              # eigenvalue-only variant
     with tb._lib.knob("TBK_BIG_BATCH", 5):                                  # whole-chip solver in several batches: same bits
         assert np.array_equal(m.solve_all(k), m.solve_all(k)) and np.array_equal(m.solve_all(k[:7]), m.solve_all(k)[:, :7])
+        # (eigenvalue-only solves of 65..1024 states take tridiagonalise + bisection by default; the Jacobi kernels' own
+        # eigenvalue-only variants -- still the route for TBK_TRIG=0, n > 1024 and a few very large matrices -- keep their
+        # batch-splitting invariant under test)
+        with tb._lib.knob("TBK_TRIG", 0):
+            evj = m.solve_all(k)
+            assert np.max(np.abs(evj - ref)) < 1e-12 * scale
+            assert np.array_equal(evj, m.solve_all(k)) and np.array_equal(m.solve_all(k[:7]), evj[:, :7])
     w = tb.wf_array(m, [14])
     gaps = w.solve_on_grid([0.0])
     owfs, ogaps = orc.solve_on_grid(m, [14], [0.0], vectorised=True)
@@ -760,6 +767,11 @@ def test_wide_batches_block_jacobi(tb):
     with tb._lib.knob("TBK_BLOCKED", 0):                                    # same batch through the other solvers
         ev0 = rib.solve_all(k)
     assert np.max(np.abs(ev0 - ev)) < 2e-12 * scale
+    with tb._lib.knob("TBK_TRIG", 0):                                       # the block-Jacobi / whole-chip EIGENVALUE-ONLY kernels
+        ev_blk = rib.solve_all(k)
+        with tb._lib.knob("TBK_BLOCKED", 0):
+            ev_big = rib.solve_all(k)
+    assert np.max(np.abs(ev_blk - ref)) < 2e-12 * scale and np.max(np.abs(ev_big - ref)) < 2e-12 * scale
     w = tb.wf_array(rib, [161])                                            # mesh mode: gaps, images, Berry phase
     gaps = w.solve_on_grid([0.0])
     owfs, ogaps = orc.solve_on_grid(rib, [161], [0.0], vectorised=True)

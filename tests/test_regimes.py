@@ -1,0 +1,175 @@
+"""Every regime of the batched Hermitian eigen-solver (launch_wave's dispatch, pythtb_amd/csrc/tbk_solve.hip) forced through
+the `knob()` context manager on the SAME supplied matrices and compared with LAPACK -- the reference's _sol_ham is one
+numpy.linalg.eigh / eigvalsh per matrix (pythtb.py:927-953).  In the driver's suite, so that a threshold moved in the
+dispatch cannot silently route a size onto a kernel nobody tested at that size.
+
+Also here: what happens to input the reference cannot solve either -- NaN in the tables or in a supplied matrix
+(np.linalg.eigh raises "Eigenvalues did not converge", pythtb.py:939,944)."""
+import contextlib
+
+import numpy as np
+import pytest
+
+import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tb():
+    import pythtb_amd
+    return pythtb_amd
+
+
+def _eigh_batch(h, vectors=True):
+    from pythtb_amd import _lib
+    ctx = _lib.default_context()
+    nk, n, _ = h.shape
+    ev = np.zeros((n, nk))
+    vec = np.zeros((n, nk, n), dtype=complex) if vectors else None
+    hc = np.ascontiguousarray(h)
+    _lib.check(_lib.lib.tbk_eigh_batch(ctx.handle, n, _lib.dptr(hc.view(float)), nk, _lib.dptr(ev),
+                                       _lib.dptr(vec.view(float)) if vectors else None))
+    return ev, vec
+
+
+def _matrices(n, nk, seed):
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    h[0] = np.diag(np.arange(n, dtype=float))                                   # diagonal
+    if nk > 2:
+        h[1] = 0.0                                                              # zero
+        u = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0]
+        d = np.repeat(np.arange((n + 1) // 2, dtype=float), 2)[:n]
+        p = u @ np.diag(d) @ u.conj().T
+        h[2] = 0.5 * (p + p.conj().T)                                           # exact pairs
+    return h
+
+
+# (n, number of matrices, knobs, what the knobs select)
+REGIMES = [
+    (3, 500, {}, "per-thread direct solver (Householder + QL)"),
+    (4, 500, {}, "per-thread direct solver"),
+    (5, 300, {}, "register Jacobi"),
+    (8, 300, {}, "register Jacobi"),
+    (7, 300, {"TBK_REG": 0}, "wavefront / workgroup LDS Jacobi instead of the register kernel"),
+    (9, 200, {}, "small batch: workgroup-per-matrix Jacobi"),
+    (16, 200, {}, "small batch: workgroup-per-matrix Jacobi"),
+    (12, 200, {"TBK_QL16_MIN": 0}, "direct solver on a DPP row, single kernel"),
+    (16, 200, {"TBK_QL16_MIN": 0}, "direct solver on a DPP row, single kernel"),
+    (11, 200, {"TBK_QL16_MIN": 0, "TBK_QL16_SPLIT_MIN": 0}, "tridiagonalise | eigenvalues | twisted-factorisation vectors"),
+    (16, 200, {"TBK_QL16_MIN": 0, "TBK_QL16_SPLIT_MIN": 0}, "tridiagonalise | eigenvalues | twisted-factorisation vectors"),
+    (16, 200, {"TBK_QL16_MIN": 0, "TBK_QL16_SPLIT_MIN": 0, "TBK_TW16_GAPTOL": "1e300"}, "... every matrix re-solved by QL replay"),
+    (14, 200, {"TBK_QL16_MIN": 0, "TBK_QL16_SPLIT_MIN": 0, "TBK_TW16": 0}, "tridiagonalise | lane-per-matrix QL | replay"),
+    (16, 200, {"TBK_QL16": 0, "TBK_FEW_MAX": 0}, "DPP-row Jacobi (n = 15, 16)"),
+    (13, 200, {"TBK_QL16": 0, "TBK_ROW16": 0, "TBK_FEW_MAX": 0}, "wavefront LDS Jacobi"),
+    (17, 100, {}, "small batch: workgroup Jacobi"),
+    (24, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, register replay (32 lanes)"),
+    (33, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, LDS replay"),
+    (48, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, register replay (two wavefronts)"),
+    (64, 60, {"TBK_QLW_MIN": 0}, "tridiagonal path, register replay (two wavefronts)"),
+    (32, 100, {"TBK_QLW_MIN": 0, "TBK_QLW_REPLAY_REG": 0}, "tridiagonal path, LDS replay forced"),
+    (40, 100, {"TBK_QLW": 0}, "workgroup LDS Jacobi"),
+    (65, 20, {}, "workgroup per L2-resident matrix / whole chip"),
+    (100, 12, {"TBK_BLOCKED": 1}, "block Jacobi"),
+    (100, 12, {"TBK_BLOCKED": 0}, "workgroup / whole-chip Jacobi"),
+    (130, 6, {"TBK_BIG_FROM": 65}, "whole-chip Jacobi rounds"),
+    (257, 2, {}, "whole-chip Jacobi rounds"),
+]
+EVAL_ONLY = [
+    (12, 200, {}, "tridiagonalise + lane-per-matrix QL (any count)"),
+    (12, 200, {"TBK_QL16_EVONLY": 0}, "single replicated kernel"),
+    (24, 100, {}, "tridiagonalise in LDS + bisection"),
+    (24, 100, {"TBK_QLW_BISECT": 0}, "tridiagonalise in LDS + lane-per-matrix QL"),
+    (48, 100, {"TBK_QLW": 0}, "Jacobi"),
+    (90, 10, {}, "tridiagonalise in L2 + bisection"),
+    (90, 10, {"TBK_TRIG": 0}, "Jacobi"),
+    (90, 10, {"TBK_TRIG": 0, "TBK_BLOCKED": 1}, "block Jacobi, eigenvalues only"),
+    (300, 3, {}, "tridiagonalise in L2 + bisection"),
+]
+
+
+@contextlib.contextmanager
+def knobs(d):
+    from pythtb_amd import _lib
+    with contextlib.ExitStack() as st:
+        for k, v in d.items():
+            st.enter_context(_lib.knob(k, v))
+        yield
+
+
+@pytest.mark.parametrize("n,nk,kn,what", REGIMES, ids=["%d-%s" % (r[0], "+".join("%s=%s" % kv for kv in r[2].items()) or "default") for r in REGIMES])
+def test_forced_regime_with_vectors(n, nk, kn, what):
+    h = _matrices(n, nk, 1000 + n)
+    with knobs(kn):
+        ev, vec = _eigh_batch(h)
+    ref = np.linalg.eigvalsh(h)
+    scale = np.maximum(np.abs(ref).max(axis=1), 1.0)
+    tol = 3e-13 if n <= 64 else 3e-12            # (Jacobi above 64 states: ~24 n eps)
+    assert np.max(np.abs(ev.T - ref) / scale[:, None]) < tol, what
+    V = vec.transpose(1, 0, 2)
+    res = np.abs(np.einsum("kij,kbj->kbi", h, V) - V * ev.T[:, :, None]).reshape(nk, -1).max(axis=1) / scale
+    orth = np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.eye(n)).reshape(nk, -1).max(axis=1)
+    assert res.max() < 10 * tol and orth.max() < 10 * tol, (what, res.max(), orth.max())
+    assert np.all(np.diff(ev, axis=0) >= 0.0)
+
+
+@pytest.mark.parametrize("n,nk,kn,what", EVAL_ONLY, ids=["%d-%s" % (r[0], "+".join("%s=%s" % kv for kv in r[2].items()) or "default") for r in EVAL_ONLY])
+def test_forced_regime_eigenvalues_only(n, nk, kn, what):
+    h = _matrices(n, nk, 2000 + n)
+    with knobs(kn):
+        ev, _ = _eigh_batch(h, vectors=False)
+    ref = np.linalg.eigvalsh(h)
+    scale = np.maximum(np.abs(ref).max(axis=1), 1.0)
+    assert np.max(np.abs(ev.T - ref) / scale[:, None]) < (3e-13 if n <= 64 else 3e-12), what
+    assert np.all(np.diff(ev, axis=0) >= 0.0)
+
+
+# ---------------------------------------------------------------------------------------------- input nobody can solve
+def _chain(tb, n, onsite0):
+    m = hp.quiet(tb.tb_model, 1, 1, [[1.0]], [[i / float(n)] for i in range(n)])
+    m.set_onsite([onsite0] + [0.1 * i for i in range(1, n)])
+    for i in range(n - 1):
+        m.set_hop(1.0 + 0.1j * i, i, i + 1, [0])
+    m.set_hop(0.7, n - 1, 0, [1])
+    return m
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 8, 12, 16, 20, 40, 70])
+def test_nan_onsite_energy_raises_like_the_reference(tb, n):
+    """pythtb.py:939,944: np.linalg.eigh on a Hamiltonian with a NaN raises LinAlgError("Eigenvalues did not converge") for
+    n >= 3.  Here every iterative kernel runs into its cap and raises the sticky flag: TbkError, never silent numbers."""
+    from pythtb_amd import _lib
+    m = _chain(tb, n, float("nan"))
+    k = np.linspace(0.0, 1.0, 37, endpoint=False)
+    for vec in (False, True):
+        with pytest.raises(_lib.TbkError):
+            m.solve_all(k, eig_vectors=vec)
+    w = tb.wf_array(m, [21])
+    with pytest.raises(_lib.TbkError):
+        w.solve_on_grid([0.0])
+    # the flag does not stick to the next, healthy call
+    good = _chain(tb, n, 0.3)
+    ev = good.solve_all(k)
+    assert np.isfinite(ev).all()
+
+
+@pytest.mark.parametrize("n", [3, 6, 12, 30])
+def test_nan_or_inf_in_a_supplied_matrix(n):
+    from pythtb_amd import _lib
+    h = _matrices(n, 20, 77)
+    bad = h.copy()
+    bad[7, 1, 1] = np.nan
+    with pytest.raises(_lib.TbkError):
+        _eigh_batch(bad)
+    worse = h.copy()
+    worse[3, 0, 0] = np.inf                     # the reference returns NaN eigenvalues here without raising
+    try:
+        ev, _ = _eigh_batch(worse)
+        assert not np.isfinite(ev[:, 3]).all()
+        assert np.isfinite(np.delete(ev, 3, axis=1)).all()
+    except _lib.TbkError:
+        pass
+    ev, vec = _eigh_batch(h)                    # and the next call is clean
+    assert np.isfinite(ev).all() and np.isfinite(vec).all()
