@@ -116,6 +116,15 @@ int tbk_solve_list_dev(tbk_model* model, const double* k_dev, int64_t nk, double
 int tbk_eigh_batch(tbk_ctx* ctx, int n, const double* ham, int64_t nk, double* eval,
                    double* evec);
 
+/* Which of the eigen-solver's regimes a batch would take (host only, no device): the dispatch of _sol_ham's replacement is
+ * ONE table of (states, eigenvectors?, input form, batch window) rows with the measured crossovers as data
+ * (tbk_solve.hip, kRegimeRules).  form: 0 k list, 1 regular mesh, 2 supplied matrices; nk: matrices of the call; batch:
+ * matrices of the global mesh (= nk for lists); compute_units <= 0: 256.  Returns a static name ("trig", "blocked", "big",
+ * "reg", "ql16", "qlw", "row16", "wg_lds", "wg_global", "wave", "ql_small", "closed_form"); *note_out (nullable) the
+ * measurement behind the matching row.                                                                                  */
+const char* tbk_solver_regime(int n, int with_vectors, int form, int64_t nk, int64_t batch,
+                              int compute_units, int has_rblocks, const char** note_out);
+
 /* ---- wf_array storage (pythtb.py:2388-2419): _wfs[k1..kD][state][comp] */
 int tbk_wfs_create(tbk_ctx* ctx, int dim_arr, const int32_t* mesh, int nsta_arr, int ncomp,
                    tbk_wfs** out);

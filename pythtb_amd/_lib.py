@@ -62,6 +62,7 @@ SIGNATURES = {
     "tbk_solve_list": (_i, [_p, _dp, _i64, _dp, _dp]),
     "tbk_solve_list_dev": (_i, [_p, _p, _i64, _p, _p]),
     "tbk_eigh_batch": (_i, [_p, _i, _dp, _i64, _dp, _dp]),
+    "tbk_solver_regime": (C.c_char_p, [_i, _i, _i, _i64, _i64, _i, _i, C.POINTER(C.c_char_p)]),
     "tbk_wfs_create": (_i, [_p, _i, _ip, _i, _i, _pp]),
     "tbk_wfs_free": (_i, [_p]),
     "tbk_wfs_upload": (_i, [_p, _dp]),

@@ -1411,73 +1411,155 @@ static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
     return TBK_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Which solver takes a batch: ONE table.  A row is (states, eigenvectors?, input form, batch window) -> regime; the first
+// row that matches and whose regime is enabled wins; the boundaries are the measured crossovers (numbers in the notes,
+// sources in DESIGN.md section 4 and profiles/).  The batch is counted on the GLOBAL mesh for mesh solves, so every window
+// and shard of an array takes the same route (bit-identical halo rows and images).  tests/test_regimes.py forces every
+// regime on the same matrices against LAPACK.
+enum class Regime { Trig, Blocked, Big, Reg, Ql16, Qlw, Row16, WgLds, WgGlobal, Wave };
+enum BatchUnit { kMatrices, kPerCU, kWork };   // the batch window counts matrices | matrices per CU | matrices * n^2
+enum { kList = 1, kMesh = 2, kSupplied = 4, kAnyForm = 7, kNoMesh = 5 };
+struct RegimeRule {
+    Regime regime;
+    int n_lo, n_hi;
+    int vec;            // 1: with eigenvectors, 0: eigenvalues only, -1: either
+    int forms;          // kList | kMesh | kSupplied
+    BatchUnit unit;
+    double lo, hi;      // batch window: lo < batch (lo < 0: none) and batch <= hi (hi < 0: none)
+    const char* note;
+};
+static const RegimeRule kRegimeRules[] = {
+    // eigenvalues only, 65..1024 states: Householder with the matrix in L2 + one bisection per eigenvalue.  One CU per matrix:
+    // 16 / 27 / 50 / 125 / 240 ms at n = 400 / 512 / 600 / 800 / 1024 whatever the batch, so few very large ones stay on Jacobi
+    {Regime::Trig, 65, 512, 0, kNoMesh, kMatrices, -1, -1, "101 x n=300: 184 -> 12.6 ms; one n=512: 104 -> 27 ms"},
+    {Regime::Trig, 513, 800, 0, kNoMesh, kMatrices, 1, -1, "8 x n=800: 257 -> 125 ms; a single one stays on the whole-chip rounds"},
+    {Regime::Trig, 801, 1024, 0, kNoMesh, kMatrices, 5, -1, "a matrix costs 240 ms at n=1024: from 6 matrices on"},
+    // batches of wide matrices: block Jacobi (n/8 - 1 passes per sweep instead of n - 1; three launches per round)
+    {Regime::Blocked, 96, TBK_MAX_NSTA, -1, kAnyForm, kWork, 1.4e6 - 1, -1, "512 x n=128: 87/105 -> 35/55 ms; 64 x n=128: 11.8 -> 18.7 (stays out)"},
+    // whole-chip Jacobi rounds: everything above 256 states, and 65..256 for small batches, eigenvalues only or n > 224
+    {Regime::Big, 257, TBK_MAX_NSTA, -1, kAnyForm, kMatrices, -1, -1, "one 800-state flake: 70 / 86 ms"},
+    {Regime::Big, 65, 256, -1, kAnyForm, kMatrices, -1, 160, "n=128: 32 k-points 21.6 -> 10.5 ms against a workgroup each"},
+    {Regime::Big, 65, 256, 0, kAnyForm, kMatrices, -1, -1, "512 x n=128 eigenvalues: 97 (workgroup) | 81 (whole chip) ms"},
+    {Regime::Big, 225, 256, 1, kAnyForm, kMatrices, -1, -1, "256 x n=256 with vectors: 670 | 648 ms"},
+    // registers, one thread per matrix
+    {Regime::Reg, 5, 8, -1, kAnyForm, kMatrices, -1, -1, "silicon (8 Wannier functions), 65^3: 3.7e7 -> 4.3e8 k/s"},
+    // 9..16: direct solver on a DPP row.  With eigenvectors only for chip-filling batches (small ones keep Jacobi's relative
+    // accuracy on nearly degenerate pairs: tests/test_reference_suite.py); eigenvalues of lists at any count
+    // (the any-count rows hold while TBK_QL16_MIN / TBK_QLW_MIN are unset; an explicit minimum applies to every form)
+    {Regime::Ql16, 9, 16, 0, kNoMesh, kMatrices, -1, -1, "262144 x n=16 eigenvalues: 3.5 -> 1.4 ms"},
+    {Regime::Ql16, 9, 16, -1, kAnyForm, kPerCU, 8, -1, "cubic16 64^3 with vectors: 12.4 (LDS Jacobi) -> 1.9 ms"},
+    // 17..64: tridiagonalise in LDS | lane-per-matrix QL or bisection | replay; the same batch rule
+    {Regime::Qlw, 17, 64, 0, kNoMesh, kMatrices, -1, -1, "one 64 x 64: 1.26 -> 0.44 ms; 16384 x n=32: 11.8 -> 1.1 ms"},
+    {Regime::Qlw, 17, 64, -1, kAnyForm, kPerCU, 8, -1, "16384 x n=32 with vectors: 11.7 -> 2.2 ms"},
+    // 13..16 on lists and supplied matrices when the direct solver is off or the batch is small: Jacobi on a DPP row
+    {Regime::Row16, 15, 16, 1, kNoMesh, kMatrices, -1, -1, "262144 x n=16 with vectors: 12.1 against 12.5 / 17.5 ms (LDS kernel)"},
+    {Regime::Row16, 13, 16, 0, kNoMesh, kMatrices, -1, -1, "eigenvalues: 6.8-7.1 against 13.1 / 19.0 ms"},
+    // a workgroup per LDS-resident matrix: every batch from 22 states, below that only batches that cannot fill the chip
+    {Regime::WgLds, 22, 64, -1, kAnyForm, kMatrices, -1, -1, "16384 x n=32: 11.0 -> 5.5 ms; n=22 9.4 -> 8.3 is the crossover"},
+    {Regime::WgLds, 5, 21, -1, kAnyForm, kPerCU, -1, 8, "one 30 x 30 matrix: 0.77 -> 0.31 ms"},
+    // a 1024-thread workgroup per L2-resident matrix (65..224 with eigenvectors, more than 160 matrices)
+    {Regime::WgGlobal, 65, 224, 1, kAnyForm, kMatrices, 160, -1, "512 x n=128 with vectors: 109 ms, the whole chip 145"},
+    // one wavefront per LDS-resident matrix, warm-started along runs
+    {Regime::Wave, 5, 21, -1, kAnyForm, kMatrices, -1, -1, ""},
+};
+
+struct RegimeQuery {
+    int n, vec, form;          // form: kList | kMesh | kSupplied
+    int64_t nk, batch;         // matrices of this launch | of the global mesh
+    int cus;
+    bool has_rblocks, qlw_off;
+};
+static Regime choose_regime(const RegimeQuery& q, const TbkKnobs& K, const char** note = nullptr) {
+    for (const RegimeRule& r : kRegimeRules) {
+        if (q.n > r.n_hi || (r.vec >= 0 && r.vec != q.vec) || !(r.forms & q.form)) continue;
+        double lo = r.lo, hi = r.hi;
+        int n_lo = r.n_lo;
+        // ---- knobs: switch a regime off, or move its boundary
+        switch (r.regime) {
+            case Regime::Trig:
+                if (K.use_trig == 0) continue;
+                if (K.use_trig == 2) lo = -1;
+                break;
+            case Regime::Blocked:
+                if (K.blocked == 0) continue;
+                if (K.blocked == 1) { lo = -1; n_lo = 65; }
+                break;
+            case Regime::Big:
+                if (K.big_from >= 0 && r.n_lo == 257) n_lo = std::max(65, K.big_from);
+                break;
+            case Regime::Reg:
+                if (K.use_reg == 0) continue;
+                break;
+            case Regime::Ql16:
+                if (K.use_ql16 == 0 || !(q.form == kSupplied || q.has_rblocks)) continue;
+                if (r.unit == kPerCU && K.ql16_min >= 0) lo = (double)K.ql16_min / q.cus;
+                if (r.unit == kMatrices && K.ql16_min >= 0) continue;   // (an explicit minimum applies to eigenvalue-only lists too)
+                break;
+            case Regime::Qlw:
+                if (K.use_qlw == 0 || q.qlw_off) continue;
+                if (r.unit == kPerCU && K.qlw_min >= 0) lo = (double)K.qlw_min / q.cus;
+                if (r.unit == kMatrices && K.qlw_min >= 0) continue;
+                break;
+            case Regime::Row16:
+                if (K.use_row16 == 0 || !(q.form == kSupplied || q.has_rblocks)) continue;
+                break;
+            case Regime::WgLds:
+                if (r.unit == kPerCU && K.few_max >= 0) hi = (double)K.few_max / q.cus;
+                break;
+            default: break;
+        }
+        if (q.n < n_lo) continue;
+        const double batch = r.unit == kMatrices ? (double)q.batch : r.unit == kPerCU ? (double)q.batch / q.cus : (double)q.batch * q.n * q.n;
+        // (the eigenvalue-only Trig rows count the matrices of THIS call: nothing to keep consistent across windows)
+        const double b2 = r.regime == Regime::Trig ? (double)q.nk : batch;
+        if (lo >= 0 && !(b2 > lo)) continue;
+        if (hi >= 0 && !(b2 <= hi)) continue;
+        if (note) *note = r.note;
+        return r.regime;
+    }
+    return q.n > 64 ? Regime::Big : Regime::Wave;
+}
+
+// Host-only view of the table (no device needed): which regime a batch would take, and the measurement behind the boundary.
+extern "C" const char* tbk_solver_regime(int n, int with_vectors, int form, int64_t nk, int64_t batch, int compute_units,
+                                         int has_rblocks, const char** note_out) {
+    static const char* names[] = {"trig", "blocked", "big", "reg", "ql16", "qlw", "row16", "wg_lds", "wg_global", "wave"};
+    if (n <= 4) return n <= 2 ? "closed_form" : "ql_small";
+    const RegimeQuery q{n, with_vectors ? 1 : 0, form == 1 ? kMesh : (form == 2 ? kSupplied : kList), nk, batch,
+                        compute_units > 0 ? compute_units : 256, has_rblocks != 0, false};
+    const char* note = "";
+    const Regime r = choose_regime(q, tbk_knobs(), &note);
+    if (note_out) *note_out = note;
+    return names[(int)r];
+}
+
 template <int MODE, bool VEC>
 static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L,
                        const GridArgs& G) {
     int* flag = ctx->flags_dev;  // sticky until read by check_noconv
     GridArgs G2 = G;
     const TbkKnobs& K = tbk_knobs();
-    const int big_from = K.big_from >= 0 ? std::max(65, K.big_from) : 257;   // smallest n sent to the whole-chip solver regardless of batch size
-    // Few matrices (fewer than ~CUs/2) cannot fill the chip one workgroup each: give them the whole-chip
-    // solver too (n = 128: 32 k-points 21.6 -> 10.5 ms; 128: equal; 512: 108 vs 134 ms).  A mesh window
-    // decides on the size of the GLOBAL mesh, so every shard of an array takes the same route.
     int64_t nk_eff = nk;
     if (MODE == 1) {
         nk_eff = 1;
         for (int d = 0; d < G.wv.dim_arr; ++d) nk_eff *= G.gmesh[d];
     }
-    // Larger batches of 65..256 states (ms; workgroup solver with 1024 threads | whole chip): eigenvalues only 512 x n=128
-    // 97 | 81, 256 x n=200 261 | 196, 256 x n=256 648 | 333 (the whole-chip solver skips V then); with vectors 109 | 145,
-    // 277 | 335, 670 | 648.
-    // Eigenvalues only (band structures of ribbons and slabs), n = 65..1024: tridiagonalise, then bisection (tbk_solve_trig.inl).
-    // One workgroup per matrix streams its matrix ~n/3 times from L2: fine for batches and for single matrices up to ~512
-    // (one CU draws ~150 GB/s); few larger ones stay on the whole-chip Jacobi rounds.  TBK_TRIG=0 disables.
-    if constexpr (MODE != 1 && !VEC) {
-        // (measured, profiles/trig_probe.py: a matrix costs 18 / 32 / 57 / 138 / 266 ms at n = 400 / 512 / 600 / 800 / 1024 whatever
-        // the batch -- one CU per matrix -- against 19 / 27-100 / 39 ms for ONE matrix on the whole-chip Jacobi rounds, whose
-        // per-sweep host read-backs make single runs vary by 4 x; TBK_TRIG=2 forces)
-        const bool pays = n <= 512 || (n <= 800 && nk >= 2) || nk >= 6;
-        if (n > 64 && n <= 1024 && K.use_trig != 0 && (pays || K.use_trig == 2)) return launch_trig<MODE>(ctx, mv, n, nk, L);
-    }
-    if (n > 64) {
-        // Block Jacobi (tbk_solve_blk.inl) makes n/8 - 1 passes over A and V per sweep instead of n - 1, but every pass
-        // costs three launches and the latency of a 16x16 sub-solve (~0.19 ms x n in total): it wins once the batch
-        // carries enough work.  Measured (profiles/blocked_bench.py, ms, eigenvalues / with vectors): 512 x n=128
-        // 87 / 105 -> 35 / 55, 101 x n=300 249 / 452 -> 100 / 143, 8 x n=800 364 / 631 -> 213 / 270; but 64 x n=128
-        // 11.8 / 19.3 -> 18.7 / 21.0, 2 x n=800 120 / 189 -> 157 / 172.
-        const bool blk = K.blocked >= 0 ? K.blocked == 1 : (n >= 96 && (double)nk_eff * n * n >= 1.4e6);
-        if (blk) return launch_blocked<MODE, VEC>(ctx, mv, n, nk, L, G);
-    }
-    if (n >= big_from || (n > 64 && (nk_eff <= 160 || !VEC || n > 224))) return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
-    if (n <= 8 && K.use_reg != 0) return launch_reg<MODE, VEC>(ctx, mv, n, nk, L, G);
-    const bool use_row16 = K.use_row16 != 0, use_ql16 = K.use_ql16 != 0;
-    // One DPP row per matrix pays off where its fixed 16x16 cost is not wasted on padding and where the
-    // LDS kernel cannot warm-start profitably: n = 15, 16 on k lists and supplied matrices (262144 k, n = 16:
-    // 6.8-7.1 ms eigenvalues against 13.1 (mesh order) / 19.0 (random order) ms, 12.1 against 12.5 / 17.5 ms
-    // with vectors; at n = 12 and below the LDS kernel wins).  Mesh solves keep the warm-started LDS kernel
-    // (a fine mesh needs ~3 sweeps there).  Needs the R-grouped table unless the matrices are supplied.
-    // n = 9..16: the direct solver (Householder + implicit QL in registers, tbk_solve_ql16.inl) on meshes, k lists and
-    // supplied matrices alike; it needs the R-grouped table unless the matrices are supplied.  Batches that cannot fill
-    // the chip (a k path, one finite piece) stay on the workgroup-per-matrix JACOBI below although the direct solver is
-    // also faster there (0.05-0.10 ms against 0.07-0.21 ms for 8..2048 matrices, profiles/ql16_small_batches.py): Jacobi
-    // resolves nearly degenerate pairs of weakly coupled copies (splitting ~1e-12) with high RELATIVE accuracy, and the
-    // reference's model-equivalence test (tests/test_tbmodel/test_different_modes.py stage c: position expectations of
-    // the eigenstates of a finite piece, three embeddings whose H differ by one ulp) depends on exactly that.
-    // TBK_QL16_MIN=<count>: batches of at most that many matrices stay on Jacobi (default 8 x CUs; 0 = none).
-    const int64_t ql16_min = K.ql16_min >= 0 ? K.ql16_min : (int64_t)ctx->cus * 8;
-    // (eigenvalues alone carry no such caveat: lists and supplied matrices of any count take the direct solver)
-    if (n >= 9 && n <= 16 && use_ql16 && (MODE == 2 || mv.nR > 0) && (nk_eff > ql16_min || (!VEC && MODE != 1 && K.ql16_min < 0)))
-        return launch_ql16<MODE, VEC>(ctx, mv, nk, L, G, nk_eff);
-    // n = 17..64, batches that fill the chip: the three-kernel tridiagonal path (tbk_solve_qlw.inl); smaller batches stay
-    // on Jacobi for the same reason as above.  TBK_QLW=0 / TBK_QLW_MIN=<count>.
-    const int64_t qlw_min = K.qlw_min >= 0 ? K.qlw_min : (int64_t)ctx->cus * 8;
-    // (eigenvalues alone carry no such caveat: lists and supplied matrices of any count take the tridiagonal path)
-    if (n >= 17 && n <= 64 && K.use_qlw != 0 && !ctx->qlw_off && (nk_eff > qlw_min || (!VEC && MODE != 1 && K.qlw_min < 0)))
-        return launch_qlw<MODE, VEC>(ctx, mv, n, nk, L, G);
-    if constexpr (MODE != 1) {
-        // (eigenvalues only: already from n = 13, where the LDS kernel takes ~9-10 ms for the same 262144 k)
-        if ((n >= 15 || (!VEC && n >= 13)) && n <= 16 && use_row16 && (MODE == 2 || mv.nR > 0))
-            return launch_row16<MODE, VEC>(ctx, mv, nk, L, G);
+    const RegimeQuery q{n, VEC ? 1 : 0, MODE == 0 ? kList : (MODE == 1 ? kMesh : kSupplied), nk, nk_eff, ctx->cus, mv.nR > 0, ctx->qlw_off};
+    const Regime regime = choose_regime(q, K);
+    switch (regime) {
+        case Regime::Trig:
+            if constexpr (MODE != 1 && !VEC) return launch_trig<MODE>(ctx, mv, n, nk, L);
+            break;
+        case Regime::Blocked: return launch_blocked<MODE, VEC>(ctx, mv, n, nk, L, G);
+        case Regime::Big: return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);
+        case Regime::Reg: return launch_reg<MODE, VEC>(ctx, mv, n, nk, L, G);
+        case Regime::Ql16: return launch_ql16<MODE, VEC>(ctx, mv, nk, L, G, nk_eff);
+        case Regime::Qlw: return launch_qlw<MODE, VEC>(ctx, mv, n, nk, L, G);
+        case Regime::Row16:
+            if constexpr (MODE != 1) return launch_row16<MODE, VEC>(ctx, mv, nk, L, G);
+            break;
+        default: break;
     }
     // A 256-thread workgroup per LDS-resident matrix instead of one wavefront:
     //  * n >= 22, any batch: a wavefront's matrix with its warm-start buffer takes 3 n(n+1) 16 B of LDS (n = 48:
@@ -1487,9 +1569,8 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     //    11.0 -> 5.5, n=40 (4.7 at 1024 k) -> 11.7 (1.8), n=48 92 -> 33, 8192 x n=64 209 -> 39; n=22 9.4 -> 8.3 is
     //    the crossover (n=20: 6.7 vs 7.5).
     //  * n < 22: only while the batch cannot fill the chip with wavefronts (one 30x30 matrix: 0.77 -> 0.31 ms).
-    const int64_t few_max = K.few_max;   // largest n < 22 batch that gets a workgroup per matrix
-    const bool few = n <= 64 && (n >= 22 || nk_eff <= (few_max >= 0 ? few_max : (int64_t)ctx->cus * 8));
-    if (n > 64 || few) {
+    const bool few = regime == Regime::WgLds;
+    if (regime == Regime::WgGlobal || few) {
         // ---- workgroup per matrix: 256 threads, cold start; n = 65..256: A and V^T in a global workspace
         // (ribbon / slab models: few, large matrices), n <= 64: in LDS.
         // a large batch walks runs of consecutive points per workgroup anyway: warm-start along them when the

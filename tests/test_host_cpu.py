@@ -365,3 +365,45 @@ def test_knobs_are_parsed_once_and_reloadable():
     with _lib.knob("TBK_GRID_SEG", 3):
         pass
     assert os.environ.get("TBK_GRID_SEG") is None
+
+
+def test_solver_dispatch_table_routes_the_measured_crossovers():
+    """tbk_solver_regime (host only): the dispatch of the batched eigen-solver is one table (tbk_solve.hip, kRegimeRules).
+    The rows' boundaries are measurements; this pins the routing at and around them, for a 256-CU chip."""
+    from pythtb_amd import _lib
+
+    def regime(n, vec, form, nk, batch=None, rblocks=1):
+        return _lib.lib.tbk_solver_regime(n, vec, form, nk, nk if batch is None else batch, 256, rblocks, None).decode()
+    LIST, MESH, SUP = 0, 1, 2
+    assert regime(2, 1, MESH, 1 << 22) == "closed_form" and regime(4, 1, MESH, 1 << 21) == "ql_small"
+    assert regime(5, 1, LIST, 100) == "reg" and regime(8, 0, MESH, 10 ** 6) == "reg"
+    # 9..16: chip-filling batches with eigenvectors take the direct solver, small ones keep Jacobi; eigenvalues at any count
+    assert regime(16, 1, MESH, 257 ** 3) == "ql16" and regime(16, 1, LIST, 2049) == "ql16"
+    assert regime(16, 1, LIST, 2048) == "row16" and regime(12, 1, LIST, 2048) == "wg_lds"
+    assert regime(12, 1, MESH, 300, batch=300) == "wg_lds" and regime(12, 1, MESH, 300, batch=10 ** 5) == "ql16"
+    assert regime(12, 0, LIST, 7) == "ql16" and regime(16, 1, LIST, 10 ** 5, rblocks=0) == "wave"
+    # 17..64
+    assert regime(32, 1, SUP, 16384) == "qlw" and regime(32, 1, SUP, 2048) == "wg_lds" and regime(20, 1, SUP, 2048) == "wg_lds"
+    assert regime(64, 0, SUP, 1) == "qlw" and regime(20, 1, LIST, 2049) == "qlw"
+    # above 64 states
+    assert regime(300, 0, LIST, 101) == "trig" and regime(513, 0, LIST, 1) == "big" and regime(513, 0, LIST, 2) == "trig"
+    # (five 1024-state matrices: too few for a CU each, enough work -- 5 x 1024^2 >= 1.4e6 -- for block Jacobi)
+    assert regime(1024, 0, SUP, 5) == "blocked" and regime(1024, 0, SUP, 6) == "trig" and regime(1025, 0, SUP, 100) == "blocked"
+    assert regime(800, 0, SUP, 1) == "big" and regime(600, 0, LIST, 1) == "big" and regime(600, 0, LIST, 2) == "trig"
+    assert regime(128, 1, LIST, 512) == "blocked" and regime(128, 1, LIST, 64) == "big" and regime(70, 1, LIST, 200) == "wg_global"
+    assert regime(95, 1, LIST, 4000) == "wg_global" and regime(230, 1, LIST, 26) == "big" and regime(230, 1, LIST, 27) == "blocked"
+    assert regime(300, 1, MESH, 101, batch=101) == "blocked" and regime(90, 1, SUP, 1) == "big" and regime(2048, 0, SUP, 1) == "blocked"
+    # knobs move the boundaries, not the code
+    with _lib.knob("TBK_QL16_MIN", 0):
+        assert regime(12, 1, LIST, 5) == "ql16"
+    with _lib.knob("TBK_QL16", 0):
+        assert regime(16, 1, LIST, 10 ** 5) == "row16" and regime(16, 1, MESH, 10 ** 5) == "wave"
+    with _lib.knob("TBK_TRIG", 0):
+        assert regime(300, 0, LIST, 101) == "blocked"
+    with _lib.knob("TBK_BLOCKED", 1):
+        assert regime(70, 1, LIST, 3) == "blocked"
+    with _lib.knob("TBK_BIG_FROM", 65):
+        assert regime(70, 1, LIST, 1000) == "big"
+    note = ctypes.c_char_p()
+    _lib.lib.tbk_solver_regime(300, 0, 0, 101, 101, 256, 1, ctypes.byref(note))
+    assert b"12.6 ms" in note.value
