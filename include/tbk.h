@@ -167,6 +167,15 @@ int tbk_wfs_solve_grid_result(tbk_wfs* wfs, double* min_gaps);
 int tbk_wfs_solve_window_async(tbk_wfs* wfs, tbk_model* model, const double* start_k,
                                const double* pbc_phase, const int64_t* offset,
                                const int64_t* global_mesh);
+/* solve_on_grid (:2421-2532) followed by berry_flux(occ, dirs=[0,1]) (:3068-3205, _one_flux_plane :3840-3865) in ONE pass over
+ * a 2-D array of 2 or 4 states: the plaquette phases are formed from the eigenvectors while they are in registers, so the
+ * array is written once and never read back.  occ: 1 or 2 bands.  Launch only; the results through
+ * tbk_wfs_solve_grid_result (min gaps) and tbk_berry_flux_result (the total: same value as the two separate calls up to the
+ * order of the sum).  TBK_EUNSUPPORTED where the fused kernel does not apply (other dimensions, state counts, long-ranged
+ * models along the last axis): issue the two calls then.                                                              */
+int tbk_wfs_solve_grid_flux_async(tbk_wfs* wfs, tbk_model* model, const double* start_k,
+                                  const double* pbc_phase, int64_t row0, int64_t global_n0,
+                                  const int32_t* occ, int nocc);
 /* impose_pbc (:2674-2749) / impose_loop (:2751-2791) on a filled array:
  * last slice along mesh_dir = first slice * phase[comp] (phase NULL: copy) */
 int tbk_wfs_impose(tbk_wfs* wfs, int mesh_dir, const double* phase_c128);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "tbk_wfs_solve_grid": (_i, [_p, _p, _dp, _dp, _i64, _i64, _dp]),
     "tbk_wfs_solve_grid_async": (_i, [_p, _p, _dp, _dp, _i64, _i64]),
     "tbk_wfs_solve_grid_result": (_i, [_p, _dp]),
+    "tbk_wfs_solve_grid_flux_async": (_i, [_p, _p, _dp, _dp, _i64, _i64, _ip, _i]),
     "tbk_wfs_solve_window_async": (_i, [_p, _p, _dp, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tbk_wfs_impose": (_i, [_p, _i, _dp]),
     "tbk_berry_flux": (_i, [_p, _ip, _i, _i, _i, _dp, _dp]),

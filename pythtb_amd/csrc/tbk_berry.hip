@@ -429,30 +429,7 @@ __device__ __forceinline__ cd one_link_det(const cd* P, const cd* Q, const int* 
     }
 }
 
-// arg(z) = atan2(y, x).  Plaquette and link phases on a fine mesh are tiny, so the
-// common case |y| <= 2^-6 x (x > 0) takes the odd Taylor series of atan through
-// t^13 (truncation < 2^-90 |t|, i.e. below half an ulp of the result); anything
-// else -- large phases, x <= 0, zeros, non-finite -- goes to the library atan2.
-__device__ __forceinline__ double arg_small_first(double y, double x) {
-    if (x > 0.0 && fabs(y) <= 0.015625 * x) {
-        const double t = y / x, t2 = t * t;
-        // three-operand v_fma_f64 spelled out: the compiler otherwise copies each coefficient into the
-        // accumulator register first (v_mov_b64 + v_fmac_f64), one extra issue slot per Horner step
-        auto fma3 = [](double a, double b, double c) {
-            double d;
-            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            return d;
-        };
-        double p = -1.0 / 13.0;
-        p = fma3(p, t2, 1.0 / 11.0);
-        p = fma3(p, t2, -1.0 / 9.0);
-        p = fma3(p, t2, 1.0 / 7.0);
-        p = fma3(p, t2, -1.0 / 5.0);
-        p = fma3(p, t2, 1.0 / 3.0);
-        return fma(-(t * t2), p, t);
-    }
-    return atan2(y, x);
-}
+// (arg_small_first: tbk_internal.h -- shared with the fused solve + flux kernel of tbk_solve_fused.inl)
 
 // ---- row-streaming flux kernel (ncomp <= 4): a wavefront owns 63 plaquette
 // columns x `ti` plaquette rows; lane = mesh column, rows are walked in order.

@@ -54,6 +54,7 @@ static void knobs_parse() {
     geti("TBK_WG_NT", k.wg_nt);
     geti("TBK_WAVE_RUN", k.wave_run);
     geti("TBK_GRID_SEG", k.grid_seg);
+    geti("TBK_FUSED_ROWS", k.fused_rows);
     geti("TBK_GRID_KERNEL", k.grid_kernel);
     geti("TBK_FLUX_TI", k.flux_ti);
     geti("TBK_FLUX_FUSED", k.flux_fused);

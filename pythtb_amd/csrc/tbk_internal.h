@@ -58,6 +58,7 @@ struct TbkKnobs {
     int few_nt = -1;            // TBK_FEW_NT        threads of the LDS workgroup solver
     int wg_nt = 1024;           // TBK_WG_NT         threads of the global-workspace workgroup solver
     int wave_run = -1;          // TBK_WAVE_RUN      chain length of the wavefront solver (1 = always cold)
+    int fused_rows = -1;        // TBK_FUSED_ROWS    mesh rows per wave tile of the fused solve + flux kernel (default 4)
     int grid_seg = -1;          // TBK_GRID_SEG      chunks per wave tile of k_grid_rows
     int grid_kernel = 0;        // TBK_GRID_KERNEL   1: term-walking mesh kernel instead of the row-polynomial one
     int flux_ti = -1;           // TBK_FLUX_TI       rows per flux tile
@@ -113,6 +114,31 @@ __host__ __device__ inline void cfmac(cd& acc, cd a, cd b) {
     acc.y += a.x * b.y - a.y * b.x;
 }
 __host__ __device__ inline double cabs2(cd a) { return a.x * a.x + a.y * a.y; }
+
+// arg(z) = atan2(y, x).  Plaquette and link phases on a fine mesh are tiny, so the
+// common case |y| <= 2^-6 x (x > 0) takes the odd Taylor series of atan through
+// t^13 (truncation < 2^-90 |t|, i.e. below half an ulp of the result); anything
+// else -- large phases, x <= 0, zeros, non-finite -- goes to the library atan2.
+__device__ __forceinline__ double arg_small_first(double y, double x) {
+    if (x > 0.0 && fabs(y) <= 0.015625 * x) {
+        const double t = y / x, t2 = t * t;
+        // three-operand v_fma_f64 spelled out: the compiler otherwise copies each coefficient into the
+        // accumulator register first (v_mov_b64 + v_fmac_f64), one extra issue slot per Horner step
+        auto fma3 = [](double a, double b, double c) {
+            double d;
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+            return d;
+        };
+        double p = -1.0 / 13.0;
+        p = fma3(p, t2, 1.0 / 11.0);
+        p = fma3(p, t2, -1.0 / 9.0);
+        p = fma3(p, t2, 1.0 / 7.0);
+        p = fma3(p, t2, -1.0 / 5.0);
+        p = fma3(p, t2, 1.0 / 3.0);
+        return fma(-(t * t2), p, t);
+    }
+    return atan2(y, x);
+}
 
 // ---------------------------------------------------------------- handles
 struct ProfRec {

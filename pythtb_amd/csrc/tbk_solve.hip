@@ -1390,6 +1390,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 #include "tbk_solve_row16.inl" // n = 15, 16 on lists: one DPP row of 16 lanes per matrix, rows of A in registers
 #include "tbk_solve_ql16.inl"  // n = 9..16: Householder + implicit QL in registers, one DPP row of 16 lanes per matrix
 #include "tbk_solve_tw16.inl"  // n = 9..16 with eigenvectors, large batches: tridiagonalise | eigenvalues | twisted-factorisation vectors (MFMA Newton-Schulz) + back-transformation
+#include "tbk_solve_fused.inl" // 2-D meshes, n = 2 / 4: solve_on_grid and berry_flux in one pass (the plaquette phases from registers)
 #include "tbk_solve_trig.inl"  // eigenvalues only, n = 65..1024: Householder with A in L2, then one thread per eigenvalue (bisection)
 #include "tbk_solve_qlw.inl"   // n = 17..64, large batches: Householder in LDS, lane-per-matrix QL, rotation replay
 #include "tbk_solve_blk.inl"   // batches of wide matrices: block Jacobi, 16x16 subproblems through k_solve_row16
@@ -1859,9 +1860,38 @@ extern "C" int tbk_wfs_solve_grid_async(tbk_wfs* w, tbk_model* m, const double* 
     return tbk_wfs_solve_window_async(w, m, start_k, pbc_phase, off, gm);
 }
 
+struct FusedFluxReq {
+    int occ[2];
+    int nocc;
+};
+static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, const double* pbc_phase, const int64_t* offset,
+                             const int64_t* global_mesh, const FusedFluxReq* ff);
+
 extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double* start_k,
                                           const double* pbc_phase, const int64_t* offset,
                                           const int64_t* global_mesh) {
+    return solve_window_impl(w, m, start_k, pbc_phase, offset, global_mesh, nullptr);
+}
+
+// solve_on_grid + berry_flux(occ, dirs = [0, 1]) of a 2-D array in one pass (tbk_solve_fused.inl); results through
+// tbk_wfs_solve_grid_result (min gaps) and tbk_berry_flux_result (the total).  TBK_EUNSUPPORTED where the fused kernel does
+// not apply (the caller then issues the two calls).
+extern "C" int tbk_wfs_solve_grid_flux_async(tbk_wfs* w, tbk_model* m, const double* start_k, const double* pbc_phase,
+                                             int64_t row0, int64_t global_n0, const int32_t* occ, int nocc) {
+    TBK_REQUIRE(w && occ, TBK_EINVAL, "tbk_wfs_solve_grid_flux: null argument");
+    TBK_REQUIRE(nocc >= 1 && nocc <= 2, TBK_EUNSUPPORTED, "tbk_wfs_solve_grid_flux: %d occupied bands (1 or 2)", nocc);
+    FusedFluxReq ff{{occ[0], nocc > 1 ? occ[1] : occ[0]}, nocc};
+    for (int a = 0; a < nocc; ++a)
+        TBK_REQUIRE(occ[a] >= 0 && occ[a] < w->view.nsta, TBK_EINVAL, "tbk_wfs_solve_grid_flux: band %d out of range", occ[a]);
+    TBK_REQUIRE(nocc == 1 || occ[0] != occ[1], TBK_EINVAL, "tbk_wfs_solve_grid_flux: repeated band");
+    int64_t off[TBK_MAX_DIM] = {row0, 0, 0, 0}, gm[TBK_MAX_DIM];
+    for (int d = 0; d < TBK_MAX_DIM; ++d) gm[d] = w->view.mesh[d];
+    gm[0] = global_n0;
+    return solve_window_impl(w, m, start_k, pbc_phase, off, gm, &ff);
+}
+
+static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, const double* pbc_phase, const int64_t* offset,
+                             const int64_t* global_mesh, const FusedFluxReq* ff) {
     TBK_REQUIRE(w && m && start_k && pbc_phase && offset && global_mesh, TBK_EINVAL, "tbk_wfs_solve_grid: null argument");
     TBK_REQUIRE(w->ctx == m->ctx, TBK_EINVAL, "tbk_wfs_solve_grid: model and wfs live on different contexts");
     const WfsView& v = w->view;
@@ -1953,6 +1983,97 @@ extern "C" int tbk_wfs_solve_window_async(tbk_wfs* w, tbk_model* m, const double
 #ifdef TBK_DIAG
     G.ablate = tbk_knobs().ablate_grid;
 #endif
+    if (ff) {
+        // ---- the fused kernel: 2-D arrays of 2 or 4 states, short-ranged along the last axis
+        const int pm = m->view.pmax;
+        TBK_REQUIRE(D == 2 && (n == 2 || n == 4) && ff->nocc <= n && pm >= 0 && pm <= 2 && (n == 2 || pm == 1) &&
+                        tbk_knobs().grid_kernel != 1 && v.npts < (int64_t)0x7fffffff,
+                    TBK_EUNSUPPORTED, "tbk_wfs_solve_grid_flux: a %d-D array of %d states (last-axis range %d): the fused kernel "
+                    "serves 2-D arrays of 2 states (range <= 2) or 4 states (range 1)", D, n, pm);
+        ProfScope ps(ctx, "solve_grid_flux");
+        const TbkKnobs& K = tbk_knobs();
+        FusedArgs F{};
+        // rows per tile (measured, profiles/fused_probe.py, us per step at 2048^2 | 4096^2): R = 2 88 | 319, 3 73 | 282, 4 72 | 271,
+        // 6 68 | 301, 8 69 | 310 -- six rows while the array fits the 256 MiB last-level cache, four beyond it
+        F.R = K.fused_rows > 0 ? std::min(K.fused_rows, 16) : (w->bytes <= ((int64_t)256 << 20) + (1 << 20) ? 6 : 4);
+        F.nrg = (v.mesh[0] + F.R - 1) / F.R;
+        F.occ[0] = ff->occ[0];
+        F.occ[1] = ff->occ[1];
+        const int64_t want = (int64_t)ctx->cus * 32;     // wave tiles that fill the chip
+        const int R1 = F.R + 1, ncell = (n * (n + 1) / 2) * (2 * pm + 1), ncar = ff->nocc * n + 1;
+        // LDS per wavefront: cells, leading-axis phases and carries of R + 1 rows, the staging tile, the per-column tables of
+        // `seg` chunks; at most 16 KB per wavefront
+        const size_t fixed_cd = (size_t)R1 * (ncell + n + ncar) + (size_t)64 * n;
+        const int seg_cap = (int)std::max<size_t>(1, (1024 - std::min<size_t>(fixed_cd, 960)) / ((size_t)64 * (1 + n)));
+        G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(seg_cap, G.cpr), (int64_t)G.cpr * F.nrg / want));
+        if (K.grid_seg >= 0) G.seg = std::max(1, std::min(std::min(K.grid_seg, seg_cap), G.cpr));
+        G.tpr = (G.cpr + G.seg - 1) / G.seg;
+        G.seg = (G.cpr + G.tpr - 1) / G.tpr;
+        G.ntiles = (int64_t)F.nrg * G.tpr;
+        const int nseam = G.tpr - 1;
+        const int64_t seam_threads = (int64_t)(v.mesh[0] - 1) * nseam;
+        const int64_t nsb = (seam_threads + 255) / 256;
+        // buffers: per-tile gap minima; flux partials (tiles, then seam blocks) and the total
+        const int64_t npart = G.ntiles * std::max(n - 1, 1);
+        if (w->gap_part_cap < npart) {
+            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            if (w->gap_part_dev) TBK_HIP(hipFree(w->gap_part_dev));
+            w->gap_part_dev = nullptr;
+            w->gap_part_cap = 0;
+            TBK_HIP(hipMalloc((void**)&w->gap_part_dev, (size_t)npart * sizeof(double)));
+            w->gap_part_cap = npart;
+        }
+        G.gap_part = w->gap_part_dev;
+        w->gap_part_n = G.ntiles;
+        if (w->flux_nslices_cap < 1) {
+            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            if (w->flux_totals_dev) TBK_HIP(hipFree(w->flux_totals_dev));
+            if (w->flux_cnt_dev) TBK_HIP(hipFree(w->flux_cnt_dev));
+            w->flux_totals_dev = nullptr;
+            w->flux_cnt_dev = nullptr;
+            TBK_HIP(hipMalloc((void**)&w->flux_totals_dev, sizeof(double)));
+            TBK_HIP(hipMalloc((void**)&w->flux_cnt_dev, 16 * sizeof(unsigned)));
+            TBK_HIP(hipMemsetAsync(w->flux_cnt_dev, 0, 16 * sizeof(unsigned), ctx->stream));
+            w->flux_nslices_cap = 1;
+        }
+        if (w->flux_partial_cap < G.ntiles + nsb) {
+            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            if (w->flux_partial_dev) TBK_HIP(hipFree(w->flux_partial_dev));
+            w->flux_partial_dev = nullptr;
+            TBK_HIP(hipMalloc((void**)&w->flux_partial_dev, (size_t)(G.ntiles + nsb) * sizeof(double)));
+            w->flux_partial_cap = G.ntiles + nsb;
+        }
+        w->flux_nslices = 1;
+        w->flux_plaq_n = 0;
+        F.partial = w->flux_partial_dev;
+        const size_t lds = (size_t)4 * (fixed_cd + (size_t)G.seg * 64 * (1 + n)) * sizeof(cd);
+        TBK_REQUIRE(lds <= 64 * 1024, TBK_EUNSUPPORTED, "tbk_wfs_solve_grid_flux: %zu bytes of LDS per block", lds);
+        const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
+#define TBK_FUSED(NN, PP, OO) hipLaunchKernelGGL((k_grid_rows_flux<NN, PP, OO>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G, F)
+        if (n == 2 && ff->nocc == 1) {
+            if (pm == 0) TBK_FUSED(2, 0, 1); else if (pm == 1) TBK_FUSED(2, 1, 1); else TBK_FUSED(2, 2, 1);
+        } else if (n == 2) {
+            if (pm == 0) TBK_FUSED(2, 0, 2); else if (pm == 1) TBK_FUSED(2, 1, 2); else TBK_FUSED(2, 2, 2);
+        } else if (ff->nocc == 1) {
+            TBK_FUSED(4, 1, 1);
+        } else {
+            TBK_FUSED(4, 1, 2);
+        }
+#undef TBK_FUSED
+        if (nsb > 0) {
+            if (n == 2 && ff->nocc == 1)
+                hipLaunchKernelGGL((k_flux_seams<2, 1>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
+            else if (n == 2)
+                hipLaunchKernelGGL((k_flux_seams<2, 2>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
+            else if (ff->nocc == 1)
+                hipLaunchKernelGGL((k_flux_seams<4, 1>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
+            else
+                hipLaunchKernelGGL((k_flux_seams<4, 2>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
+        }
+        hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(1024), 0, ctx->stream, (const double*)F.partial, (int64_t)(G.ntiles + nsb), w->flux_totals_dev);
+        TBK_HIP(hipGetLastError());
+        return TBK_OK;
+    }
     ProfScope ps(ctx, "solve_grid");
     if (n <= 4) {
         TBK_REQUIRE(v.npts / v.mesh[D - 1] < (int64_t)0xffffffffu && G.nchunks < (int64_t)0x7fffffff * 4, TBK_EUNSUPPORTED,

@@ -1,0 +1,333 @@
+// tbk_solve_fused.inl -- included by tbk_solve.hip after k_grid_rows.
+//
+// solve_on_grid + berry_flux of a 2-D mesh in ONE pass (wf_array.solve_on_grid, pythtb.py:2421-2532, followed by
+// berry_flux(occ), :3068-3205 / _one_flux_plane :3840-3865): the plaquette phases are formed from the eigenvectors while they
+// are still in registers, so the array is written once and never read back.  The two-kernel step moves 16 n^2 B per point out
+// and 16 nocc n B back in (config C: 268 + 134 MB; the flux kernel then waits on a memory system that is still writing the
+// solve's output back, 0.45 of the HBM roofline at 4096^2); this kernel moves the 16 n^2 B only.
+//
+// Tile = R consecutive mesh rows x `seg` 64-point chunks, one wavefront.  Like k_grid_rows the lanes first build the row
+// coefficient cells C_ab,p -- here of R + 1 rows: the row after the tile's last one is its HALO, solved again (the kernels are
+// deterministic functions of the point, so the halo's vectors are the very bits its owner tile stores) and not stored.
+// Chunks outside, rows inside: at (chunk, row) a lane solves its point, stages and stores it exactly like k_grid_rows, and then
+//   Uy(row; j-1 -> j) = det <u(row, j-1) | u(row, j)>      left neighbour by a one-lane wavefront shift (DPP wave_shr:1);
+//                                                           lane 0 takes lane 63 of the previous chunk from an LDS carry
+//   Ux(row-1, j)       = det <u(row-1, j) | u(row, j)>      the previous row's vectors stay in registers
+//   F(row-1, j-1)      = -arg[ Ux(row-1, j-1) Uy(row; j-1 -> j) conj Ux(row-1, j) conj Uy(row-1; j-1 -> j) ]
+// (the reference's loop (i,j) -> (i+1,j) -> (i+1,j+1) -> (i,j+1) -> (i,j), pythtb.py:3855-3861, as link determinants; the lane
+// on column j owns the plaquette to its LEFT).  Per-lane sums in a fixed order, a wave tree, one partial per tile.
+// The plaquette column between two tiles of a row group (1 in 64 seg) is left to k_flux_seams, which reads its four corners
+// from the finished array.  k_sum_fixed adds the partials in a fixed order: bit-reproducible totals, no float atomics.
+//
+// Extra arithmetic: (R + 1) / R eigen-solves per point and the link / phase arithmetic of k_flux_rows -- on a kernel whose
+// VALU was 37 % busy (n = 2) behind its stores.
+
+struct FusedArgs {
+    int R;              // rows per tile
+    int nrg;            // row groups = ceil(mesh[0] / R)
+    int occ[2];
+    double* partial;    // [ntiles + nseam_blocks]
+};
+
+// value of lane - 1; lane 0 receives `first` (DPP wave_shr:1 leaves lane 0's destination untouched)
+__device__ __forceinline__ double fused_shr1(const double v, const double first) {
+    const I2 i = __builtin_bit_cast(I2, v), f = __builtin_bit_cast(I2, first);
+    const I2 o{__builtin_amdgcn_update_dpp(f.lo, i.lo, 0x138, 0xf, 0xf, false),
+               __builtin_amdgcn_update_dpp(f.hi, i.hi, 0x138, 0xf, 0xf, false)};
+    return __builtin_bit_cast(double, o);
+}
+__device__ __forceinline__ cd fused_shr1(const cd v, const cd first) { return cd{fused_shr1(v.x, first.x), fused_shr1(v.y, first.y)}; }
+
+// det <p_a | q_b>, a, b < NOCC (conjugate on the first, sum over the N components: _wf_dpr, pythtb.py:3793-3796)
+template <int N, int NOCC>
+__device__ __forceinline__ cd fused_link(const cd (&p)[NOCC][N], const cd (&q)[NOCC][N]) {
+    cd M[NOCC][NOCC];
+#pragma unroll
+    for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+        for (int b = 0; b < NOCC; ++b) {
+            cd acc{0.0, 0.0};
+#pragma unroll
+            for (int o = 0; o < N; ++o) cfmac(acc, p[a][o], q[b][o]);
+            M[a][b] = acc;
+        }
+    if constexpr (NOCC == 1) return M[0][0];
+    else return csub(cmul(M[0][0], M[1][1]), cmul(M[0][1], M[1][0]));
+}
+
+template <int N, int PM, int NOCC>
+// (154 VGPRs at N = 2: three wavefronts per SIMD.  Forcing four -- __launch_bounds__(256, 4) -- spills 31 registers to scratch,
+// and a scratch access is a vector-memory operation that waits for every store issued before it: never in this loop)
+__global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, const GridArgs G, const FusedArgs F) {
+    extern __shared__ __align__(16) unsigned char lds_rows[];
+    static_assert(PM >= 0, "k_grid_rows_flux: static range of the last lattice component");
+    constexpr int NSLOT = N * (N + 1) / 2;
+    constexpr int npow = 2 * PM + 1;
+    constexpr int ncell = NSLOT * npow;
+    constexpr int NCAR = NOCC * N + 1;              // carried per row: the occupied vectors and Ux of lane 63
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int R1 = F.R + 1;
+    const int per_wave = R1 * (ncell + N + NCAR) + 64 * N + G.seg * 64 * (1 + N);
+    cd* const base = reinterpret_cast<cd*>(lds_rows) + wib * per_wave;
+    cd* const C = base;                             // [R1][ncell]
+    cd* const frowL = C + R1 * ncell;               // [R1][N]
+    cd* const carry = frowL + R1 * N;               // [R1][NCAR]
+    cd* const stage = carry + R1 * NCAR;            // [64 N]
+    // the tile's per-column table entries z_last(j), f_last(j, o): fetched ONCE, so that the main loop holds no vector-memory
+    // load at all -- vmcnt counts loads and stores in issue order, and any load consumed inside the loop would wait for every
+    // store issued before it (k_grid_rows keeps its prefetch legal with a static store count; here the row count is data)
+    cd* const ztab = stage + 64 * N;                // [seg][64]
+    cd* const ftab = ztab + G.seg * 64;             // [seg][64][N]
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wib;
+    const bool live = tile < G.ntiles;
+    const int nlast = G.wv.mesh[1], M0 = G.wv.mesh[0];
+    int r0 = 0, jc0 = 0, jc1 = 0, nrows = 0;
+    if (live) {
+        const int rg = (int)(tile / G.tpr);
+        const int ts = (int)(tile - (int64_t)rg * G.tpr);
+        r0 = rg * F.R;
+        nrows = min(R1, M0 - r0);                   // rows solved by this tile (the last one is the halo when it exists)
+        jc0 = ts * G.seg;
+        jc1 = min(jc0 + G.seg, G.cpr);
+        for (int cell = lane; cell < nrows * ncell; cell += 64) {
+            const int rr = cell / ncell, c = cell - rr * ncell;
+            const cd z[4] = {G.tz[0][r0 + rr], cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}};
+            const int t0 = mv.cell_ptr[c], t1 = mv.cell_ptr[c + 1];
+            cd acc{0.0, 0.0};
+            for (int t = t0; t < t1; ++t) {
+                int4 Rv = mv.term_R[t];
+                Rv.y = 0;
+                cfma(acc, mv.term_amp[t], phase_of_R(z, Rv));
+            }
+            C[cell] = acc;
+        }
+        for (int e = lane; e < nrows * N; e += 64) {
+            const int rr = e / N, o = e - rr * N;
+            frowL[e] = G.tf[0][(int64_t)(r0 + rr) * N + o];
+        }
+        for (int e = lane; e < (jc1 - jc0) * 64; e += 64) {
+            const int jj = min(jc0 * 64 + e, nlast - 1);
+            ztab[e] = G.tz[1][jj];
+#pragma unroll
+            for (int o = 0; o < N; ++o) ftab[e * N + o] = G.tf[1][(int64_t)jj * N + o];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    double gmin[N > 1 ? N - 1 : 1];
+#pragma unroll
+    for (int b = 0; b + 1 < N; ++b) gmin[b] = __longlong_as_double(0x7ff0000000000000ll);
+    auto slot = [](const int s) { return (N & 1) ? s : (s ^ ((s >> 3) & 3)); };   // (see k_grid_rows)
+    int wslot[N], rslot[N];
+#pragma unroll
+    for (int o = 0; o < N; ++o) {
+        wslot[o] = slot(lane * N + o);
+        rslot[o] = slot(o * 64 + lane);
+    }
+    double wsel0[N], wsel1[N];
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+        wsel0[b] = F.occ[0] == b ? 1.0 : 0.0;
+        wsel1[b] = F.occ[NOCC > 1 ? 1 : 0] == b ? 1.0 : 0.0;
+    }
+    double psum = 0.0;
+    for (int jc = jc0; jc < jc1; ++jc) {
+        const cd zl = ztab[(jc - jc0) * 64 + lane];
+        cd tfl[N];
+#pragma unroll
+        for (int o = 0; o < N; ++o) tfl[o] = ftab[((jc - jc0) * 64 + lane) * N + o];
+        const int j = jc * 64 + lane;
+        const int nvalid_pts = min(64, nlast - jc * 64);
+        const bool full = nvalid_pts == 64;
+        // the plaquette to the left of column j exists for 1 <= j <= nlast - 1; the first column of the tile has no left
+        // neighbour inside the tile (k_flux_seams)
+        const bool col_ok = j >= 1 && j < nlast && (lane > 0 || jc > jc0);
+        cd vprev[NOCC][N], uy_prev{1.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+            for (int o = 0; o < N; ++o) vprev[a][o] = cd{0.0, 0.0};
+        for (int rr = 0; rr < nrows; ++rr) {
+            const cd* Crow = C + rr * ncell;
+            SmallMat<N> M;
+            int sl = 0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+#pragma unroll
+                for (int b = a; b < N; ++b, ++sl) {
+                    const cd* Cs = Crow + sl * npow + PM;
+                    cd acc = Cs[0];
+                    cd zp = zl;
+#pragma unroll
+                    for (int p = 1; p <= PM; ++p) {
+                        cfma(acc, Cs[p], zp);
+                        cfma(acc, Cs[-p], cconj(zp));
+                        if (p < PM) zp = cmul(zp, zl);
+                    }
+                    if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
+                }
+            }
+            init_vectors<N, true>(M);
+            if constexpr (N > 2) {
+                if (!jacobi_small<N, true>(M) && G.flags) G.flags[0] = 1;
+                sort_small<N>(M);
+            } else {
+                jacobi_small<N, true>(M);
+            }
+            const bool stored = rr < F.R;              // (the halo row belongs to the next row group)
+            if (stored) {
+#pragma unroll
+                for (int b = 0; b + 1 < N; ++b) gmin[b] = fmin(gmin[b], M.dg[b + 1] - M.dg[b]);
+            }
+            cd fo[N];
+#pragma unroll
+            for (int o = 0; o < N; ++o) fo[o] = cmul(frowL[rr * N + o], tfl[o]);
+            // the stored components of the occupied states: what berry_flux would read back
+            cd psi[NOCC][N];
+#pragma unroll
+            for (int o = 0; o < N; ++o) {
+                // (the band is picked with 0 / 1 weights: written as "M.v[o][occ]", or as a chain of selects on occ == b, the
+                // compiler parks the candidates in SCRATCH memory and indexes them -- and a scratch load is a vector-memory
+                // operation, so every row of every chunk then waited for all of its own stores to land: 2.4 x slower)
+                cd c0{0.0, 0.0}, c1{0.0, 0.0};
+#pragma unroll
+                for (int b = 0; b < N; ++b) {
+                    c0.x = fma(wsel0[b], M.v[o][b].x, c0.x);
+                    c0.y = fma(wsel0[b], M.v[o][b].y, c0.y);
+                    if constexpr (NOCC > 1) {
+                        c1.x = fma(wsel1[b], M.v[o][b].x, c1.x);
+                        c1.y = fma(wsel1[b], M.v[o][b].y, c1.y);
+                    }
+                }
+                psi[0][o] = cmul(c0, fo[o]);
+                if constexpr (NOCC > 1) psi[1][o] = cmul(c1, fo[o]);
+            }
+            if (stored) {
+                const int nvalid = nvalid_pts * N;
+                const int64_t point0 = (int64_t)(r0 + rr) * nlast + (int64_t)jc * 64;
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int o = 0; o < N; ++o) stage[wslot[o]] = cmul(M.v[o][r], fo[o]);
+                    asm volatile("" ::: "memory");
+                    cd* dst = G.wv.data + ((int64_t)r * G.wv.npts + point0) * N;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const int e = i * 64 + lane;
+                        if (full || e < nvalid) dst[e] = stage[rslot[i]];
+                    }
+                }
+            }
+            // ---- links and the plaquette row between rr - 1 and rr
+            const cd* car = carry + rr * NCAR;
+            cd left[NOCC][N];
+#pragma unroll
+            for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+                for (int o = 0; o < N; ++o) left[a][o] = fused_shr1(psi[a][o], car[a * N + o]);
+            const cd uy = fused_link<N, NOCC>(left, psi);
+            cd ux{1.0, 0.0};
+            if (rr > 0) {
+                ux = fused_link<N, NOCC>(vprev, psi);
+                const cd uxl = fused_shr1(ux, car[NOCC * N]);
+                const cd z = cmul(cmul(uxl, uy), cconj(cmul(ux, uy_prev)));
+                const double pha = -arg_small_first(z.y, z.x);
+                psum += col_ok ? pha : 0.0;
+            }
+            if (lane == 63) {
+                cd* cw = carry + rr * NCAR;
+#pragma unroll
+                for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+                    for (int o = 0; o < N; ++o) cw[a * N + o] = psi[a][o];
+                cw[NOCC * N] = ux;
+            }
+#pragma unroll
+            for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+                for (int o = 0; o < N; ++o) vprev[a][o] = psi[a][o];
+            uy_prev = uy;
+        }
+    }
+    if constexpr (N > 1) {
+#pragma unroll
+        for (int b = 0; b + 1 < N; ++b) {
+            double g = gmin[b];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) g = fmin(g, __shfl_xor(g, off));
+            if (lane == 0) G.gap_part[tile * (N - 1) + b] = g;
+        }
+    }
+    // the tile's flux: a fixed-shape tree over the lanes' ordered sums
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
+    if (lane == 0) F.partial[tile] = psum;
+}
+
+// ---- the plaquette columns between two tiles of a row group: thread = (plaquette row i, seam s); column j = seam * seg * 64 - 1.
+// Reads its four corners from the finished array (band-major planes) -- 1 / (64 seg) of the plaquettes.
+template <int N, int NOCC>
+__global__ __launch_bounds__(256) void k_flux_seams(const WfsView v, const int occ0, const int occ1, const int seg, const int nseam,
+                                                    double* __restrict__ partial) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int nlast = v.mesh[1];
+    const int64_t total = (int64_t)(v.mesh[0] - 1) * nseam;
+    double pha = 0.0;
+    if (t < total) {
+        const int i = (int)(t / nseam), s = (int)(t - (int64_t)i * nseam);
+        const int j = (s + 1) * seg * 64 - 1;                  // plaquette between columns j and j + 1
+        if (j + 1 < nlast) {
+            auto load = [&](const int ii, const int jj, cd (&u)[NOCC][N]) {
+                const int64_t pt = (int64_t)ii * nlast + jj;
+#pragma unroll
+                for (int o = 0; o < N; ++o) {
+                    u[0][o] = wf_at(v, occ0, pt)[o];
+                    if constexpr (NOCC > 1) u[1][o] = wf_at(v, occ1, pt)[o];
+                }
+            };
+            cd a[NOCC][N], b[NOCC][N], c[NOCC][N], d[NOCC][N];
+            load(i, j, a);
+            load(i + 1, j, b);
+            load(i + 1, j + 1, c);
+            load(i, j + 1, d);
+            const cd ux0 = fused_link<N, NOCC>(a, b), uy1 = fused_link<N, NOCC>(b, c);
+            const cd ux1 = fused_link<N, NOCC>(d, c), uy0 = fused_link<N, NOCC>(a, d);
+            const cd z = cmul(cmul(ux0, uy1), cconj(cmul(ux1, uy0)));
+            pha = -arg_small_first(z.y, z.x);
+        }
+    }
+    // block sum in a fixed order
+    __shared__ double red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pha += __shfl_xor(pha, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pha;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// fixed-shape sum of n partials into *total (one block; the same order every run)
+__global__ __launch_bounds__(1024) void k_sum_fixed(const double* __restrict__ p, const int64_t n, double* __restrict__ total) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        s0 += p[i];
+        s1 += p[i + 1024];
+        s2 += p[i + 2048];
+        s3 += p[i + 3072];
+    }
+    for (; i < n; i += 1024) s0 += p[i];
+    double s = (s0 + s1) + (s2 + s3);
+    __shared__ double red[16];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        *total = tot;
+    }
+}

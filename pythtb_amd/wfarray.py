@@ -236,6 +236,41 @@ class wf_array(object):
             return None
         return gaps[:n - 1]
 
+    def solve_on_grid_flux(self, start_k, occ="All"):
+        """Extension (not in the reference): `solve_on_grid(start_k)` and `berry_flux(occ)` of a 2-D array in ONE pass over
+        the mesh -- the plaquette phases are formed while the eigenvectors are still in registers, so the array is written
+        once and never read back (tbk_wfs_solve_grid_flux_async).  Returns (min gaps, total flux), the values the two
+        calls return (the flux up to the order of its sum).  Where the fused kernel does not apply (other than 2-D arrays
+        of 2 or 4 states, more than two bands) the two calls are made."""
+        from ._lib import TbkError
+        m = self._model
+        occ_arr = self._occ(occ)
+        if (self._dim_arr == 2 and self._dim_arr == m._dim_k and self._nsta_arr == m._nsta and m._nsta in (2, 4)
+                and 1 <= len(occ_arr) <= 2):
+            start = np.ascontiguousarray(np.array(start_k, dtype=float).reshape(-1))
+            if start.shape != (self._dim_arr,):
+                raise Exception("\n\nk-vector of wrong shape!")
+            n = m._nsta
+            pbc = np.zeros((self._dim_arr, n), dtype=complex)
+            for d in range(self._dim_arr):
+                pbc[d] = np.repeat(np.exp(-2.j * np.pi * self._orb[:, m._per[d]]), self._nspin)
+            h = self._dev_handle(self._shape())
+            occ32 = np.ascontiguousarray(occ_arr, dtype=np.int32)
+            rc = _lib.lib.tbk_wfs_solve_grid_flux_async(h, m._device_model(), _lib.dptr(start), _lib.dptr(pbc.view(float)), 0,
+                                                       int(self._mesh_arr[0]), _lib.iptr(occ32), len(occ32))
+            if rc == 0:
+                gaps = np.zeros(max(n - 1, 1), dtype=float)
+                _lib.check(_lib.lib.tbk_wfs_solve_grid_result(h, _lib.dptr(gaps)))
+                tot = np.zeros(1)
+                _lib.check(_lib.lib.tbk_berry_flux_result(h, _lib.dptr(tot), None))
+                self._start_k = start_k
+                self._device_wrote()
+                return gaps[:n - 1], float(tot[0])
+            if rc != 4:                                          # TBK_EUNSUPPORTED: fall through to the two calls
+                _lib.check(rc)
+        gaps = self.solve_on_grid(start_k)
+        return gaps, self.berry_flux(occ)
+
     def solve_on_grid_window(self, start_k, offset, global_mesh):
         """Extension for k-sharded runs (not in the reference): this array holds the points
         [offset[d], offset[d]+mesh[d]) of a global solve_on_grid mesh of global_mesh[d] points per
