@@ -195,6 +195,12 @@ class Grid(object):
     def flux(self, occ32):
         self._lib.check(self.lib.tbk_berry_flux_async(self.h, self._lib.iptr(occ32), len(occ32), 0, 1, 0))
 
+    def solve_flux(self, start, occ32):
+        """solve_on_grid + berry_flux(occ) in one pass (tbk_wfs_solve_grid_flux_async): the array is written once and never read back"""
+        self.start = np.ascontiguousarray(start, dtype=float)
+        self._lib.check(self.lib.tbk_wfs_solve_grid_flux_async(self.h, self.hm, self._lib.dptr(self.start), self._lib.dptr(self.pbc.view(float)),
+                                                               self.row0, self.g_n0, self._lib.iptr(occ32), len(occ32)))
+
     def gaps(self):
         g = np.zeros(max(self.n - 1, 1))
         self._lib.check(self.lib.tbk_wfs_solve_grid_result(self.h, self._lib.dptr(g)))
@@ -464,6 +470,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the sustained / python-API / other-config legs")
     ap.add_argument("--no-check", action="store_true", help="diagnostics: skip the Chern-number assertion")
+    ap.add_argument("--two-calls", action="store_true", help="the step as two launches (solve_grid, then berry_flux reading the array "
+                    "back) instead of the fused pass")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU test of the multi-rank control flow
     args = ap.parse_args()
 
@@ -523,9 +531,14 @@ def main():
     start = [-0.5, -0.5]
     occ = np.array([0], dtype=np.int32)
 
-    def step():
+    def step_two_calls():
         grid.solve(start)
         grid.flux(occ)
+
+    def step_fused():
+        grid.solve_flux(start, occ)
+
+    step = step_two_calls if (args.two_calls or args.stub) else step_fused
 
     def barrier():
         ctx.sync()
@@ -572,6 +585,19 @@ def main():
                                "chern": float(grid.flux_total()[0] / (2 * np.pi))}
         # ---- the same kernels with every launch bracketed over 100 steps (per-kernel averages on a warm, busy chip)
         extras["kernels_every_launch_bracketed"] = kernel_times(ctx, step, 100, ev_ms)
+        # ---- the step as the two launches of the drop-in API (wf.solve_on_grid(); wf.berry_flux()): k_grid_rows + k_flux_rows
+        if step is not step_two_calls:
+            for _ in range(5):
+                step_two_calls()
+            ctx.sync()
+            s0 = time.perf_counter()
+            for _ in range(2000):
+                step_two_calls()
+            ctx.sync()
+            s1 = time.perf_counter()
+            extras["two_call_step"] = {"ms_per_step": 1e3 * (s1 - s0) / 2000, "value": MESH * MESH * 2000 / (s1 - s0),
+                                       "chern": float(grid.flux_total()[0] / (2 * np.pi)),
+                                       "kernels": kernel_times(ctx, step_two_calls, 100, ev_ms)}
         try:
             extras["python_api"] = python_api_leg(tb, model)
         except Exception as e:
@@ -611,9 +637,11 @@ def main():
         for name, rec in prof.items():
             kern[name] = {"launches": rec["launches"], "avg_bracket_ms": rec["total_ms"] / max(rec["launches"], 1)}
         npt = MESH * MESH
-        alg = {"solve_grid": bytes_solve(N_STA) * npt, "berry_flux": bytes_berry(1, N_STA) * npt}
-        vkey = {"solve_grid": "k_grid_rows<2,1>", "berry_flux": "k_flux_rows<1,2>"}
-        dom = max(("solve_grid", "berry_flux"), key=lambda k: kern.get(k, {"avg_bracket_ms": 0})["avg_bracket_ms"])
+        # (the fused pass writes the array once and reads nothing back: its algorithmic traffic is the solve's 16 n^2 B per point)
+        alg = {"solve_grid": bytes_solve(N_STA) * npt, "berry_flux": bytes_berry(1, N_STA) * npt,
+               "solve_grid_flux": bytes_solve(N_STA) * npt}
+        vkey = {"solve_grid": "k_grid_rows<2,1>", "berry_flux": "k_flux_rows<1,2>", "solve_grid_flux": "k_grid_rows_flux<2,1,1>"}
+        dom = max(("solve_grid_flux", "solve_grid", "berry_flux"), key=lambda k: kern.get(k, {"avg_bracket_ms": 0})["avg_bracket_ms"])
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes (rocprofv3 --pmc), per launch
         if os.path.exists(tpath):
@@ -621,9 +649,13 @@ def main():
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = "profiles/traffic.json <- %s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % tj.get("source")
         roofs = {}
-        for name in ("solve_grid", "berry_flux"):
+        for name in ("solve_grid_flux", "solve_grid", "berry_flux"):
             if name in kern:
                 roofs[name] = roof(alg[name], kern[name]["avg_bracket_ms"], vkey[name], (MESH + 1) * (MESH + 1), valu)
+        # the two-launch step's kernels (k_grid_rows, k_flux_rows), measured in their own leg below
+        for name, rec in extras.get("two_call_step", {}).get("kernels", {}).items():
+            if name in alg and name not in roofs:
+                roofs[name] = roof(alg[name], rec["avg_bracket_ms"], vkey[name], (MESH + 1) * (MESH + 1), valu)
         out = {
             "metric": "k-points solved/sec (H(k)+eigh) and Berry-flux/sec, Haldane 2048^2 mesh",
             "value": nk_step * args.steps / t_max, "unit": "k-points/s",
@@ -632,6 +664,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Haldane (2 orb, 9 hops) wf_array solve_on_grid + berry_flux([0]), "
                                    "%d x %d k-mesh per GPU (BASELINE.json configs[2])" % (MESH, MESH),
+                       "step": "two launches (solve_grid, berry_flux)" if (args.two_calls or args.stub) else
+                               "one fused pass (tbk_wfs_solve_grid_flux_async: eigenvectors written once, plaquette phases from registers)",
                        "global_mesh": [MESH * world, MESH], "start_k": [-0.5, -0.5],
                        "sharding": "k-slabs along mesh axis 0, halo row recomputed", "gather": gather},
             "roofline": dict(roofs.get(dom, {}), kernel=dom, traffic=traffic, traffic_source=traffic_source),

@@ -1990,7 +1990,6 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
                         tbk_knobs().grid_kernel != 1 && v.npts < (int64_t)0x7fffffff,
                     TBK_EUNSUPPORTED, "tbk_wfs_solve_grid_flux: a %d-D array of %d states (last-axis range %d): the fused kernel "
                     "serves 2-D arrays of 2 states (range <= 2) or 4 states (range 1)", D, n, pm);
-        ProfScope ps(ctx, "solve_grid_flux");
         const TbkKnobs& K = tbk_knobs();
         FusedArgs F{};
         // rows per tile (measured, profiles/fused_probe.py, us per step at 2048^2 | 4096^2): R = 2 88 | 319, 3 73 | 282, 4 72 | 271,
@@ -2049,6 +2048,8 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         const size_t lds = (size_t)4 * (fixed_cd + (size_t)G.seg * 64 * (1 + n)) * sizeof(cd);
         TBK_REQUIRE(lds <= 64 * 1024, TBK_EUNSUPPORTED, "tbk_wfs_solve_grid_flux: %zu bytes of LDS per block", lds);
         const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
+        {
+        ProfScope ps(ctx, "solve_grid_flux");   // (the fused kernel alone)
 #define TBK_FUSED(NN, PP, OO) hipLaunchKernelGGL((k_grid_rows_flux<NN, PP, OO>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G, F)
         if (n == 2 && ff->nocc == 1) {
             if (pm == 0) TBK_FUSED(2, 0, 1); else if (pm == 1) TBK_FUSED(2, 1, 1); else TBK_FUSED(2, 2, 1);
@@ -2060,6 +2061,10 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
             TBK_FUSED(4, 1, 2);
         }
 #undef TBK_FUSED
+        }
+        // (tried: the final sum inside the seam kernel's last-arriving block -- 14 us for that kernel instead of 4.9 + 4.8 for the
+        // two launches: one block reading 8.7 k partials with agent-scope loads is slower than a 1024-thread block of its own)
+        ProfScope ps2(ctx, "flux_seams_sum");
         if (nsb > 0) {
             if (n == 2 && ff->nocc == 1)
                 hipLaunchKernelGGL((k_flux_seams<2, 1>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
