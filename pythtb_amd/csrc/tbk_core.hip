@@ -34,6 +34,8 @@ static void knobs_parse() {
     geti("TBK_QL16", k.use_ql16);
     geti("TBK_QLW", k.use_qlw);
     geti("TBK_TRIG", k.use_trig);
+    geti("TBK_TRIGV", k.use_trigv);
+    geti("TBK_TRIGV_NC", k.trigv_nc);
     geti("TBK_TRIG_NT", k.trig_nt);
     getl("TBK_QLW_MIN", k.qlw_min);
     geti("TBK_QLW_NT", k.qlw_nt);

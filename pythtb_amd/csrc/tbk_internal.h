@@ -40,6 +40,8 @@ struct TbkKnobs {
     long long ql16_min = -1;    // TBK_QL16_MIN      batches of at most this many matrices stay on the workgroup-per-matrix Jacobi (default 8 x CUs)
     int trig_nt = -1;           // TBK_TRIG_NT       threads per matrix of the L2 Householder kernel (256 | 512 | 1024; at least n)
     int use_trig = 1;           // TBK_TRIG          0: eigenvalue-only n = 65..1024 through the Jacobi solvers instead of tridiagonalise + bisection
+    int use_trigv = 1;          // TBK_TRIGV         0: eigenvectors of 65..1024 states through the Jacobi solvers instead of the direct method (tbk_solve_trigv.inl)
+    int trigv_nc = -1;          // TBK_TRIGV_NC      columns per LDS strip of the back-transformation (4 | 8 | 16)
     int use_qlw = 1;            // TBK_QLW           0: n = 17..64 through the Jacobi kernels whatever the batch size
     long long qlw_min = -1;     // TBK_QLW_MIN       batches of at most this many matrices stay on the Jacobi kernels (default 8 x CUs)
     int qlw_replay_reg = 1;     // TBK_QLW_REPLAY_REG  0: n <= 32 replays the rotations on Z in LDS (the form n = 33..64 uses) instead of in registers

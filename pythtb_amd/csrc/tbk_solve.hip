@@ -1392,6 +1392,7 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 #include "tbk_solve_tw16.inl"  // n = 9..16 with eigenvectors, large batches: tridiagonalise | eigenvalues | twisted-factorisation vectors (MFMA Newton-Schulz) + back-transformation
 #include "tbk_solve_fused.inl" // 2-D meshes, n = 2 / 4: solve_on_grid and berry_flux in one pass (the plaquette phases from registers)
 #include "tbk_solve_trig.inl"  // eigenvalues only, n = 65..1024: Householder with A in L2, then one thread per eigenvalue (bisection)
+#include "tbk_solve_trigv.inl" // eigenvectors for n = 65..1024 by the direct method: tridiagonalise (reflectors kept) | bisection | twisted-factorisation vectors | Newton-Schulz | back-transformation
 #include "tbk_solve_qlw.inl"   // n = 17..64, large batches: Householder in LDS, lane-per-matrix QL, rotation replay
 #include "tbk_solve_blk.inl"   // batches of wide matrices: block Jacobi, 16x16 subproblems through k_solve_row16
 
@@ -1418,7 +1419,7 @@ static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
 // sources in DESIGN.md section 4 and profiles/).  The batch is counted on the GLOBAL mesh for mesh solves, so every window
 // and shard of an array takes the same route (bit-identical halo rows and images).  tests/test_regimes.py forces every
 // regime on the same matrices against LAPACK.
-enum class Regime { Trig, Blocked, Big, Reg, Ql16, Qlw, Row16, WgLds, WgGlobal, Wave };
+enum class Regime { Trig, TrigV, Blocked, Big, Reg, Ql16, Qlw, Row16, WgLds, WgGlobal, Wave };
 enum BatchUnit { kMatrices, kPerCU, kWork };   // the batch window counts matrices | matrices per CU | matrices * n^2
 enum { kList = 1, kMesh = 2, kSupplied = 4, kAnyForm = 7, kNoMesh = 5 };
 struct RegimeRule {
@@ -1436,6 +1437,10 @@ static const RegimeRule kRegimeRules[] = {
     {Regime::Trig, 65, 512, 0, kNoMesh, kMatrices, -1, -1, "101 x n=300: 184 -> 12.6 ms; one n=512: 104 -> 27 ms"},
     {Regime::Trig, 513, 800, 0, kNoMesh, kMatrices, 1, -1, "8 x n=800: 257 -> 125 ms; a single one stays on the whole-chip rounds"},
     {Regime::Trig, 801, 1024, 0, kNoMesh, kMatrices, 5, -1, "a matrix costs 240 ms at n=1024: from 6 matrices on"},
+    // with eigenvectors, 65..1024 states: the same reduction with the reflectors kept, twisted-factorisation vectors, Newton-Schulz,
+    // back-transformation on LDS column strips (tbk_solve_trigv.inl).  One CU per matrix in the reduction, like Trig.
+    {Regime::TrigV, 65, 512, 1, kAnyForm, kMatrices, -1, -1, "101 x n=300 with vectors: 143 (block Jacobi) -> see DESIGN.md"},
+    {Regime::TrigV, 513, 1024, 1, kAnyForm, kMatrices, 5, -1, "few very large ones stay on the whole-chip rounds"},
     // batches of wide matrices: block Jacobi (n/8 - 1 passes per sweep instead of n - 1; three launches per round)
     {Regime::Blocked, 96, TBK_MAX_NSTA, -1, kAnyForm, kWork, 1.4e6 - 1, -1, "512 x n=128: 87/105 -> 35/55 ms; 64 x n=128: 11.8 -> 18.7 (stays out)"},
     // whole-chip Jacobi rounds: everything above 256 states, and 65..256 for small batches, eigenvalues only or n > 224
@@ -1482,6 +1487,9 @@ static Regime choose_regime(const RegimeQuery& q, const TbkKnobs& K, const char*
                 if (K.use_trig == 0) continue;
                 if (K.use_trig == 2) lo = -1;
                 break;
+            case Regime::TrigV:
+                if (K.use_trigv == 0 || q.qlw_off) continue;   // (qlw_off: the call is being repeated on the Jacobi kernels)
+                break;
             case Regime::Blocked:
                 if (K.blocked == 0) continue;
                 if (K.blocked == 1) { lo = -1; n_lo = 65; }
@@ -1513,7 +1521,7 @@ static Regime choose_regime(const RegimeQuery& q, const TbkKnobs& K, const char*
         if (q.n < n_lo) continue;
         const double batch = r.unit == kMatrices ? (double)q.batch : r.unit == kPerCU ? (double)q.batch / q.cus : (double)q.batch * q.n * q.n;
         // (the eigenvalue-only Trig rows count the matrices of THIS call: nothing to keep consistent across windows)
-        const double b2 = r.regime == Regime::Trig ? (double)q.nk : batch;
+        const double b2 = r.regime == Regime::Trig ? (double)q.nk : batch;   // (TrigV: the global batch, so that every window agrees)
         if (lo >= 0 && !(b2 > lo)) continue;
         if (hi >= 0 && !(b2 <= hi)) continue;
         if (note) *note = r.note;
@@ -1525,7 +1533,7 @@ static Regime choose_regime(const RegimeQuery& q, const TbkKnobs& K, const char*
 // Host-only view of the table (no device needed): which regime a batch would take, and the measurement behind the boundary.
 extern "C" const char* tbk_solver_regime(int n, int with_vectors, int form, int64_t nk, int64_t batch, int compute_units,
                                          int has_rblocks, const char** note_out) {
-    static const char* names[] = {"trig", "blocked", "big", "reg", "ql16", "qlw", "row16", "wg_lds", "wg_global", "wave"};
+    static const char* names[] = {"trig", "trigv", "blocked", "big", "reg", "ql16", "qlw", "row16", "wg_lds", "wg_global", "wave"};
     if (n <= 4) return n <= 2 ? "closed_form" : "ql_small";
     const RegimeQuery q{n, with_vectors ? 1 : 0, form == 1 ? kMesh : (form == 2 ? kSupplied : kList), nk, batch,
                         compute_units > 0 ? compute_units : 256, has_rblocks != 0, false};
@@ -1551,6 +1559,9 @@ static int launch_wave(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     switch (regime) {
         case Regime::Trig:
             if constexpr (MODE != 1 && !VEC) return launch_trig<MODE>(ctx, mv, n, nk, L);
+            break;
+        case Regime::TrigV:
+            if constexpr (VEC) return launch_trigv<MODE>(ctx, mv, n, nk, L, G);
             break;
         case Regime::Blocked: return launch_blocked<MODE, VEC>(ctx, mv, n, nk, L, G);
         case Regime::Big: return launch_big<MODE, VEC>(ctx, mv, n, nk, L, G);

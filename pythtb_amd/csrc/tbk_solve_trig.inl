@@ -37,9 +37,16 @@ __device__ __forceinline__ double trig_block_sum(double v, double* red, const in
 // MODE 0: k list, 2: supplied matrices.  Block b works on matrix id0 + b; work holds nc matrices of n x n.
 // ALDS: the matrix fits the LDS of a CU next to the vectors (n <= 96): the same steps on an LDS-resident A -- a row costs
 // ~0.1 us of latency instead of ~1 us from L2, and the small sizes are all latency.
-template <int MODE, bool ALDS, int NT>
+// KEEP (tbk_solve_trigv.inl: eigenvectors wanted): the reflectors stay behind for the back-transformation -- row k of A keeps
+// conj(u_k[c]) for c >= k + 2 (no later step touches it), aux[(idc n + k) 3 + 0 .. 2] = (u_k[k+1]), (beta_k, reflected?), (t_k =
+// T[k+1][k], complex: the diagonal unitary D that makes the subdiagonal real is D_{k+1} = D_k t_k / |t_k|).  MODE 1 (a mesh
+// window, KEEP only): the point's k from grid_point.
+template <int MODE, bool ALDS, int NT, bool KEEP = false>
 __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const int64_t nk, const ListArgs L, const int64_t id0,
-                                                              const int64_t nc, cd* __restrict__ work, double2* __restrict__ de) {
+                                                              const int64_t nc, cd* __restrict__ work, double2* __restrict__ de,
+                                                              const GridArgs G = GridArgs{}, double2* __restrict__ aux = nullptr) {
+    static_assert(!KEEP || !ALDS, "k_tridiag_glb: the reflectors are kept in the global workspace");
+    static_assert(MODE != 1 || KEEP, "k_tridiag_glb: mesh windows always want eigenvectors");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int n = mv.nsta, ld = ALDS ? (n | 1) : n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -61,8 +68,11 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
 #pragma unroll
         for (int d = 0; d < 4; ++d)
             if (d < mv.dim_k) kk[d] = L.k[id * mv.dim_k + d];
+    } else if constexpr (MODE == 1) {
+        bool wrap[4];
+        grid_point(G, id, kk, wrap);
     }
-    assemble_lds<MODE, NT>(mv, L, id, kk, A, ld, ph, tid);
+    assemble_lds<MODE == 1 ? 0 : MODE, NT>(mv, L, id, kk, A, ld, ph, tid);
     __syncthreads();
 
     const int x = tid;                        // this thread's row in the per-row steps (n <= NT)
@@ -72,13 +82,14 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
         cd u;
         double beta, mag;
         bool on;
+        cd t;                                 // t_k = T[k+1][k]
     };
     auto reflector = [&](const cd colx, const int k) {
         if (x == k + 1) shr[0] = colx;
         const double rest = trig_block_sum<NT>(x > k + 1 && x < n ? cabs2(colx) : 0.0, red, tid);   // (its barriers publish shr[0])
         const cd alpha = shr[0];
         const double absa2 = cabs2(alpha);
-        Refl R{cd{0.0, 0.0}, 0.0, sqrt(absa2), rest > 0.0};
+        Refl R{cd{0.0, 0.0}, 0.0, sqrt(absa2), rest > 0.0, alpha};
         if (R.on) {
             const double nrm = sqrt(rest + absa2);
             double absa = 0.0;
@@ -90,6 +101,7 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
             R.u = x == k + 1 ? cd{phs.x * (absa + nrm), phs.y * (absa + nrm)} : colx;   // u = column + phase * norm * e_{k+1}
             R.beta = 1.0 / (nrm * (nrm + absa));
             R.mag = nrm;                                                               // t_k = -phase * nrm
+            R.t = cd{-phs.x * nrm, -phs.y * nrm};
         }
         return R;
     };
@@ -131,7 +143,15 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
         }
         // the NEXT step's reflector: column k+1 below the diagonal as it will be after this step's update,
         // conj(A[k+1][x] - (u_{k+1} conj(q_x) + q_{k+1} conj(u_x)))  (row k+1: contiguous)
-        Refl nxt{cd{0.0, 0.0}, 0.0, 0.0, false};
+        if constexpr (KEEP) {
+            if (x == k + 1) {
+                double2* a3 = aux + ((int64_t)idc * n + k) * 3;
+                a3[0] = double2{cur.u.x, cur.u.y};
+                a3[1] = double2{cur.beta, cur.on ? 1.0 : 0.0};
+                a3[2] = double2{cur.t.x, cur.t.y};
+            }
+        }
+        Refl nxt{cd{0.0, 0.0}, 0.0, 0.0, false, cd{0.0, 0.0}};
         const bool more = k + 3 < n;
         if (more) {
             cd colx{0.0, 0.0};
@@ -190,6 +210,12 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
         if (n >= 2) {
             const cd t = A[(size_t)(n - 2) * ld + (n - 1)];
             eb[n - 2] = sqrt(cabs2(t));
+            if constexpr (KEEP) {                 // T[n-1][n-2] = conj(A[n-2][n-1]): never reflected
+                double2* a3 = aux + ((int64_t)idc * n + (n - 2)) * 3;
+                a3[0] = double2{0.0, 0.0};
+                a3[1] = double2{0.0, 0.0};
+                a3[2] = double2{t.x, -t.y};
+            }
         }
         eb[n - 1] = 0.0;
     }

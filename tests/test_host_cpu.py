@@ -390,9 +390,14 @@ def test_solver_dispatch_table_routes_the_measured_crossovers():
     # (five 1024-state matrices: too few for a CU each, enough work -- 5 x 1024^2 >= 1.4e6 -- for block Jacobi)
     assert regime(1024, 0, SUP, 5) == "blocked" and regime(1024, 0, SUP, 6) == "trig" and regime(1025, 0, SUP, 100) == "blocked"
     assert regime(800, 0, SUP, 1) == "big" and regime(600, 0, LIST, 1) == "big" and regime(600, 0, LIST, 2) == "trig"
-    assert regime(128, 1, LIST, 512) == "blocked" and regime(128, 1, LIST, 64) == "big" and regime(70, 1, LIST, 200) == "wg_global"
-    assert regime(95, 1, LIST, 4000) == "wg_global" and regime(230, 1, LIST, 26) == "big" and regime(230, 1, LIST, 27) == "blocked"
-    assert regime(300, 1, MESH, 101, batch=101) == "blocked" and regime(90, 1, SUP, 1) == "big" and regime(2048, 0, SUP, 1) == "blocked"
+    # with eigenvectors, 65..1024 states: the direct method (tbk_solve_trigv.inl); above, and with TBK_TRIGV=0, the Jacobi solvers
+    assert regime(128, 1, LIST, 512) == "trigv" and regime(300, 1, MESH, 101, batch=101) == "trigv" and regime(90, 1, SUP, 1) == "trigv"
+    assert regime(800, 1, SUP, 5) == "blocked" and regime(800, 1, SUP, 6) == "trigv" and regime(800, 1, SUP, 1) == "big"
+    assert regime(1025, 1, SUP, 3) == "blocked" and regime(2048, 0, SUP, 1) == "blocked"
+    with _lib.knob("TBK_TRIGV", 0):
+        assert regime(128, 1, LIST, 512) == "blocked" and regime(128, 1, LIST, 64) == "big" and regime(70, 1, LIST, 200) == "wg_global"
+        assert regime(95, 1, LIST, 4000) == "wg_global" and regime(230, 1, LIST, 26) == "big" and regime(230, 1, LIST, 27) == "blocked"
+        assert regime(300, 1, MESH, 101, batch=101) == "blocked" and regime(90, 1, SUP, 1) == "big"
     # knobs move the boundaries, not the code
     with _lib.knob("TBK_QL16_MIN", 0):
         assert regime(12, 1, LIST, 5) == "ql16"
@@ -400,9 +405,9 @@ def test_solver_dispatch_table_routes_the_measured_crossovers():
         assert regime(16, 1, LIST, 10 ** 5) == "row16" and regime(16, 1, MESH, 10 ** 5) == "wave"
     with _lib.knob("TBK_TRIG", 0):
         assert regime(300, 0, LIST, 101) == "blocked"
-    with _lib.knob("TBK_BLOCKED", 1):
+    with _lib.knob("TBK_BLOCKED", 1), _lib.knob("TBK_TRIGV", 0):
         assert regime(70, 1, LIST, 3) == "blocked"
-    with _lib.knob("TBK_BIG_FROM", 65):
+    with _lib.knob("TBK_BIG_FROM", 65), _lib.knob("TBK_TRIGV", 0):
         assert regime(70, 1, LIST, 1000) == "big"
     note = ctypes.c_char_p()
     _lib.lib.tbk_solver_regime(300, 0, 0, 101, 101, 256, 1, ctypes.byref(note))

@@ -71,11 +71,15 @@ REGIMES = [
     (64, 60, {"TBK_QLW_MIN": 0}, "tridiagonal path, register replay (two wavefronts)"),
     (32, 100, {"TBK_QLW_MIN": 0, "TBK_QLW_REPLAY_REG": 0}, "tridiagonal path, LDS replay forced"),
     (40, 100, {"TBK_QLW": 0}, "workgroup LDS Jacobi"),
-    (65, 20, {}, "workgroup per L2-resident matrix / whole chip"),
-    (100, 12, {"TBK_BLOCKED": 1}, "block Jacobi"),
-    (100, 12, {"TBK_BLOCKED": 0}, "workgroup / whole-chip Jacobi"),
-    (130, 6, {"TBK_BIG_FROM": 65}, "whole-chip Jacobi rounds"),
-    (257, 2, {}, "whole-chip Jacobi rounds"),
+    (65, 20, {}, "direct method: tridiagonalise | bisection | twisted vectors | Newton-Schulz | back-transformation"),
+    (100, 12, {}, "direct method"),
+    (230, 5, {}, "direct method, 8-column strips"),
+    (300, 3, {}, "direct method"),
+    (65, 20, {"TBK_TRIGV": 0}, "workgroup per L2-resident matrix / whole chip"),
+    (100, 12, {"TBK_TRIGV": 0, "TBK_BLOCKED": 1}, "block Jacobi"),
+    (100, 12, {"TBK_TRIGV": 0, "TBK_BLOCKED": 0}, "workgroup / whole-chip Jacobi"),
+    (130, 6, {"TBK_TRIGV": 0, "TBK_BIG_FROM": 65}, "whole-chip Jacobi rounds"),
+    (257, 2, {"TBK_TRIGV": 0}, "whole-chip Jacobi rounds"),
 ]
 EVAL_ONLY = [
     (12, 200, {}, "tridiagonalise + lane-per-matrix QL (any count)"),
