@@ -284,8 +284,8 @@ def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
                     "kpts": nk, "kernels": kt,
                     "kpts_per_s_eigenvalues": nk / (kt["solve_list_val"]["avg_bracket_ms"] * 1e-3),
                     "kpts_per_s_with_vectors": nk / (kt["solve_list_vec"]["avg_bracket_ms"] * 1e-3),
-                    "roofline": {"solve_list_val": roof(8 * (2 + 2) * nk, kt["solve_list_val"]["avg_bracket_ms"]),
-                                 "solve_list_vec": roof((8 * (2 + 2) + 16 * 4) * nk, kt["solve_list_vec"]["avg_bracket_ms"])},
+                    "roofline": {"solve_list_val": roof(8 * (2 + 2) * nk, kt["solve_list_val"]["avg_bracket_ms"], "k_solve_small<2,0,false>", nk, valu),
+                                 "solve_list_vec": roof((8 * (2 + 2) + 16 * 4) * nk, kt["solve_list_vec"]["avg_bracket_ms"], "k_solve_small<2,0,true>", nk, valu)},
                     "python_call_incl_pcie_s": t_api,
                     "check": {"sum": float(ev.sum()), "min": float(ev.min()), "max": float(ev.max()),
                               "api_equals_resident": bool(np.array_equal(ev_api, ev))}})
@@ -387,7 +387,7 @@ def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
                     "kpts": npt, "kernels": kt, "solve_kpts_per_s": npt / (kt["solve_grid"]["avg_bracket_ms"] * 1e-3),
                     "berry_links_per_s": side * side * (side - 1) / (bp_ms * 1e-3) if bp_ms > 0 else None,
                     "roofline": {"solve_grid": roof(bytes_solve(16) * npt, kt["solve_grid"]["avg_bracket_ms"],
-                                                    "k_solve_ql16<1,true>", side ** 3, valu)},
+                                                    "k_tw16<1>", side ** 3, valu)},
                     "check": {"gap78": float(gaps[7]), "phase_checksum": float(np.sum(np.cos(phases)))}})
         g.free()
     except Exception as e:

@@ -12,6 +12,7 @@ OUT=$REPO/gpurun_out/prof_${TAG}cfg
 SUM=$REPO/gpurun_out/summary_${TAG}cfg
 mkdir -p $OUT $SUM
 cd /tmp && export TMPDIR=/tmp
+export TBK_TW16_STREAMS=${TBK_TW16_STREAMS:-1}   # per-kernel durations and counters: one chunk of the n = 9..16 path in flight at a time
 CMD="python3 $REPO/bench_configs.py $WHICH --reps 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $SUM/bench_configs_under_trace.jsonl 2> $OUT/trace.err
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
@@ -23,5 +24,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
 done
 cd $REPO
 python3 profiles/summarise.py $OUT $SUM > $SUM/summary.txt 2>&1
-python3 $REPO/bench_configs.py $WHICH --reps 5 > $SUM/bench_configs.jsonl 2> $SUM/bench_configs.err
+unset TBK_TW16_STREAMS
+python3 $REPO/bench_configs.py $WHICH --reps 5 > $SUM/bench_configs.jsonl 2> $SUM/bench_configs.err   # (production setting: three chunks in flight)
 ls -la $SUM

@@ -61,11 +61,15 @@ for k, cs in table.items():
         traffic[k] = {"fetch_bytes_raw": rd, "fetch_bytes_x2": 2.0 * rd, "write_bytes": wr,
                       "hbm_bytes_per_launch": 2.0 * rd + wr}
 # aliases under the names bench.py uses for its HIP-event brackets
-for alias, names in (("solve_grid", ("k_grid_rows", "k_grid_small", "k_solve_wave")), ("berry_flux", ("k_flux_rows", "k_flux<"))):
+for alias, names in (("solve_grid_flux", ("k_grid_rows_flux",)), ("solve_grid", ("k_grid_rows<", "k_grid_small", "k_solve_wave")),
+                     ("berry_flux", ("k_flux_rows", "k_flux<"))):
     for nm in names:
         for full in sorted(traffic):
             if full.startswith(nm) and alias not in traffic:
                 traffic[alias] = dict(traffic[full], kernel=full)
+# where the numbers come from (bench.py quotes it next to roofline.traffic)
+for k in traffic:
+    traffic[k]["source"] = "profiles/%s/pmc_per_dispatch.json" % os.path.basename(os.path.normpath(dst)).replace("summary_", "")
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, "kernel_stats.csv")).read())
 print(json.dumps(traffic, indent=1))
