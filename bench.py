@@ -12,7 +12,11 @@ over all plaquettes and its deterministic sum.  Inputs (model tables) are reside
 in HBM before the timed region; nothing crosses PCIe inside it.
 
 `value` = k-points of the K timed steps / wall time (max over ranks), exactly as the
-driver's contract asks.  Beside it, on ONE GPU, the same JSON line carries (all
+driver's contract asks.  Order on every rank: W warm-up steps | the K-step burst on the still-idle chip
+(`cold_burst`, reported, not the value) | `--preheat-s` seconds (default 0.5) of the same step, untimed | barrier |
+the K timed steps | barrier.  An MI355X that has been idle needs more than 35 ms of work before its clocks
+are up (profiles/burst_vs_warmup.sh: the burst costs 73-77 us per step after 5 or 500 warm-up steps, 67 us
+after 3000); W = 5 steps are 0.4 ms.  Beside it, on ONE GPU, the same JSON line carries (all
 outside the timed region):
   roofline        dominant kernel: algorithmic bytes / average launch duration from HIP events on the
                   kernels' stream (the RAW bracket, event overhead included: conservative); valu_frac = VALU
@@ -468,6 +472,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preheat-s", type=float, default=0.5,
+                    help="seconds of the same step run back to back, untimed, between the W warm-up steps and the K timed ones: "
+                         "an idle MI355X needs > 35 ms of work before its clocks are up (profiles/burst_vs_warmup.sh); "
+                         "0 = none.  The K-step burst WITHOUT it is in the line as cold_burst")
     ap.add_argument("--headline-only", action="store_true", help="skip the sustained / python-API / other-config legs")
     ap.add_argument("--no-check", action="store_true", help="diagnostics: skip the Chern-number assertion")
     ap.add_argument("--two-calls", action="store_true", help="the step as two launches (solve_grid, then berry_flux reading the array "
@@ -547,6 +555,25 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # ---- the chip has been idle until now and W steps are ~0.4 ms of work: the same K-step burst here (kept in the line as
+    # cold_burst) runs ~10 % slower than any later one.  Then `--preheat-s` seconds of the same step, untimed.
+    preheat = None
+    if args.preheat_s > 0 and not args.stub:
+        barrier()
+        c0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ctx.sync()
+        c1 = time.perf_counter()
+        n_pre, p0 = 0, time.perf_counter()
+        while time.perf_counter() - p0 < args.preheat_s:
+            for _ in range(200):
+                step()
+            ctx.sync()
+            n_pre += 200
+        preheat = {"cold_burst": {"steps": args.steps, "ms_per_step": 1e3 * (c1 - c0) / args.steps, "when": "right after the W warm-up steps"},
+                   "preheat": {"steps": n_pre, "seconds": time.perf_counter() - p0,
+                               "what": "the same step back to back, untimed, before the K timed steps (--preheat-s)"}}
     # HIP-event brackets on the kernels' own stream, inside the timed region.  A bracket
     # costs ~3 us of stream time (3 kernels x 2 events = 20% of a step), so every 7th
     # launch is bracketed: coprime with the 3 launches per step, every kernel is sampled
@@ -569,7 +596,7 @@ def main():
     gaps = grid.gaps()
     tot = grid.flux_total()
 
-    extras = {}
+    extras = dict(preheat or {})
     if world == 1 and not args.headline_only and not args.stub:
         # ---- sustained: at least one second of back-to-back steps (the K-step burst above is ~1.6 ms)
         n_sus = max(args.steps, int(math.ceil(1.2 / max(elapsed / args.steps, 1e-6))))

@@ -2003,9 +2003,11 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
                     "serves 2-D arrays of 2 states (range <= 2) or 4 states (range 1)", D, n, pm);
         const TbkKnobs& K = tbk_knobs();
         FusedArgs F{};
-        // rows per tile (measured, profiles/fused_probe.py, us per step at 2048^2 | 4096^2): R = 2 88 | 319, 3 73 | 282, 4 72 | 271,
-        // 6 68 | 301, 8 69 | 310 -- six rows while the array fits the 256 MiB last-level cache, four beyond it
-        F.R = K.fused_rows > 0 ? std::min(K.fused_rows, 16) : (w->bytes <= ((int64_t)256 << 20) + (1 << 20) ? 6 : 4);
+        // tile shape (measured, profiles/fused_sweep.py, us per step, rows R x chunks seg).  2048^2 (the array fits the 256 MiB
+        // last-level cache): R = 3 73-86, 4 67-79, 5 67-75, 6 65-74, 8 63-87, 12 63-66, best around 6 x 2.  4096^2 (beyond it): tall
+        // and narrow wins -- seg = 1: R = 4 303, 6 266, 8 258, 10 251, 12 257; seg >= 2: 275-318
+        const bool in_llc = w->bytes <= ((int64_t)256 << 20) + (1 << 20);
+        F.R = K.fused_rows > 0 ? std::min(K.fused_rows, 16) : (in_llc ? 6 : 10);
         F.nrg = (v.mesh[0] + F.R - 1) / F.R;
         F.occ[0] = ff->occ[0];
         F.occ[1] = ff->occ[1];
@@ -2016,6 +2018,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         const size_t fixed_cd = (size_t)R1 * (ncell + n + ncar) + (size_t)64 * n;
         const int seg_cap = (int)std::max<size_t>(1, (1024 - std::min<size_t>(fixed_cd, 960)) / ((size_t)64 * (1 + n)));
         G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(seg_cap, G.cpr), (int64_t)G.cpr * F.nrg / want));
+        if (!in_llc) G.seg = 1;
         if (K.grid_seg >= 0) G.seg = std::max(1, std::min(std::min(K.grid_seg, seg_cap), G.cpr));
         G.tpr = (G.cpr + G.seg - 1) / G.seg;
         G.seg = (G.cpr + G.tpr - 1) / G.tpr;

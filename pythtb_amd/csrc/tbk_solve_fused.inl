@@ -18,6 +18,10 @@
 // on column j owns the plaquette to its LEFT).  Per-lane sums in a fixed order, a wave tree, one partial per tile.
 // The plaquette column between two tiles of a row group (1 in 64 seg) is left to k_flux_seams, which reads its four corners
 // from the finished array.  k_sum_fixed adds the partials in a fixed order: bit-reproducible totals, no float atomics.
+// (Tried: the seam plaquettes inside this launch -- wavefronts of seam x 32 rows, one point per lane solved again, links by
+// lane exchange.  Per step at 2048^2 / 4096^2: at the head of the launch 59.3 / 270 us, at its tail 58.4 / 264, the separate
+// kernel 59.3 / 252-258, no seams at all 56.8 / 255: a seam wavefront is a chain of table loads in front of one eigen-solve,
+// 1072 (8.5 k at 4096^2) of them cost what the second launch costs.)
 //
 // Extra arithmetic: (R + 1) / R eigen-solves per point and the link / phase arithmetic of k_flux_rows -- on a kernel whose
 // VALU was 37 % busy (n = 2) behind its stores.
@@ -55,9 +59,12 @@ __device__ __forceinline__ cd fused_link(const cd (&p)[NOCC][N], const cd (&q)[N
     else return csub(cmul(M[0][0], M[1][1]), cmul(M[0][1], M[1][0]));
 }
 
+
 template <int N, int PM, int NOCC>
-// (154 VGPRs at N = 2: three wavefronts per SIMD.  Forcing four -- __launch_bounds__(256, 4) -- spills 31 registers to scratch,
-// and a scratch access is a vector-memory operation that waits for every store issued before it: never in this loop)
+// (90 VGPRs at N = 2, five wavefronts per SIMD -- with MachineLICM off for this file (Makefile).  With it the compiler parked the
+// 20 coefficients of atan2's rarely taken branch in 40 registers for the whole kernel: 154 VGPRs, three wavefronts; forcing four
+// with __launch_bounds__(256, 4) kept the constants and spilled 31 live values to scratch -- and a scratch access is a
+// vector-memory operation that waits for every store issued before it: never in this loop)
 __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, const GridArgs G, const FusedArgs F) {
     extern __shared__ __align__(16) unsigned char lds_rows[];
     static_assert(PM >= 0, "k_grid_rows_flux: static range of the last lattice component");
@@ -203,7 +210,12 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
                 psi[0][o] = cmul(c0, fo[o]);
                 if constexpr (NOCC > 1) psi[1][o] = cmul(c1, fo[o]);
             }
-            if (stored) {
+            bool do_store = stored;
+#ifdef TBK_DIAG
+            // diagnostic build (TBK_ABLATE_GRID): 1 = no global stores, 3 = no links / phases, 4 = neither
+            if (G.ablate == 1 || G.ablate == 4) do_store = do_store && M.dg[0] == 1.2345e300;
+#endif
+            if (do_store) {
                 const int nvalid = nvalid_pts * N;
                 const int64_t point0 = (int64_t)(r0 + rr) * nlast + (int64_t)jc * 64;
 #pragma unroll
@@ -220,6 +232,12 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
                     }
                 }
             }
+#ifdef TBK_DIAG
+            if (G.ablate >= 3) {
+                psum += psi[0][0].x;
+                continue;
+            }
+#endif
             // ---- links and the plaquette row between rr - 1 and rr
             const cd* car = carry + rr * NCAR;
             cd left[NOCC][N];
