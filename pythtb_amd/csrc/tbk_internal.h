@@ -61,6 +61,7 @@ struct TbkKnobs {
     int wg_nt = 1024;           // TBK_WG_NT         threads of the global-workspace workgroup solver
     int wave_run = -1;          // TBK_WAVE_RUN      chain length of the wavefront solver (1 = always cold)
     int fused_rows = -1;        // TBK_FUSED_ROWS    mesh rows per wave tile of the fused solve + flux kernel (default 6; 10 beyond the LLC)
+    int fused_sum = 1;          // TBK_FUSED_SUM     0: the flux total of the fused pass by a kernel of its own (k_sum_fixed)
     int grid_seg = -1;          // TBK_GRID_SEG      chunks per wave tile of k_grid_rows
     int grid_kernel = 0;        // TBK_GRID_KERNEL   1: term-walking mesh kernel instead of the row-polynomial one
     int flux_ti = -1;           // TBK_FLUX_TI       rows per flux tile

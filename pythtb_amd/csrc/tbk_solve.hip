@@ -2049,12 +2049,12 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
             TBK_HIP(hipMemsetAsync(w->flux_cnt_dev, 0, 16 * sizeof(unsigned), ctx->stream));
             w->flux_nslices_cap = 1;
         }
-        if (w->flux_partial_cap < G.ntiles + nsb) {
+        if (w->flux_partial_cap < G.ntiles + nsb + 2) {
             TBK_HIP(hipStreamSynchronize(ctx->stream));
             if (w->flux_partial_dev) TBK_HIP(hipFree(w->flux_partial_dev));
             w->flux_partial_dev = nullptr;
-            TBK_HIP(hipMalloc((void**)&w->flux_partial_dev, (size_t)(G.ntiles + nsb) * sizeof(double)));
-            w->flux_partial_cap = G.ntiles + nsb;
+            TBK_HIP(hipMalloc((void**)&w->flux_partial_dev, (size_t)(G.ntiles + nsb + 2) * sizeof(double)));
+            w->flux_partial_cap = G.ntiles + nsb + 2;
         }
         w->flux_nslices = 1;
         w->flux_plaq_n = 0;
@@ -2076,20 +2076,22 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         }
 #undef TBK_FUSED
         }
-        // (tried: the final sum inside the seam kernel's last-arriving block -- 14 us for that kernel instead of 4.9 + 4.8 for the
-        // two launches: one block reading 8.7 k partials with agent-scope loads is slower than a 1024-thread block of its own)
+        // ---- seams + total in one launch (k_flux_seams_sum); TBK_FUSED_SUM=0: the total by a kernel of its own
         ProfScope ps2(ctx, "flux_seams_sum");
-        if (nsb > 0) {
-            if (n == 2 && ff->nocc == 1)
-                hipLaunchKernelGGL((k_flux_seams<2, 1>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
-            else if (n == 2)
-                hipLaunchKernelGGL((k_flux_seams<2, 2>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
-            else if (ff->nocc == 1)
-                hipLaunchKernelGGL((k_flux_seams<4, 1>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
-            else
-                hipLaunchKernelGGL((k_flux_seams<4, 2>), dim3((unsigned)nsb), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam, F.partial + G.ntiles);
-        }
-        hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(1024), 0, ctx->stream, (const double*)F.partial, (int64_t)(G.ntiles + nsb), w->flux_totals_dev);
+        const bool own_sum = K.fused_sum == 0;
+        const unsigned sblocks = (unsigned)std::max<int64_t>(nsb, 1);
+        double* const blk_partial = F.partial + G.ntiles;
+#define TBK_SEAMS(NN, OO)                                                                                                              \
+    hipLaunchKernelGGL((k_flux_seams_sum<NN, OO>), dim3(sblocks), dim3(256), 0, ctx->stream, v, F.occ[0], F.occ[1], G.seg, nseam,        \
+                       (const double*)F.partial, own_sum ? (int64_t)0 : G.ntiles, blk_partial, w->flux_cnt_dev,                            \
+                       own_sum ? blk_partial + sblocks : w->flux_totals_dev)
+        if (n == 2 && ff->nocc == 1) TBK_SEAMS(2, 1);
+        else if (n == 2) TBK_SEAMS(2, 2);
+        else if (ff->nocc == 1) TBK_SEAMS(4, 1);
+        else TBK_SEAMS(4, 2);
+#undef TBK_SEAMS
+        if (own_sum)   // (the seam kernel's own total goes to a spare slot; the blocks' sums stand behind the tiles' partials)
+            hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(1024), 0, ctx->stream, (const double*)F.partial, (int64_t)(G.ntiles + sblocks), w->flux_totals_dev);
         TBK_HIP(hipGetLastError());
         return TBK_OK;
     }

@@ -17,7 +17,7 @@
 // (the reference's loop (i,j) -> (i+1,j) -> (i+1,j+1) -> (i,j+1) -> (i,j), pythtb.py:3855-3861, as link determinants; the lane
 // on column j owns the plaquette to its LEFT).  Per-lane sums in a fixed order, a wave tree, one partial per tile.
 // The plaquette column between two tiles of a row group (1 in 64 seg) is left to k_flux_seams, which reads its four corners
-// from the finished array.  k_sum_fixed adds the partials in a fixed order: bit-reproducible totals, no float atomics.
+// from the finished array and also adds everything up in a fixed order: bit-reproducible totals, no float atomics.
 // (Tried: the seam plaquettes inside this launch -- wavefronts of seam x 32 rows, one point per lane solved again, links by
 // lane exchange.  Per step at 2048^2 / 4096^2: at the head of the launch 59.3 / 270 us, at its tail 58.4 / 264, the separate
 // kernel 59.3 / 252-258, no seams at all 56.8 / 255: a seam wavefront is a chain of table loads in front of one eigen-solve,
@@ -284,16 +284,21 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
     if (lane == 0) F.partial[tile] = psum;
 }
 
-// ---- the plaquette columns between two tiles of a row group: thread = (plaquette row i, seam s); column j = seam * seg * 64 - 1.
-// Reads its four corners from the finished array (band-major planes) -- 1 / (64 seg) of the plaquettes.
+// ---- the plaquette columns between two tiles of a row group, and the total.  Thread = (plaquette row i, seam s), column
+// j = seam * seg * 64 - 1: reads its four corners from the finished array (band-major planes) -- 1 / (64 seg) of the plaquettes.
+// Block b also adds slice b of the tiles' partials; the block that arrives last (two-level ticket, as in k_flux_rows) adds the
+// blocks' sums in a fixed order: the total is bit-reproducible and there is no third launch (k_sum_fixed as a kernel of its own
+// was 4.8 us bracketed, ~3.7 us of a back-to-back step).  The last block reads gridDim.x values (128 at 2048^2), one per
+// thread -- handing it all 5.8 k tile partials instead was the 14 us of the first attempt.
 template <int N, int NOCC>
-__global__ __launch_bounds__(256) void k_flux_seams(const WfsView v, const int occ0, const int occ1, const int seg, const int nseam,
-                                                    double* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_flux_seams_sum(const WfsView v, const int occ0, const int occ1, const int seg, const int nseam,
+                                                        const double* __restrict__ tile_partial, const int64_t ntiles,
+                                                        double* blk_partial, unsigned* counters, double* __restrict__ total) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int nlast = v.mesh[1];
-    const int64_t total = (int64_t)(v.mesh[0] - 1) * nseam;
+    const int64_t nthreads = (int64_t)(v.mesh[0] - 1) * nseam;
     double pha = 0.0;
-    if (t < total) {
+    if (t < nthreads) {
         const int i = (int)(t / nseam), s = (int)(t - (int64_t)i * nseam);
         const int j = (s + 1) * seg * 64 - 1;                  // plaquette between columns j and j + 1
         if (j + 1 < nlast) {
@@ -316,13 +321,64 @@ __global__ __launch_bounds__(256) void k_flux_seams(const WfsView v, const int o
             pha = -arg_small_first(z.y, z.x);
         }
     }
+    // slice of the tiles' partials (written by the launch before this one)
+    const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(i0 + per, ntiles);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) pha += tile_partial[i];
     // block sum in a fixed order
-    __shared__ double red[4];
+    __shared__ double red[256];
+    __shared__ int last_flag;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) pha += __shfl_xor(pha, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pha;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const double mine = (red[0] + red[1]) + (red[2] + red[3]);
+        const unsigned nb = gridDim.x, blk = blockIdx.x;
+        int last = 0;
+        // hand-off without cache-wide fences: one 8-byte agent-scope store, drained before the ticket
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(blk_partial) + blk, (unsigned long long)__double_as_longlong(mine),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nb > 1u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned shard = blk & 7u;
+            const unsigned shard_size = (nb - shard + 7u) / 8u;
+            if (atomicAdd(counters + shard, 1u) == shard_size - 1u) {
+                const unsigned nshards = min(nb, 8u);
+                if (atomicAdd(counters + 8, 1u) == nshards - 1u) last = 1;
+            }
+        } else {
+            *total = mine;
+        }
+        last_flag = last;
+    }
+    __syncthreads();
+    if (last_flag) {
+        const unsigned long long* pb = reinterpret_cast<const unsigned long long*>(blk_partial);
+        auto ld = [&](const unsigned idx) {
+            return __longlong_as_double((long long)__hip_atomic_load(pb + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        };
+        const unsigned nb = gridDim.x;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        unsigned i = threadIdx.x;
+        for (; i + 3u * 256u < nb; i += 4u * 256u) {
+            s0 += ld(i);
+            s1 += ld(i + 256u);
+            s2 += ld(i + 512u);
+            s3 += ld(i + 768u);
+        }
+        for (; i < nb; i += 256u) s0 += ld(i);
+        __syncthreads();
+        red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+#pragma unroll
+        for (int w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *total = red[0];
+        if (threadIdx.x < 9) counters[threadIdx.x] = 0u;       // re-arm for the next launch
+    }
 }
 
 // fixed-shape sum of n partials into *total (one block; the same order every run)
