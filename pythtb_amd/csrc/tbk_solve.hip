@@ -2005,9 +2005,10 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         FusedArgs F{};
         // tile shape (measured, profiles/fused_sweep.py, us per step, rows R x chunks seg).  2048^2 (the array fits the 256 MiB
         // last-level cache): R = 3 73-86, 4 67-79, 5 67-75, 6 65-74, 8 63-87, 12 63-66, best around 6 x 2.  4096^2 (beyond it): tall
-        // and narrow wins -- seg = 1: R = 4 303, 6 266, 8 258, 10 251, 12 257; seg >= 2: 275-318
+        // and narrow wins -- seg = 1: R = 4 303, 6 266, 8 258, 10 251, 12 257; seg >= 2: 275-318.  After the register diet (five
+        // wavefronts per SIMD, no column tables in LDS at seg = 1): 2048^2 flat over R = 5-12 (60-63), 4096^2 R = 8 257, 10 265
         const bool in_llc = w->bytes <= ((int64_t)256 << 20) + (1 << 20);
-        F.R = K.fused_rows > 0 ? std::min(K.fused_rows, 16) : (in_llc ? 6 : 10);
+        F.R = K.fused_rows > 0 ? std::min(K.fused_rows, 16) : (in_llc ? 6 : 8);
         F.nrg = (v.mesh[0] + F.R - 1) / F.R;
         F.occ[0] = ff->occ[0];
         F.occ[1] = ff->occ[1];
@@ -2015,7 +2016,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         const int R1 = F.R + 1, ncell = (n * (n + 1) / 2) * (2 * pm + 1), ncar = ff->nocc * n + 1;
         // LDS per wavefront: cells, leading-axis phases and carries of R + 1 rows, the staging tile, the per-column tables of
         // `seg` chunks; at most 16 KB per wavefront
-        const size_t fixed_cd = (size_t)R1 * (ncell + n + ncar) + (size_t)64 * n;
+        const size_t fixed_cd = (size_t)R1 * (ncell + n + ncar) + (size_t)64 * n;   // (k_grid_rows_flux: NB = 1 band staged at once)
         const int seg_cap = (int)std::max<size_t>(1, (1024 - std::min<size_t>(fixed_cd, 960)) / ((size_t)64 * (1 + n)));
         G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(seg_cap, G.cpr), (int64_t)G.cpr * F.nrg / want));
         if (!in_llc) G.seg = 1;
@@ -2059,7 +2060,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         w->flux_nslices = 1;
         w->flux_plaq_n = 0;
         F.partial = w->flux_partial_dev;
-        const size_t lds = (size_t)4 * (fixed_cd + (size_t)G.seg * 64 * (1 + n)) * sizeof(cd);
+        const size_t lds = (size_t)4 * (fixed_cd + (G.seg > 1 ? (size_t)G.seg * 64 * (1 + n) : 0)) * sizeof(cd);   // (seg = 1: no column tables in LDS)
         TBK_REQUIRE(lds <= 64 * 1024, TBK_EUNSUPPORTED, "tbk_wfs_solve_grid_flux: %zu bytes of LDS per block", lds);
         const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
         {

@@ -72,18 +72,21 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
     constexpr int npow = 2 * PM + 1;
     constexpr int ncell = NSLOT * npow;
     constexpr int NCAR = NOCC * N + 1;              // carried per row: the occupied vectors and Ux of lane 63
+    // bands staged at once.  (Tried NB = 2 at N = 2 -- one LDS round trip per row instead of two, 2 KB more LDS per wavefront:
+    // 2048^2 58.6 against 58.4 us per step, 4096^2 265 against 265; on a slower box 66.4 against 64.4 and 257 against 270)
+    constexpr int NB = 1;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int R1 = F.R + 1;
-    const int per_wave = R1 * (ncell + N + NCAR) + 64 * N + G.seg * 64 * (1 + N);
+    const int per_wave = R1 * (ncell + N + NCAR) + 64 * N * NB + (G.seg > 1 ? G.seg * 64 * (1 + N) : 0);
     cd* const base = reinterpret_cast<cd*>(lds_rows) + wib * per_wave;
     cd* const C = base;                             // [R1][ncell]
     cd* const frowL = C + R1 * ncell;               // [R1][N]
     cd* const carry = frowL + R1 * N;               // [R1][NCAR]
-    cd* const stage = carry + R1 * NCAR;            // [64 N]
+    cd* const stage = carry + R1 * NCAR;            // [NB][64 N]
     // the tile's per-column table entries z_last(j), f_last(j, o): fetched ONCE, so that the main loop holds no vector-memory
     // load at all -- vmcnt counts loads and stores in issue order, and any load consumed inside the loop would wait for every
     // store issued before it (k_grid_rows keeps its prefetch legal with a static store count; here the row count is data)
-    cd* const ztab = stage + 64 * N;                // [seg][64]
+    cd* const ztab = stage + 64 * N * NB;           // [seg][64]
     cd* const ftab = ztab + G.seg * 64;             // [seg][64][N]
     const int64_t tile = (int64_t)blockIdx.x * 4 + wib;
     const bool live = tile < G.ntiles;
@@ -112,12 +115,28 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
             const int rr = e / N, o = e - rr * N;
             frowL[e] = G.tf[0][(int64_t)(r0 + rr) * N + o];
         }
-        for (int e = lane; e < (jc1 - jc0) * 64; e += 64) {
-            const int jj = min(jc0 * 64 + e, nlast - 1);
-            ztab[e] = G.tz[1][jj];
+        if (G.seg > 1) {
+            for (int e = lane; e < (jc1 - jc0) * 64; e += 64) {
+                const int jj = min(jc0 * 64 + e, nlast - 1);
+                ztab[e] = G.tz[1][jj];
 #pragma unroll
-            for (int o = 0; o < N; ++o) ftab[e * N + o] = G.tf[1][(int64_t)jj * N + o];
+                for (int o = 0; o < N; ++o) ftab[e * N + o] = G.tf[1][(int64_t)jj * N + o];
+            }
         }
+    }
+    // one chunk per tile (seg = 1): its table entries go straight to registers -- fetched here, before any store is issued, and
+    // consumed here (the empty asm), so that no wait on them lands inside the row loop
+    cd zl1{1.0, 0.0}, tfl1[N];
+#pragma unroll
+    for (int o = 0; o < N; ++o) tfl1[o] = cd{0.0, 0.0};
+    if (live && G.seg == 1) {
+        const int jj = min(jc0 * 64 + lane, nlast - 1);
+        zl1 = G.tz[1][jj];
+#pragma unroll
+        for (int o = 0; o < N; ++o) tfl1[o] = G.tf[1][(int64_t)jj * N + o];
+        asm volatile("" : "+v"(zl1.x), "+v"(zl1.y));
+#pragma unroll
+        for (int o = 0; o < N; ++o) asm volatile("" : "+v"(tfl1[o].x), "+v"(tfl1[o].y));
     }
     __syncthreads();
     if (!live) return;
@@ -140,10 +159,14 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
     }
     double psum = 0.0;
     for (int jc = jc0; jc < jc1; ++jc) {
-        const cd zl = ztab[(jc - jc0) * 64 + lane];
-        cd tfl[N];
+        cd zl = zl1, tfl[N];
 #pragma unroll
-        for (int o = 0; o < N; ++o) tfl[o] = ftab[((jc - jc0) * 64 + lane) * N + o];
+        for (int o = 0; o < N; ++o) tfl[o] = tfl1[o];
+        if (G.seg > 1) {
+            zl = ztab[(jc - jc0) * 64 + lane];
+#pragma unroll
+            for (int o = 0; o < N; ++o) tfl[o] = ftab[((jc - jc0) * 64 + lane) * N + o];
+        }
         const int j = jc * 64 + lane;
         const int nvalid_pts = min(64, nlast - jc * 64);
         const bool full = nvalid_pts == 64;
@@ -218,17 +241,28 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
             if (do_store) {
                 const int nvalid = nvalid_pts * N;
                 const int64_t point0 = (int64_t)(r0 + rr) * nlast + (int64_t)jc * 64;
+                // NB bands go through the staging tile at once
 #pragma unroll
-                for (int r = 0; r < N; ++r) {
+                for (int rb = 0; rb < N; rb += NB) {
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int o = 0; o < N; ++o) stage[wslot[o]] = cmul(M.v[o][r], fo[o]);
-                    asm volatile("" ::: "memory");
-                    cd* dst = G.wv.data + ((int64_t)r * G.wv.npts + point0) * N;
+                    for (int r = rb; r < rb + NB; ++r)
 #pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        const int e = i * 64 + lane;
-                        if (full || e < nvalid) dst[e] = stage[rslot[i]];
+                        for (int o = 0; o < N; ++o) stage[(r - rb) * 64 * N + wslot[o]] = cmul(M.v[o][r], fo[o]);
+                    asm volatile("" ::: "memory");
+                    cd out[NB][N];
+#pragma unroll
+                    for (int r = 0; r < NB; ++r)
+#pragma unroll
+                        for (int i = 0; i < N; ++i) out[r][i] = stage[r * 64 * N + rslot[i]];
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) {
+                        cd* dst = G.wv.data + ((int64_t)(rb + r) * G.wv.npts + point0) * N;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) {
+                            const int e = i * 64 + lane;
+                            if (full || e < nvalid) dst[e] = out[r][i];
+                        }
                     }
                 }
             }
