@@ -11,6 +11,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
 # (a key "a+b+c" sums the per-dispatch counts of several kernels that each cover the same points)
 SOURCES = [
+    # round 3, final build (tbk_solve / tbk_berry compiled without MachineLICM, seams + total in one kernel): r03j, r03j2, r03jcfg
+    ("k_grid_rows_flux<2,1,1>", "r03j/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
+    ("k_grid_rows<2,1>", "r03j2/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r03j2/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r03jcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r03jcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_tw16<1>", "r03jcfg/pmc_per_dispatch.json", "k_tw16_tridiag<1>+k_tw16_eigvals<1>+k_tw16_vectors<1>", 65 ** 3),
+    ("k_solve_small<2,0,false>", "r03jcfg/pmc_per_dispatch.json", "k_solve_small<2,0,false>", 1024 * 1024),
+    ("k_solve_small<2,0,true>", "r03jcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
     # round 3: the fused headline kernel, the two-launch step's kernels, configs[1] / [3] / [4] (r03hcfg: TBK_TW16_STREAMS=1, so
     # that every kernel's counters belong to it alone)
     ("k_grid_rows_flux<2,1,1>", "r03h/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
