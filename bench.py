@@ -312,9 +312,25 @@ def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
         kt = kernel_times(ctx, step, 5, ev_ms)
         npt = 4096 * 4096
         chern = float(g.flux_total()[0] / (2 * np.pi))
+
+        def fused():
+            g.solve_flux(start, occ)
+        for _ in range(3):
+            fused()
+        ctx.sync()
+        f0 = time.perf_counter()
+        for _ in range(50):
+            fused()
+        ctx.sync()
+        f_ms = 1e3 * (time.perf_counter() - f0) / 50
+        chern_f = float(g.flux_total()[0] / (2 * np.pi))
+        ktf = kernel_times(ctx, fused, 5, ev_ms)
         out.append({"config": "Haldane solve_on_grid + berry_flux at 4096^2 (1.07 GB array: 4x the 256 MiB last-level cache)",
-                    "kpts": npt, "kernels": kt, "chern": chern,
-                    "roofline": {"solve_grid": roof(bytes_solve(2) * npt, kt["solve_grid"]["avg_bracket_ms"],
+                    "kpts": npt, "kernels": dict(kt, **ktf), "chern": chern,
+                    "fused_step": {"ms_per_step": f_ms, "kpts_per_s": npt / (f_ms * 1e-3), "chern": chern_f, "steps": 50},
+                    "roofline": {"solve_grid_flux": roof(bytes_solve(2) * npt, ktf["solve_grid_flux"]["avg_bracket_ms"],
+                                                         "k_grid_rows_flux<2,1,1>", 4097 * 4097, valu),
+                                 "solve_grid": roof(bytes_solve(2) * npt, kt["solve_grid"]["avg_bracket_ms"],
                                                     "k_grid_rows<2,1>", 4097 * 4097, valu),
                                  "berry_flux": roof(bytes_berry(1, 2) * npt, kt["berry_flux"]["avg_bracket_ms"],
                                                     "k_flux_rows<1,2>", 4097 * 4097, valu)},
