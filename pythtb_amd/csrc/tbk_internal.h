@@ -61,6 +61,7 @@ struct TbkKnobs {
     int wg_nt = 1024;           // TBK_WG_NT         threads of the global-workspace workgroup solver
     int wave_run = -1;          // TBK_WAVE_RUN      chain length of the wavefront solver (1 = always cold)
     int fused_rows = -1;        // TBK_FUSED_ROWS    mesh rows per wave tile of the fused solve + flux kernel (default 6; 10 beyond the LLC)
+    int small_kpt = -1;         // TBK_SMALL_KPT     k points per lane of the n <= 4 list kernels: 1, 2; default 2 from 2^19 points
     int fused_sum = 1;          // TBK_FUSED_SUM     0: the flux total of the fused pass by a kernel of its own (k_sum_fixed)
     int grid_seg = -1;          // TBK_GRID_SEG      chunks per wave tile of k_grid_rows
     int grid_kernel = 0;        // TBK_GRID_KERNEL   1: term-walking mesh kernel instead of the row-polynomial one
@@ -122,22 +123,34 @@ __host__ __device__ inline double cabs2(cd a) { return a.x * a.x + a.y * a.y; }
 // common case |y| <= 2^-6 x (x > 0) takes the odd Taylor series of atan through
 // t^13 (truncation < 2^-90 |t|, i.e. below half an ulp of the result); anything
 // else -- large phases, x <= 0, zeros, non-finite -- goes to the library atan2.
+// a * b + c, a * c, a + c with the UNIFORM constant c in a scalar register pair.  Spelled out because the compiler otherwise
+// copies every polynomial coefficient into a vector register first (v_mov_b32 x 2, or v_mov_b64 + v_fmac_f64): one to two extra
+// VALU issue slots per Horner step, and -- hoisted out of a loop -- two VGPRs per coefficient for the whole kernel.  An s_mov
+// issues on the scalar unit beside the other wavefronts' vector work.
+__device__ __forceinline__ double tbk_fma_vs(const double a, const double b, const double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double tbk_mul_vs(const double a, const double c) {
+    double d;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double tbk_add_vs(const double a, const double c) {
+    double d;
+    asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
+    return d;
+}
+
 __device__ __forceinline__ double arg_small_first(double y, double x) {
     if (x > 0.0 && fabs(y) <= 0.015625 * x) {
         const double t = y / x, t2 = t * t;
-        // three-operand v_fma_f64 spelled out: the compiler otherwise copies each coefficient into the
-        // accumulator register first (v_mov_b64 + v_fmac_f64), one extra issue slot per Horner step
-        auto fma3 = [](double a, double b, double c) {
-            double d;
-            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-            return d;
-        };
-        double p = -1.0 / 13.0;
-        p = fma3(p, t2, 1.0 / 11.0);
-        p = fma3(p, t2, -1.0 / 9.0);
-        p = fma3(p, t2, 1.0 / 7.0);
-        p = fma3(p, t2, -1.0 / 5.0);
-        p = fma3(p, t2, 1.0 / 3.0);
+        double p = tbk_add_vs(tbk_mul_vs(t2, -1.0 / 13.0), 1.0 / 11.0);
+        p = tbk_fma_vs(p, t2, -1.0 / 9.0);
+        p = tbk_fma_vs(p, t2, 1.0 / 7.0);
+        p = tbk_fma_vs(p, t2, -1.0 / 5.0);
+        p = tbk_fma_vs(p, t2, 1.0 / 3.0);
         return fma(-(t * t2), p, t);
     }
     return atan2(y, x);

@@ -73,9 +73,37 @@ __device__ __forceinline__ bool tbk_before(const double o, const double mine, co
     return on ? (mn && j < x) : (mn || o < mine || (o == mine && j < x));
 }
 
-__device__ __forceinline__ cd expi2pi(double x) {
-    double s, c;
-    sincospi(2.0 * x, &s, &c);
+// exp(2 pi i x).  Exact argument reduction (2x - rint(2x) and the quadrant are exact in binary floating point, like sincospi's),
+// then sin(pi t) / t and cos(pi t) on |t| <= 1/4 as polynomials in t^2 (Chebyshev fits computed with mpmath at 60 digits: fit
+// errors 3e-18 and 3e-20 relative; measured against mpmath on 10^4 arguments: <= 1 ulp each).  32 VALU instructions where the
+// library's sincospi is 90 -- 50 of them copies of its coefficients into vector registers; the k-list kernels of 2..4 states
+// were VALU-bound on exactly that (configs[1]: 455 instructions per k-point, two calls).
+__device__ __forceinline__ cd expi2pi(const double x) {
+    const double f = x - __builtin_rint(x);            // [-1/2, 1/2]: the angle is 2 pi f
+    const double q = __builtin_rint(4.0 * f);          // -2 .. 2: the quadrant
+    const double h = fma(q, -0.25, f);                 // [-1/8, 1/8]
+    const double t = h + h;                            // the angle is pi t + q pi / 2, |t| <= 1/4
+    const int m = (int)q & 3;
+    const double u = t * t;
+    double sp = tbk_add_vs(tbk_mul_vs(u, 0.00046153185538358102), -0.0073700215869077707);
+    sp = tbk_fma_vs(sp, u, 0.082145869180001746);
+    sp = tbk_fma_vs(sp, u, -0.59926452893964488);
+    sp = tbk_fma_vs(sp, u, 2.5501640398733763);
+    sp = tbk_fma_vs(sp, u, -5.1677127800499543);
+    sp = tbk_fma_vs(sp, u, 3.1415926535897931);
+    sp *= t;
+    double cp = tbk_add_vs(tbk_mul_vs(u, -0.00010356747255199479), 0.0019294657440800042);
+    cp = tbk_fma_vs(cp, u, -0.025806885652951306);
+    cp = tbk_fma_vs(cp, u, 0.23533063019088787);
+    cp = tbk_fma_vs(cp, u, -1.3352627688519174);
+    cp = tbk_fma_vs(cp, u, 4.0587121264167472);
+    cp = tbk_fma_vs(cp, u, -4.934802200544679);
+    cp = tbk_fma_vs(cp, u, 1.0);
+    // quadrant m = q mod 4:  0: (c, s) = (cp, sp);  1: (-sp, cp);  2: (-cp, -sp);  3: (sp, -cp)
+    const bool swap = (m & 1) != 0;
+    double c = swap ? sp : cp, s = swap ? cp : sp;
+    c = ((m + 1) & 2) ? -c : c;
+    s = (m & 2) ? -s : s;
     return cd{c, s};
 }
 
@@ -644,6 +672,100 @@ __global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const i
             cd* out = L.evec + ((int64_t)rk[b] * nk + idx) * N;
 #pragma unroll
             for (int o = 0; o < N; ++o) out[o] = cmul(M.v[o][b], fo[o]);
+        }
+    }
+}
+
+// ---- the same for KPT k-points per thread (eigenvalue-only k lists of 2..4 states from 2^19 points).
+// The list kernel above is bound by neither arithmetic nor bytes: a wavefront lives 15 k cycles of which 5.6 k wait on its 43
+// dependent scalar table loads and 1.5 k issue scalar control flow (the loops over a slot's terms and over |R_d| factors) --
+// replacing sincospi by the 32-instruction expi2pi (-25 % VALU) changed nothing: 21.9 -> 22.3 us per 2^20 points.  With KPT
+// points per lane the same scalar stream serves KPT times the vector work.  Point j of a thread is 256 j further on: coalesced.
+template <int N, int KPT>
+__device__ __forceinline__ void assemble_small_multi(const ModelView& mv, const cd (&z)[KPT][4], SmallMat<N> (&M)[KPT]) {
+    int slot = 0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+#pragma unroll
+        for (int b = a; b < N; ++b, ++slot) {
+            const int t0 = mv.slot_ptr[slot], t1 = mv.slot_ptr[slot + 1];
+            cd acc[KPT];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) acc[j] = cd{0.0, 0.0};
+            for (int t = t0; t < t1; ++t) {
+                const cd amp = mv.term_amp[t];
+                const int4 R = mv.term_R[t];
+                // (phase_of_R's loops once per term, all points inside: the same products in the same order as slot_sum)
+                cd e[KPT];
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) e[j] = cd{1.0, 0.0};
+                const int r[4] = {R.x, R.y, R.z, R.w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int m = r[d] < 0 ? -r[d] : r[d];
+                    const double sg = r[d] < 0 ? -1.0 : 1.0;
+                    for (int q = 0; q < m; ++q)
+#pragma unroll
+                        for (int j = 0; j < KPT; ++j) e[j] = cmul(e[j], cd{z[j][d].x, sg * z[j][d].y});
+                }
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) cfma(acc[j], amp, e[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                if (b == a) M[j].dg[a] = acc[j].x; else M[j].up[a][b] = acc[j];
+            }
+        }
+    }
+}
+
+template <int N, bool VEC, int KPT>
+__global__ __launch_bounds__(256) void k_solve_small_multi(const ModelView mv, const int64_t nk, const ListArgs L) {
+    const int64_t idx0 = (int64_t)blockIdx.x * (256 * KPT) + threadIdx.x;
+    if (idx0 >= nk) return;
+    double kk[KPT][4];
+    cd z[KPT][4];
+    int64_t idx[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        idx[j] = idx0 + 256 * j;
+        const int64_t src = idx[j] < nk ? idx[j] : nk - 1;      // (a point past the end shadows the last one and is not stored)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            kk[j][d] = d < mv.dim_k ? L.k[src * mv.dim_k + d] : 0.0;
+            z[j][d] = d < mv.dim_k ? expi2pi(kk[j][d]) : cd{1.0, 0.0};
+        }
+    }
+    SmallMat<N> M[KPT];
+    assemble_small_multi<N, KPT>(mv, z, M);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        init_vectors<N, VEC>(M[j]);
+        if constexpr (N > 2) {
+            if (!jacobi_small<N, VEC>(M[j]) && L.flags) L.flags[0] = 1;
+        } else {
+            jacobi_small<N, VEC>(M[j]);
+        }
+        int rk[N];
+        double sorted[N];
+        ranks_small<N>(M[j].dg, rk, sorted);
+        if (idx[j] < nk) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) L.eval[(int64_t)b * nk + idx[j]] = sorted[b];
+            if (VEC) {
+                cd fo[N];
+#pragma unroll
+                for (int o = 0; o < N; ++o) {
+                    if (mv.nspin == 2 && (o & 1)) fo[o] = fo[o - (o > 0)];
+                    else fo[o] = cconj(expi2pi(kdot(kk[j], mv.orb[o])));
+                }
+#pragma unroll
+                for (int b = 0; b < N; ++b) {
+                    cd* out = L.evec + ((int64_t)rk[b] * nk + idx[j]) * N;
+#pragma unroll
+                    for (int o = 0; o < N; ++o) out[o] = cmul(M[j].v[o][b], fo[o]);
+                }
+            }
         }
     }
 }
@@ -1402,6 +1524,21 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 template <int MODE, bool VEC>
 static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L) {
     const unsigned blocks = (unsigned)((nk + 255) / 256);
+    // eigenvalue-only k lists that fill the chip more than once: two points per lane (k_solve_small_multi; 2^20 Haldane points
+    // 21.8 -> 19.9 us; with eigenvectors the second point's registers cost more than the shared scalar stream saves: 30.1 ->
+    // 31.2 us, so those keep one point per lane).  TBK_SMALL_KPT=1 / 2 forces either form where both exist.
+    if constexpr (MODE == 0) {
+        const int kpt = tbk_knobs().small_kpt;
+        const bool many = kpt == 2 || (kpt < 0 && !VEC && nk >= ((int64_t)1 << 19));
+        if (many && (n == 2 || (!VEC && (n == 3 || n == 4)))) {
+            const unsigned b2 = (unsigned)((nk + 511) / 512);
+            if (n == 2) hipLaunchKernelGGL((k_solve_small_multi<2, VEC, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
+            else if (n == 3) hipLaunchKernelGGL((k_solve_small_multi<3, false, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
+            else hipLaunchKernelGGL((k_solve_small_multi<4, false, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
+    }
     switch (n) {
         case 1: hipLaunchKernelGGL((k_solve_small<1, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
         case 2: hipLaunchKernelGGL((k_solve_small<2, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;

@@ -130,6 +130,49 @@ def test_forced_regime_eigenvalues_only(n, nk, kn, what):
     assert np.all(np.diff(ev, axis=0) >= 0.0)
 
 
+def test_device_exp_2_pi_i_x_is_accurate(tb):
+    """expi2pi (pythtb_amd/csrc/tbk_solve.hip: exact reduction + two polynomials, replaces the library's sincospi) seen through
+    a one-orbital chain: E(k) = cos(2 pi k) and the stored component exp(-2 pi i k) -- |error| <= 3e-16 on random arguments,
+    quadrant boundaries, huge and tiny ones; exact values where they are representable."""
+    m = hp.quiet(tb.tb_model, 1, 1, [[1.0]], [[1.0]])
+    m.set_hop(0.5, 0, 0, [1])
+    rng = np.random.default_rng(1)
+    special = np.concatenate([np.arange(-32, 33) / 16.0, [1e6 + 0.3, -1e9 - 0.125, 0.5 - 2.0 ** -53, 2.0 ** -60, 2.0 ** 52 + 0.5,
+                                                            0.125 + 2.0 ** -55, 0.125 - 2.0 ** -56]])
+    k = np.concatenate([rng.uniform(-2, 2, 100000), special])
+    ev, vec = m.solve_all(k, eig_vectors=True)
+    kl = k.astype(np.longdouble)
+    ang = 2 * np.pi * (kl - np.rint(kl))
+    assert np.max(np.abs(ev[0] - np.cos(ang))) <= 3e-16
+    assert np.max(np.abs(vec[0, :, 0].real - np.cos(ang))) <= 3e-16 and np.max(np.abs(vec[0, :, 0].imag + np.sin(ang))) <= 3e-16
+    exact = m.solve_all(np.array([0.0, 0.25, 0.5, 0.75, 1.0, -0.25, 3.5]))[0]
+    assert np.array_equal(exact, np.array([1.0, 0.0, -1.0, 0.0, 1.0, 0.0, -1.0]))
+
+
+# ------------------------------------------------------------------ k lists of 2..4 states: one or two k-points per lane
+@pytest.mark.parametrize("n,nk", [(2, 1), (2, 255), (2, 513), (2, 70001), (3, 1000), (4, 769), (1, 300)])
+def test_two_points_per_lane_is_bit_identical(tb, n, nk):
+    """k_solve_small_multi (chip-filling k lists, pythtb_amd/csrc/tbk_solve.hip) forms every point with the same operations in
+    the same order as the one-point kernel: the same bits, whatever the list length (points past the end are not stored)."""
+    from pythtb_amd import _lib
+    m = _chain(tb, n, 0.3) if n > 1 else hp.quiet(tb.tb_model, 1, 1, [[1.0]], [[0.0]])
+    if n == 1:
+        m.set_hop(0.5, 0, 0, [1])
+    k = np.random.default_rng(n * 1000 + nk).uniform(-1.0, 2.0, nk)
+    out = {}
+    for kpt in (1, 2):
+        with _lib.knob("TBK_SMALL_KPT", kpt):
+            ev = m.solve_all(k)
+            evv, vec = m.solve_all(k, eig_vectors=True)
+        out[kpt] = (ev, evv, vec)
+    assert np.array_equal(out[1][0], out[2][0])
+    assert np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][2], out[2][2])
+    h = np.array([m._gen_ham([kk]) for kk in k[:50]]) if hasattr(m, "_gen_ham") else None
+    if h is not None:
+        ref = np.linalg.eigvalsh(h)
+        assert np.max(np.abs(out[2][0].T[:50] - ref)) < 1e-13
+
+
 # ---------------------------------------------------------------------------------------------- input nobody can solve
 def _chain(tb, n, onsite0):
     m = hp.quiet(tb.tb_model, 1, 1, [[1.0]], [[i / float(n)] for i in range(n)])
