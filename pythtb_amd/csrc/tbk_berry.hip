@@ -952,7 +952,7 @@ __device__ __forceinline__ void lds_sync_wave() {
 }
 
 template <int NOCC, int NLD>   // NLD = ceil(NOCC * ncomp / 64): 16-byte loads per lane and point
-__global__ __launch_bounds__(256) void k_chain_links_wave(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ ws) {
+__global__ __launch_bounds__(256, 5) void k_chain_links_wave(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ ws) {
     extern __shared__ __align__(16) unsigned char chainw_lds[];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + wib;
@@ -1051,6 +1051,112 @@ __global__ __launch_bounds__(256) void k_chain_links_wave(const ChainArgs A, con
 #undef TBK_PARK4
 }
 
+// ---- the same link matrices for 5..8 bands, FOUR links per step and a 2 x 2 block of M per lane (lane = link g, block (ta, tb)).
+// k_chain_links_wave above spends a whole wavefront step on one point: 33 LDS instructions and 135 vector instructions (most of
+// them 64-bit index arithmetic) for 64 FMAs per lane, two barriers, and 2 x 2 KB in flight per wavefront -- it moves 3 TB/s with
+// the LDS 33 % and the VALU 32 % busy (profiles/r03jcfg): latency.  Here a step loads four points at once (8 KB in flight per
+// wavefront), a lane reads 2 + 2 staged rows for 4 entries of M (half the LDS reads per entry), and the index arithmetic, the
+// barriers and the waits are paid once per four links.  The accumulation order of an entry is the one of the kernel above
+// (even and odd components in two accumulators).  The workspace layout is unchanged: k_chain_lu_wave reads it.
+#define TBK_CHAINT_G 4
+template <int NOCC, int NLD>
+__global__ __launch_bounds__(256) void k_chain_links_tile(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ ws) {
+    static_assert(NOCC >= 5 && NOCC <= 8, "k_chain_links_tile: 5..8 bands");
+    extern __shared__ __align__(16) unsigned char chainw_lds[];
+    constexpr int G = TBK_CHAINT_G, NT = (NOCC + 1) / 2, NN = NOCC * NOCC;
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wib;
+    if (t >= ns * A.nseg) return;                    // (no workgroup barrier below: waves are independent)
+    const int64_t seg = t / ns, sl = t - seg * ns, s = s0 + sl;
+    const int ncomp = A.v.ncomp;
+    const int ldp = ncomp + 1;
+    const int pbuf = NOCC * ldp + 1;
+    cd* const buf = reinterpret_cast<cd*>(chainw_lds) + (size_t)wib * (G + 1) * pbuf;   // slots 0 .. G: points i .. i + G
+    const int64_t plane = A.v.npts * ncomp;
+    const int i0 = (int)seg * A.seg_len;
+    const int i1 = min(i0 + A.seg_len, A.nlinks);
+    const int np = i1 - i0;                          // links of this segment; its points are 0 .. np
+    const cd* P = A.v.data + (axis_offset(A.other, s) + (int64_t)i0 * A.sdir) * ncomp;
+    const int64_t step = A.sdir * ncomp;
+    const int nel = NOCC * ncomp;
+    int64_t goff[NLD];
+    int dst[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = j * 64 + lane;
+        const bool ok = e < nel;
+        const int a = ok ? e / ncomp : 0, c = ok ? e - a * ncomp : 0;
+        goff[j] = (int64_t)A.occ[a] * plane + c;
+        dst[j] = ok ? a * ldp + c : NOCC * ldp;
+    }
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d x[G][NLD], xl[NLD];
+    auto load_group = [&](const int first) {         // points first .. first + G - 1 of the segment (clamped to its last point)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const cd* p = P + (int64_t)min(first + g, np) * step;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) x[g][j] = *reinterpret_cast<const v2d*>(p + goff[j]);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) xl[j] = *reinterpret_cast<const v2d*>(P + goff[j]);   // point 0
+    load_group(1);
+    // this lane's block of M
+    const int g = lane >> 4, tl = lane & 15;
+    const int ta = tl / NT, tb = tl - ta * NT;
+    const bool active = tl < NT * NT;
+    const int a0 = min(2 * ta, NOCC - 1), a1 = min(2 * ta + 1, NOCC - 1), b0 = min(2 * tb, NOCC - 1), b1 = min(2 * tb + 1, NOCC - 1);
+    const bool va1 = 2 * ta + 1 < NOCC, vb1 = 2 * tb + 1 < NOCC;
+    cd* const out = ws + ((int64_t)sl * A.nlinks + i0) * NN;
+    for (int i = 0; i < np; i += G) {
+        // points i (kept from the previous step) and i + 1 .. i + G (arriving) go to LDS; the registers take the next group
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) *reinterpret_cast<v2d*>(buf + dst[j]) = xl[j];
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) *reinterpret_cast<v2d*>(buf + (gg + 1) * pbuf + dst[j]) = x[gg][j];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) xl[j] = x[G - 1][j];
+        load_group(i + G + 1);
+        lds_sync_wave();
+        if (active && i + g < np) {
+            const cd* pa = buf + g * pbuf;
+            const cd* pb = pa + pbuf;
+            const cd *ua0 = pa + a0 * ldp, *ua1 = pa + a1 * ldp, *ub0 = pb + b0 * ldp, *ub1 = pb + b1 * ldp;
+            cd m00 = cmulc(ua0[0], ub0[0]), m01 = cmulc(ua0[0], ub1[0]), m10 = cmulc(ua1[0], ub0[0]), m11 = cmulc(ua1[0], ub1[0]);
+            cd n00 = cmulc(ua0[1], ub0[1]), n01 = cmulc(ua0[1], ub1[1]), n10 = cmulc(ua1[1], ub0[1]), n11 = cmulc(ua1[1], ub1[1]);
+            int c = 2;
+            for (; c + 1 < ncomp; c += 2) {
+                const cd p0 = ua0[c], p1 = ua1[c], q0 = ub0[c], q1 = ub1[c];
+                cfmac(m00, p0, q0);
+                cfmac(m01, p0, q1);
+                cfmac(m10, p1, q0);
+                cfmac(m11, p1, q1);
+                const cd r0 = ua0[c + 1], r1 = ua1[c + 1], t0 = ub0[c + 1], t1 = ub1[c + 1];
+                cfmac(n00, r0, t0);
+                cfmac(n01, r0, t1);
+                cfmac(n10, r1, t0);
+                cfmac(n11, r1, t1);
+            }
+            if (c < ncomp) {
+                const cd p0 = ua0[c], p1 = ua1[c], q0 = ub0[c], q1 = ub1[c];
+                cfmac(m00, p0, q0);
+                cfmac(m01, p0, q1);
+                cfmac(m10, p1, q0);
+                cfmac(m11, p1, q1);
+            }
+            cd* o = out + (int64_t)(i + g) * NN;
+            o[a0 * NOCC + b0] = cadd(m00, n00);
+            if (vb1) o[a0 * NOCC + b1] = cadd(m01, n01);
+            if (va1) o[a1 * NOCC + b0] = cadd(m10, n10);
+            if (va1 && vb1) o[a1 * NOCC + b1] = cadd(m11, n11);
+        }
+        lds_sync_wave();
+    }
+}
+
 #define TBK_CHAINW_PASS 32
 template <int NOCC>
 __global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, const int64_t s0, const int64_t ns, const cd* __restrict__ ws,
@@ -1133,6 +1239,9 @@ static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A,
     cd* ws = (cd*)ctx->work;
     const size_t lds_a = (size_t)4 * 2 * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);
     const size_t lds_b = (size_t)TBK_CHAINW_PASS * (nn + 1) * sizeof(cd);
+    // 5..8 bands: four links per wavefront step (k_chain_links_tile) while its five staged points fit 64 KB per block
+    const size_t lds_t = (size_t)4 * (TBK_CHAINT_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);
+    const bool use_tile = nocc >= 5 && tbk_knobs().chain_tile != 0 && lds_t <= 64 * 1024;
     const int nld = (nocc * v.ncomp + 63) / 64;
     const dim3 blk(256);
     for (int64_t s0 = 0; s0 < A.nstrings; s0 += nsb) {
@@ -1141,7 +1250,15 @@ static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A,
         const dim3 ga((unsigned)((nw + 3) / 4)), gb((unsigned)nw);
 #define TBK_CHAINW(NN, LL)                                                                                                          \
     {                                                                                                                               \
-        { ProfScope p1(ctx, "chain_links"); hipLaunchKernelGGL((k_chain_links_wave<NN, LL>), ga, blk, lds_a, ctx->stream, A, s0, ns, ws); } \
+        {                                                                                                                           \
+            ProfScope p1(ctx, "chain_links");                                                                                       \
+            if constexpr (NN >= 5) {                                                                                                \
+                if (use_tile) hipLaunchKernelGGL((k_chain_links_tile<NN, LL>), ga, blk, lds_t, ctx->stream, A, s0, ns, ws);         \
+                else hipLaunchKernelGGL((k_chain_links_wave<NN, LL>), ga, blk, lds_a, ctx->stream, A, s0, ns, ws);                  \
+            } else {                                                                                                                \
+                hipLaunchKernelGGL((k_chain_links_wave<NN, LL>), ga, blk, lds_a, ctx->stream, A, s0, ns, ws);                       \
+            }                                                                                                                       \
+        }                                                                                                                           \
         { ProfScope p2(ctx, "chain_lu"); hipLaunchKernelGGL((k_chain_lu_wave<NN>), gb, dim3(64), lds_b, ctx->stream, A, s0, ns, (const cd*)ws, dets_out); } \
     }
 #define TBK_CHAINW_N(NN)                                  \

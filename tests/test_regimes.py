@@ -173,6 +173,30 @@ def test_two_points_per_lane_is_bit_identical(tb, n, nk):
         assert np.max(np.abs(out[2][0].T[:50] - ref)) < 1e-13
 
 
+# ------------------------------------------------- link matrices of 5..8 wide bands: four links per wavefront step or one
+@pytest.mark.parametrize("norb,mesh", [(9, (7, 11, 6)), (16, (5, 4, 14)), (12, (3, 9, 10))])
+def test_links_four_per_step_equal_one_per_step(tb, norb, mesh):
+    """k_chain_links_tile (pythtb_amd/csrc/tbk_berry.hip) against k_chain_links_wave on the same array: string lengths that are
+    no multiple of four, odd component counts, every band count 5..8 and every direction -- the same bits (the accumulation
+    order of an entry is the same), and the oracle's phases (pythtb.py:3038-3066) to rounding."""
+    from pythtb_amd import _lib
+    from oracle import tb_oracle as orc
+    m = hp.random_model(tb.tb_model, norb, 3, 1, seed=norb, nhop=5 * norb, rmax=1)
+    w = tb.wf_array(m, list(mesh))
+    w.solve_on_grid([0.1, -0.2, 0.05])
+    for nocc in (5, 6, 7, 8):
+        for d in (0, 1, 2):
+            got = {}
+            for tile in (1, 0):
+                with _lib.knob("TBK_CHAIN_TILE", tile):
+                    got[tile] = np.asarray(w.berry_phase(range(nocc), d, contin=False))
+            assert np.array_equal(got[1], got[0]), (nocc, d)
+            if nocc == 6 and d == 2:
+                ref = np.asarray(orc.berry_phase(w.to_host(), 3, list(range(nocc)), d, contin=False))
+                dphi = (got[1] - ref + np.pi) % (2 * np.pi) - np.pi
+                assert np.max(np.abs(dphi)) < 1e-10
+
+
 # ---------------------------------------------------------------------------------------------- input nobody can solve
 def _chain(tb, n, onsite0):
     m = hp.quiet(tb.tb_model, 1, 1, [[1.0]], [[i / float(n)] for i in range(n)])
