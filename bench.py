@@ -288,7 +288,7 @@ def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
                     "kpts": nk, "kernels": kt,
                     "kpts_per_s_eigenvalues": nk / (kt["solve_list_val"]["avg_bracket_ms"] * 1e-3),
                     "kpts_per_s_with_vectors": nk / (kt["solve_list_vec"]["avg_bracket_ms"] * 1e-3),
-                    "roofline": {"solve_list_val": roof(8 * (2 + 2) * nk, kt["solve_list_val"]["avg_bracket_ms"], "k_solve_small<2,0,false>", nk, valu),
+                    "roofline": {"solve_list_val": roof(8 * (2 + 2) * nk, kt["solve_list_val"]["avg_bracket_ms"], "k_solve_small_multi<2,false,2>", nk, valu),
                                  "solve_list_vec": roof((8 * (2 + 2) + 16 * 4) * nk, kt["solve_list_vec"]["avg_bracket_ms"], "k_solve_small<2,0,true>", nk, valu)},
                     "python_call_incl_pcie_s": t_api,
                     "check": {"sum": float(ev.sum()), "min": float(ev.min()), "max": float(ev.max()),
