@@ -371,6 +371,20 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
     }
     double d[N], e[N];
     cd delta{1.0, 0.0};                        // D_{K+1} = D_K t_K / |t_K| makes the subdiagonal real
+    // With eigenvectors nothing is accumulated on the way: the reflectors (u_K, beta_K) and the diagonal unitary D are kept, the
+    // QL rotations -- real -- act on a REAL N x N matrix Q (half the arithmetic of rotating complex rows, half the registers of
+    // Z), and the eigenvectors are H_0 .. H_{N-3} D Q at the end, like the larger direct solvers do it.  (Before: Z complex,
+    // updated by every reflection and every rotation -- 210 VGPRs and two wavefronts per SIMD for k_grid_rows<4,1>.)
+    cd us[N > 2 ? N - 2 : 1][N];
+    double betas[N > 2 ? N - 2 : 1];
+    cd dph[N];
+    dph[0] = cd{1.0, 0.0};
+#pragma unroll
+    for (int K = 0; K + 2 < N; ++K) {
+        betas[K] = 0.0;
+#pragma unroll
+        for (int r = 0; r < N; ++r) us[K][r] = cd{0.0, 0.0};
+    }
 #pragma unroll
     for (int K = 0; K + 1 < N; ++K) {
         cd tK = a[K + 1][K];
@@ -419,18 +433,9 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
                         a[r][c].y -= (u[r].y * q[c].x - u[r].x * q[c].y) + (q[r].y * u[c].x - q[r].x * u[c].y);
                     }
                 if (VEC) {
+                    betas[K] = beta;
 #pragma unroll
-                    for (int r = 0; r < N; ++r) {       // Z -= (beta Z u) u^+
-                        cd w{0.0, 0.0};
-#pragma unroll
-                        for (int c = K + 1; c < N; ++c) cfma(w, M.v[r][c], u[c]);
-                        w = cd{w.x * beta, w.y * beta};
-#pragma unroll
-                        for (int c = K + 1; c < N; ++c) {
-                            M.v[r][c].x -= w.x * u[c].x + w.y * u[c].y;
-                            M.v[r][c].y -= w.y * u[c].x - w.x * u[c].y;
-                        }
-                    }
+                    for (int r = 0; r < N; ++r) us[K][r] = u[r];
                 }
             }
         }
@@ -443,13 +448,15 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
             delta = cmul(delta, cd{tK.x * inv, tK.y * inv});
         }
         e[K] = mag;
-        if (VEC) {
-#pragma unroll
-            for (int r = 0; r < N; ++r) M.v[r][K + 1] = cmul(M.v[r][K + 1], delta);
-        }
+        dph[K + 1] = delta;
     }
     d[N - 1] = a[N - 1][N - 1].x;
     e[N - 1] = 0.0;
+    double Q[N][N];
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int c = 0; c < N; ++c) Q[r][c] = r == c ? 1.0 : 0.0;
 
     int l = 0;
     int iter = 0;
@@ -508,9 +515,9 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
                     if (VEC) {
 #pragma unroll
                         for (int r_ = 0; r_ < N; ++r_) {
-                            const cd zi = M.v[r_][i], zj = M.v[r_][i + 1];
-                            M.v[r_][i + 1] = cd{sn * zi.x + cs * zj.x, sn * zi.y + cs * zj.y};
-                            M.v[r_][i] = cd{cs * zi.x - sn * zj.x, cs * zi.y - sn * zj.y};
+                            const double zi = Q[r_][i], zj = Q[r_][i + 1];
+                            Q[r_][i + 1] = sn * zi + cs * zj;
+                            Q[r_][i] = cs * zi - sn * zj;
                         }
                     }
                 } else {                       // r == 0 (underflow): tql2's recovery
@@ -530,6 +537,30 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) M.dg[j] = d[j];
+    if (VEC) {
+#pragma unroll
+        for (int b = 0; b < N; ++b) {          // column b of Z = H_0 .. H_{N-3} D Q
+            cd z[N];
+#pragma unroll
+            for (int r = 0; r < N; ++r) z[r] = cd{dph[r].x * Q[r][b], dph[r].y * Q[r][b]};
+#pragma unroll
+            for (int K = N - 3; K >= 0; --K) {
+                if (betas[K] != 0.0) {
+                    cd w{0.0, 0.0};
+#pragma unroll
+                    for (int r = K + 1; r < N; ++r) cfmac(w, us[K][r], z[r]);      // u^+ z
+                    w = cd{w.x * betas[K], w.y * betas[K]};
+#pragma unroll
+                    for (int r = K + 1; r < N; ++r) {
+                        z[r].x -= us[K][r].x * w.x - us[K][r].y * w.y;
+                        z[r].y -= us[K][r].x * w.y + us[K][r].y * w.x;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < N; ++r) M.v[r][b] = z[r];
+        }
+    }
     return iter < 30 * N;      // (LAPACK's limit: 30 shifts per eigenvalue)
 }
 
