@@ -2228,7 +2228,12 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         w->flux_nslices = 1;
         w->flux_plaq_n = 0;
         F.partial = w->flux_partial_dev;
-        const size_t lds = (size_t)4 * (fixed_cd + (G.seg > 1 ? (size_t)G.seg * 64 * (1 + n) : 0)) * sizeof(cd);   // (seg = 1: no column tables in LDS)
+        size_t lds = (size_t)4 * (fixed_cd + (G.seg > 1 ? (size_t)G.seg * 64 * (1 + n) : 0)) * sizeof(cd);   // (seg = 1: no column tables in LDS)
+        // beyond the last-level cache FEWER resident wavefronts write faster (us per step at 4096^2 for 2 / 3 / 4 / 5 per SIMD:
+        // 284 / 245 / 259 / 263; at 2048^2: 72.0 / 61.7 / 59.5 / 58.7): the cap is set through the LDS request (160 KB per CU /
+        // blocks per CU), the only launch-time handle on occupancy
+        const int occ_cap = K.fused_occ > 0 ? K.fused_occ : (in_llc ? 0 : 3);
+        if (occ_cap > 0 && occ_cap < 8) lds = std::max(lds, (size_t)(160 * 1024) / (size_t)(occ_cap + 1) + 1024);
         TBK_REQUIRE(lds <= 64 * 1024, TBK_EUNSUPPORTED, "tbk_wfs_solve_grid_flux: %zu bytes of LDS per block", lds);
         const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
         {

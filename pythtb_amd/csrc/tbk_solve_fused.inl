@@ -126,17 +126,17 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
     }
     // one chunk per tile (seg = 1): its table entries go straight to registers -- fetched here, before any store is issued, and
     // consumed here (the empty asm), so that no wait on them lands inside the row loop
-    cd zl1{1.0, 0.0}, tfl1[N];
+    cd zl{1.0, 0.0}, tfl[N];
 #pragma unroll
-    for (int o = 0; o < N; ++o) tfl1[o] = cd{0.0, 0.0};
+    for (int o = 0; o < N; ++o) tfl[o] = cd{0.0, 0.0};
     if (live && G.seg == 1) {
         const int jj = min(jc0 * 64 + lane, nlast - 1);
-        zl1 = G.tz[1][jj];
+        zl = G.tz[1][jj];
 #pragma unroll
-        for (int o = 0; o < N; ++o) tfl1[o] = G.tf[1][(int64_t)jj * N + o];
-        asm volatile("" : "+v"(zl1.x), "+v"(zl1.y));
+        for (int o = 0; o < N; ++o) tfl[o] = G.tf[1][(int64_t)jj * N + o];
+        asm volatile("" : "+v"(zl.x), "+v"(zl.y));
 #pragma unroll
-        for (int o = 0; o < N; ++o) asm volatile("" : "+v"(tfl1[o].x), "+v"(tfl1[o].y));
+        for (int o = 0; o < N; ++o) asm volatile("" : "+v"(tfl[o].x), "+v"(tfl[o].y));
     }
     __syncthreads();
     if (!live) return;
@@ -159,9 +159,6 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
     }
     double psum = 0.0;
     for (int jc = jc0; jc < jc1; ++jc) {
-        cd zl = zl1, tfl[N];
-#pragma unroll
-        for (int o = 0; o < N; ++o) tfl[o] = tfl1[o];
         if (G.seg > 1) {
             zl = ztab[(jc - jc0) * 64 + lane];
 #pragma unroll
