@@ -59,6 +59,7 @@ static void knobs_parse() {
     geti("TBK_FUSED_ROWS", k.fused_rows);
     geti("TBK_FUSED_SUM", k.fused_sum);
     geti("TBK_FUSED_OCC", k.fused_occ);
+    geti("TBK_GRID_OCC", k.grid_occ);
     geti("TBK_SMALL_KPT", k.small_kpt);
     geti("TBK_GRID_KERNEL", k.grid_kernel);
     geti("TBK_FLUX_TI", k.flux_ti);

@@ -62,6 +62,7 @@ struct TbkKnobs {
     int wave_run = -1;          // TBK_WAVE_RUN      chain length of the wavefront solver (1 = always cold)
     int fused_rows = -1;        // TBK_FUSED_ROWS    mesh rows per wave tile of the fused solve + flux kernel (default 6; 10 beyond the LLC)
     int small_kpt = -1;         // TBK_SMALL_KPT     k points per lane of the n <= 4 list kernels: 1, 2; default 2 from 2^19 points
+    int grid_occ = -1;          // TBK_GRID_OCC      cap on the resident wavefronts per SIMD of k_grid_rows (diagnostic; default none)
     int fused_occ = -1;         // TBK_FUSED_OCC     cap on the resident wavefronts per SIMD of the fused kernel (default: none inside the LLC, 3 beyond)
     int fused_sum = 1;          // TBK_FUSED_SUM     0: the flux total of the fused pass by a kernel of its own (k_sum_fixed)
     int grid_seg = -1;          // TBK_GRID_SEG      chunks per wave tile of k_grid_rows

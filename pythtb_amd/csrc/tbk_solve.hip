@@ -2280,8 +2280,11 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         G.tpr = (G.cpr + G.seg - 1) / G.seg;
         G.seg = (G.cpr + G.tpr - 1) / G.tpr;             // balance the tiles of a row (33 chunks -> 7,7,7,7,5)
         G.ntiles = nrows * G.tpr;
-        const size_t lds = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
+        size_t lds = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
         if (lds <= 48 * 1024 && tbk_knobs().grid_kernel != 1) {
+            // (TBK_GRID_OCC: cap on the resident wavefronts per SIMD through the LDS request, as in the fused pass)
+            if (tbk_knobs().grid_occ > 0 && tbk_knobs().grid_occ < 8)
+                lds = std::max(lds, (size_t)(160 * 1024) / (size_t)(tbk_knobs().grid_occ + 1) + 1024);
             const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
             const int64_t npart = G.ntiles * std::max(n - 1, 1);
             if (w->gap_part_cap < npart) {
