@@ -1058,14 +1058,14 @@ __global__ __launch_bounds__(256, 5) void k_chain_links_wave(const ChainArgs A, 
 // wavefront), a lane reads 2 + 2 staged rows for 4 entries of M (half the LDS reads per entry), and the index arithmetic, the
 // barriers and the waits are paid once per four links.  The accumulation order of an entry is the one of the kernel above
 // (even and odd components in two accumulators).  The workspace layout is unchanged: k_chain_lu_wave reads it.
-#define TBK_CHAINT_G 4
+#define TBK_CHAINT_G 8   // links per wavefront step (a multiple of 4: sixteen lanes per link, four links per pass)
 template <int NOCC, int NLD>
 __global__ __launch_bounds__(256) void k_chain_links_tile(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ ws) {
     static_assert(NOCC >= 5 && NOCC <= 8, "k_chain_links_tile: 5..8 bands");
     extern __shared__ __align__(16) unsigned char chainw_lds[];
     constexpr int G = TBK_CHAINT_G, NT = (NOCC + 1) / 2, NN = NOCC * NOCC;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;   // (2 or 4 wavefronts per block: whatever fits 64 KB of LDS)
     if (t >= ns * A.nseg) return;                    // (no workgroup barrier below: waves are independent)
     const int64_t seg = t / ns, sl = t - seg * ns, s = s0 + sl;
     const int ncomp = A.v.ncomp;
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_chain_links_tile(const ChainArgs A, con
     for (int j = 0; j < NLD; ++j) xl[j] = *reinterpret_cast<const v2d*>(P + goff[j]);   // point 0
     load_group(1);
     // this lane's block of M
-    const int g = lane >> 4, tl = lane & 15;
+    const int g4 = lane >> 4, tl = lane & 15;
     const int ta = tl / NT, tb = tl - ta * NT;
     const bool active = tl < NT * NT;
     const int a0 = min(2 * ta, NOCC - 1), a1 = min(2 * ta + 1, NOCC - 1), b0 = min(2 * tb, NOCC - 1), b1 = min(2 * tb + 1, NOCC - 1);
@@ -1121,6 +1121,9 @@ __global__ __launch_bounds__(256) void k_chain_links_tile(const ChainArgs A, con
         for (int j = 0; j < NLD; ++j) xl[j] = x[G - 1][j];
         load_group(i + G + 1);
         lds_sync_wave();
+#pragma unroll
+        for (int gp = 0; gp < G; gp += 4) {
+        const int g = g4 + gp;
         if (active && i + g < np) {
             const cd* pa = buf + g * pbuf;
             const cd* pb = pa + pbuf;
@@ -1152,6 +1155,7 @@ __global__ __launch_bounds__(256) void k_chain_links_tile(const ChainArgs A, con
             if (vb1) o[a0 * NOCC + b1] = cadd(m01, n01);
             if (va1) o[a1 * NOCC + b0] = cadd(m10, n10);
             if (va1 && vb1) o[a1 * NOCC + b1] = cadd(m11, n11);
+        }
         }
         lds_sync_wave();
     }
@@ -1240,7 +1244,9 @@ static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A,
     const size_t lds_a = (size_t)4 * 2 * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);
     const size_t lds_b = (size_t)TBK_CHAINW_PASS * (nn + 1) * sizeof(cd);
     // 5..8 bands: four links per wavefront step (k_chain_links_tile) while its five staged points fit 64 KB per block
-    const size_t lds_t = (size_t)4 * (TBK_CHAINT_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);
+    const size_t lds_t1 = (size_t)(TBK_CHAINT_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);   // per wavefront
+    const int wpb_t = 4 * lds_t1 <= 64 * 1024 ? 4 : 2;
+    const size_t lds_t = wpb_t * lds_t1;
     const bool use_tile = nocc >= 5 && tbk_knobs().chain_tile != 0 && lds_t <= 64 * 1024;
     const int nld = (nocc * v.ncomp + 63) / 64;
     const dim3 blk(256);
@@ -1253,7 +1259,7 @@ static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A,
         {                                                                                                                           \
             ProfScope p1(ctx, "chain_links");                                                                                       \
             if constexpr (NN >= 5) {                                                                                                \
-                if (use_tile) hipLaunchKernelGGL((k_chain_links_tile<NN, LL>), ga, blk, lds_t, ctx->stream, A, s0, ns, ws);         \
+                if (use_tile) hipLaunchKernelGGL((k_chain_links_tile<NN, LL>), dim3((unsigned)((nw + wpb_t - 1) / wpb_t)), dim3(64 * wpb_t), lds_t, ctx->stream, A, s0, ns, ws); \
                 else hipLaunchKernelGGL((k_chain_links_wave<NN, LL>), ga, blk, lds_a, ctx->stream, A, s0, ns, ws);                  \
             } else {                                                                                                                \
                 hipLaunchKernelGGL((k_chain_links_wave<NN, LL>), ga, blk, lds_a, ctx->stream, A, s0, ns, ws);                       \
