@@ -1229,7 +1229,8 @@ __global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, cons
 static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A, int nocc, cd* dets_out) {
     const int nn = nocc * nocc;
     const size_t per_string = (size_t)A.nlinks * nn * sizeof(cd);
-    const int64_t nsb = std::max<int64_t>(1, std::min<int64_t>(A.nstrings, (int64_t)(((size_t)1 << 30) / per_string)));
+    const size_t ws_cap = (size_t)std::max(1, tbk_knobs().chain_ws_mb) << 20;
+    const int64_t nsb = std::max<int64_t>(1, std::min<int64_t>(A.nstrings, (int64_t)(ws_cap / per_string)));
     const size_t wbytes = (size_t)nsb * per_string;
     if (wbytes > ctx->work_bytes) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
