@@ -69,6 +69,7 @@ struct TbkKnobs {
     int grid_kernel = 0;        // TBK_GRID_KERNEL   1: term-walking mesh kernel instead of the row-polynomial one
     int flux_ti = -1;           // TBK_FLUX_TI       rows per flux tile
     int flux_fused = 0;         // TBK_FLUX_FUSED    1: final flux sum inside the kernel
+    int trigv_from = -1;        // TBK_TRIGV_FROM    smallest n of the workgroup-scale direct eigenvector path (default 65; A/B runs down to 17)
     int chain_ws_mb = 1024;     // TBK_CHAIN_WS_MB   link-matrix workspace per batch of strings, MiB
     int chain_tile = 1;         // TBK_CHAIN_TILE    0: one link per wavefront step (k_chain_links_wave) also for 5..8 bands
     int chain_wave = 1;         // TBK_CHAIN_WAVE    0: thread-per-string link determinants also for 1..8 bands of wide (>= 8 component) states

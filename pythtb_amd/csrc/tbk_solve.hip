@@ -1626,6 +1626,11 @@ static const RegimeRule kRegimeRules[] = {
     // 17..64: tridiagonalise in LDS | lane-per-matrix QL or bisection | replay; the same batch rule
     {Regime::Qlw, 17, 64, 0, kNoMesh, kMatrices, -1, -1, "one 64 x 64: 1.26 -> 0.44 ms; 16384 x n=32: 11.8 -> 1.1 ms"},
     {Regime::Qlw, 17, 64, -1, kAnyForm, kPerCU, 8, -1, "16384 x n=32 with vectors: 11.7 -> 2.2 ms"},
+    // 40..64 with eigenvectors BELOW that batch: the workgroup-scale direct method of 65..1024 states instead of workgroup Jacobi
+    // (ms per call, Jacobi | direct, profiles/trigv_small_batches.py: n=64 x 16 1.18 | 0.87, x 1024 5.35 | 1.89; n=48 x 16 0.67 |
+    // 0.63, x 1024 2.13 | 1.17; n=40 x 256 0.50 | 0.57, x 1024 1.69 | 0.92; n=32 x 1024 0.61 | 0.68 stays) -- and 3-6 x smaller errors
+    {Regime::TrigV, 48, 64, 1, kAnyForm, kPerCU, -1, 8, "n=64: 1024 matrices 5.35 (workgroup Jacobi) -> 1.89 ms; 16: 1.18 -> 0.87"},
+    {Regime::TrigV, 40, 47, 1, kAnyForm, kPerCU, 2, 8, "n=40: 1024 matrices 1.69 -> 0.92 ms; 256: 0.50 | 0.57 stays on Jacobi"},
     // 13..16 on lists and supplied matrices when the direct solver is off or the batch is small: Jacobi on a DPP row
     {Regime::Row16, 15, 16, 1, kNoMesh, kMatrices, -1, -1, "262144 x n=16 with vectors: 12.1 against 12.5 / 17.5 ms (LDS kernel)"},
     {Regime::Row16, 13, 16, 0, kNoMesh, kMatrices, -1, -1, "eigenvalues: 6.8-7.1 against 13.1 / 19.0 ms"},
@@ -1657,6 +1662,7 @@ static Regime choose_regime(const RegimeQuery& q, const TbkKnobs& K, const char*
                 break;
             case Regime::TrigV:
                 if (K.use_trigv == 0 || q.qlw_off) continue;   // (qlw_off: the call is being repeated on the Jacobi kernels)
+                if (K.trigv_from > 0 && r.n_lo == 65) n_lo = std::max(17, K.trigv_from);
                 break;
             case Regime::Blocked:
                 if (K.blocked == 0) continue;

@@ -385,6 +385,10 @@ def test_solver_dispatch_table_routes_the_measured_crossovers():
     # 17..64
     assert regime(32, 1, SUP, 16384) == "qlw" and regime(32, 1, SUP, 2048) == "wg_lds" and regime(20, 1, SUP, 2048) == "wg_lds"
     assert regime(64, 0, SUP, 1) == "qlw" and regime(20, 1, LIST, 2049) == "qlw"
+    # ... and 40..64 with eigenvectors below the QL batch take the direct method of 65+ states instead of workgroup Jacobi
+    assert regime(64, 1, SUP, 16) == "trigv" and regime(48, 1, LIST, 2048) == "trigv" and regime(48, 1, LIST, 2049) == "qlw"
+    assert regime(47, 1, SUP, 512) == "wg_lds" and regime(47, 1, SUP, 513) == "trigv" and regime(39, 1, SUP, 1024) == "wg_lds"
+    assert regime(64, 0, MESH, 100, batch=100) == "wg_lds"       # (eigenvalues only on a mesh: unchanged)
     # above 64 states
     assert regime(300, 0, LIST, 101) == "trig" and regime(513, 0, LIST, 1) == "big" and regime(513, 0, LIST, 2) == "trig"
     # (five 1024-state matrices: too few for a CU each, enough work -- 5 x 1024^2 >= 1.4e6 -- for block Jacobi)
@@ -398,6 +402,7 @@ def test_solver_dispatch_table_routes_the_measured_crossovers():
         assert regime(128, 1, LIST, 512) == "blocked" and regime(128, 1, LIST, 64) == "big" and regime(70, 1, LIST, 200) == "wg_global"
         assert regime(95, 1, LIST, 4000) == "wg_global" and regime(230, 1, LIST, 26) == "big" and regime(230, 1, LIST, 27) == "blocked"
         assert regime(300, 1, MESH, 101, batch=101) == "blocked" and regime(90, 1, SUP, 1) == "big"
+        assert regime(64, 1, SUP, 16) == "wg_lds"
     # knobs move the boundaries, not the code
     with _lib.knob("TBK_QL16_MIN", 0):
         assert regime(12, 1, LIST, 5) == "ql16"

@@ -71,6 +71,10 @@ REGIMES = [
     (64, 60, {"TBK_QLW_MIN": 0}, "tridiagonal path, register replay (two wavefronts)"),
     (32, 100, {"TBK_QLW_MIN": 0, "TBK_QLW_REPLAY_REG": 0}, "tridiagonal path, LDS replay forced"),
     (40, 100, {"TBK_QLW": 0}, "workgroup LDS Jacobi"),
+    (48, 40, {}, "below the QL batch threshold: the direct method of 65+ states"),
+    (64, 300, {}, "below the QL batch threshold: the direct method of 65+ states"),
+    (40, 700, {}, "below the QL batch threshold: the direct method of 65+ states"),
+    (56, 300, {"TBK_TRIGV": 0}, "workgroup LDS Jacobi"),
     (65, 20, {}, "direct method: tridiagonalise | bisection | twisted vectors | Newton-Schulz | back-transformation"),
     (100, 12, {}, "direct method"),
     (230, 5, {}, "direct method, 8-column strips"),
@@ -171,6 +175,33 @@ def test_two_points_per_lane_is_bit_identical(tb, n, nk):
     if h is not None:
         ref = np.linalg.eigvalsh(h)
         assert np.max(np.abs(out[2][0].T[:50] - ref)) < 1e-13
+
+
+# ------------------------------------------ 40..64 states, small batches: the direct method on k lists and meshes too
+@pytest.mark.parametrize("norb,nk,mesh", [(48, 37, (6, 5)), (64, 20, (4, 4)), (42, 600, (25, 24))])
+def test_direct_method_on_small_batches_of_models(tb, norb, nk, mesh):
+    """solve_all and solve_on_grid of a 40..64-state model on a batch below the QL threshold take tbk_solve_trigv.inl (kRegimeRules):
+    eigenvalues and eigenvectors against LAPACK on the model's own H(k) (pythtb.py:927-953), the array against the list."""
+    from pythtb_amd import _lib
+    m = hp.random_model(tb.tb_model, norb, 2, 1, seed=norb + nk, nhop=4 * norb, rmax=1)
+    assert _lib.lib.tbk_solver_regime(norb, 1, 0, nk, nk, 256, 1, None) == b"trigv"
+    k = np.random.default_rng(5).uniform(-0.5, 0.5, (nk, 2))
+    ev, vec = m.solve_all(k, eig_vectors=True)
+    for i in (0, nk // 2, nk - 1):
+        h = m._gen_ham(k[i])
+        ref = np.linalg.eigvalsh(h)
+        assert np.max(np.abs(ev[:, i] - ref)) < 2e-13 * max(1.0, np.abs(ref).max())
+        V = vec[:, i, :]                                   # [band][orbital]
+        assert np.max(np.abs(V @ h.T - ev[:, i, None] * V)) < 5e-13 * max(1.0, np.abs(ref).max())
+        assert np.max(np.abs(V.conj() @ V.T - np.eye(norb))) < 5e-13
+    w = tb.wf_array(m, list(mesh))
+    w.solve_on_grid([0.0, 0.0])
+    a = w.to_host()
+    kk = [0.0 + 2.0 / (mesh[0] - 1), 0.0 + 1.0 / (mesh[1] - 1)]
+    ev1, vec1 = m.solve_one(kk, eig_vectors=True)
+    # the same point through the mesh kernels: equal up to the phase of each eigenvector
+    ov = np.abs(np.einsum("bo,bo->b", a[2, 1].conj(), vec1))
+    assert np.max(np.abs(ov - 1.0)) < 1e-10
 
 
 # ------------------------------------------------- link matrices of 5..8 wide bands: four links per wavefront step or one
