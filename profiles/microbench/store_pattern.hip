@@ -7,6 +7,8 @@
 //   mode 3: mode 1 with one plane only (same bytes: points doubled) -- are two streams per wave the problem?
 //   mode 4: mode 2 + the three 16-byte table loads per lane and chunk (L2-resident tables)
 //   mode 5: mode 4 + a dependent start-up chain per tile (three dependent loads and a barrier)
+//   mode 8: mode 1 with every store shifted by one mesh point (32 bytes): 1 KiB stores that start in the middle of a cache line,
+//           as tiles overlapping their left neighbour by one column would issue them
 //   mode 7: mode 1 without the transposition: a lane writes its OWN point's 32 bytes as two 16-byte stores, i.e. every store
 //           instruction covers 2 KiB with a 32-byte lane stride (half of every cache line per instruction, no LDS staging)
 // hipcc --offload-arch=gfx950 -O3 store_pattern.hip -o store_pattern && ./store_pattern
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256) void k_pat(cd* data, int nrow, int nlast, int 
         const long point0 = row * nlast + (long)jc * 64;
         for (int r = 0; r < 2; ++r) {
             cd* dst = MODE == 3 ? data + (point0 * 2 + (long)r * 64) * 2 : data + ((long)r * npts + point0) * 2;
+            if (MODE == 8) dst += 2 * 64 - 2;     // (one point to the left of the next chunk: stays inside the allocation)
             if (MODE == 2 || MODE >= 4) {
                 stage[lane * 2 + 0] = cd{v + lane + t0.x + extra, v + t1.y};
                 stage[lane * 2 + 1] = cd{v + t2.x, v + lane + r + t0.y};
@@ -118,7 +121,7 @@ int main() {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     cd* tab; hipMalloc(&tab, 16 * 3 * 4096); hipMemset(tab, 0, 16 * 3 * 4096);
     int* chain; hipMalloc(&chain, 256); hipMemset(chain, 0, 256);
-    for (int mode = 0; mode < 8; ++mode) {
+    for (int mode = 0; mode < 9; ++mode) {
         for (int seg : {7, 9}) {
             const int cpr = (nlast + 63) / 64, tpr = (cpr + seg - 1) / seg, s2 = (cpr + tpr - 1) / tpr;
             const long ntiles = (long)nrow * tpr;
@@ -130,6 +133,7 @@ int main() {
                 else if (mode == 2) hipLaunchKernelGGL(k_pat<2>, dim3((ntiles + 3) / 4), dim3(256), 0, 0, p, nrow, nlast, s2, tpr, ntiles, 1.0 + rep, tab, chain);
                 else if (mode == 3) hipLaunchKernelGGL(k_pat<3>, dim3((ntiles + 3) / 4), dim3(256), 0, 0, p, nrow, nlast, s2, tpr, ntiles, 1.0 + rep, tab, chain);
                 else if (mode == 4) hipLaunchKernelGGL(k_pat<4>, dim3((ntiles + 3) / 4), dim3(256), 0, 0, p, nrow, nlast, s2, tpr, ntiles, 1.0 + rep, tab, chain);
+                else if (mode == 8) hipLaunchKernelGGL(k_pat<8>, dim3((ntiles + 3) / 4), dim3(256), 0, 0, p, nrow, nlast, s2, tpr, ntiles, 1.0 + rep, tab, chain);
                 else if (mode == 7) hipLaunchKernelGGL(k_pat<7>, dim3((ntiles + 3) / 4), dim3(256), 0, 0, p, nrow, nlast, s2, tpr, ntiles, 1.0 + rep, tab, chain);
                 else if (mode == 6) hipLaunchKernelGGL(k_pre, dim3((ntiles + 3) / 4), dim3(256), 0, 0, p, nrow, nlast, s2, tpr, ntiles, 1.0 + rep, tab);
                 else hipLaunchKernelGGL(k_pat<5>, dim3((ntiles + 3) / 4), dim3(256), 0, 0, p, nrow, nlast, s2, tpr, ntiles, 1.0 + rep, tab, chain);
