@@ -1458,16 +1458,44 @@ __global__ __launch_bounds__(64) void k_chain_final(const ChainArgs A) {
     }
 }
 
+// -angle of the two eigenvalues of a (numerically) unitary 2 x 2 matrix U = [[u00, u01], [u10, u11]] (pythtb.py:3834-3838 takes
+// them from numpy.linalg.eigvals).  U = h V with h^2 = det U / |det U| and V in SU(2), V = [[a, b], [-conj b, conj a]]: the
+// eigenvalues are h (c +- i s), c = Re a, s = sqrt(Im(a)^2 + |b|^2) -- no cancellation at the Kramers degeneracies of a
+// time-reversal symmetric model, where lambda = (tr +- sqrt(tr^2 - 4 det)) / 2 would lose half of the digits.
+__device__ __forceinline__ void unit_eigenphases2(const cd u00, const cd u01, const cd u10, const cd u11, double& p0, double& p1) {
+    const cd d = det2(u00, u01, u10, u11);
+    const double dn = sqrt(cabs2(d));
+    cd dh = dn > 0.0 ? cd{d.x / dn, d.y / dn} : cd{1.0, 0.0};
+    // principal square root of the unit number dh
+    cd h;
+    {
+        const double re = sqrt(0.5 * (1.0 + fabs(dh.x)));
+        const double im = 0.5 * dh.y / re;
+        h = dh.x >= 0.0 ? cd{re, im} : cd{fabs(im), copysign(re, dh.y)};
+    }
+    const cd hc = cconj(h);
+    const cd v00 = cmul(u00, hc), v11 = cmul(u11, hc), v01 = cmul(u01, hc), v10 = cmul(u10, hc);
+    const cd a{0.5 * (v00.x + v11.x), 0.5 * (v00.y - v11.y)};          // (a + conj a') / 2
+    const cd b{0.5 * (v01.x - v10.x), 0.5 * (v01.y + v10.y)};          // (b - conj(-conj b')) / 2 = (v01 - conj v10) / 2
+    const double c = a.x, sn = sqrt(a.y * a.y + cabs2(b));
+    const cd l0 = cmul(h, cd{c, sn}), l1 = cmul(h, cd{c, -sn});
+    p0 = -atan2(l0.y, l0.x);
+    p1 = -atan2(l1.y, l1.x);
+}
+
 // Same finish for long strings (many segments): one wavefront per string.  Lane l
 // multiplies its contiguous run of segments in order, then an ordered pairwise
 // tree over the lanes through LDS (associativity keeps the order), lane 0 finishes.
-template <int MAXN, bool EVALS>
+// NC > 0: the band count as a compile-time constant -- every loop over bands unrolls and R, T, M live in registers (with the
+// count read from A.nocc they are indexed dynamically, i.e. scratch memory: 52 us per launch for two bands, whatever the number
+// of strings, all of it latency).  NC = 2 also takes its eigenphases in closed form (unit_eigenphases2).
+template <int MAXN, bool EVALS, int NC = 0>
 __global__ __launch_bounds__(64) void k_chain_final_wave(const ChainArgs A) {
     extern __shared__ __align__(16) unsigned char lds_chain[];
     cd* ex = reinterpret_cast<cd*>(lds_chain);
     const int64_t s = blockIdx.x;
     const int lane = threadIdx.x;
-    const int nocc = A.nocc;
+    const int nocc = NC > 0 ? NC : A.nocc;
     const int nn = EVALS ? nocc * nocc : 1;
     const int P = A.final_lanes;                           // participating lanes (power of two <= 64)
     const int run = (A.nseg + P - 1) / P;
@@ -1475,18 +1503,23 @@ __global__ __launch_bounds__(64) void k_chain_final_wave(const ChainArgs A) {
     cd R[EVALS ? MAXN * MAXN : 1], T[EVALS ? MAXN * MAXN : 1];
     auto load_seg = [&](int g, cd* dst) {
         const cd* M = A.partial + ((int64_t)g * A.nstrings + s) * nn;
+#pragma unroll
         for (int e = 0; e < nn; ++e) dst[e] = M[e];
     };
     auto mul_into_R = [&](const cd* M) {                    // R <- R * M
         if constexpr (!EVALS) {
             R[0] = cmul(R[0], M[0]);
         } else {
+#pragma unroll
             for (int a = 0; a < nocc; ++a)
+#pragma unroll
                 for (int b = 0; b < nocc; ++b) {
                     cd acc{0.0, 0.0};
+#pragma unroll
                     for (int j = 0; j < nocc; ++j) cfma(acc, R[a * nocc + j], M[j * nocc + b]);
                     T[a * nocc + b] = acc;
                 }
+#pragma unroll
             for (int e = 0; e < nn; ++e) R[e] = T[e];
         }
     };
@@ -1499,19 +1532,27 @@ __global__ __launch_bounds__(64) void k_chain_final_wave(const ChainArgs A) {
             mul_into_R(M);
         }
     } else {                                               // identity: neutral in the ordered product
+#pragma unroll
         for (int e = 0; e < nn; ++e) R[e] = cd{0.0, 0.0};
         if constexpr (!EVALS) R[0] = cd{1.0, 0.0};
-        else for (int a = 0; a < nocc; ++a) R[a * nocc + a] = cd{1.0, 0.0};
+        else {
+#pragma unroll
+            for (int a = 0; a < nocc; ++a) R[a * nocc + a] = cd{1.0, 0.0};
+        }
     }
-    if (lane < P)
+    if (lane < P) {
+#pragma unroll
         for (int e = 0; e < nn; ++e) ex[lane * nn + e] = R[e];
+    }
     __syncthreads();
     for (int off = 1; off < P; off <<= 1) {
         const bool act = lane < P && (lane % (2 * off)) == 0 && lane + off < P;
         if (act) mul_into_R(ex + (lane + off) * nn);
         __syncthreads();
-        if (act)
+        if (act) {
+#pragma unroll
             for (int e = 0; e < nn; ++e) ex[lane * nn + e] = R[e];
+        }
         __syncthreads();
     }
     if (lane != 0) return;
@@ -1761,6 +1802,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             const size_t lds = (size_t)P * nn * sizeof(cd);
             const dim3 g2((unsigned)A.nstrings), b2(64);
             if (!ev) hipLaunchKernelGGL((k_chain_final_wave<1, false>), g2, b2, lds, ctx->stream, A);
+            else if (nocc == 2) hipLaunchKernelGGL((k_chain_final_wave<2, true, 2>), g2, b2, lds, ctx->stream, A);
             else if (nocc <= 4) hipLaunchKernelGGL((k_chain_final_wave<4, true>), g2, b2, lds, ctx->stream, A);
             else if (nocc <= 8) hipLaunchKernelGGL((k_chain_final_wave<8, true>), g2, b2, lds, ctx->stream, A);
             else hipLaunchKernelGGL((k_chain_final_wave<TBK_MAX_NOCC, true>), g2, b2, lds, ctx->stream, A);
