@@ -952,7 +952,7 @@ __device__ __forceinline__ void lds_sync_wave() {
 }
 
 template <int NOCC, int NLD>   // NLD = ceil(NOCC * ncomp / 64): 16-byte loads per lane and point
-__global__ __launch_bounds__(256, 5) void k_chain_links_wave(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ ws) {
+__global__ __launch_bounds__(256, (NLD <= 2 ? 5 : 4)) void k_chain_links_wave(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ ws) {
     extern __shared__ __align__(16) unsigned char chainw_lds[];
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + wib;
