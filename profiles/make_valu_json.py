@@ -11,15 +11,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
 # (a key "a+b+c" sums the per-dispatch counts of several kernels that each cover the same points)
 SOURCES = [
-    # round 3, final build (+ expi2pi, two k-points per lane on eigenvalue-only lists, four links per step): r03k, r03k2, r03kcfg
-    ("k_grid_rows_flux<2,1,1>", "r03k/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
-    ("k_grid_rows<2,1>", "r03k2/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r03k2/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r03kcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r03kcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_tw16<1>", "r03kcfg/pmc_per_dispatch.json", "k_tw16_tridiag<1>+k_tw16_eigvals<1>+k_tw16_vectors<1>", 65 ** 3),
-    ("k_solve_small_multi<2,false,2>", "r03kcfg/pmc_per_dispatch.json", "k_solve_small_multi<2,false,2>", 1024 * 1024),
-    ("k_solve_small<2,0,true>", "r03kcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
+    # round 3, final build (+ expi2pi, two k-points per lane on eigenvalue-only lists, four links per step): r03l, r03l2, r03lcfg (r03k* = the same a few commits earlier)
+    ("k_grid_rows_flux<2,1,1>", "r03l/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
+    ("k_grid_rows<2,1>", "r03l2/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r03l2/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r03lcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r03lcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_tw16<1>", "r03lcfg/pmc_per_dispatch.json", "k_tw16_tridiag<1>+k_tw16_eigvals<1>+k_tw16_vectors<1>", 65 ** 3),
+    ("k_solve_small_multi<2,false,2>", "r03lcfg/pmc_per_dispatch.json", "k_solve_small_multi<2,false,2>", 1024 * 1024),
+    ("k_solve_small<2,0,true>", "r03lcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
     # the same before those three changes (tbk_solve / tbk_berry compiled without MachineLICM, seams + total in one kernel): r03j, r03j2, r03jcfg
     ("k_grid_rows_flux<2,1,1>", "r03j/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
     ("k_grid_rows<2,1>", "r03j2/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
