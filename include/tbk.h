@@ -98,6 +98,16 @@ int tbk_model_flatten_host(int dim_k, int norb, int nspin, const double* orb, co
                            int32_t* term_R, double* term_amp, int32_t* info);
 int tbk_model_info(tbk_model* model, int* dim_k, int* nsta, int64_t* nterm);
 
+/* Host-only: continuity of Berry phases along the first index of a result array (berry_phase(contin=True), pythtb.py:2980-3036).
+ * tbk_one_phase_cont  = _one_phase_cont  (pythtb.py:3876-3889): pha[n] unwrapped by 2 pi steps, the first entry anchored at clos.
+ * tbk_array_phases_cont = _array_phases_cont (pythtb.py:3891-3921): arr[n0][nb] eigenphase sets; set i is matched greedily to the
+ * previous (already continuous) set by distance on the unit circle -- the LAST index among equal minima, like the reference's <= --
+ * and unwrapped; clos[nb] anchors set 0.  `stride` = doubles between consecutive sets / entries (a column of a larger array).
+ * No device call, no context.                                                                                                   */
+int tbk_one_phase_cont(const double* pha, int64_t n, int64_t stride, double clos, double* out, int64_t out_stride);
+int tbk_array_phases_cont(const double* arr, int64_t n0, int nb, int64_t stride, const double* clos, double* out,
+                          int64_t out_stride);
+
 /* ---- H(k) and eigen-solve ------------------------------------------- */
 /* _gen_ham (pythtb.py:874-925) for nk points: ham_out[nk][nsta][nsta] c128.
  * k: nk x dim_k reduced coordinates (ignored when dim_k == 0).            */

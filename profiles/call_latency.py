@@ -44,3 +44,9 @@ print("set_onsite + solve_one (re-upload)    %8.1f us" % wall(edit_and_solve))
 c3 = hp.chain3(tb.tb_model, -1.0, 2.0, 0.3)
 fin = c3.cut_piece(10, 0)
 print("finite chain (n=30) solve_all+vec     %8.1f us" % wall(lambda: fin.solve_all(eig_vectors=True)))
+
+km = hp.kane_mele(tb.tb_model, "odd")
+wk = tb.wf_array(km, [41, 41])
+wk.solve_on_grid([-0.5, -0.5])
+print("Kane-Mele 41x41 berry_phase([0,1], 1, berry_evals=True)  %8.1f us" % wall(lambda: wk.berry_phase([0, 1], 1, contin=True, berry_evals=True)))
+print("Kane-Mele 41x41 berry_phase([0,1], 1)                    %8.1f us" % wall(lambda: wk.berry_phase([0, 1], 1)))

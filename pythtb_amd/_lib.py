@@ -39,6 +39,8 @@ SIGNATURES = {
     "tbk_device_count": (_i, [C.POINTER(C.c_int)]),
     "tbk_knobs_reload": (_i, []),
     "tbk_build_has_diagnostics": (_i, []),
+    "tbk_one_phase_cont": (_i, [_dp, _i64, _i64, C.c_double, _dp, _i64]),
+    "tbk_array_phases_cont": (_i, [_dp, _i64, _i, _i64, _dp, _dp, _i64]),
     "tbk_model_flatten_host": (_i, [_i, _i, _i, _dp, _dp, _i64, _ip, _ip, _ip, _dp, _i64, C.POINTER(C.c_int64), _ip, _ip, _dp, _ip]),
     "tbk_ctx_create": (_i, [_i, _pp]),
     "tbk_ctx_destroy": (_i, [_p]),

@@ -1413,6 +1413,31 @@ __global__ __launch_bounds__(256) void k_chain_partial(const ChainArgs A) {
     }
 }
 
+// -angle of the two eigenvalues of a (numerically) unitary 2 x 2 matrix U = [[u00, u01], [u10, u11]] (pythtb.py:3834-3838 takes
+// them from numpy.linalg.eigvals).  U = h V with h^2 = det U / |det U| and V in SU(2), V = [[a, b], [-conj b, conj a]]: the
+// eigenvalues are h (c +- i s), c = Re a, s = sqrt(Im(a)^2 + |b|^2) -- no cancellation at the Kramers degeneracies of a
+// time-reversal symmetric model, where lambda = (tr +- sqrt(tr^2 - 4 det)) / 2 would lose half of the digits.
+__device__ __forceinline__ void unit_eigenphases2(const cd u00, const cd u01, const cd u10, const cd u11, double& p0, double& p1) {
+    const cd d = det2(u00, u01, u10, u11);
+    const double dn = sqrt(cabs2(d));
+    cd dh = dn > 0.0 ? cd{d.x / dn, d.y / dn} : cd{1.0, 0.0};
+    // principal square root of the unit number dh
+    cd h;
+    {
+        const double re = sqrt(0.5 * (1.0 + fabs(dh.x)));
+        const double im = 0.5 * dh.y / re;
+        h = dh.x >= 0.0 ? cd{re, im} : cd{fabs(im), copysign(re, dh.y)};
+    }
+    const cd hc = cconj(h);
+    const cd v00 = cmul(u00, hc), v11 = cmul(u11, hc), v01 = cmul(u01, hc), v10 = cmul(u10, hc);
+    const cd a{0.5 * (v00.x + v11.x), 0.5 * (v00.y - v11.y)};          // (a + conj a') / 2
+    const cd b{0.5 * (v01.x - v10.x), 0.5 * (v01.y + v10.y)};          // (b - conj(-conj b')) / 2 = (v01 - conj v10) / 2
+    const double c = a.x, sn = sqrt(a.y * a.y + cabs2(b));
+    const cd l0 = cmul(h, cd{c, sn}), l1 = cmul(h, cd{c, -sn});
+    p0 = -atan2(l0.y, l0.x);
+    p1 = -atan2(l1.y, l1.x);
+}
+
 // combine the segments of each string in order and finish
 template <int MAXN, bool EVALS>
 __global__ __launch_bounds__(64) void k_chain_final(const ChainArgs A) {
@@ -1428,6 +1453,24 @@ __global__ __launch_bounds__(64) void k_chain_final(const ChainArgs A) {
             cd acc{1.0, 0.0};
             for (int g = 0; g < A.nseg; ++g) acc = cmul(acc, A.partial[(int64_t)g * A.nstrings + s]);
             A.out[s] = -atan2(acc.y, acc.x);
+            return;
+        }
+        if (nocc == 2) {       // two bands: registers and the closed form (the general path below indexes local arrays dynamically)
+            cd r0 = A.partial[s * 4], r1 = A.partial[s * 4 + 1], r2 = A.partial[s * 4 + 2], r3 = A.partial[s * 4 + 3];
+            for (int g = 1; g < A.nseg; ++g) {
+                const cd* M = A.partial + ((int64_t)g * A.nstrings + s) * 4;
+                const cd m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+                cd t0{0.0, 0.0}, t1{0.0, 0.0}, t2{0.0, 0.0}, t3{0.0, 0.0};
+                cfma(t0, r0, m0); cfma(t0, r1, m2);
+                cfma(t1, r0, m1); cfma(t1, r1, m3);
+                cfma(t2, r2, m0); cfma(t2, r3, m2);
+                cfma(t3, r2, m1); cfma(t3, r3, m3);
+                r0 = t0; r1 = t1; r2 = t2; r3 = t3;
+            }
+            double p0, p1;
+            unit_eigenphases2(r0, r1, r2, r3, p0, p1);
+            A.out[s * 2] = fmin(p0, p1);
+            A.out[s * 2 + 1] = fmax(p0, p1);
             return;
         }
         cd R[MAXN * MAXN], T[MAXN * MAXN], ev[MAXN], rc[MAXN], rs[MAXN];
@@ -1456,31 +1499,6 @@ __global__ __launch_bounds__(64) void k_chain_final(const ChainArgs A) {
             o[pos] = ph;
         }
     }
-}
-
-// -angle of the two eigenvalues of a (numerically) unitary 2 x 2 matrix U = [[u00, u01], [u10, u11]] (pythtb.py:3834-3838 takes
-// them from numpy.linalg.eigvals).  U = h V with h^2 = det U / |det U| and V in SU(2), V = [[a, b], [-conj b, conj a]]: the
-// eigenvalues are h (c +- i s), c = Re a, s = sqrt(Im(a)^2 + |b|^2) -- no cancellation at the Kramers degeneracies of a
-// time-reversal symmetric model, where lambda = (tr +- sqrt(tr^2 - 4 det)) / 2 would lose half of the digits.
-__device__ __forceinline__ void unit_eigenphases2(const cd u00, const cd u01, const cd u10, const cd u11, double& p0, double& p1) {
-    const cd d = det2(u00, u01, u10, u11);
-    const double dn = sqrt(cabs2(d));
-    cd dh = dn > 0.0 ? cd{d.x / dn, d.y / dn} : cd{1.0, 0.0};
-    // principal square root of the unit number dh
-    cd h;
-    {
-        const double re = sqrt(0.5 * (1.0 + fabs(dh.x)));
-        const double im = 0.5 * dh.y / re;
-        h = dh.x >= 0.0 ? cd{re, im} : cd{fabs(im), copysign(re, dh.y)};
-    }
-    const cd hc = cconj(h);
-    const cd v00 = cmul(u00, hc), v11 = cmul(u11, hc), v01 = cmul(u01, hc), v10 = cmul(u10, hc);
-    const cd a{0.5 * (v00.x + v11.x), 0.5 * (v00.y - v11.y)};          // (a + conj a') / 2
-    const cd b{0.5 * (v01.x - v10.x), 0.5 * (v01.y + v10.y)};          // (b - conj(-conj b')) / 2 = (v01 - conj v10) / 2
-    const double c = a.x, sn = sqrt(a.y * a.y + cabs2(b));
-    const cd l0 = cmul(h, cd{c, sn}), l1 = cmul(h, cd{c, -sn});
-    p0 = -atan2(l0.y, l0.x);
-    p1 = -atan2(l1.y, l1.x);
 }
 
 // Same finish for long strings (many segments): one wavefront per string.  Lane l

@@ -8,6 +8,7 @@
 #include <map>
 #include <new>
 #include "tbk_internal.h"
+#include <cmath>
 
 static thread_local char g_err[1024] = "";
 
@@ -558,6 +559,60 @@ static int model_flatten(int dim_k, int norb, int nspin, const double* orb, cons
 // kernels will read it.  Lets the CPU test-suite (and a sanitizer build) check the table construction
 // against the reference's _gen_ham without a GPU.  term_cap = capacity of the three output arrays;
 // *nterm receives the number of terms (call with term_cap = 0 to size).  info[4] = {pmax, nR, nnz, nslot}.
+// ---- continuity of Berry phases (host only): the reference's _one_phase_cont / _array_phases_cont, which a Python loop made the
+// largest part of a small berry_phase(contin=True, berry_evals=True) call (250 of 310 us for 41 strings of two bands)
+extern "C" int tbk_one_phase_cont(const double* pha, int64_t n, int64_t stride, double clos, double* out, int64_t out_stride) {
+    TBK_REQUIRE(pha && out && n >= 0, TBK_EINVAL, "tbk_one_phase_cont: bad argument");
+    const double two_pi = 2.0 * M_PI;
+    double ref = clos;
+    for (int64_t i = 0; i < n; ++i) {
+        double v = pha[i * stride];
+        if (std::isfinite(v) && std::isfinite(ref))
+            while (std::fabs(ref - v) > M_PI) v += ref - v > M_PI ? two_pi : -two_pi;
+        out[i * out_stride] = v;
+        ref = v;
+    }
+    return TBK_OK;
+}
+extern "C" int tbk_array_phases_cont(const double* arr, int64_t n0, int nb, int64_t stride, const double* clos, double* out,
+                                     int64_t out_stride) {
+    TBK_REQUIRE(arr && clos && out && n0 >= 0 && nb >= 1, TBK_EINVAL, "tbk_array_phases_cont: bad argument");
+    const double two_pi = 2.0 * M_PI;
+    std::vector<double> ref(clos, clos + nb), cx(nb), cy(nb);
+    std::vector<int> free_idx;
+    for (int64_t i = 0; i < n0; ++i) {
+        const double* cur = arr + i * stride;
+        double* o = out + i * out_stride;
+        free_idx.resize(nb);
+        for (int b = 0; b < nb; ++b) {
+            free_idx[b] = b;
+            cx[b] = std::cos(cur[b]);
+            cy[b] = std::sin(cur[b]);
+        }
+        for (int j = 0; j < nb; ++j) {
+            const double rx = std::cos(ref[j]), ry = std::sin(ref[j]);
+            // distance on the unit circle to every entry still free; the LAST index among equal minima
+            size_t best = 0;
+            double dbest = 0.0;
+            for (size_t f = 0; f < free_idx.size(); ++f) {
+                const double d = std::hypot(rx - cx[free_idx[f]], ry - cy[free_idx[f]]);
+                if (f == 0 || d <= dbest) {
+                    best = f;
+                    dbest = d;
+                }
+            }
+            const int pick = free_idx[best];
+            free_idx.erase(free_idx.begin() + (long)best);
+            double v = cur[pick];
+            if (std::isfinite(v) && std::isfinite(ref[j]))
+                while (std::fabs(ref[j] - v) > M_PI) v += ref[j] - v > M_PI ? two_pi : -two_pi;
+            o[j] = v;
+        }
+        for (int j = 0; j < nb; ++j) ref[j] = o[j];
+    }
+    return TBK_OK;
+}
+
 extern "C" int tbk_model_flatten_host(int dim_k, int norb, int nspin, const double* orb, const double* onsite, int64_t nhop,
                                       const int32_t* hop_i, const int32_t* hop_j, const int32_t* hop_R, const double* hop_amp,
                                       int64_t term_cap, int64_t* nterm, int32_t* term_slot, int32_t* term_R, double* term_amp,

@@ -26,36 +26,22 @@ def _no_2pi(x, clos):
 
 
 def _one_phase_cont(pha, clos):
-    """Sequential 2 pi unwrapping anchored at `clos` (pythtb.py:3876-3889)."""
-    out = np.array(pha, dtype=float, copy=True)
-    ref = clos
-    for i in range(len(out)):
-        v = out[i]
-        while abs(ref - v) > np.pi:
-            v += _TWO_PI if ref - v > np.pi else -_TWO_PI
-        out[i] = v
-        ref = v
+    """Sequential 2 pi unwrapping anchored at `clos` (pythtb.py:3876-3889); the loop runs in libtbk (tbk_one_phase_cont)."""
+    arr = np.ascontiguousarray(pha, dtype=float)
+    out = np.empty_like(arr)
+    _lib.check(_lib.lib.tbk_one_phase_cont(_lib.dptr(arr), arr.shape[0], 1, float(clos), _lib.dptr(out), 1))
     return out
 
 
 def _array_phases_cont(arr_pha, clos):
-    """Greedy nearest matching of eigenphase sets on the unit circle along the
-    first index, then 2 pi unwrapping (pythtb.py:3891-3921)."""
-    out = np.zeros_like(arr_pha)
-    ref = np.array(clos, dtype=float)
-    for i in range(arr_pha.shape[0]):
-        free = list(range(arr_pha.shape[1]))
-        cur = np.exp(1.0j * arr_pha[i])
-        for j in range(ref.shape[0]):
-            dist = np.abs(np.exp(1.0j * ref[j]) - cur[free])
-            # the reference keeps the LAST index among equal minima (<= comparison)
-            best = free[len(dist) - 1 - int(np.argmin(dist[::-1]))]
-            free.remove(best)
-            v = arr_pha[i, best]
-            while abs(ref[j] - v) > np.pi:
-                v += _TWO_PI if ref[j] - v > np.pi else -_TWO_PI
-            out[i, j] = v
-        ref = out[i]
+    """Greedy nearest matching of eigenphase sets on the unit circle along the first index, then 2 pi unwrapping
+    (pythtb.py:3891-3921; the reference keeps the LAST index among equal minima).  The double loop runs in libtbk
+    (tbk_array_phases_cont): as a Python loop it was 250 of the 310 us of a 41-string, two-band berry_phase call."""
+    arr = np.ascontiguousarray(arr_pha, dtype=float)
+    ref = np.ascontiguousarray(clos, dtype=float)
+    out = np.empty_like(arr)
+    _lib.check(_lib.lib.tbk_array_phases_cont(_lib.dptr(arr), arr.shape[0], arr.shape[1], arr.shape[1], _lib.dptr(ref),
+                                              _lib.dptr(out), arr.shape[1]))
     return out
 
 

@@ -417,3 +417,27 @@ def test_solver_dispatch_table_routes_the_measured_crossovers():
     note = ctypes.c_char_p()
     _lib.lib.tbk_solver_regime(300, 0, 0, 101, 101, 256, 1, ctypes.byref(note))
     assert b"12.6 ms" in note.value
+
+
+def test_phase_continuity_in_c_equals_the_reference_loops():
+    """tbk_one_phase_cont / tbk_array_phases_cont (host only) against the oracle's restatement of _one_phase_cont and
+    _array_phases_cont (pythtb.py:3876-3921): random phase sets, exact ties (Kramers pairs: the LAST index among equal minima),
+    jumps of several 2 pi, single-band sets."""
+    from oracle import tb_oracle as orc
+    from pythtb_amd import wfarray as wa
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 7, 60):
+        pha = rng.uniform(-20.0, 20.0, n)
+        for clos in (0.0, 3.0, -7.5, pha[0]):
+            assert np.array_equal(wa._one_phase_cont(pha, clos), orc.one_phase_cont(pha, clos))
+    for n0, nb in ((1, 1), (5, 1), (9, 2), (30, 4), (12, 7)):
+        arr = rng.uniform(-np.pi, np.pi, (n0, nb))
+        arr[n0 // 2] = np.sort(arr[n0 // 2])
+        if nb >= 2:
+            arr[n0 // 3, 1] = arr[n0 // 3, 0]                 # an exact tie
+            arr[-1, :2] = [0.3, 0.3]
+        arr[0] += 2 * np.pi * rng.integers(-2, 3, nb)
+        for clos in (arr[0], np.zeros(nb), rng.uniform(-9, 9, nb)):
+            got = wa._array_phases_cont(arr, clos)
+            ref = orc.array_phases_cont(arr, np.array(clos, dtype=float))
+            assert np.array_equal(got, ref), (n0, nb)
