@@ -427,9 +427,20 @@ def python_api_leg(tb, model, reps=5):
         gaps = wf.solve_on_grid([-0.5, -0.5])
         flux = wf.berry_flux([0])
         ts.append(time.perf_counter() - t0)
-    return {"call": "wf.solve_on_grid([-0.5,-0.5]); wf.berry_flux([0])  (wf_array([2049,2049]))", "reps": reps,
-            "ms_per_step_min": 1e3 * min(ts), "ms_per_step_median": 1e3 * sorted(ts)[len(ts) // 2],
-            "kpts_per_s": MESH * MESH / sorted(ts)[len(ts) // 2], "chern": float(flux / (2 * np.pi)), "min_gap": float(gaps[0])}
+    out = {"call": "wf.solve_on_grid([-0.5,-0.5]); wf.berry_flux([0])  (wf_array([2049,2049]))", "reps": reps,
+           "ms_per_step_min": 1e3 * min(ts), "ms_per_step_median": 1e3 * sorted(ts)[len(ts) // 2],
+           "kpts_per_s": MESH * MESH / sorted(ts)[len(ts) // 2], "chern": float(flux / (2 * np.pi)), "min_gap": float(gaps[0])}
+    # the same result from ONE call (the fused pass of the timed loop, through the Python method)
+    wf.solve_on_grid_flux([-0.5, -0.5], [0])
+    tf = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        gaps, flux = wf.solve_on_grid_flux([-0.5, -0.5], [0])
+        tf.append(time.perf_counter() - t0)
+    out["fused_call"] = {"call": "wf.solve_on_grid_flux([-0.5,-0.5], [0])", "ms_per_step_min": 1e3 * min(tf),
+                         "ms_per_step_median": 1e3 * sorted(tf)[len(tf) // 2], "chern": float(flux / (2 * np.pi)),
+                         "min_gap": float(gaps[0])}
+    return out
 
 
 class _StubCtx(object):
