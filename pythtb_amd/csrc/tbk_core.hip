@@ -62,6 +62,7 @@ static void knobs_parse() {
     geti("TBK_FUSED_OCC", k.fused_occ);
     geti("TBK_GRID_OCC", k.grid_occ);
     geti("TBK_SMALL_KPT", k.small_kpt);
+    geti("TBK_ZERO_COPY_KB", k.zero_copy_kb);
     geti("TBK_GRID_KERNEL", k.grid_kernel);
     geti("TBK_FLUX_TI", k.flux_ti);
     geti("TBK_FLUX_FUSED", k.flux_fused);
@@ -142,6 +143,7 @@ extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
     }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->scratch) hipFree(c->scratch);
+    if (c->zc_host) hipHostFree(c->zc_host);
     if (c->flags_dev) hipFree(c->flags_dev);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->work) hipFree(c->work);
@@ -200,6 +202,31 @@ int tbk_ctx_scratch(tbk_ctx* c, size_t bytes, void** out) {
         c->scratch_bytes = want;
     }
     *out = c->scratch;
+    return TBK_OK;
+}
+
+// mapped host memory of at least `bytes` (grown on demand; null when the platform refuses: callers then copy)
+int tbk_ctx_zero_copy(tbk_ctx* c, size_t bytes, void** host, void** dev) {
+    if (bytes > c->zc_bytes) {
+        TBK_HIP(hipStreamSynchronize(c->stream));
+        if (c->zc_host) hipHostFree(c->zc_host);
+        c->zc_host = c->zc_dev = nullptr;
+        c->zc_bytes = 0;
+        const size_t want = std::max(bytes, (size_t)256 << 10);
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, want, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h) hipHostFree(h);
+            *host = *dev = nullptr;
+            return TBK_OK;
+        }
+        c->zc_host = h;
+        c->zc_dev = d;
+        c->zc_bytes = want;
+    }
+    *host = c->zc_host;
+    *dev = c->zc_dev;
     return TBK_OK;
 }
 

@@ -61,6 +61,7 @@ struct TbkKnobs {
     int wg_nt = 1024;           // TBK_WG_NT         threads of the global-workspace workgroup solver
     int wave_run = -1;          // TBK_WAVE_RUN      chain length of the wavefront solver (1 = always cold)
     int fused_rows = -1;        // TBK_FUSED_ROWS    mesh rows per wave tile of the fused solve + flux kernel (default 6; 10 beyond the LLC)
+    int zero_copy_kb = 64;      // TBK_ZERO_COPY_KB  k list + results of a solve_all / solve_one call up to this size go through mapped host memory (0: always copy)
     int small_kpt = -1;         // TBK_SMALL_KPT     k points per lane of the n <= 4 list kernels: 1, 2; default 2 from 2^19 points
     int grid_occ = -1;          // TBK_GRID_OCC      cap on the resident wavefronts per SIMD of k_grid_rows (diagnostic; default none)
     int fused_occ = -1;         // TBK_FUSED_OCC     cap on the resident wavefronts per SIMD of the fused kernel (default: none inside the LLC, 3 beyond)
@@ -190,6 +191,11 @@ struct tbk_ctx {
     // scratch reused across calls (grown on demand, stream-ordered use only)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    // host memory the device reads and writes directly (hipHostMalloc, mapped): small calls hand their k list over and take their
+    // eigenvalues / eigenvectors back through it -- one stream synchronisation instead of a copy each way (tbk_solve_list)
+    void* zc_host = nullptr;
+    void* zc_dev = nullptr;
+    size_t zc_bytes = 0;
     void* pinned = nullptr;    // 64 KiB of pinned host memory for small results
     int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
     void* work = nullptr;      // workspace of the workgroup-per-matrix eigen-solver (n > 64)
@@ -203,6 +209,7 @@ struct tbk_ctx {
 };
 
 int tbk_ctx_scratch(tbk_ctx* ctx, size_t bytes, void** out);
+int tbk_ctx_zero_copy(tbk_ctx* ctx, size_t bytes, void** host, void** dev);
 // small device-to-host result (min gaps, flux totals, status words): through a pinned staging buffer -- an async copy into
 // pageable memory is staged by the runtime and cost ~10 us more per call on the Python-API path -- then stream sync
 int tbk_small_d2h(tbk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "tbk_internal.h"
+#include <cstring>
 
 #define TBK_JACOBI_MAX_SWEEPS 30
 
@@ -1920,6 +1921,30 @@ extern "C" int tbk_solve_list(tbk_model* m, const double* k, int64_t nk, double*
     const size_t eb = (size_t)nk * n * sizeof(double);
     const size_t vb = evec ? (size_t)nk * n * n * sizeof(cd) : 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // small calls (a band-structure path, solve_one): the k list and the results go through host memory that the device reads
+    // and writes itself -- one synchronisation instead of a host-to-device and a device-to-host copy around the launch
+    // (solve_all on a 121-point path 30 -> see profiles/call_latency.py)
+    const size_t zc_need = al(kb) + al(eb) + al(vb);
+    if (tbk_knobs().zero_copy_kb > 0 && zc_need <= (size_t)tbk_knobs().zero_copy_kb << 10) {
+        void* zh = nullptr;
+        void* zd = nullptr;
+        int rcz = tbk_ctx_zero_copy(ctx, zc_need, &zh, &zd);
+        if (rcz) return rcz;
+        if (zh) {
+            unsigned char* hp_ = (unsigned char*)zh;
+            unsigned char* dp_ = (unsigned char*)zd;
+            if (m->dim_k > 0) {
+                TBK_REQUIRE(k, TBK_EINVAL, "tbk_solve_list: null k");
+                memcpy(hp_, k, kb);
+            }
+            rcz = tbk_solve_list_dev_checked(m, (const double*)dp_, nk, (double*)(dp_ + al(kb)), evec ? (double*)(dp_ + al(kb) + al(eb)) : nullptr);
+            if (rcz) return rcz;
+            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            memcpy(eval, hp_ + al(kb), eb);
+            if (evec) memcpy(evec, hp_ + al(kb) + al(eb), vb);
+            return TBK_OK;
+        }
+    }
     void* base = nullptr;
     int rc = tbk_ctx_scratch(ctx, 256 + al(kb) + al(eb) + al(vb), &base);
     if (rc) return rc;
@@ -2011,22 +2036,38 @@ extern "C" int tbk_gen_ham(tbk_model* m, const double* k, int64_t nk, double* ha
     const size_t kb = (size_t)nk * std::max(m->dim_k, 1) * sizeof(double);
     const size_t hb = (size_t)nk * n * n * sizeof(cd);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // (small calls through mapped host memory, like tbk_solve_list)
+    void* zh = nullptr;
+    void* zd = nullptr;
+    if (tbk_knobs().zero_copy_kb > 0 && al(kb) + al(hb) <= (size_t)tbk_knobs().zero_copy_kb << 10) {
+        int rcz = tbk_ctx_zero_copy(ctx, al(kb) + al(hb), &zh, &zd);
+        if (rcz) return rcz;
+    }
     void* base = nullptr;
-    int rc = tbk_ctx_scratch(ctx, 256 + al(kb) + al(hb), &base);
-    if (rc) return rc;
-    double* k_dev = (double*)((unsigned char*)base + 256);
-    cd* h_dev = (cd*)((unsigned char*)base + 256 + al(kb));
+    if (!zh) {
+        int rc = tbk_ctx_scratch(ctx, 256 + al(kb) + al(hb), &base);
+        if (rc) return rc;
+    }
+    double* k_dev = zh ? (double*)zd : (double*)((unsigned char*)base + 256);
+    cd* h_dev = zh ? (cd*)((unsigned char*)zd + al(kb)) : (cd*)((unsigned char*)base + 256 + al(kb));
     if (m->dim_k > 0) {
         TBK_REQUIRE(k, TBK_EINVAL, "tbk_gen_ham: null k");
-        TBK_HIP(hipMemcpyAsync(k_dev, k, kb, hipMemcpyHostToDevice, ctx->stream));
+        if (zh) memcpy(zh, k, kb);
+        else TBK_HIP(hipMemcpyAsync(k_dev, k, kb, hipMemcpyHostToDevice, ctx->stream));
     }
-    TBK_HIP(hipMemsetAsync(h_dev, 0, hb, ctx->stream));
+    if (zh) memset((unsigned char*)zh + al(kb), 0, hb);
+    else TBK_HIP(hipMemsetAsync(h_dev, 0, hb, ctx->stream));
     {
         ProfScope ps(ctx, "gen_ham");
         const int64_t total = nk * m->nslot;
         hipLaunchKernelGGL(k_gen_ham, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                            m->view, nk, k_dev, h_dev);
         TBK_HIP(hipGetLastError());
+    }
+    if (zh) {
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(ham_out, (unsigned char*)zh + al(kb), hb);
+        return TBK_OK;
     }
     TBK_HIP(hipMemcpyAsync(ham_out, h_dev, hb, hipMemcpyDeviceToHost, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
