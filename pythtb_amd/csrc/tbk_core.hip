@@ -144,6 +144,7 @@ extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->scratch) hipFree(c->scratch);
     if (c->zc_host) hipHostFree(c->zc_host);
+    for (auto& b : c->blob_pool) hipFree(b.p);
     if (c->flags_dev) hipFree(c->flags_dev);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->work) hipFree(c->work);
@@ -210,6 +211,7 @@ int tbk_ctx_zero_copy(tbk_ctx* c, size_t bytes, void** host, void** dev) {
     if (bytes > c->zc_bytes) {
         TBK_HIP(hipStreamSynchronize(c->stream));
         if (c->zc_host) hipHostFree(c->zc_host);
+    for (auto& b : c->blob_pool) hipFree(b.p);
         c->zc_host = c->zc_dev = nullptr;
         c->zc_bytes = 0;
         const size_t want = std::max(bytes, (size_t)256 << 10);
@@ -695,11 +697,22 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     m->nterm = nterm;
     m->upload_id = ++g_model_uploads;
     TBK_HIP(hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(&m->blob, total);
-    if (e != hipSuccess) {
-        delete m;
-        tbk_set_error("tbk_model_upload: hipMalloc(%zu): %s", total, hipGetErrorString(e));
-        return TBK_ENOMEM;
+    m->blob_bytes = total;
+    for (size_t i = 0; i < ctx->blob_pool.size(); ++i) {      // a freed model's blob that fits (its owner synchronised before parking it)
+        if (ctx->blob_pool[i].bytes >= total && ctx->blob_pool[i].bytes <= 4 * total + 4096) {
+            m->blob = ctx->blob_pool[i].p;
+            m->blob_bytes = ctx->blob_pool[i].bytes;
+            ctx->blob_pool.erase(ctx->blob_pool.begin() + (long)i);
+            break;
+        }
+    }
+    if (!m->blob) {
+        hipError_t e = hipMalloc(&m->blob, total);
+        if (e != hipSuccess) {
+            delete m;
+            tbk_set_error("tbk_model_upload: hipMalloc(%zu): %s", total, hipGetErrorString(e));
+            return TBK_ENOMEM;
+        }
     }
     TBK_HIP(hipMemcpyAsync(m->blob, host.data(), total, hipMemcpyHostToDevice, ctx->stream));
     TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -728,7 +741,10 @@ extern "C" int tbk_model_free(tbk_model* m) {
     if (!m) return TBK_OK;
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
-    if (m->blob) hipFree(m->blob);
+    if (m->blob) {
+        if (m->blob_bytes <= ((size_t)1 << 20) && m->ctx->blob_pool.size() < 8) m->ctx->blob_pool.push_back(tbk_ctx::Blob{m->blob, m->blob_bytes});
+        else hipFree(m->blob);
+    }
     delete m;
     return TBK_OK;
 }

@@ -193,6 +193,10 @@ struct tbk_ctx {
     size_t scratch_bytes = 0;
     // host memory the device reads and writes directly (hipHostMalloc, mapped): small calls hand their k list over and take their
     // eigenvalues / eigenvectors back through it -- one stream synchronisation instead of a copy each way (tbk_solve_list)
+    // table blobs of freed models (<= 1 MiB each, at most 8): a parameter sweep edits and re-uploads a small model per point, and a
+    // hipMalloc + hipFree pair costs more than the solve it serves
+    struct Blob { void* p; size_t bytes; };
+    std::vector<Blob> blob_pool;
     void* zc_host = nullptr;
     void* zc_dev = nullptr;
     size_t zc_bytes = 0;
@@ -256,6 +260,7 @@ struct tbk_model {
     int64_t nterm = 0;
     int64_t upload_id = 0; // unique per tbk_model_upload (cache keys must not use the blob address: hipMalloc reuses it)
     void* blob = nullptr;  // one device allocation holding all tables
+    size_t blob_bytes = 0; // its size (small ones are parked in the context's pool when the model is freed)
     ModelView view{};
 };
 
