@@ -87,9 +87,14 @@ for case in range(ncase):
         want = orc.berry_phase(owfs, dim_k, occ, d if dim_k > 1 else None, contin=False)
         p_err = np.abs(wrap(got - want)).max()
         if nocc > 1:             # Wilson-loop eigenphases, compared as sets on the circle
-            got = np.sort(w.berry_phase(occ, d if dim_k > 1 else None, contin=False, berry_evals=True), -1)
-            want = np.sort(orc.berry_phase(owfs, dim_k, occ, d if dim_k > 1 else None, contin=False, berry_evals=True), -1)
-            w_err = min(np.abs(wrap(np.roll(got, sh, -1) - want)).max() for sh in (-1, 0, 1))
+            try:
+                got = np.sort(w.berry_phase(occ, d if dim_k > 1 else None, contin=False, berry_evals=True), -1)
+                want = np.sort(orc.berry_phase(owfs, dim_k, occ, d if dim_k > 1 else None, contin=False, berry_evals=True), -1)
+                w_err = min(np.abs(wrap(np.roll(got, sh, -1) - want)).max() for sh in (-1, 0, 1))
+            except tb._lib.TbkError as exc:
+                # the library refuses a numerically singular link (no polar factor); whether it IS singular is checked below
+                print("case %3d: berry_evals raised (%s)" % (case, " ".join(str(exc).split())[:90]))
+                w_err = 1.0
             p_err = max(p_err, w_err)
     errs = dict(eval=e_err, resid=r_err, orth=o_err, gap=g_err, flux=f_err, phase=p_err)
     flag = e_err > 1e-12 or r_err > 1e-11 or o_err > 1e-12 or g_err > 1e-11 or f_err > 1e-8 or p_err > 1e-8
