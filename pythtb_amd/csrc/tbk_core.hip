@@ -145,6 +145,7 @@ extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
     if (c->scratch) hipFree(c->scratch);
     if (c->zc_host) hipHostFree(c->zc_host);
     for (auto& b : c->blob_pool) hipFree(b.p);
+    c->blob_pool.clear();
     if (c->flags_dev) hipFree(c->flags_dev);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->work) hipFree(c->work);
@@ -211,7 +212,6 @@ int tbk_ctx_zero_copy(tbk_ctx* c, size_t bytes, void** host, void** dev) {
     if (bytes > c->zc_bytes) {
         TBK_HIP(hipStreamSynchronize(c->stream));
         if (c->zc_host) hipHostFree(c->zc_host);
-    for (auto& b : c->blob_pool) hipFree(b.p);
         c->zc_host = c->zc_dev = nullptr;
         c->zc_bytes = 0;
         const size_t want = std::max(bytes, (size_t)256 << 10);
