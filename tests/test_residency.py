@@ -264,3 +264,34 @@ def test_choose_states_copies_band_planes_on_the_device(tb):
     assert e._wfs.shape == (301, 97, 3, 2, 2) and e._nsta_arr == 3
     with pytest.raises(IndexError):
         w.choose_states([4])
+
+
+@pytest.mark.gpu
+def test_parked_model_blobs_survive_the_first_small_solve():
+    """A fresh context: models are uploaded and freed (their small table blobs are parked in the context), THEN the first small
+    solve allocates the mapped host buffer, then a parked blob is reused by the next upload.  (The buffer's first allocation once
+    freed the parked blobs without emptying the pool: the next upload copied into freed memory.)  C ABI directly, because the
+    Python classes always use the default context."""
+    import ctypes as C
+    import pythtb_amd as tb
+    from pythtb_amd import _lib
+    lib = _lib.lib
+    ctx = _lib.Context()
+    m = hp.haldane(tb.tb_model, 0.2)
+    ref = m.solve_all(np.array([[0.1, 0.2], [0.3, -0.4]]))          # default context
+
+    def upload():
+        orb, onsite, hi, hj, hR, amp = m._flat_tables()
+        h = C.c_void_p()
+        _lib.check(lib.tbk_model_upload(ctx.handle, m._dim_k, m._norb, m._nspin, _lib.dptr(orb), _lib.dptr(onsite.view(float)), len(hi),
+                                        _lib.iptr(hi), _lib.iptr(hj), _lib.iptr(hR.reshape(-1)), _lib.dptr(amp.view(float)), C.byref(h)))
+        return h
+    for _ in range(3):                                               # three blobs parked, no solve yet
+        _lib.check(lib.tbk_model_free(upload()))
+    k = np.array([[0.1, 0.2], [0.3, -0.4]])
+    for _ in range(4):
+        h = upload()                                                 # reuses a parked blob
+        ev = np.zeros((2, 2))
+        _lib.check(lib.tbk_solve_list(h, _lib.dptr(k), 2, _lib.dptr(ev), None))   # the first one allocates the mapped buffer
+        assert np.array_equal(ev, ref)
+        _lib.check(lib.tbk_model_free(h))
