@@ -11,6 +11,7 @@ from .model import tb_model
 from .wfarray import wf_array
 from .w90 import w90
 from . import shard
+from .topology import z2_from_wilson_centres
 
 __version__ = "0.1.0"
-__all__ = ["tb_model", "wf_array", "w90", "shard", "__version__"]
+__all__ = ["tb_model", "wf_array", "w90", "shard", "z2_from_wilson_centres", "__version__"]

@@ -9,6 +9,7 @@ to the caller, after which the device copy is refreshed before its next use).
 """
 import copy
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -69,12 +70,16 @@ class wf_array(object):
         self._dev = None           # tbk_wfs handle
         self._dev_shape = None
         self._dev_valid = False
+        self._pt_views = {}        # flat index -> snapshot of a point handed out as a writable view of the mirror
+        self._pt_copies = []       # (flat index, array, snapshot) of points handed out as detached writable arrays
 
     # ------------------------------------------------------------------ storage
     # Two copies of the array exist: the device buffer (what every kernel reads and writes) and a lazily
     # created NumPy mirror.  Who is authoritative:
-    #   * device, after solve_on_grid / impose_* and as long as the caller only uses wf[i,j] (read-only
-    #     views / single-point transfers), wf[i,j] = v (single-point upload), berry_*, position_*;
+    #   * device, after solve_on_grid / impose_* and as long as the caller only uses wf[i,j], wf[i,j] = v
+    #     (single-point upload), berry_*, position_*.  wf[i,j] is WRITABLE like the reference's view
+    #     (pythtb.py:2662-2666): the points handed out are remembered with a snapshot, compared before the
+    #     next device use and the changed ones uploaded (_sync_point_writes) -- one point each, never the array;
     #   * host, once the caller has taken the writable mirror through the private attribute `_wfs` (in the
     #     reference that attribute IS the storage, so a script may keep the array and write to it at any
     #     time): from then on the mirror is re-uploaded before every device use and refreshed after every
@@ -101,8 +106,10 @@ class wf_array(object):
 
     @property
     def _wfs(self):
+        self._sync_point_writes()
         arr = self._host_array()
         self._host_exported = True         # the caller may keep the array and write through it at any time
+        self._pt_views = {}                # (the whole mirror is live now: no per-point bookkeeping)
         return arr
 
     @_wfs.setter
@@ -111,6 +118,69 @@ class wf_array(object):
         self._host_valid = True
         self._host_exported = False
         self._dev_valid = False
+        self._pt_views = {}
+        self._pt_copies = []
+
+    # ---- writable wf[i,j] on a device-resident array (pythtb.py:2662-2666 returns a live view of the storage)
+    _PT_TRACK_MAX = 1 << 16           # handed-out points remembered before the bookkeeping is compacted / given up
+
+    def _point_rows(self):
+        """The mirror as [point][state, orb(, spin)] (a view)."""
+        return self._host.reshape((-1,) + self._shape()[self._dim_arr:])
+
+    def _upload_point(self, idx, val):
+        if self._dev_valid and self._dev is not None:
+            pt = np.ascontiguousarray(val, dtype=complex)
+            ia = np.array([idx], dtype=np.int64)
+            _lib.check(_lib.lib.tbk_wfs_upload_points(self._dev, ia.ctypes.data_as(C.POINTER(C.c_int64)), 1,
+                                                      _lib.dptr(pt.view(float))))
+
+    def _sync_point_writes(self):
+        """Carry writes made through arrays obtained from wf[i,j] into the authoritative copy: every handed-out
+        point is compared with the snapshot taken when it was handed out (or last synchronised)."""
+        if self._pt_views:
+            # (after a device-side write the mirror as a whole is stale, but its handed-out points were refreshed)
+            if self._host is not None and not self._host_exported:
+                rows = self._point_rows()
+                for idx, snap in self._pt_views.items():
+                    cur = rows[idx]
+                    if not np.array_equal(cur, snap):
+                        self._upload_point(idx, cur)
+                        snap[...] = cur
+            else:
+                self._pt_views = {}
+        if self._pt_copies:
+            keep = []
+            for idx, arr, snap in self._pt_copies:
+                if not np.array_equal(arr, snap):
+                    self._upload_point(idx, arr)
+                    if self._host is not None and self._host_valid:
+                        self._point_rows()[idx] = arr
+                    snap[...] = arr
+                if sys.getrefcount(arr) > 3:           # still held by the caller (else: this tuple, `arr`, the argument)
+                    keep.append((idx, arr, snap))
+            self._pt_copies = keep
+
+    def _refresh_handed_points(self):
+        """A kernel rewrote the device copy: arrays the caller still holds from wf[i,j] show the new values,
+        like the reference's views of its storage."""
+        self._pt_copies = [(i, a, s) for i, a, s in self._pt_copies if sys.getrefcount(a) > 3]
+        idxs = sorted(set(self._pt_views) | {i for i, _, _ in self._pt_copies})
+        if not idxs:
+            return
+        ia = np.ascontiguousarray(idxs, dtype=np.int64)
+        buf = np.zeros((len(idxs),) + self._shape()[self._dim_arr:], dtype=complex)
+        _lib.check(_lib.lib.tbk_wfs_download_points(self._dev, ia.ctypes.data_as(C.POINTER(C.c_int64)), len(idxs),
+                                                    _lib.dptr(buf.view(float))))
+        pos = {i: n for n, i in enumerate(idxs)}
+        if self._pt_views and self._host is not None:
+            rows = self._point_rows()
+            for i, snap in self._pt_views.items():
+                rows[i] = buf[pos[i]]
+                snap[...] = buf[pos[i]]
+        for i, arr, snap in self._pt_copies:
+            arr[...] = buf[pos[i]]
+            snap[...] = buf[pos[i]]
 
     def mark_dirty(self):
         """Extension: declare that the host mirror was modified in place (only needed after
@@ -125,6 +195,7 @@ class wf_array(object):
 
     def to_host(self):
         """Extension: read-only NumPy snapshot of the whole array (one download, no later re-uploads)."""
+        self._sync_point_writes()
         out = self._host_array().view()
         out.flags.writeable = False
         return out
@@ -135,6 +206,11 @@ class wf_array(object):
         self._host_valid = False
         if self._host_exported:            # keep the array the caller holds live, like the reference's storage
             self._host_array()
+        elif self._pt_views or self._pt_copies:
+            if tuple(self._dev_shape or ()) == self._shape():
+                self._refresh_handed_points()
+            else:
+                self._pt_views, self._pt_copies = {}, []
 
     def _free_dev(self):
         if self._dev is not None:
@@ -159,6 +235,7 @@ class wf_array(object):
         return h
 
     def _ensure_dev(self):
+        self._sync_point_writes()
         if self._dev_valid and self._dev is not None and not (self._host_exported and self._host_valid):
             return self._dev
         host = self._host_array()
@@ -170,6 +247,7 @@ class wf_array(object):
         return h
 
     def __getstate__(self):
+        self._sync_point_writes()
         st = dict(self.__dict__)
         st["_host"] = None if self._host is None and not self._dev_valid else np.copy(self._host_array())
         st["_host_valid"] = st["_host"] is not None
@@ -177,6 +255,8 @@ class wf_array(object):
         st["_dev_shape"] = None
         st["_dev_valid"] = False
         st["_host_exported"] = False
+        st["_pt_views"] = {}
+        st["_pt_copies"] = []
         return st
 
     def __del__(self):
@@ -303,7 +383,7 @@ class wf_array(object):
         resident array -- 69.5 GB for BASELINE configs[4] -- only to throw the copy away)."""
         new = wf_array.__new__(wf_array)
         for k, v in self.__dict__.items():
-            if k in ("_host", "_dev", "_dev_shape"):
+            if k in ("_host", "_dev", "_dev_shape", "_pt_views", "_pt_copies"):
                 continue
             new.__dict__[k] = copy.deepcopy(v)
         new._host = None
@@ -312,6 +392,8 @@ class wf_array(object):
         new._dev = None
         new._dev_shape = None
         new._dev_valid = False
+        new._pt_views = {}
+        new._pt_copies = []
         return new
 
     def choose_states(self, subset):
@@ -322,6 +404,7 @@ class wf_array(object):
             raise Exception("\n\nParameter subset must be a one-dimensional array.")
         if self._dim_arr > 4:
             raise Exception("\n\n_dim_array too large.")
+        self._sync_point_writes()
         new = self._clone_meta()
         new._nsta_arr = subset.shape[0]
         dev_current = self._dev_valid and self._dev is not None and not (self._host_exported and self._host_valid)
@@ -375,31 +458,54 @@ class wf_array(object):
         return self._dev_valid and self._dev is not None and not (self._host_valid and self._host is not None)
 
     def __getitem__(self, key):
-        """States at one mesh point, `(nsta_arr, norb[, 2])` (pythtb.py:2644-2661).  The result is READ-ONLY
-        (write with `wf[i,j] = value`): a view of the host mirror when there is one, else -- for a large
-        resident array -- just this point fetched from the device."""
+        """States at one mesh point, `(nsta_arr, norb[, 2])`, WRITABLE like the reference's view of its storage
+        (pythtb.py:2644-2666: `wf[i,j][0] *= phase` changes the array).  A view of the host mirror when there is
+        one, else -- for a large resident array -- just this point fetched from the device; either way the point
+        is remembered with a snapshot and writes made through the returned array reach the device copy before its
+        next use (_sync_point_writes)."""
         self._check_key(key)
+        self._sync_point_writes()
         if self._device_only() and int(np.prod(self._shape())) * 16 > self._SMALL_MIRROR_BYTES:
             out = np.zeros(self._shape()[self._dim_arr:], dtype=complex)
-            idx = np.array([self._flat_index(key)], dtype=np.int64)
+            fi = self._flat_index(key)
+            idx = np.array([fi], dtype=np.int64)
             _lib.check(_lib.lib.tbk_wfs_download_points(self._dev, idx.ctypes.data_as(C.POINTER(C.c_int64)), 1,
                                                         _lib.dptr(out.view(float))))
-        else:
-            out = self._host_array()[key].view()
-        out.flags.writeable = False
+            self._pt_copies.append((fi, out, out.copy()))
+            if len(self._pt_copies) >= self._PT_TRACK_MAX:
+                self._sync_point_writes()                      # (drops the entries nobody holds any more)
+            return out
+        out = self._host_array()[key]
+        if self._dev_valid and self._dev is not None and not self._host_exported:
+            fi = self._flat_index(key)
+            if fi not in self._pt_views:
+                if len(self._pt_views) >= self._PT_TRACK_MAX:
+                    # too many live points to follow one by one: the whole mirror becomes the live copy, as with `_wfs`
+                    self._host_exported = True
+                    self._pt_views = {}
+                    return out
+                self._pt_views[fi] = np.array(out)
         return out
 
     def __setitem__(self, key, value):
         """pythtb.py:2663-2672.  On a resident array only this point crosses PCIe."""
         self._check_key(key)
+        self._sync_point_writes()
         val = np.array(value, dtype=complex)
         if self._dev_valid and self._dev is not None:
             pt = np.ascontiguousarray(np.broadcast_to(val, self._shape()[self._dim_arr:]))
-            idx = np.array([self._flat_index(key)], dtype=np.int64)
+            fi = self._flat_index(key)
+            idx = np.array([fi], dtype=np.int64)
             _lib.check(_lib.lib.tbk_wfs_upload_points(self._dev, idx.ctypes.data_as(C.POINTER(C.c_int64)), 1,
                                                       _lib.dptr(pt.view(float))))
             if self._host is not None and self._host_valid:
                 self._host[key] = val
+            if fi in self._pt_views:
+                self._pt_views[fi][...] = pt
+            for i, arr, snap in self._pt_copies:               # arrays handed out for this point follow the storage
+                if i == fi:
+                    arr[...] = pt
+                    snap[...] = pt
         else:
             self._host_array()[key] = val
 
@@ -444,6 +550,7 @@ class wf_array(object):
             if self._dim_arr == 1 and len(key) == 1:
                 key = key[0]
         self._check_key(key)
+        self._sync_point_writes()
         if self._dev_valid and self._dev is not None and not (self._host_exported and self._host_valid):
             # (the reference indexes _wfs[key][occ] with NumPy: negative state indices count from the end, whichever copy
             # of the array happens to be current)

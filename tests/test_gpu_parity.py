@@ -519,6 +519,22 @@ def test_config_D_kane_mele_wilson_loop(tb):
         g = load_golden("full_size")
         assert np.max(np.abs(gaps - g["D_min_gaps"])) < 1e-11
         assert_phase_sets_close(wc, g["D_wan_cent"], 1e-8)
+    # the Z2 integer BASELINE configs[3] names: the centres wind an odd number of times over half the zone
+    assert tb.z2_from_wilson_centres(wc) == 1 and tb.z2_from_wilson_centres(wc, half="lower") == 1
+
+
+@pytest.mark.parametrize("phase,z2", [("odd", 1), ("even", 0)])
+def test_kane_mele_z2_index(tb, phase, z2):
+    """Wilson-loop Z2 of both Kane-Mele phases (examples/kane_mele.py:27-34) on the 41 x 41 array of the reference's
+    example, along either direction, from the device's eigenphases."""
+    w = tb.wf_array(hp.kane_mele(tb.tb_model, phase), [41, 41])
+    w.solve_on_grid([-0.5, -0.5])
+    for d in (0, 1):
+        wc = w.berry_phase([0, 1], dir=d, contin=False, berry_evals=True)
+        assert tb.z2_from_wilson_centres(wc) == z2 and tb.z2_from_wilson_centres(wc, half="lower") == z2
+    if phase == "even":
+        g = load_golden("grid_km_even_41")
+        assert tb.z2_from_wilson_centres(w.berry_phase([0, 1], dir=1, contin=False, berry_evals=True)) == 0 and g is not None
 
 
 # ------------------------------------------------------------------ edge cases and plumbing

@@ -222,6 +222,31 @@ def test_wf_array_host_side():
         tb.wf_array(m, [4, 1])
     with pytest.raises(Exception, match="not an integer"):
         tb.wf_array(m, [4, 4], nsta_arr=1.5)
+    # wf[i,j] is a live, writable view like the reference's (pythtb.py:2662-2666)
+    w[1, 2][0] *= 2.0
+    v = w[2, 3]
+    v[1, 0] = 7.0
+    assert w[1, 2][0, 1] == 4 and w._wfs[1, 2, 0, 0] == 2 and w[2, 3][1, 0] == 7 and w._wfs[2, 3, 1, 0] == 7
+
+
+def test_z2_index_from_the_reference_wannier_centres():
+    """Z2 from the `wan_cent` arrays the reference's own kane_mele test holds (tests/test_examples/kane_mele: index 0
+    "even", 1 "odd"; centres in units of 2 pi on 41 strings) and from the full-size configs[3] array captured from
+    the reference: odd -> 1, even -> 0, either half of the zone."""
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "reference_tests", "kane_mele", "kane_mele_wan_cent.npy"))
+    for t, want in ((0, 0), (1, 1)):
+        for half in ("upper", "lower"):
+            assert tb.z2_from_wilson_centres(2 * np.pi * ref[t], half=half) == want
+    full = os.path.join(ROOT, "tests", "golden", "full_size.npz")
+    if os.path.exists(full):
+        assert tb.z2_from_wilson_centres(np.load(full)["D_wan_cent"]) == 1
+    # two decoupled copies of a winding band wind twice: trivial
+    k = np.linspace(-0.5, 0.5, 41)
+    twice = np.stack([2 * np.pi * k + 0.3, 2 * np.pi * k + 0.3 + np.pi], axis=1)
+    once = np.stack([np.where(k >= 0, 2 * np.pi * k, -2 * np.pi * k) + 0.1, -np.where(k >= 0, 2 * np.pi * k, -2 * np.pi * k) - 0.1], axis=1)
+    assert tb.z2_from_wilson_centres(once) == 1
+    with pytest.raises(Exception, match="odd number"):
+        tb.z2_from_wilson_centres(twice[:40])
 
 
 def test_phase_continuity_helpers_match_oracle():
