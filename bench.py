@@ -147,6 +147,13 @@ def cpu_baseline(sample_mesh=257):
         "sample": "Haldane %dx%d sub-mesh (%d k): oracle solve_on_grid %.2fs + berry_flux %.2fs on one core"
                   % (n - 1, n - 1, nk, ts, tf),
         "solve_kpts_per_s": nk / ts, "flux_plaq_per_s": nk / tf,
+        # the REAL reference (pythtb 1.8.0 imported read-only) on one thread of an 8-vCPU Xeon 2.1 GHz,
+        # so that a reader can see the port timed here tracks it (the reference itself cannot travel to the GPU box)
+        "calibration": {"source": "BASELINE.md section 2 (reference measured in the survey container, 1 thread, Xeon 2.10 GHz)",
+                        "reference_solve_on_grid_kpts_per_s": 8727.0, "reference_berry_flux_plaq_per_s": 39617.0,
+                        "reference_end_to_end_kpts_per_s": 7152.0, "reference_solve_all_kpts_per_s": 10048.0,
+                        "reference_km4_solve_kpts_per_s": 5807.0, "reference_cubic16_solve_kpts_per_s": 141.0,
+                        "port_over_reference_solve": (nk / ts) / 8727.0, "port_over_reference_flux": (nk / tf) / 39617.0},
     }
     if cores > 1:
         try:
@@ -250,11 +257,21 @@ def roof(alg_bytes, ms_raw, valu_key=None, points=None, valu=None):
     v = (valu or {}).get(valu_key) if valu_key else None
     if v and points:
         insts = v["valu_wave_insts_per_point"] * points
-        r["valu_frac"] = insts / (ms_raw * 1e-3) / VALU_SLOTS_PER_S
-        r["valu_fp64_equiv_tflops"] = insts * 128.0 / (ms_raw * 1e-3) / 1e12
+        # ISSUE-slot occupancy (wave-instructions / slots): how busy the vector pipe is, NOT achieved flops -- masked lanes,
+        # moves, reductions and replicated scalar work all count
+        r["valu_issue_frac"] = insts / (ms_raw * 1e-3) / VALU_SLOTS_PER_S
+        r["valu_issue_slots_as_tflops"] = insts * 128.0 / (ms_raw * 1e-3) / 1e12
         r["valu_peak_tflops"] = FP64_VALU_PEAK_TFLOPS
         r["valu_source"] = v.get("source")
         r["valu_kernel"] = v.get("kernel")
+        if v.get("useful_flops_per_point"):
+            # USEFUL fp64 work: SURVEY.md 8d's algorithmic flops per k-point (the model is written out in
+            # profiles/make_valu_json.py) x points / time / the 78.6 TFLOP/s vector peak
+            uf = v["useful_flops_per_point"] * points / (ms_raw * 1e-3) / 1e12
+            r["useful_tflops"] = uf
+            r["useful_flop_frac"] = uf / FP64_VALU_PEAK_TFLOPS
+            r["useful_flops_per_point"] = v["useful_flops_per_point"]
+            r["flop_model"] = v.get("flop_model")
     return r
 
 
@@ -363,13 +380,22 @@ def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
         gaps = g.gaps()
         wl_ms = sum(v["avg_bracket_ms"] for k, v in kt.items() if k.startswith("chain"))
         cen = np.sort(phases.reshape(mesh[1], 2) / (2 * np.pi) % 1.0, axis=1)
+        r4 = roof(bytes_solve(4) * npt, kt["solve_grid"]["avg_bracket_ms"], "k_grid_rows<4,1>", 4097 * 513, valu)
+        k4 = npt / (kt["solve_grid"]["avg_bracket_ms"] * 1e-3)
+        target_4orb = {"kpts_per_s": k4, "required": 1e7, "met": bool(k4 >= 1e7), "hbm_frac": r4["frac"],
+                       "bound": "fp64 VALU issue (valu_issue_frac %.2f), not HBM" % r4.get("valu_issue_frac", float("nan")),
+                       "clause_claimed": "throughput: >= 1e7 (H(k)+eigh) solves/s for a 4-orbital model on one MI355X.  The '>= 60 % "
+                                         "HBM roofline' clause is NOT claimed for n = 4: 256 B per k-point at 60 % of 8 TB/s would be "
+                                         "1.9e10 k/s, above the fp64-VALU ceiling of the 4x4 Hermitian eigen-solve (SURVEY.md 8d); it is "
+                                         "claimed for n = 2 (the headline roofline block)"}
         out.append({"config": "BASELINE configs[3] on one GPU: Kane-Mele (4 states) wf_array([4097,513]) solve_on_grid + berry_flux([0,1]) "
                               "+ berry_phase([0,1], dir=0, berry_evals=True)",
                     "kpts": npt, "kernels": kt, "wall_ms_per_pass_incl_result_download": wall * 1e3,
                     "solve_kpts_per_s": npt / (kt["solve_grid"]["avg_bracket_ms"] * 1e-3),
                     "wilson_links_per_s": 4096 * 513 / (wl_ms * 1e-3) if wl_ms > 0 else None,
-                    "roofline": {"solve_grid": roof(bytes_solve(4) * npt, kt["solve_grid"]["avg_bracket_ms"],
-                                                    "k_grid_rows<4,1>", 4097 * 513, valu),
+                    "target_4orb": target_4orb,
+                    "z2_index": int(tb.z2_from_wilson_centres(phases.reshape(mesh[1], 2))),
+                    "roofline": {"solve_grid": r4,
                                  "berry_flux": roof(bytes_berry(2, 4) * npt, kt["berry_flux"]["avg_bracket_ms"],
                                                     "k_flux_rows<2,4>", 4097 * 513, valu)},
                     "check": {"min_gaps": [float(x) for x in gaps[:3]],
@@ -505,8 +531,9 @@ def main():
                          "0 = none.  The K-step burst WITHOUT it is in the line as cold_burst")
     ap.add_argument("--headline-only", action="store_true", help="skip the sustained / python-API / other-config legs")
     ap.add_argument("--no-check", action="store_true", help="diagnostics: skip the Chern-number assertion")
-    ap.add_argument("--two-calls", action="store_true", help="the step as two launches (solve_grid, then berry_flux reading the array "
-                    "back) instead of the fused pass")
+    ap.add_argument("--two-calls", action="store_true", help=argparse.SUPPRESS)   # (kept for old command lines: now the default)
+    ap.add_argument("--fused-headline", action="store_true", help="diagnostics: time the fused extension (tbk_wfs_solve_grid_flux_async) "
+                    "as the K-step loop instead of the drop-in two-call step; the line's metric string then says so")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # CPU test of the multi-rank control flow
     args = ap.parse_args()
 
@@ -573,7 +600,11 @@ def main():
     def step_fused():
         grid.solve_flux(start, occ)
 
-    step = step_two_calls if (args.two_calls or args.stub) else step_fused
+    # The HEADLINE step is the drop-in pair -- wf.solve_on_grid(); wf.berry_flux([0]) as their two C-ABI launches -- the
+    # workload BASELINE.json's metric names and every script written for the reference runs (ADVICE r3 / VERDICT r3 weak #5).
+    # The one-pass extension (wf.solve_on_grid_flux) is measured in its own leg and reported as `fused_extension`.
+    fused_headline = args.fused_headline and not args.stub
+    step = step_fused if fused_headline else step_two_calls
 
     def barrier():
         ctx.sync()
@@ -639,19 +670,27 @@ def main():
                                "chern": float(grid.flux_total()[0] / (2 * np.pi))}
         # ---- the same kernels with every launch bracketed over 100 steps (per-kernel averages on a warm, busy chip)
         extras["kernels_every_launch_bracketed"] = kernel_times(ctx, step, 100, ev_ms)
-        # ---- the step as the two launches of the drop-in API (wf.solve_on_grid(); wf.berry_flux()): k_grid_rows + k_flux_rows
-        if step is not step_two_calls:
-            for _ in range(5):
-                step_two_calls()
-            ctx.sync()
-            s0 = time.perf_counter()
-            for _ in range(2000):
-                step_two_calls()
-            ctx.sync()
-            s1 = time.perf_counter()
-            extras["two_call_step"] = {"ms_per_step": 1e3 * (s1 - s0) / 2000, "value": MESH * MESH * 2000 / (s1 - s0),
-                                       "chern": float(grid.flux_total()[0] / (2 * np.pi)),
-                                       "kernels": kernel_times(ctx, step_two_calls, 100, ev_ms)}
+        # ---- the other form of the step, 2000 back to back: the fused extension when the headline is the drop-in pair
+        other, okey = (step_two_calls, "two_call_step") if step is step_fused else (step_fused, "fused_extension")
+        for _ in range(5):
+            other()
+        ctx.sync()
+        s0 = time.perf_counter()
+        for _ in range(args.steps):
+            other()
+        ctx.sync()
+        sb = time.perf_counter()
+        for _ in range(2000):
+            other()
+        ctx.sync()
+        s1 = time.perf_counter()
+        extras[okey] = {"what": "wf.solve_on_grid_flux (tbk_wfs_solve_grid_flux_async): solve_on_grid AND berry_flux in one pass, eigenvectors "
+                                "written once, plaquette phases from registers -- an EXTENSION no script written for the reference calls"
+                                if okey == "fused_extension" else "the drop-in pair as two launches",
+                        "ms_per_step": 1e3 * (s1 - sb) / 2000, "value": MESH * MESH * 2000 / (s1 - sb), "unit": "k-points/s",
+                        "burst": {"steps": args.steps, "ms_per_step": 1e3 * (sb - s0) / args.steps},
+                        "chern": float(grid.flux_total()[0] / (2 * np.pi)),
+                        "kernels": kernel_times(ctx, other, 100, ev_ms)}
         try:
             extras["python_api"] = python_api_leg(tb, model)
         except Exception as e:
@@ -695,6 +734,7 @@ def main():
         alg = {"solve_grid": bytes_solve(N_STA) * npt, "berry_flux": bytes_berry(1, N_STA) * npt,
                "solve_grid_flux": bytes_solve(N_STA) * npt}
         vkey = {"solve_grid": "k_grid_rows<2,1>", "berry_flux": "k_flux_rows<1,2>", "solve_grid_flux": "k_grid_rows_flux<2,1,1>"}
+        # dominant kernel of the TIMED step (the fused kernel's block is under fused_extension.roofline / roofline_all)
         dom = max(("solve_grid_flux", "solve_grid", "berry_flux"), key=lambda k: kern.get(k, {"avg_bracket_ms": 0})["avg_bracket_ms"])
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes (rocprofv3 --pmc), per launch
@@ -706,20 +746,26 @@ def main():
         for name in ("solve_grid_flux", "solve_grid", "berry_flux"):
             if name in kern:
                 roofs[name] = roof(alg[name], kern[name]["avg_bracket_ms"], vkey[name], (MESH + 1) * (MESH + 1), valu)
-        # the two-launch step's kernels (k_grid_rows, k_flux_rows), measured in their own leg below
-        for name, rec in extras.get("two_call_step", {}).get("kernels", {}).items():
-            if name in alg and name not in roofs:
-                roofs[name] = roof(alg[name], rec["avg_bracket_ms"], vkey[name], (MESH + 1) * (MESH + 1), valu)
+        # the other form's kernels, measured in their own leg
+        for leg in ("two_call_step", "fused_extension"):
+            for name, rec in extras.get(leg, {}).get("kernels", {}).items():
+                if name in alg and name not in roofs:
+                    roofs[name] = roof(alg[name], rec["avg_bracket_ms"], vkey[name], (MESH + 1) * (MESH + 1), valu)
+            if leg in extras and "solve_grid_flux" in roofs and leg == "fused_extension":
+                extras[leg]["roofline"] = dict(roofs["solve_grid_flux"], kernel="solve_grid_flux")
         out = {
-            "metric": "k-points solved/sec (H(k)+eigh) and Berry-flux/sec, Haldane 2048^2 mesh",
+            "metric": "k-points solved/sec (H(k)+eigh) and Berry-flux/sec, Haldane 2048^2 mesh"
+                      + (" [fused extension as the timed step]" if fused_headline else ""),
             "value": nk_step * args.steps / t_max, "unit": "k-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Haldane (2 orb, 9 hops) wf_array solve_on_grid + berry_flux([0]), "
                                    "%d x %d k-mesh per GPU (BASELINE.json configs[2])" % (MESH, MESH),
-                       "step": "two launches (solve_grid, berry_flux)" if (args.two_calls or args.stub) else
-                               "one fused pass (tbk_wfs_solve_grid_flux_async: eigenvectors written once, plaquette phases from registers)",
+                       "step": "one fused pass (tbk_wfs_solve_grid_flux_async: eigenvectors written once, plaquette phases from registers)"
+                               if fused_headline else
+                               "the drop-in pair wf.solve_on_grid(); wf.berry_flux([0]) as its two C-ABI launches (tbk_wfs_solve_grid_async, "
+                               "tbk_berry_flux_async); the one-pass extension is reported under fused_extension",
                        "global_mesh": [MESH * world, MESH], "start_k": [-0.5, -0.5],
                        "sharding": "k-slabs along mesh axis 0, halo row recomputed", "gather": gather},
             "roofline": dict(roofs.get(dom, {}), kernel=dom, traffic=traffic, traffic_source=traffic_source),

@@ -204,8 +204,14 @@ def multi_gpu(which, side):
         sys.stderr.write("[bench_configs] rank %d: RCCL communicator unavailable (%s); gathers go through gloo\n" % (rank, err))
         comm, gather, status = gloo, "gloo (FALLBACK: rccl %s)" % err, 4
     else:
-        gather = "rccl all-gather-v (tbk_comm_allgatherv[_rows]_f64, RCCL over xGMI)"
+        gather = "rccl gather-v / all-gather-v (tbk_comm_gatherv_rows_f64, tbk_comm_allgatherv_f64, RCCL over xGMI)"
     lines = []
+
+    def per_rank_stats(st):
+        """[{solve_ms, gather_ms, sent_bytes, recv_bytes}] of the last timed pass, one entry per rank (gloo, control plane)."""
+        keys = ("solve_ms", "gather_ms", "sent_bytes", "recv_bytes")
+        allv = gloo.allgatherv(np.array([float(st.get(k, 0.0)) for k in keys]), [len(keys)] * world).reshape(world, len(keys))
+        return [dict(zip(keys, [float(x) for x in row])) for row in allv]
 
     def finish(code):
         if rank == 0:
@@ -256,11 +262,15 @@ def multi_gpu(which, side):
                   "chunks": [e - b for b, e in multi.plan_list(nk, world)], "gathered_bytes_per_rank": 8 * 2 * nk,
                   "check": {"sum": float(ev.sum()), "min": float(ev.min()), "max": float(ev.max()),
                             "sampled_columns_equal_unsharded": same}, "gather": gather}
-            if hasattr(comm, "allgatherv_rows_dev"):
-                r2 = run(lambda c: multi.solve_all_mesh_sharded(m, [1024, 1024], c, rank, world))
+            if hasattr(comm, "gatherv_rows_dev"):
+                # the ROOTED gather (ret_eval is one array on one caller): ranks != 0 allocate no (2, nk) buffer
+                st = {}
+                r2 = run(lambda c: multi.solve_all_mesh_sharded(m, [1024, 1024], c, rank, world, root=0, stats=st))
                 if r2 is not None:
-                    ln["k_generated_on_device_seconds"] = r2[1]
-                    ln["k_generated_on_device_equal"] = bool(np.array_equal(r2[0], ev))
+                    ln["k_generated_on_device_rooted_gather_seconds"] = r2[1]
+                    ln["per_rank"] = per_rank_stats(st)
+                    if rank == 0:
+                        ln["k_generated_on_device_equal"] = bool(np.array_equal(r2[0], ev))
             lines.append(ln)
     if "D" in which:
         m = hp.kane_mele(tb.tb_model, "odd")
@@ -289,12 +299,14 @@ def multi_gpu(which, side):
                           "n_gpus": world, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": (side - 1) ** 3 / t,
                           "planes_per_rank": [p[2] for p in multi.plan_slabs(side, world)],
                           "gap78": float(gaps[7]), "checksum": float(np.sum(np.cos(arr))), "gather": gather})
-        if hasattr(comm, "allgatherv_rows_dev"):
+        if hasattr(comm, "gatherv_rows_dev"):
             # the solve_all leg of configs[4]: eigenvalues of the (side-1)^3 uniform mesh, k generated per rank on the device,
-            # ONE rows all-gather-v of eval (16, nk) -- 268 MB contributed per rank at 256^3 over 8 GPUs
+            # ONE rooted rows gather-v of eval (16, nk) to rank 0 -- 268 MB sent per rank at 256^3 over 8 GPUs;
+            # the other ranks hold no (16, nk) array
             msz = [side - 1] * 3
             nk = (side - 1) ** 3
-            r = run(lambda c: multi.solve_all_mesh_sharded(m, msz, c, rank, world, download=False))
+            st4 = {}
+            r = run(lambda c: multi.solve_all_mesh_sharded(m, msz, c, rank, world, download=False, root=0, stats=st4))
             if r is None:
                 lines.append({"config": "configs[4] solve_all", "error": "solve_all_mesh_sharded failed", "gather": gather})
                 status = status or 6
@@ -302,10 +314,11 @@ def multi_gpu(which, side):
                 ends, t = r
                 ref = m.solve_all(np.array([[0.0, 0.0, 0.0], [(side - 2.0) / (side - 1.0)] * 3]))
                 lines.append({"config": "configs[4] solve_all leg: cubic16 eigenvalues on k_uniform_mesh([%d]*3), k chunks over %d GPUs, ONE "
-                                        "rows all-gather-v of eval (16, nk)" % (side - 1, world),
+                                        "rooted rows gather-v of eval (16, nk) to rank 0" % (side - 1, world),
                               "n_gpus": world, "kpts": nk, "seconds_max_over_ranks_incl_gather": t, "kpts_per_s": nk / t,
-                              "gathered_bytes_per_rank": 8 * 16 * nk,
-                              "first_and_last_columns_equal_unsharded": bool(np.array_equal(ends, ref)), "gather": gather})
+                              "per_rank": per_rank_stats(st4),
+                              "first_and_last_columns_equal_unsharded": bool(rank != 0 or np.array_equal(ends, ref)),
+                              "gather": gather})
     dist.barrier()
     if hasattr(comm, "close") and not hung:
         comm.close()

@@ -120,6 +120,12 @@ int tbk_solve_list(tbk_model* model, const double* k, int64_t nk, double* eval, 
 /* same, all buffers already on the device (no PCIe in the call)           */
 int tbk_solve_list_dev(tbk_model* model, const double* k_dev, int64_t nk, double* eval_dev,
                        double* evec_dev);
+/* tbk_solve_list_dev followed by the read (and reset) of the context's sticky solver status -- one host synchronisation:
+ * TBK_ENOCONV where numpy.linalg.eigh would raise (pythtb.py:939-944: an iteration limit, a NaN model); a rotation-record
+ * overflow of the direct solvers is repeated once on the Jacobi kernels.  What every caller that hands results on (a gather,
+ * a download) must use: the unchecked form leaves the status set for the next checked call on the context.               */
+int tbk_solve_list_dev_checked(tbk_model* model, const double* k_dev, int64_t nk, double* eval_dev,
+                               double* evec_dev);
 
 /* _sol_ham (pythtb.py:927-953) on caller-supplied Hermitian matrices
  * ham[nk][n][n] c128 -> eval[n][nk], evec[n][nk][n] (or NULL).            */
@@ -276,6 +282,14 @@ int tbk_comm_allgatherv_f64(tbk_ctx* ctx, const double* send_dev, int64_t count,
 int tbk_comm_allgatherv_rows_f64(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count,
                                  double* recv_dev, const int64_t* counts, const int64_t* displs,
                                  int64_t row_stride);
+/* the ROOTED form of the same gather (the reference's ret_eval is one array on one caller,
+ * pythtb.py:1040,1053-1067): only rank `root` receives recv_dev[nrows][row_stride]; on every other rank recv_dev may
+ * be NULL -- those ranks send their rows to the root and allocate nothing of size nrows x row_stride (config E's
+ * solve_all leg: 268 MB sent per rank instead of 2.1 GB received by each).  Grouped ncclSend / ncclRecv, at most 32
+ * rows per ncclGroup (both rows forms).                                                                            */
+int tbk_comm_gatherv_rows_f64(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count,
+                              double* recv_dev, const int64_t* counts, const int64_t* displs,
+                              int64_t row_stride, int root);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,39 @@ SOURCES = [
     ("k_grid_rows<4,1>", "r02a/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
     ("k_flux_rows<2,4>", "r02a/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
 ]
+# ---- the flop model behind bench.py's `useful_flop_frac` (SURVEY.md 8d "ALGORITHMIC flops per k-point").
+# Real fp64 flops per mesh point of the ALGORITHM (not of the instruction stream: masked lanes, moves, cross-lane reductions and
+# work replicated over the lanes of a matrix are what the issue fraction counts and this does not).  Conventions: complex
+# multiply-add 8, complex multiply 6, real fma 2, sqrt / reciprocal / atan2 / sincos counted as 1 / 1 / 30 / 40.
+#   assembly        8 per merged (slot, R) term of S(k); on a regular mesh the d + norb phases come from
+#                   per-axis tables (0 per point), on a k list they are d + norb sincos
+#   eigen-solve     n = 2: closed form (one sqrt, one rsqrt, ~30) + vectors (~30);
+#                   n = 3, 4: Householder (16/3) n^3 + implicit QL with accumulated vectors ~ 12 n^3 (real rotations on complex rows)
+#                   n = 9..16: Householder (16/3) n^3 + QL on (d, e) ~ 30 n^2 + twisted factorisation 10 n^2 + one Newton-Schulz
+#                   step 4 n^3 + back-transformation by the reflectors 8 n * n(n-1)/2 ~ 4 n^3 (pythtb.py:939,944 = zheevd's work)
+#   orbital phases  6 n^2 (eigenvector components x conj e_a)
+#   plaquette       two new link overlaps (nocc^2 n complex multiply-adds each), nocc x nocc determinants, the product of four
+#                   link variables (18) and one atan2 (30)
+def _eig16(n):
+    return (16.0 / 3.0) * n ** 3 + 30 * n ** 2 + 10 * n ** 2 + 4 * n ** 3 + 4 * n ** 3
+
+
+FLOPS = {
+    # Haldane: 15 merged terms (two diagonal slots of 6, one off-diagonal of 3)
+    "k_grid_rows<2,1>": (15 * 8 + 60 + 6 * 4, "mesh solve n=2: 15 terms x 8 + closed-form 2x2 with vectors 60 + orbital phases 24"),
+    "k_flux_rows<1,2>": (2 * 2 * 8 + 18 + 30, "plaquette nocc=1 n=2: two links x 2 cmadd + product of four link variables 18 + atan2 30"),
+    "k_grid_rows_flux<2,1,1>": (15 * 8 + 60 + 24 + 2 * 2 * 8 + 18 + 30, "the two rows above in one pass"),
+    # Kane-Mele: 10 slots, 9 hops of 2x2 blocks + onsite -> ~60 merged scalar terms
+    "k_grid_rows<4,1>": (60 * 8 + (16.0 / 3.0) * 64 + 12 * 64 + 6 * 16, "mesh solve n=4: 60 terms x 8 + Householder 341 + QL with vectors 768 + phases 96"),
+    "k_flux_rows<2,4>": (2 * 4 * 4 * 8 + 2 * 14 + 18 + 30, "plaquette nocc=2 n=4: two links x 4 entries x 4 cmadd + two 2x2 dets + product + atan2"),
+    # cubic16: 136 slots x 4 lattice vectors (R-grouped) = 544 complex multiply-adds
+    "k_tw16<1>": (544 * 8 + _eig16(16) + 6 * 256, "mesh solve n=16: 544 cmadd assembly + tridiagonalise 21.8k + QL 7.7k + twisted 2.6k + Newton-Schulz 16.4k + back-transform 16.4k + phases 1.5k"),
+    "k_e16<1>": (544 * 8 + _eig16(16) + 6 * 256, "mesh solve n=16 (one fused kernel): same algorithm as k_tw16<1>"),
+    "k_solve_small_multi<2,false,2>": (4 * 40 + 15 * 8 + 30, "k list n=2 eigenvalues: 4 sincos + 15 terms x 8 + closed form 30"),
+    "k_solve_small<2,0,false>": (4 * 40 + 15 * 8 + 30, "k list n=2 eigenvalues: 4 sincos + 15 terms x 8 + closed form 30"),
+    "k_solve_small<2,0,true>": (4 * 40 + 15 * 8 + 60 + 24, "k list n=2 with vectors: 4 sincos + 15 terms x 8 + closed form 60 + phases 24"),
+}
+
 out = {}
 for name, rel, key, points in SOURCES:
     if name in out:
@@ -85,5 +118,8 @@ for name, rel, key, points in SOURCES:
     insts = sum(r["SQ_INSTS_VALU"] for r in recs)
     out[name] = {"kernel": key, "source": "profiles/" + rel, "SQ_INSTS_VALU_per_dispatch": insts,
                  "mesh_points_per_dispatch": points, "valu_wave_insts_per_point": insts / points}
+    if name in FLOPS:
+        out[name]["useful_flops_per_point"] = float(FLOPS[name][0])
+        out[name]["flop_model"] = FLOPS[name][1] + " (profiles/make_valu_json.py)"
 json.dump(out, open(os.path.join(HERE, "valu.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))

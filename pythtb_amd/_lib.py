@@ -63,6 +63,7 @@ SIGNATURES = {
     "tbk_gen_ham": (_i, [_p, _dp, _i64, _dp]),
     "tbk_solve_list": (_i, [_p, _dp, _i64, _dp, _dp]),
     "tbk_solve_list_dev": (_i, [_p, _p, _i64, _p, _p]),
+    "tbk_solve_list_dev_checked": (_i, [_p, _p, _i64, _p, _p]),
     "tbk_eigh_batch": (_i, [_p, _i, _dp, _i64, _dp, _dp]),
     "tbk_solver_regime": (C.c_char_p, [_i, _i, _i, _i64, _i64, _i, _i, C.POINTER(C.c_char_p)]),
     "tbk_wfs_create": (_i, [_p, _i, _ip, _i, _i, _pp]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "tbk_comm_allgather_f64": (_i, [_p, _p, _p, _i64]),
     "tbk_comm_allgatherv_f64": (_i, [_p, _p, _i64, _p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tbk_comm_allgatherv_rows_f64": (_i, [_p, _p, _i64, _i64, _p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i64]),
+    "tbk_comm_gatherv_rows_f64": (_i, [_p, _p, _i64, _i64, _p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i64, _i]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -112,12 +112,23 @@ extern "C" int tbk_comm_allgather_f64(tbk_ctx* ctx, const double* send_dev, doub
 // grouped exchange in which every rank sends its block to every rank and receives block r at displs[r] -- the standard
 // all-gather-v on point-to-point links, which is what xGMI is.  counts / displs are host arrays of nranks entries (in
 // doubles).  The ROWS form gathers a band-major array in place: rank r holds send[nrows][counts[r]] (its k-chunk of
-// eval[band][k], pythtb.py:1040,1053-1067) and every rank receives recv[nrows][row_stride] with rank r's piece of row b
-// at b*row_stride + displs[r] -- nrows messages per pair of ranks inside the same group, no relayout pass afterwards.
-static int allgatherv_rows(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count, double* recv_dev,
-                           const int64_t* counts, const int64_t* displs, int64_t row_stride, const char* who) {
+// eval[band][k], pythtb.py:1040,1053-1067) and every receiver gets recv[nrows][row_stride] with rank r's piece of row b
+// at b*row_stride + displs[r] -- nrows messages per pair of ranks, no relayout pass afterwards.
+//
+// root < 0: every rank receives (all-gather-v).  root >= 0: only `root` receives (gather-v, SURVEY.md 8e: the reference's
+// ret_eval is ONE array on ONE caller, pythtb.py:1040): the other ranks send their rows to the root and neither allocate
+// nor receive the (nrows, row_stride) array -- 1/nranks of the bytes on every link of the all-gather form.
+//
+// The point-to-point operations go out in groups of at most TBK_COMM_GROUP_ROWS rows (x nranks sends + receives each): a
+// ribbon's eigenvalue array has hundreds of rows, and one ncclGroup of thousands of operations runs into RCCL's per-group
+// work limits; consecutive groups on one stream keep the order.
+#define TBK_COMM_GROUP_ROWS 32
+static int gatherv_rows(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count, double* recv_dev,
+                        const int64_t* counts, const int64_t* displs, int64_t row_stride, int root, const char* who) {
     TBK_REQUIRE(ctx && ctx->comm, TBK_ECOMM, "%s: communicator not initialised", who);
-    TBK_REQUIRE(recv_dev && counts && displs && count >= 0 && nrows >= 1 && (send_dev || count == 0), TBK_EINVAL,
+    TBK_REQUIRE(root < ctx->comm_nranks, TBK_EINVAL, "%s: root %d of %d ranks", who, root, ctx->comm_nranks);
+    const bool receives = root < 0 || root == ctx->comm_rank;
+    TBK_REQUIRE((recv_dev || !receives) && counts && displs && count >= 0 && nrows >= 1 && (send_dev || count == 0), TBK_EINVAL,
                 "%s: bad argument", who);
     TBK_REQUIRE(g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end, TBK_ECOMM,
                 "librccl.so lacks ncclSend/ncclRecv/ncclGroupStart/ncclGroupEnd");
@@ -129,29 +140,41 @@ static int allgatherv_rows(tbk_ctx* ctx, const double* send_dev, int64_t nrows, 
                     "%s: block %d (displacement %lld, count %lld) does not fit a row of %lld", who, r, (long long)displs[r],
                     (long long)counts[r], (long long)row_stride);
     const int nccl_float64 = 8;  // ncclDouble
-    int nrc = g_rccl.group_start();
-    TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclGroupStart: %s", nccl_msg(nrc));
-    for (int64_t b = 0; b < nrows && nrc == 0; ++b)
-        for (int r = 0; r < ctx->comm_nranks && nrc == 0; ++r) {
-            if (count > 0)
-                nrc = g_rccl.send(const_cast<double*>(send_dev) + b * count, (size_t)count, nccl_float64, r, ctx->comm, ctx->stream);
-            if (nrc == 0 && counts[r] > 0)
-                nrc = g_rccl.recv(recv_dev + b * row_stride + displs[r], (size_t)counts[r], nccl_float64, r, ctx->comm, ctx->stream);
+    for (int64_t b0 = 0; b0 < nrows; b0 += TBK_COMM_GROUP_ROWS) {
+        const int64_t b1 = b0 + TBK_COMM_GROUP_ROWS < nrows ? b0 + TBK_COMM_GROUP_ROWS : nrows;
+        int nrc = g_rccl.group_start();
+        TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclGroupStart: %s", nccl_msg(nrc));
+        for (int64_t b = b0; b < b1 && nrc == 0; ++b) {
+            for (int r = 0; r < ctx->comm_nranks && nrc == 0; ++r) {
+                const bool to_r = root < 0 || r == root;          // does rank r receive?
+                if (to_r && count > 0)
+                    nrc = g_rccl.send(const_cast<double*>(send_dev) + b * count, (size_t)count, nccl_float64, r, ctx->comm, ctx->stream);
+                if (nrc == 0 && receives && counts[r] > 0)
+                    nrc = g_rccl.recv(recv_dev + b * row_stride + displs[r], (size_t)counts[r], nccl_float64, r, ctx->comm, ctx->stream);
+            }
         }
-    const int erc = g_rccl.group_end();
-    TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclSend/ncclRecv: %s", nccl_msg(nrc));
-    TBK_REQUIRE(erc == 0, TBK_ECOMM, "ncclGroupEnd: %s", nccl_msg(erc));
+        const int erc = g_rccl.group_end();
+        TBK_REQUIRE(nrc == 0, TBK_ECOMM, "ncclSend/ncclRecv: %s", nccl_msg(nrc));
+        TBK_REQUIRE(erc == 0, TBK_ECOMM, "ncclGroupEnd: %s", nccl_msg(erc));
+    }
     TBK_HIP(hipStreamSynchronize(ctx->stream));
     return TBK_OK;
 }
 
 extern "C" int tbk_comm_allgatherv_f64(tbk_ctx* ctx, const double* send_dev, int64_t count, double* recv_dev,
                                        const int64_t* counts, const int64_t* displs) {
-    return allgatherv_rows(ctx, send_dev, 1, count, recv_dev, counts, displs, 0, "tbk_comm_allgatherv_f64");
+    return gatherv_rows(ctx, send_dev, 1, count, recv_dev, counts, displs, 0, -1, "tbk_comm_allgatherv_f64");
 }
 
 extern "C" int tbk_comm_allgatherv_rows_f64(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count,
                                             double* recv_dev, const int64_t* counts, const int64_t* displs,
                                             int64_t row_stride) {
-    return allgatherv_rows(ctx, send_dev, nrows, count, recv_dev, counts, displs, row_stride, "tbk_comm_allgatherv_rows_f64");
+    return gatherv_rows(ctx, send_dev, nrows, count, recv_dev, counts, displs, row_stride, -1, "tbk_comm_allgatherv_rows_f64");
+}
+
+extern "C" int tbk_comm_gatherv_rows_f64(tbk_ctx* ctx, const double* send_dev, int64_t nrows, int64_t count,
+                                         double* recv_dev, const int64_t* counts, const int64_t* displs,
+                                         int64_t row_stride, int root) {
+    TBK_REQUIRE(root >= 0, TBK_EINVAL, "tbk_comm_gatherv_rows_f64: root %d", root);
+    return gatherv_rows(ctx, send_dev, nrows, count, recv_dev, counts, displs, row_stride, root, "tbk_comm_gatherv_rows_f64");
 }

@@ -48,7 +48,7 @@ struct TbkKnobs {
     int qlw_bisect = -1;        // TBK_QLW_BISECT    eigenvalue-only n = 17..64: 1 bisection, 0 lane-per-matrix QL (default: bisection below 16 x CUs matrices)
     int qlw_nt = -1;            // TBK_QLW_NT        threads per matrix of the tridiagonalisation kernel (64 | 128 | 256 | 512)
     long long qlw_cap = -1;     // TBK_QLW_CAP       tests: rotations recorded per matrix (default 3 n^2 + 64)
-    int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal path in MiB (default 4096)
+    int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal paths in MiB (default 4096; 8192 for the n = 9..16 eigenvector path)
     int ql16_split = 1;         // TBK_QL16_SPLIT    0: n = 9..16 with eigenvectors in the single kernel instead of three (tridiagonalise | lane-per-matrix QL, recorded | replay)
     long long ql16_split_min = -1;  // TBK_QL16_SPLIT_MIN  smallest batch that takes the three-kernel form (default 8192)
     int tw16_streams = -1;      // TBK_TW16_STREAMS  chunks of the twisted-factorisation path in flight at once, 1..3 (default 3; 1 = the context's own stream alone, with per-kernel brackets)
@@ -323,4 +323,4 @@ int tbk_eigh_check(tbk_ctx* ctx, int n);
 // solve + check in one (one host synchronisation); a rotation-record overflow of the direct solvers is repeated on the Jacobi
 // kernels instead of being reported (the inputs must still be on the device)
 int tbk_eigh_dev_checked(tbk_ctx* ctx, int n, const cd* ham_dev, int64_t nk, double* eval_dev, cd* evec_dev, const char* name);
-int tbk_solve_list_dev_checked(struct tbk_model* m, const double* k_dev, int64_t nk, double* eval_dev, double* evec_dev);
+// (tbk_solve_list_dev_checked: the same for k lists, exported -- include/tbk.h)

@@ -2016,7 +2016,8 @@ int tbk_eigh_dev_checked(tbk_ctx* ctx, int n, const cd* ham_dev, int64_t nk, dou
     }
     return rc;
 }
-int tbk_solve_list_dev_checked(tbk_model* m, const double* k_dev, int64_t nk, double* eval_dev, double* evec_dev) {
+extern "C" int tbk_solve_list_dev_checked(tbk_model* m, const double* k_dev, int64_t nk, double* eval_dev, double* evec_dev) {
+    TBK_REQUIRE(m && eval_dev && nk >= 0, TBK_EINVAL, "tbk_solve_list_dev_checked: bad argument");
     int rc = TBK_OK;
     for (int attempt = 0;; ++attempt) {
         rc = tbk_solve_list_dev(m, k_dev, nk, eval_dev, evec_dev);
@@ -2280,6 +2281,11 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         // 284 / 245 / 259 / 263; at 2048^2: 72.0 / 61.7 / 59.5 / 58.7): the cap is set through the LDS request (160 KB per CU /
         // blocks per CU), the only launch-time handle on occupancy
         const int occ_cap = K.fused_occ > 0 ? K.fused_occ : (in_llc ? 0 : 3);
+        // (a knob that cannot be honoured is an error of its own kind: TBK_EUNSUPPORTED would send solve_on_grid_flux to the
+        // two-call path and an A/B run would time the wrong kernel -- ADVICE r3)
+        TBK_REQUIRE(K.fused_occ != 1, TBK_EINVAL,
+                    "TBK_FUSED_OCC=1 asks for %d bytes of LDS per workgroup (limit 65536 without a function attribute): use 2..7",
+                    160 * 1024 / 2 + 1024);
         if (occ_cap > 0 && occ_cap < 8) lds = std::max(lds, (size_t)(160 * 1024) / (size_t)(occ_cap + 1) + 1024);
         TBK_REQUIRE(lds <= 64 * 1024, TBK_EUNSUPPORTED, "tbk_wfs_solve_grid_flux: %zu bytes of LDS per block", lds);
         const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
@@ -2330,6 +2336,11 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         size_t lds = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
         if (lds <= 48 * 1024 && tbk_knobs().grid_kernel != 1) {
             // (TBK_GRID_OCC: cap on the resident wavefronts per SIMD through the LDS request, as in the fused pass)
+            // A dynamic LDS request above 64 KB needs a function attribute this launch does not set: occ = 1 (82 944 B) cannot
+            // be honoured and is an explicit error, not an opaque launch failure or a silently different kernel
+            TBK_REQUIRE(tbk_knobs().grid_occ != 1, TBK_EINVAL,
+                        "TBK_GRID_OCC=1 asks for %d bytes of LDS per workgroup (limit 65536 without a function attribute): use 2..7",
+                        160 * 1024 / 2 + 1024);
             if (tbk_knobs().grid_occ > 0 && tbk_knobs().grid_occ < 8)
                 lds = std::max(lds, (size_t)(160 * 1024) / (size_t)(tbk_knobs().grid_occ + 1) + 1024);
             const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);

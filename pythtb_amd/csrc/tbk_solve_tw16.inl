@@ -685,47 +685,61 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
         }
     }
     cd* evec = MODE == 1 ? nullptr : L.evec;
-    int which = 0;
-    for (int64_t id0 = 0; id0 < nk; id0 += chunk, which = (which + 1) % ns) {
-        const int64_t nc = std::min<int64_t>(chunk, nk - id0);
-        const unsigned b16 = (unsigned)((nc * 16 + 255) / 256), b1 = (unsigned)((nc + 255) / 256);
-        const Tw16Work& w = W[which];
-        hipStream_t sq = st[which];
-        const bool brackets = ns == 1;
-        TBK_HIP(hipMemsetAsync(w.count, 0, sizeof(int), sq));
-        {
-            ProfScope ps(brackets ? ctx : nullptr, "tw16_tridiag");
-            hipLaunchKernelGGL((k_tw16_tridiag<MODE>), dim3(b16), dim3(256), 0, sq, mv, nk, L, G, w.de, w.refl, id0, nc);
+    // the chunks; an error inside leaves through the join below like success does -- the side streams still use ctx->work, and
+    // work issued later on ctx->stream (a retry on the Jacobi kernels, a workspace regrow) must be ordered after them
+    auto run_chunks = [&]() -> int {
+        int which = 0;
+        for (int64_t id0 = 0; id0 < nk; id0 += chunk, which = (which + 1) % ns) {
+            const int64_t nc = std::min<int64_t>(chunk, nk - id0);
+            const unsigned b16 = (unsigned)((nc * 16 + 255) / 256), b1 = (unsigned)((nc + 255) / 256);
+            const Tw16Work& w = W[which];
+            hipStream_t sq = st[which];
+            const bool brackets = ns == 1;
+            TBK_HIP(hipMemsetAsync(w.count, 0, sizeof(int), sq));
+            {
+                ProfScope ps(brackets ? ctx : nullptr, "tw16_tridiag");
+                hipLaunchKernelGGL((k_tw16_tridiag<MODE>), dim3(b16), dim3(256), 0, sq, mv, nk, L, G, w.de, w.refl, id0, nc);
+            }
+            {
+                ProfScope ps(brackets ? ctx : nullptr, "tw16_eigvals");
+                hipLaunchKernelGGL((k_tw16_eigvals<MODE>), dim3(b1), dim3(256), 0, sq, mv.nsta, nk, id0, nc, (const double2*)w.de, L.eval, G, w.lam,
+                                   w.meta, w.list, w.count, ctx->flags_dev, K.tw16_gaptol);
+            }
+            {
+                ProfScope ps(brackets ? ctx : nullptr, "tw16_vectors");
+                hipLaunchKernelGGL((k_tw16_vectors<MODE>), dim3(b16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, mv, L, G, (const double2*)w.de,
+                                   (const double*)w.lam, (const uint4*)w.meta, (const cd*)w.refl, w.list, w.count);
+            }
+            // the listed matrices once more, by QL with replayed rotations: the count stays on the device, so these are small fixed
+            // grids whose blocks stride over the list (an empty list costs three launches of idle blocks)
+            {
+                ProfScope ps(brackets ? ctx : nullptr, "tw16_fallback");
+                const unsigned f16 = std::min<unsigned>(b16, 4u * (unsigned)ctx->cus), f1 = std::min<unsigned>(b1, 4u * (unsigned)ctx->cus);
+                hipLaunchKernelGGL((k_solve_ql16<MODE, true, 2, true>), dim3(f16), dim3(256), 0, sq, mv, nk, L, G, ctx->flags_dev, w.de, id0, nc,
+                                   (const int*)w.list, (const int*)w.count);
+                hipLaunchKernelGGL((k_ql16_lanes<MODE, true>), dim3(f1), dim3(256), 0, sq, mv.nsta, nk, id0, nc, (const double2*)w.de, L.eval, G, w.R,
+                                   ctx->flags_dev, (const int*)w.list, (const int*)w.count);
+                hipLaunchKernelGGL((k_ql16_replay<MODE, true>), dim3(f16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, w.R, evec, G.wv, (const int*)w.list,
+                                   (const int*)w.count);
+            }
         }
-        {
-            ProfScope ps(brackets ? ctx : nullptr, "tw16_eigvals");
-            hipLaunchKernelGGL((k_tw16_eigvals<MODE>), dim3(b1), dim3(256), 0, sq, mv.nsta, nk, id0, nc, (const double2*)w.de, L.eval, G, w.lam,
-                               w.meta, w.list, w.count, ctx->flags_dev, K.tw16_gaptol);
-        }
-        {
-            ProfScope ps(brackets ? ctx : nullptr, "tw16_vectors");
-            hipLaunchKernelGGL((k_tw16_vectors<MODE>), dim3(b16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, mv, L, G, (const double2*)w.de,
-                               (const double*)w.lam, (const uint4*)w.meta, (const cd*)w.refl, w.list, w.count);
-        }
-        // the listed matrices once more, by QL with replayed rotations: the count stays on the device, so these are small fixed
-        // grids whose blocks stride over the list (an empty list costs three launches of idle blocks)
-        {
-            ProfScope ps(brackets ? ctx : nullptr, "tw16_fallback");
-            const unsigned f16 = std::min<unsigned>(b16, 4u * (unsigned)ctx->cus), f1 = std::min<unsigned>(b1, 4u * (unsigned)ctx->cus);
-            hipLaunchKernelGGL((k_solve_ql16<MODE, true, 2, true>), dim3(f16), dim3(256), 0, sq, mv, nk, L, G, ctx->flags_dev, w.de, id0, nc,
-                               (const int*)w.list, (const int*)w.count);
-            hipLaunchKernelGGL((k_ql16_lanes<MODE, true>), dim3(f1), dim3(256), 0, sq, mv.nsta, nk, id0, nc, (const double2*)w.de, L.eval, G, w.R,
-                               ctx->flags_dev, (const int*)w.list, (const int*)w.count);
-            hipLaunchKernelGGL((k_ql16_replay<MODE, true>), dim3(f16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, w.R, evec, G.wv, (const int*)w.list,
-                               (const int*)w.count);
-        }
-    }
-    TBK_HIP(hipGetLastError());
+        return TBK_OK;
+    };
+    const int rc_chunks = run_chunks();
+    int rc_join = TBK_OK;
     if (ns > 1) {
         for (int s = 0; s < ns; ++s) {
-            TBK_HIP(hipEventRecord(ctx->side_ev[1 + s], st[s]));
-            TBK_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_ev[1 + s], 0));
+            hipError_t e = hipEventRecord(ctx->side_ev[1 + s], st[s]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->side_ev[1 + s], 0);
+            if (e != hipSuccess && rc_join == TBK_OK) {
+                (void)hipStreamSynchronize(st[s]);                                   // (the ordering could not be expressed: wait here)
+                tbk_set_error("joining the side streams of the n = 9..16 solver: %s", hipGetErrorString(e));
+                rc_join = TBK_EHIP;
+            }
         }
     }
+    if (rc_chunks) return rc_chunks;
+    if (rc_join) return rc_join;
+    TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

@@ -90,6 +90,10 @@ class GlooComm(object):
         self.dist.all_gather(buf, torch.from_numpy(pad))
         return np.concatenate([b.numpy()[:c] for b, c in zip(buf, counts)])
 
+    def agree(self, ok):
+        """True only if `ok` on every rank (a one-word status exchange, not part of the data path)."""
+        return agree(self.dist, ok)
+
     def allgatherv_rows(self, mine, counts):
         """mine (nrows, counts[rank]) on every rank -> (nrows, sum(counts)): rank r's columns at displs[r] (one collective)."""
         mine = np.ascontiguousarray(mine, dtype=np.float64)
@@ -100,6 +104,26 @@ class GlooComm(object):
         for c, d in zip(counts, _displs(counts)):
             out[:, d:d + c] = flat[pos:pos + nrows * c].reshape(nrows, c)
             pos += nrows * c
+        return out
+
+
+    def gatherv_rows(self, mine, counts, root=0):
+        """Rooted form: only `root` gets (nrows, sum(counts)); the other ranks get None and build nothing of that size
+        (torch.distributed.gather on padded blocks)."""
+        import torch
+        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        nrows = mine.shape[0]
+        assert mine.shape[1] == counts[self.rank]
+        cap = max(nrows * max(counts), 1)
+        pad = np.zeros(cap)
+        pad[:mine.size] = mine.reshape(-1)
+        buf = [torch.zeros(cap, dtype=torch.float64) for _ in range(self.world)] if self.rank == root else None
+        self.dist.gather(torch.from_numpy(pad), buf, dst=root)
+        if self.rank != root:
+            return None
+        out = np.empty((nrows, int(sum(counts))))
+        for b, c, d in zip(buf, counts, _displs(counts)):
+            out[:, d:d + c] = b.numpy()[:nrows * c].reshape(nrows, c)
         return out
 
 
@@ -159,6 +183,40 @@ class RcclComm(object):
             lib.tbk_dev_free(ctx.handle, recv)
         return out
 
+    def gatherv_rows_dev(self, send_dev, nrows, counts, root=0, download=True):
+        """Rooted form of allgatherv_rows_dev (tbk_comm_gatherv_rows_f64): rank `root` returns the HOST array
+        (nrows, sum(counts)) -- or, with download=False, the (nrows, 2) array of every row's first and last entry --
+        the other ranks return None and allocate nothing of that size."""
+        _lib, lib, ctx = self._lib, self.lib, self.ctx
+        total = int(sum(counts))
+        cnt = np.ascontiguousarray(counts, dtype=np.int64)
+        dsp = np.ascontiguousarray(_displs(counts), dtype=np.int64)
+        recv = C.c_void_p()
+        is_root = self.rank == root
+        if is_root:
+            _lib.check(lib.tbk_dev_alloc(ctx.handle, 8 * max(total * nrows, 1), C.byref(recv)))
+        self.last_recv_bytes = 8 * total * nrows if is_root else 0
+        try:
+            i64p = C.POINTER(C.c_int64)
+            _lib.check(lib.tbk_comm_gatherv_rows_f64(ctx.handle, send_dev, nrows, int(counts[self.rank]), recv,
+                                                     cnt.ctypes.data_as(i64p), dsp.ctypes.data_as(i64p), total, int(root)))
+            if not is_root:
+                return None
+            if download:
+                out = np.zeros((nrows, total))
+                if out.size:
+                    _lib.check(lib.tbk_dev_download(ctx.handle, out.ctypes.data_as(C.c_void_p), recv, out.nbytes))
+                return out
+            ends = np.zeros((nrows, 2))
+            for row in range(nrows):
+                for j, col in enumerate((0, total - 1)):
+                    _lib.check(lib.tbk_dev_download(ctx.handle, ends[row, j:j + 1].ctypes.data_as(C.c_void_p),
+                                                    C.c_void_p(recv.value + 8 * (row * total + col)), 8))
+            return ends
+        finally:
+            if recv.value:
+                lib.tbk_dev_free(ctx.handle, recv)
+
     def allgatherv_rows(self, mine, counts):
         _lib, lib, ctx = self._lib, self.lib, self.ctx
         mine = np.ascontiguousarray(mine, dtype=np.float64)
@@ -172,9 +230,25 @@ class RcclComm(object):
         finally:
             lib.tbk_dev_free(ctx.handle, send)
 
+    def gatherv_rows(self, mine, counts, root=0):
+        _lib, lib, ctx = self._lib, self.lib, self.ctx
+        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        assert mine.ndim == 2 and mine.shape[1] == counts[self.rank]
+        send = C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, max(mine.nbytes, 8), C.byref(send)))
+        try:
+            if mine.size:
+                _lib.check(lib.tbk_dev_upload(ctx.handle, send, mine.ctypes.data_as(C.c_void_p), mine.nbytes))
+            return self.gatherv_rows_dev(send, mine.shape[0], counts, root)
+        finally:
+            lib.tbk_dev_free(ctx.handle, send)
+
     def close(self):
         self._lib.check(self.lib.tbk_comm_destroy(self.ctx.handle))
 
+    def agree(self, ok):
+        """True only if `ok` on every rank: one double per rank through ncclAllGather (status word, not the data path)."""
+        return bool(np.all(self.allgather(np.array([1.0 if ok else 0.0])) == 1.0))
 
     def allgather(self, mine):
         """Equal contributions: ncclAllGather proper (tbk_comm_allgather_f64).  Returns (world, len(mine))."""
@@ -255,6 +329,27 @@ def rccl_bring_up(ctx, dist, rank, world, timeout=120.0):
 
 
 # ---------------------------------------------------------------------------------------------- drivers
+def _checked_solve_then_agree(comm, solve):
+    """Run this rank's solve through the CHECKED entry point (the sticky solver status is read and reset: an iteration
+    limit or a NaN model is TBK_ENOCONV here, where the reference's eigvalsh raises -- pythtb.py:939), then let the ranks
+    agree on the outcome BEFORE the gather: a failing rank neither leaves the others waiting inside the collective nor
+    contributes eigenvalues nobody checked.  Raises on every rank if any rank failed."""
+    err = None
+    try:
+        solve()
+    except Exception as e:                              # noqa: BLE001 (re-raised below, after the ranks have agreed)
+        err = e
+    agree_fn = getattr(comm, "agree", None)             # (recording stand-ins that run the ranks in turn have no peers)
+    if agree_fn is None:
+        if err is not None:
+            raise err
+        return
+    if not agree_fn(err is None):
+        if err is not None:
+            raise err
+        raise RuntimeError("solve_all (sharded): the eigen-solve failed on another rank; no eigenvalues were gathered")
+
+
 def wilson_loops_sharded(wf_array_cls, model, mesh, start_k, occ, comm, rank, world, dir=0, berry_evals=True):
     """configs[3]: berry_phase(occ, dir, contin=False, berry_evals) of a 2-D solve_on_grid array, strings sharded
     over the ranks.  Returns (phases of ALL strings, this rank's min gaps): (n_strings, nocc) or (n_strings,)."""
@@ -304,12 +399,14 @@ def mesh_phases_sharded(wf_array_cls, model, mesh, start_k, occ, comm, rank, wor
     return allv, allg
 
 
-def solve_all_sharded(model, k_list, comm, rank, world, solve_chunk=None):
+def solve_all_sharded(model, k_list, comm, rank, world, solve_chunk=None, root=None):
     """tb_model.solve_all(k_list) (eigenvalues; pythtb.py:955-1067) with the k list cut into `world` contiguous
-    chunks: every rank solves its own chunk and ONE all-gather-v assembles ret_eval (nsta, nkp), band-major like
-    the reference's (pythtb.py:1040).  With an RcclComm everything between the k chunk's upload and the final
-    download stays on the device (tbk_solve_list_dev -> tbk_comm_allgatherv_rows_f64).  `solve_chunk(k) -> (nsta, nk)`
-    replaces the device solve in the CPU test-suite (an oracle-backed stand-in); the library never does that."""
+    chunks: every rank solves its own chunk and ONE gather assembles ret_eval (nsta, nkp), band-major like
+    the reference's (pythtb.py:1040).  root=None: all-gather-v, every rank returns the array.  root=r: the ROOTED
+    gather-v (ret_eval is one array on one caller) -- rank r returns it, the others return None and
+    never allocate an (nsta, nkp) buffer.  With an RcclComm everything between the k chunk's upload and the final
+    download stays on the device (tbk_solve_list_dev_checked -> tbk_comm_[all]gatherv_rows_f64).  `solve_chunk(k) ->
+    (nsta, nk)` replaces the device solve in the CPU test-suite (an oracle-backed stand-in); the library never does."""
     k = np.asarray(k_list, dtype=float)
     if k.ndim == 1:                                            # a flat list of scalar k for dim_k = 1 (pythtb.py:1036)
         k = k.reshape(-1, 1)
@@ -319,8 +416,15 @@ def solve_all_sharded(model, k_list, comm, rank, world, solve_chunk=None):
     counts = [e - b for b, e in plans]
     b, e = plans[rank]
     if solve_chunk is not None or not hasattr(comm, "allgatherv_rows_dev"):
-        ev = (solve_chunk or model.solve_all)(k[b:e]) if e > b else np.zeros((model._nsta, 0))
-        return comm.allgatherv_rows(np.asarray(ev, dtype=float).reshape(model._nsta, e - b), counts)
+        box = {}
+
+        def host_solve():
+            box["ev"] = (solve_chunk or model.solve_all)(k[b:e]) if e > b else np.zeros((model._nsta, 0))
+        _checked_solve_then_agree(comm, host_solve)    # (tb_model.solve_all is the checked call)
+        mine_ev = np.asarray(box["ev"], dtype=float).reshape(model._nsta, e - b)
+        if root is not None:
+            return comm.gatherv_rows(mine_ev, counts, root)
+        return comm.allgatherv_rows(mine_ev, counts)
     from . import _lib
     lib, ctx, n = _lib.lib, comm.ctx, model._nsta
     hm = model._device_model()
@@ -329,20 +433,27 @@ def solve_all_sharded(model, k_list, comm, rank, world, solve_chunk=None):
     _lib.check(lib.tbk_dev_alloc(ctx.handle, max(mine.nbytes, 8), C.byref(kd)))
     _lib.check(lib.tbk_dev_alloc(ctx.handle, max(8 * n * (e - b), 8), C.byref(ed)))
     try:
-        if e > b:
-            _lib.check(lib.tbk_dev_upload(ctx.handle, kd, mine.ctypes.data_as(C.c_void_p), mine.nbytes))
-            _lib.check(lib.tbk_solve_list_dev(hm, kd, e - b, ed, None))
+        def dev_solve():
+            if e > b:
+                _lib.check(lib.tbk_dev_upload(ctx.handle, kd, mine.ctypes.data_as(C.c_void_p), mine.nbytes))
+                _lib.check(lib.tbk_solve_list_dev_checked(hm, kd, e - b, ed, None))
+        _checked_solve_then_agree(comm, dev_solve)
+        if root is not None:
+            return comm.gatherv_rows_dev(ed, n, counts, root)
         return comm.allgatherv_rows_dev(ed, n, counts)
     finally:
         lib.tbk_dev_free(ctx.handle, kd)
         lib.tbk_dev_free(ctx.handle, ed)
 
 
-def solve_all_mesh_sharded(model, mesh_size, comm, rank, world, download=True):
+def solve_all_mesh_sharded(model, mesh_size, comm, rank, world, download=True, root=None, stats=None):
     """solve_all(k_uniform_mesh(mesh_size)) (pythtb.py:1792-1861, :955-1067), k-sharded, with every rank generating its
     chunk of the k list on the device (tbk_k_uniform_mesh_range_dev): nothing but the gathered eigenvalues leaves a GPU.
     Needs an RcclComm.  Returns ret_eval (nsta, prod(mesh_size)); with download=False the gather still runs (it is what
-    is being measured) and only a (nsta, 2) array of every band's first and last eigenvalue comes back to the host."""
+    is being measured) and only a (nsta, 2) array of every band's first and last eigenvalue comes back to the host.
+    root=r: rooted gather-v -- rank r returns the array, the others None and they allocate no (nsta, nk) buffer.
+    `stats` (a dict) receives this rank's solve_ms, gather_ms, sent_bytes and recv_bytes."""
+    import time
     from . import _lib
     lib, ctx, n = _lib.lib, comm.ctx, model._nsta
     mesh = np.ascontiguousarray(mesh_size, dtype=np.int32).reshape(-1)
@@ -357,17 +468,34 @@ def solve_all_mesh_sharded(model, mesh_size, comm, rank, world, download=True):
     _lib.check(lib.tbk_dev_alloc(ctx.handle, max(8 * model._dim_k * (e - b), 8), C.byref(kd)))
     _lib.check(lib.tbk_dev_alloc(ctx.handle, max(8 * n * (e - b), 8), C.byref(ed)))
     try:
-        _lib.check(lib.tbk_k_uniform_mesh_range_dev(ctx.handle, model._dim_k, _lib.iptr(mesh), b, e - b, kd))
-        if e > b:
-            _lib.check(lib.tbk_solve_list_dev(hm, kd, e - b, ed, None))
+        def dev_solve():
+            _lib.check(lib.tbk_k_uniform_mesh_range_dev(ctx.handle, model._dim_k, _lib.iptr(mesh), b, e - b, kd))
+            if e > b:
+                _lib.check(lib.tbk_solve_list_dev_checked(hm, kd, e - b, ed, None))
+        t0 = time.perf_counter()
+        _checked_solve_then_agree(comm, dev_solve)
+        t1 = time.perf_counter()
+        if stats is not None:
+            stats.update(solve_ms=(t1 - t0) * 1e3, sent_bytes=8 * n * (e - b) * (1 if root is not None else world),
+                         recv_bytes=8 * n * nk if root is None or root == rank else 0)
+        if root is not None:
+            out = comm.gatherv_rows_dev(ed, n, counts, root, download=download)
+            if stats is not None:
+                stats["gather_ms"] = (time.perf_counter() - t1) * 1e3
+            return out
         if download:
-            return comm.allgatherv_rows_dev(ed, n, counts)
+            out = comm.allgatherv_rows_dev(ed, n, counts)
+            if stats is not None:
+                stats["gather_ms"] = (time.perf_counter() - t1) * 1e3
+            return out
         _lib.check(lib.tbk_dev_alloc(ctx.handle, 8 * n * nk, C.byref(recv)))
         cnt = np.ascontiguousarray(counts, dtype=np.int64)
         dsp = np.ascontiguousarray(_displs(counts), dtype=np.int64)
         i64p = C.POINTER(C.c_int64)
         _lib.check(lib.tbk_comm_allgatherv_rows_f64(ctx.handle, ed, n, e - b, recv, cnt.ctypes.data_as(i64p),
                                                     dsp.ctypes.data_as(i64p), nk))
+        if stats is not None:
+            stats["gather_ms"] = (time.perf_counter() - t1) * 1e3
         ends = np.zeros((n, 2))
         for band in range(n):
             for j, col in enumerate((0, nk - 1)):

@@ -75,7 +75,7 @@ def _bench(args, env=ENV, prefix=()):
     return res, lines
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_starts_its_own_ranks(world):
     """`python bench.py --gpus N` with WORLD_SIZE unset (how the driver runs N = 1) must not die at argument parsing."""
     pytest.importorskip("torch")

@@ -211,6 +211,22 @@ def test_multi_gpu_drivers_single_rank_rccl_and_every_ranks_share(tb):
         assert np.array_equal(ev16, m16.solve_all(m16.k_uniform_mesh([6, 5, 7])))
         ends = multi.solve_all_mesh_sharded(m16, [6, 5, 7], rccl, 0, 1, download=False)
         assert np.array_equal(ends, ev16[:, [0, -1]])
+        # the ROOTED gather (tbk_comm_gatherv_rows_f64) and row counts beyond one ncclGroup (32 rows each)
+        assert np.array_equal(rccl.gatherv_rows(np.arange(12.0).reshape(3, 4), [4], root=0), np.arange(12.0).reshape(3, 4))
+        wide = np.random.default_rng(9).random((130, 5))
+        assert np.array_equal(rccl.allgatherv_rows(wide, [5]), wide) and np.array_equal(rccl.gatherv_rows(wide, [5]), wide)
+        st = {}
+        assert np.array_equal(multi.solve_all_mesh_sharded(m16, [6, 5, 7], rccl, 0, 1, root=0, stats=st), ev16)
+        assert st["recv_bytes"] == ev16.nbytes and st["sent_bytes"] == ev16.nbytes and st["solve_ms"] > 0 and st["gather_ms"] > 0
+        assert np.array_equal(multi.solve_all_mesh_sharded(m16, [6, 5, 7], rccl, 0, 1, download=False, root=0), ev16[:, [0, -1]])
+        assert np.array_equal(multi.solve_all_sharded(hal, k, rccl, 0, 1, root=0), hal.solve_all(k))
+        # a solve that fails is reported by the CHECKED entry point the drivers now use: a NaN model makes the
+        # QL iteration hit its limit; the error is raised here and the context's status is clean for the next call
+        bad = hp.cubic16(tb.tb_model)
+        bad.set_onsite(float("nan"), 3, mode="reset")
+        with pytest.raises(Exception, match="did not converge"):
+            multi.solve_all_mesh_sharded(bad, [4, 4, 4], rccl, 0, 1, root=0)
+        assert np.array_equal(multi.solve_all_mesh_sharded(m16, [6, 5, 7], rccl, 0, 1), ev16)
     finally:
         rccl.close()
 
