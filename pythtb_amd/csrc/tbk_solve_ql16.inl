@@ -33,23 +33,7 @@
 // bit-identical by construction.  Matrices smaller than 16 are padded with decoupled zero rows (they
 // never mix and are ranked last).
 
-template <int N>
-__device__ __forceinline__ double row_ror_d(const double v) {   // value of lane (x + N) mod 16 of the same row
-    const I2 i = __builtin_bit_cast(I2, v);
-    const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x120 + N, 0xf, 0xf, true),
-               __builtin_amdgcn_update_dpp(0, i.hi, 0x120 + N, 0xf, 0xf, true)};
-    return __builtin_bit_cast(double, o);
-}
-// sum over the 16 lanes of a row, the same bits in every lane (each step adds a value to its mirror image)
-__device__ __forceinline__ double row_allsum(double v) {
-    v += row_ror_d<8>(v);
-    v += row_ror_d<4>(v);
-    v += row_ror_d<2>(v);
-    v += row_ror_d<1>(v);
-    return v;
-}
-template <int SRC>
-__device__ __forceinline__ cd rowbcast_c(const cd v) { return cd{rowbcast_d<SRC>(v.x), rowbcast_d<SRC>(v.y)}; }
+// (row_ror_d, row_allsum, rowbcast_c: tbk_solve_dev.h)
 
 // ---- Householder step K: pass 1 (p = A u, w = Z u over the columns c > K) and pass 2 (rank-2 updates)
 template <int K, int CIDX, bool VEC>
@@ -161,54 +145,13 @@ __device__ __forceinline__ void ql16_bcast_ev(const double dd, double (&ev)[16])
     if constexpr (J + 1 < 16) ql16_bcast_ev<J + 1>(dd, ev);
 }
 
-#define TBK_QL_MAX_ITER 480   // 30 shifts per eigenvalue, LAPACK's limit
+// (TBK_QL_MAX_ITER, qle_pos, qle_pick: tbk_solve_dev.h)
 
 // ---- eigenvalues only: after the tridiagonalisation nothing is left to do on Z, and the QL recurrence replicated over the
 // 16 lanes of a matrix would be ALL of the remaining work (~5 k wave-instructions per matrix).  So the eigenvalue-only solve
 // is two kernels: k_solve_ql16<.., false, 1> stops after the tridiagonalisation and leaves (d_j, e_j) in a workspace laid out
 // [j][matrix]; k_tridiag_eigvals then gives every LANE one matrix -- static register indices, nothing replicated, coalesced
 // loads and stores -- ~0.4 k wave-instructions per matrix.
-// REC: the rotation of position I goes to rot[I * stride]; lstop = lowest position rotated so far
-template <int I, bool REC = false>
-__device__ __forceinline__ void qle_pos(double (&d)[16], double (&e)[16], double& sn, double& cs, double& pp, double& g, bool& alive,
-                                        const bool live, const int l, const int m, double2* __restrict__ rot = nullptr,
-                                        int* lstop = nullptr, const int64_t stride = 0) {
-    if (live && alive && I >= l && I < m) {
-        const double f = sn * e[I], b = cs * e[I];
-        const double t = f * f + g * g;
-        if (t > 0.0) {
-            const double inv = rsqrt_full(t), r = t * inv;
-            e[I + 1] = I + 1 == m ? 0.0 : r;     // (e_m is zeroed at the end of a sweep)
-            sn = f * inv;
-            cs = g * inv;
-            const double gg = d[I + 1] - pp;
-            const double r2 = (d[I] - gg) * sn + 2.0 * cs * b;
-            pp = sn * r2;
-            d[I + 1] = gg + pp;
-            g = cs * r2 - b;
-            if (I == l) {                        // last position of the sweep
-                d[I] -= pp;
-                e[I] = g;
-            }
-            if constexpr (REC) {
-                rot[(int64_t)I * stride] = double2{cs, sn};
-                *lstop = I;
-            }
-        } else {                                 // r == 0 (underflow): tql2's recovery
-            d[I + 1] -= pp;
-            e[I + 1] = 0.0;                          // (e_{i+1} = r = 0)
-            alive = false;
-        }
-    }
-    if constexpr (I > 0) qle_pos<I - 1, REC>(d, e, sn, cs, pp, g, alive, live, l, m, rot, lstop, stride);
-}
-template <int J>
-__device__ __forceinline__ double qle_pick(const double (&a)[16], const int idx, const double acc) {
-    const double r = idx == J ? a[J] : acc;
-    if constexpr (J + 1 < 16) return qle_pick<J + 1>(a, idx, r);
-    else return r;
-}
-
 // de[j * nk + id] = (d_j, e_j) of matrix id  ->  eval[rank][id], ascending (the n real rows; padding rows rank last)
 __global__ __launch_bounds__(256) void k_tridiag_eigvals(const int n, const int64_t nk, const double2* __restrict__ de,
                                                          double* __restrict__ eval, int* noconv_flag) {

@@ -18,31 +18,7 @@
 // Every point starts cold, so a point's result depends on the point alone (periodic images, halo
 // rows and shard windows are bit-identical by construction).
 
-struct I2 {
-    int lo, hi;
-};
-__device__ __forceinline__ double bperm_d(const int addr, const double v) {
-    const I2 i = __builtin_bit_cast(I2, v);
-    const I2 o{__builtin_amdgcn_ds_bpermute(addr, i.lo), __builtin_amdgcn_ds_bpermute(addr, i.hi)};
-    return __builtin_bit_cast(double, o);
-}
-__device__ __forceinline__ cd bperm_c(const int addr, const cd v) { return cd{bperm_d(addr, v.x), bperm_d(addr, v.y)}; }
-__device__ __forceinline__ double perm_push_d(const int addr, const double v) {   // lane sends v to lane addr/4
-    const I2 i = __builtin_bit_cast(I2, v);
-    const I2 o{__builtin_amdgcn_ds_permute(addr, i.lo), __builtin_amdgcn_ds_permute(addr, i.hi)};
-    return __builtin_bit_cast(double, o);
-}
-template <int SRC>
-__device__ __forceinline__ double rowbcast_d(const double v) {   // value of lane SRC of each 16-lane row
-    const I2 i = __builtin_bit_cast(I2, v);
-    // (bound_ctrl with full row/bank masks: the old value is dead, so the compiler emits ONE v_mov_b32_dpp per dword --
-    // with a live old operand it was a plain v_mov to seed the destination plus the DPP move)
-    const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x150 + SRC, 0xf, 0xf, true),
-               __builtin_amdgcn_update_dpp(0, i.hi, 0x150 + SRC, 0xf, 0xf, true)};
-    return __builtin_bit_cast(double, o);
-}
-template <int SRC>
-__device__ __forceinline__ int rowbcast_i(const int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xf, 0xf, true); }
+// (I2, bperm_*, rowbcast_d / rowbcast_i, sel16: tbk_solve_dev.h)
 
 // round R of the 15-round tournament on 16 players: pair l = 0 is (15, R), pair l = 1..7 is
 // ((R+l) mod 15, (R-l) mod 15)
@@ -51,13 +27,6 @@ struct Pair16 {
     static constexpr int p = L == 0 ? 15 : (R + L) % 15;
     static constexpr int q = L == 0 ? R : (R - L + 15) % 15;
 };
-
-template <int J>
-__device__ __forceinline__ cd sel16(const cd (&a)[16], const int idx, const cd acc) {
-    const cd r = idx == J ? a[J] : acc;
-    if constexpr (J + 1 < 16) return sel16<J + 1>(a, idx, r);
-    else return r;
-}
 
 // column rotations of one round on the registers of a row (A) and of a column of V^T
 template <int R, int L, bool VEC>
