@@ -46,6 +46,7 @@ static void knobs_parse() {
     getl("TBK_QLW_CAP", k.qlw_cap);
     geti("TBK_QL16_EVONLY", k.ql16_evonly);
     geti("TBK_TW16", k.tw16);
+    geti("TBK_E16", k.e16);
     geti("TBK_TW16_STREAMS", k.tw16_streams);
     if (const char* e = getenv("TBK_TW16_GAPTOL")) k.tw16_gaptol = atof(e);
     geti("TBK_QL16_SPLIT", k.ql16_split);

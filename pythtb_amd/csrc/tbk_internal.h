@@ -52,6 +52,7 @@ struct TbkKnobs {
     int ql16_split = 1;         // TBK_QL16_SPLIT    0: n = 9..16 with eigenvectors in the single kernel instead of three (tridiagonalise | lane-per-matrix QL, recorded | replay)
     long long ql16_split_min = -1;  // TBK_QL16_SPLIT_MIN  smallest batch that takes the three-kernel form (default 8192)
     int tw16_streams = -1;      // TBK_TW16_STREAMS  chunks of the twisted-factorisation path in flight at once, 1..3 (default 3; 1 = the context's own stream alone, with per-kernel brackets)
+    int e16 = 1;                // TBK_E16           0: n = 9..16 with eigenvectors through round 3's three kernels (tridiagonalise | QL eigenvalues | twisted vectors) instead of the ONE fused kernel k_e16
     int tw16 = 1;               // TBK_TW16          0: n = 9..16 with eigenvectors through the QL-replay three-kernel form instead of twisted-factorisation vectors
     double tw16_gaptol = 1e-5;  // TBK_TW16_GAPTOL   relative eigenvalue gap (of one unreduced block) below which a matrix is solved again by QL replay
     int ql16_evonly = 1;        // TBK_QL16_EVONLY   0: eigenvalue-only n = 9..16 lists through the single replicated kernel instead of tridiagonalise + lane-per-matrix QL

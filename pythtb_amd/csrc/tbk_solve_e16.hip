@@ -1,0 +1,20 @@
+// tbk_solve_e16.hip -- translation unit of the fused n = 9..16 eigen-solver (k_e16, tbk_solve_e16.inl): H(k) assembly, Householder
+// tridiagonalisation, eigenvalues, eigenvectors and back-transformation of a matrix in ONE wavefront pass with the reflectors kept
+// in LDS (pythtb.py:927-953 `_sol_ham` with eig_vectors, :2499-2511 the mesh loop).  Its own file so that the 100-second compile of
+// tbk_solve.hip is not in the loop of this kernel's development; the dispatch (launch_tw16, tbk_solve_tw16.inl) calls in here.
+#include "tbk_solve_dev.h"
+#include "tbk_solve_e16.inl"
+
+// The matrices [id0, id0 + nc) of a k list (mode 0), a mesh window (1) or supplied matrices (2) on `stream`; the matrices left to
+// the QL-replay kernels come back as list[0 .. *count) (positions relative to id0; *count must be zero on the stream before).
+int tbk_e16_launch(int mode, hipStream_t stream, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G, int64_t id0,
+                   int64_t nc, int* list, int* count, double gaptol) {
+    TBK_REQUIRE(mode >= 0 && mode <= 2 && nc >= 1 && nc < (int64_t)0x7fffffff / 16 && mv.nsta >= 2 && mv.nsta <= 16, TBK_EINVAL,
+                "tbk_e16_launch: mode %d, %lld matrices of %d states", mode, (long long)nc, mv.nsta);
+    const unsigned blocks = (unsigned)((nc * 16 + 255) / 256);
+    if (mode == 0) hipLaunchKernelGGL((k_e16<0>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol);
+    else if (mode == 1) hipLaunchKernelGGL((k_e16<1>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol);
+    else hipLaunchKernelGGL((k_e16<2>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}

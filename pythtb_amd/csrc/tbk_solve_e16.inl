@@ -1,0 +1,793 @@
+// tbk_solve_e16.inl -- n = 9..16 states per k WITH eigenvectors, chip-filling batches (config E: cubic16 on 257^3 points), in
+// ONE kernel with nothing but the eigenvectors leaving the compute unit (round 4).  Included by tbk_solve_e16.hip (the
+// product's translation unit) and by profiles/microbench/e16_bench.hip.
+//
+// The direct solver numpy.linalg.eigh runs for the reference (pythtb.py:939-947) -- Householder tridiagonalisation, eigenvalues
+// of the real tridiagonal T, eigenvectors of T, back-transformation -- on 16 lanes per matrix, four matrices per wavefront, like
+// round 3's three kernels (tbk_solve_tw16.inl), but with the stage that forced the cut redone so that it fits the same lanes:
+//
+//   round 3:  k_tw16_tridiag (16 lanes / matrix)  ->  k_tw16_eigvals (implicit QL, ONE lane per matrix: 64 matrices per
+//             wavefront, a 200 us dependent chain)  ->  k_tw16_vectors (16 lanes / matrix).  The reflectors (2.2 KB per matrix)
+//             and (d, e), the eigenvalues and the ranks went through HBM in between: 9.5 KB of traffic per matrix for 4 KB of
+//             eigenvectors (2.39 x).  QL cannot come into the 16-lane kernels: it is one sequential chain per matrix.
+//   here:     lane j of a matrix computes eigenvalue j itself -- (a) Sturm counts of T - x (LDL^T pivots with IEEE infinities, the
+//             hardware reciprocal estimate: a count is exact for a matrix within 1e-8 |T| of T, which is all isolation needs):
+//             one 16-point multisection shared by the lanes of a matrix, then bisection; (b) Newton's iteration on the
+//             characteristic polynomial of the UNREDUCED BLOCK of T that owns the eigenvalue (three-term recurrence with its
+//             derivative; the bracket kept by the same recurrence's sign changes), quadratic from a bracket that isolates the
+//             root; (c) the Rayleigh-quotient correction the twisted factorisation gives for free.  ~0.5 k wave-instructions per
+//             matrix, what the lane-per-matrix QL cost, with all 64 lanes busy and no second kernel: the reflectors stay in
+//             the wavefront's LDS region from the reflection that makes them to the back-transformation that applies them.
+//
+// HBM traffic: 16 n^2 bytes per matrix written, the model's tables read (L2) -- 1.0 x algorithmic.  No workspace.
+//
+// Matrices this cannot serve -- two eigenvalues of one unreduced block closer than gaptol |T| (the Newton-Schulz step no longer
+// reaches rounding level), a Newton iteration that has not converged, a twisted-factorisation residual that fails -- are put on
+// a list and solved again by the QL-replay kernels of tbk_solve_ql16.inl (LIST mode), exactly as round 3's path did; the
+// decision depends on the matrix alone, so periodic images, halo rows and shard windows stay bit-identical.
+
+#define E16_REC 143                       // 16-byte entries of a matrix's reflector record: 119 elements of u_K packed by column,
+                                          // 16 phases of the diagonal unitary, 14 beta_K (7 entries), 1 spare; the stride keeps
+                                          // the four broadcasts of a read on different banks
+#define E16_XCH 144                       // 16-byte entries of the wavefront's exchange region (2304 B): q of a reflection,
+                                          // (d, e) of T, Sturm counts, one matrix's V for the matrix cores
+#define E16_WAVE_LDS ((4 * E16_REC + E16_XCH) * 16)   // 11 456 B per wavefront: 3 wavefronts per SIMD fit 160 KB
+__host__ __device__ constexpr int e16_off(const int K) { return 15 * K - K * (K - 1) / 2; }   // first element of u_K
+
+// LDS through pointers that carry their address space (the loads and stores are ds_read / ds_write whatever the compiler can
+// prove about the pointer) and plain vector element types (struct copies across address spaces do not compile on the host pass)
+typedef double e16_d2 __attribute__((ext_vector_type(2)));
+typedef double e16_d4 __attribute__((ext_vector_type(4)));
+typedef unsigned e16_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned e16_u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) e16_d2 e16_lcd;     // one complex number / one (d, e) pair: 16 bytes
+typedef __attribute__((address_space(3))) double e16_ld;
+typedef __attribute__((address_space(3))) e16_u2 e16_lu2;
+typedef __attribute__((address_space(3))) e16_u4 e16_lu4;
+__device__ __forceinline__ cd e16_get(const e16_lcd* p) {
+    const e16_d2 t = *p;
+    return cd{t.x, t.y};
+}
+__device__ __forceinline__ void e16_put(e16_lcd* p, const cd v) { *p = e16_d2{v.x, v.y}; }
+// the LDS regions are private to a wavefront, whose LDS operations execute in order: no barriers, no waits; only the
+// compiler has to keep the order (the views of a region differ in type)
+#define E16_ORDER() asm volatile("" ::: "memory")
+
+// ---------------------------------------------------------------- 1. Householder tridiagonalisation, reflectors into LDS
+// ru[C] = element C of u_K (C = K+1 .. 15), i.e. ru = record + off(K) - (K + 1)
+template <int K, int C>
+__device__ __forceinline__ void e16_pass1(const cd (&a)[16], const e16_lcd* ru, cd& p) {
+    const cd uc = e16_get(ru + C);
+    p.x = fma(a[C].x, uc.x, p.x);
+    p.x = fma(-a[C].y, uc.y, p.x);
+    p.y = fma(a[C].x, uc.y, p.y);
+    p.y = fma(a[C].y, uc.x, p.y);
+    if constexpr (C + 1 < 16) e16_pass1<K, C + 1>(a, ru, p);
+}
+template <int K, int C>
+__device__ __forceinline__ void e16_pass2(cd (&a)[16], const e16_lcd* ru, const e16_lcd* lq, const cd u, const cd q) {
+    const cd uc = e16_get(ru + C), qc = e16_get(lq + C);
+    // A[x][c] -= u_x conj(q_c) + q_x conj(u_c)
+    a[C].x = fma(-u.x, qc.x, fma(-u.y, qc.y, fma(-q.x, uc.x, fma(-q.y, uc.y, a[C].x))));
+    a[C].y = fma(-u.y, qc.x, fma(u.x, qc.y, fma(-q.y, uc.x, fma(q.x, uc.y, a[C].y))));
+    if constexpr (C + 1 < 16) e16_pass2<K, C + 1>(a, ru, lq, u, q);
+}
+// Step K on the rows of A (lane x = row x); returns T[K+1][K] before the phase fix.  rec: this matrix's record, lq: its 17
+// exchange slots.  The record keeps u_K UNSCALED and beta_K = 2 / (u^+ u) beside it, so that the slot a lane stores its element
+// in for the other rows to read is the slot the back-transformation reads it from.
+template <int K>
+__device__ __forceinline__ cd e16_house(cd (&a)[16], const int x, e16_lcd* rec, e16_lcd* lq) {
+    const bool below = x > K;
+    const cd xk = below ? a[K] : cd{0.0, 0.0};
+    // (decided on the entries below the subdiagonal alone, like LAPACK's zlarfg: see ql16_house)
+    const double rest = row_allsum(x > K + 1 ? cabs2(xk) : 0.0);
+    const cd alpha = rowbcast_c<K + 1>(a[K]);            // A[K+1][K]
+    const double absa2 = cabs2(alpha);
+    const double sigma = rest + absa2;
+    e16_lcd* const ru = rec + (e16_off(K) - (K + 1));
+    e16_ld* const betas = reinterpret_cast<e16_ld*>(rec + 135);
+    cd tK = alpha;
+    if (rest > 0.0) {                                    // row-uniform
+        const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
+        double absa = 0.0;
+        cd ph{1.0, 0.0};
+        if (absa2 > 0.0) {
+            const double inv_a = rsqrt_full(absa2);
+            absa = absa2 * inv_a;
+            ph = cd{alpha.x * inv_a, alpha.y * inv_a};
+        }
+        const cd u = x == K + 1 ? cd{ph.x * (absa + nrm), ph.y * (absa + nrm)} : xk;
+        const double sb = rsqrt_full(nrm * (nrm + absa)), beta = sb * sb;   // beta = 2 / (u^+ u)
+        tK = cd{-ph.x * nrm, -ph.y * nrm};
+        if (below) e16_put(ru + x, u);
+        if (x == 0) betas[K] = beta;
+        E16_ORDER();
+        cd p{0.0, 0.0};
+        e16_pass1<K, K + 1>(a, ru, p);
+        p = cd{p.x * beta, p.y * beta};
+        const double kappa = 0.5 * beta * row_allsum(u.x * p.x + u.y * p.y);
+        const cd q = below ? cd{fma(-kappa, u.x, p.x), fma(-kappa, u.y, p.y)} : cd{0.0, 0.0};
+        e16_put(lq + x, q);
+        E16_ORDER();
+        e16_pass2<K, K + 1>(a, ru, lq, u, q);
+        E16_ORDER();
+    } else {                                             // nothing to reflect: H_K = I
+        if (below) e16_put(ru + x, cd{0.0, 0.0});
+        if (x == 0) betas[K] = 0.0;
+        E16_ORDER();
+    }
+    return tK;
+}
+
+// ---------------------------------------------------------------- 2. eigenvalue j of T on lane j
+// Number of eigenvalues of the (scaled) T below x, and which pivots were negative (bit i: q_i < 0).  q_i = (d_i - x) -
+// e_{i-1}^2 / q_{i-1} with IEEE arithmetic: a zero pivot gives an infinite next one and the recurrence recovers, the count
+// being one of the two one-sided limits (which is all a bracket needs); e2 holds 1e-300 instead of 0 at the splits of T so
+// that 0 x inf never appears.  v_rcp_f64 without refinement: the count is exact for a matrix within ~1e-8 |T| of T.
+template <int I>
+__device__ __forceinline__ void e16_count_step(const double (&d)[16], const double (&e2)[16], const int n, const double x, double& q,
+                                               unsigned& acc) {
+    if (I < n) {                                         // (wave-uniform)
+        const double r = __builtin_amdgcn_rcp(q);
+        q = I == 0 ? d[0] - x : fma(-e2[I > 0 ? I - 1 : 0], r, d[I] - x);
+        acc = __builtin_amdgcn_alignbit(acc, __double2hiint(q), 31);   // (acc << 1) | sign(q)
+    } else {
+        acc <<= 1;
+    }
+    if constexpr (I + 1 < 16) e16_count_step<I + 1>(d, e2, n, x, q, acc);
+}
+// -> bit (15 - i) of the result: pivot i negative
+__device__ __forceinline__ unsigned e16_signs(const double (&d)[16], const double (&e2)[16], const int n, const double x) {
+    double q = 1.0;
+    unsigned acc = 0;
+    e16_count_step<0>(d, e2, n, x, q, acc);
+    return acc & 0xffffu;
+}
+
+// One evaluation of the characteristic polynomial of the block [bl, bh] of T at x with its derivative and the number of sign
+// changes of the sequence (= eigenvalues of the block below x): p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}.
+template <int I>
+__device__ __forceinline__ void e16_poly_step(const double (&d)[16], const double (&e2)[16], const int bl, const int bh, const double x,
+                                              double& p1, double& p2, double& dp1, double& dp2, unsigned& chg) {
+    if (I >= bl && I <= bh) {
+        const double t = d[I] - x;
+        const double ee = I > 0 ? (I > bl ? e2[I > 0 ? I - 1 : 0] : 0.0) : 0.0;
+        const double p = fma(t, p1, -ee * p2);
+        const double dp = fma(t, dp1, -ee * dp2) - p1;
+        chg += (unsigned)((__double2hiint(p) ^ __double2hiint(p1)) >> 31) & 1u;
+        p2 = p1;
+        dp2 = dp1;
+        p1 = p;
+        dp1 = dp;
+    }
+    if constexpr (I + 1 < 16) e16_poly_step<I + 1>(d, e2, bl, bh, x, p1, p2, dp1, dp2, chg);
+}
+
+// value of the NEXT lane of the 16-lane row (DPP row_shl:1 -- data moves towards lane 0; lane 15 reads 0) and of the PREVIOUS one
+// (row_shr:1; lane 0 reads 0)
+__device__ __forceinline__ double e16_next(const double v) {
+    const I2 i = __builtin_bit_cast(I2, v);
+    const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x101, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, i.hi, 0x101, 0xf, 0xf, true)};
+    return __builtin_bit_cast(double, o);
+}
+__device__ __forceinline__ double e16_prev(const double v) {
+    const I2 i = __builtin_bit_cast(I2, v);
+    const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x111, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, i.hi, 0x111, 0xf, 0xf, true)};
+    return __builtin_bit_cast(double, o);
+}
+
+#ifdef E16_DEBUG
+__device__ double e16_dbg[64 * 16];
+#define E16_DBG(slotv, j, k, val) do { if ((slotv) == E16_DEBUG) e16_dbg[(j) * 16 + (k)] = (double)(val); } while (0)
+#else
+#define E16_DBG(slotv, j, k, val) do { } while (0)
+#endif
+
+#ifdef E16_MARKS   // (ISA inspection only: phase boundaries visible in the assembly listing)
+#define E16_MARK(n) asm volatile("s_nop 0 ; E16_MARK " #n ::: "memory")
+#else
+#define E16_MARK(n) do { } while (0)
+#endif
+
+#define E16_NBISECT 8
+#define E16_NEWTON_MAX 12
+
+// d, e: T of this lane's matrix (replicated over its 16 lanes); on return scaled by `scale` (a power of two: exact) with the
+// negligible couplings zeroed, lam = eigenvalue j of the scaled T, [bl, bh] its unreduced block.  flag: this lane could not do
+// its part (no convergence).  n: real states (rows n.. of T are decoupled padding and take no part).
+__device__ __forceinline__ void e16_eigenvalue(double (&d)[16], double (&e)[16], const int n, const int j, e16_lu2* xch /* [16] of this matrix */,
+                                               double& scale, double& lam, int& bl, int& bh, unsigned& split, bool& flag, const int64_t dbg_slot = -1) {
+    // ---- splits and scale
+    split = 0x8000u;
+    double tn = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < 15) {
+            const bool ng = !(fabs(e[i]) > 2.220446049250313e-16 * (fabs(d[i]) + fabs(d[i + 1]))) || i >= n - 1;
+            split |= ng ? (1u << i) : 0u;
+            e[i] = ng ? 0.0 : e[i];
+        }
+    }
+    e[15] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < n) tn = fmax(tn, fabs(d[i]) + (i > 0 ? fabs(e[i - 1]) : 0.0) + fabs(e[i]));
+    {
+        int ex = 0;
+        (void)frexp(tn, &ex);                            // tn = m 2^ex, m in [1/2, 1)
+        scale = tn > 0.0 && tn < INFINITY ? ldexp(1.0, -ex) : 1.0;
+    }
+    double e2[16];
+    double gl = INFINITY, gu = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        d[i] *= scale;
+        e[i] *= scale;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        e2[i] = (split >> i) & 1u ? 1e-300 : e[i] * e[i];
+        if (i < n) {
+            const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + fabs(e[i]);
+            gl = fmin(gl, d[i] - rad);
+            gu = fmax(gu, d[i] + rad);
+        }
+    }
+    // (a hair wider than Gershgorin's discs, so that the counts at the ends are 0 and n whatever the rounding)
+    gl -= 1e-13;
+    gu += 1e-13;
+
+    E16_MARK(21);
+    // ---- one multisection shared by the 16 lanes: lane j looks at point j of 16 inside (gl, gu)
+    const double w = (gu - gl) * (1.0 / 17.0);
+    const double tj = fma(w, (double)(j + 1), gl);
+    const unsigned sj = e16_signs(d, e2, n, tj);
+    xch[j] = e16_u2{(unsigned)__builtin_popcount(sj), sj};
+    E16_ORDER();
+    double lo = gl, hi = gu;
+    unsigned clo = 0, chi = (unsigned)n, slo = 0, shi = n >= 16 ? 0xffffu : (((1u << n) - 1u) << (16 - n));
+    {
+        // m = points whose count is <= j (the counts do not decrease): eigenvalue j lies between points m-1 and m
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            const e16_u4 two = *reinterpret_cast<const e16_lu4*>(xch + k);
+            const bool b0 = two.x <= (unsigned)j, b1 = two.z <= (unsigned)j;
+            // the last point with count <= j gives lo; the first with count > j gives hi
+            clo = b0 ? two.x : clo;
+            slo = b0 ? two.y : slo;
+            clo = b1 ? two.z : clo;
+            slo = b1 ? two.w : slo;
+            m += (b0 ? 1 : 0) + (b1 ? 1 : 0);
+        }
+        unsigned ch2 = chi, sh2 = shi;
+#pragma unroll
+        for (int k = 14; k >= 0; k -= 2) {
+            const e16_u4 two = *reinterpret_cast<const e16_lu4*>(xch + k);
+            const bool b1 = two.z > (unsigned)j, b0 = two.x > (unsigned)j;
+            ch2 = b1 ? two.z : ch2;
+            sh2 = b1 ? two.w : sh2;
+            ch2 = b0 ? two.x : ch2;
+            sh2 = b0 ? two.y : sh2;
+        }
+        chi = ch2;
+        shi = sh2;
+        lo = m > 0 ? fma(w, (double)m, gl) : gl;
+        hi = m < 16 ? fma(w, (double)(m + 1), gl) : gu;
+    }
+    E16_ORDER();
+    E16_MARK(22);
+    // ---- bisection on the global count
+#pragma unroll 1
+    for (int it = 0; it < E16_NBISECT; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        const unsigned s = e16_signs(d, e2, n, mid);
+        const unsigned c = (unsigned)__builtin_popcount(s);
+        const bool left = c <= (unsigned)j;              // eigenvalue j is at or above mid
+        lo = left ? mid : lo;
+        clo = left ? c : clo;
+        slo = left ? s : slo;
+        hi = left ? hi : mid;
+        chi = left ? chi : c;
+        shi = left ? shi : s;
+    }
+    E16_MARK(23);
+    // ---- the block that owns eigenvalue j: it is member r = j - clo of the chi - clo eigenvalues inside (lo, hi]; walking the
+    // blocks in order, block b holds inc_b = count_b(hi) - count_b(lo) of them (Kramers pairs of a cleanly split T live in
+    // different blocks).  kb = index of the eigenvalue inside its block.
+    bl = 0;
+    bh = n - 1;
+    int kb = (int)clo + ((int)j - (int)clo);             // (= j: the whole T is one block)
+    if (__builtin_amdgcn_ballot_w64((split & 0x7fffu & ((1u << (n - 1)) - 1u)) != 0) != 0) {   // (wave-uniform: some T of the wavefront splits)
+        const int r = j - (int)clo;
+        int cum = 0, cl = 0, ch = 0, start = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            cl += (int)((slo >> (15 - i)) & 1u);
+            ch += (int)((shi >> (15 - i)) & 1u);
+            const bool endb = ((split >> i) & 1u) != 0 && i < n;
+            if (endb) {
+                const int inc = ch - cl;
+                const bool here = !found && r < cum + inc;
+                bl = here ? start : bl;
+                bh = here ? i : bh;
+                kb = here ? cl + (r - cum) : kb;
+                found = found || here;
+                cum += inc > 0 ? inc : 0;
+                cl = 0;
+                ch = 0;
+                start = i + 1;
+            }
+        }
+        // (inconsistent counts -- possible only within the 1e-8 |T| of the reciprocal estimate of an eigenvalue of a leading
+        // block: the matrix goes to the list)
+        flag = flag || !found;
+        if (!found) {
+            bl = 0;
+            bh = n - 1;
+            kb = j;
+        }
+    }
+    E16_MARK(24);
+    // ---- Newton on the block's characteristic polynomial, bracket kept by the block's own Sturm count
+    double x = 0.5 * (lo + hi);
+    bool conv = j >= n;
+    E16_DBG(dbg_slot, j, 0, lo);
+    E16_DBG(dbg_slot, j, 1, hi);
+    E16_DBG(dbg_slot, j, 2, clo);
+    E16_DBG(dbg_slot, j, 3, chi);
+    E16_DBG(dbg_slot, j, 4, kb);
+    E16_DBG(dbg_slot, j, 5, bl * 100 + bh);
+    int dbg_it = 0;
+#pragma unroll 1
+    for (int it = 0; it < E16_NEWTON_MAX; ++it) {
+        if (__builtin_amdgcn_ballot_w64(!conv) == 0) break;
+        double p1 = 1.0, p2 = 0.0, dp1 = 0.0, dp2 = 0.0;
+        unsigned chg = 0;
+        e16_poly_step<0>(d, e2, bl, bh, x, p1, p2, dp1, dp2, chg);
+        // chg eigenvalues of the block lie below x (a zero of the sequence counts with the positive values)
+        const bool left = (int)chg <= kb;                // the root is at or above x
+        const double nlo = left ? x : lo, nhi = left ? hi : x;
+        double y = __builtin_amdgcn_rcp(dp1);
+        y = fma(fma(-dp1, y, 1.0), y, y);
+        double xn = fma(-p1, y, x);
+        // A step is taken if it stays inside the bracket -- with a slack of 64 eps |T|: from the far side of a root whose near
+        // bound has already closed in to rounding level, the (correct) step lands a few 1e-15 beyond that bound, and the midpoint
+        // that a strict test would take instead is half the old error away (12 such steps ended 1e-7 from the root).
+        const bool inside = xn > nlo - 1.4210854715202004e-14 && xn < nhi + 1.4210854715202004e-14;   // (false for NaN / inf: a vanishing derivative)
+        xn = inside ? xn : 0.5 * (nlo + nhi);
+        // converged: the step is at the noise level of the recurrence (|T| is in [1/2, 1) here: 64 eps absolute)
+        const bool done = p1 == 0.0 || fabs(xn - x) <= 1.4210854715202004e-14 || !(nhi - nlo > 0.0);
+        if (!conv) {
+            lo = nlo;
+            hi = nhi;
+            x = p1 == 0.0 ? x : xn;
+            conv = done;
+            ++dbg_it;
+            E16_DBG(dbg_slot, j, 9, inside ? 1.0 : 0.0);
+            E16_DBG(dbg_slot, j, 10, p1);
+            E16_DBG(dbg_slot, j, 11, dp1);
+            E16_DBG(dbg_slot, j, 12, (double)chg);
+        }
+    }
+    flag = flag || !conv;
+    lam = x;
+    if (j >= n) {                                        // a padding row: decoupled, its eigenvector is e_j (V stays orthogonal)
+        bl = j;
+        bh = j;
+        lam = qle_pick<0>(d, j, 0.0);
+    }
+    E16_DBG(dbg_slot, j, 6, x);
+    E16_DBG(dbg_slot, j, 7, dbg_it);
+    E16_DBG(dbg_slot, j, 8, conv ? 1.0 : 0.0);
+}
+
+// ---------------------------------------------------------------- 3. eigenvector of T for lam by the twisted factorisation
+__device__ __forceinline__ double e16_rcp(const double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    y = fma(fma(-p, y, 1.0), y, y);
+    y = fma(fma(-p, y, 1.0), y, y);
+    return y;
+}
+#define E16_TINY 1e-290
+__device__ __forceinline__ double e16_guard(const double p) { return fabs(p) < E16_TINY ? -E16_TINY : p; }
+
+// v = unit eigenvector of the (scaled, split) T for its eigenvalue lam inside the block [bl, bh]; dlam = the Rayleigh-quotient
+// correction gamma_r / |z|^2; returns true when the residual |gamma_r| / |z| is not at rounding level
+__device__ __forceinline__ bool e16_twisted(const double (&d0)[16], const double (&e)[16], const double lam, const int bl, const int bh,
+                                            double (&v)[16], double& dlam) {
+    double d[16];
+    double tnorm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        d[i] = d0[i] - lam;                            // s_i = d_i - lambda
+        tnorm = fmax(tnorm, fabs(d[i]));
+    }
+    // top-down pivots dp_{i+1} = s_{i+1} - e_i lp_i, lp_i = e_i / dp_i; bottom-up dm_i = s_i - e_i um_i, um_i = e_i / dm_{i+1}
+    double lp[15], um[15];
+    {
+        double dp = d[0], dm = d[15];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            lp[i] = e[i] * e16_rcp(e16_guard(dp));
+            dp = fma(-e[i], lp[i], d[i + 1]);
+            const int k = 14 - i;
+            um[k] = e[k] * e16_rcp(e16_guard(dm));
+            dm = fma(-e[k], um[k], d[k]);
+        }
+    }
+    // gamma_k = s_k - e_{k-1} lp_{k-1} - e_k um_k; r = position of the smallest |gamma| inside the block
+    double gmin = INFINITY, gam_r = 0.0;
+    int r = bl;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double gk = d[k];
+        if (k > 0) gk = fma(-e[k - 1], lp[k - 1], gk);
+        if (k < 15) gk = fma(-e[k], um[k], gk);
+        const bool in = k >= bl && k <= bh;
+        if (in && fabs(gk) < gmin) {
+            gmin = fabs(gk);
+            gam_r = gk;
+            r = k;
+        }
+    }
+    // z_r = 1; downwards z_i = -lp_i z_{i+1} (i < r), upwards z_{i+1} = -um_i z_i (i >= r)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = i == r ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 14; i >= 0; --i) v[i] = i < r ? -lp[i] * v[i + 1] : v[i];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) v[i + 1] = i >= r ? -um[i] * v[i] : v[i + 1];
+    double nz2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) nz2 = fma(v[i], v[i], nz2);
+    const double inz = rsqrt_full(nz2);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] *= inz;
+    dlam = gam_r * inz * inz;
+    // residual |(T - lambda) z| / |z| = |gamma_r| / |z|: a few eps |T| for an eigenvalue that accurate
+    const double tn = tnorm + fabs(lam);
+    return !(fabs(gam_r) * inz <= 1e-11 * tn);
+}
+
+// ---------------------------------------------------------------- the kernel
+// MODE 0: k list, 1: regular mesh into a wf_array, 2: supplied matrices.  The launch covers the matrices [id0, id0 + nc);
+// list / count: the matrices (relative to id0) left to the QL-replay kernels.
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G, const int64_t id0,
+                                                const int64_t nc, int* __restrict__ list, int* __restrict__ count, const double gaptol) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * E16_WAVE_LDS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = lane & 15, mat = lane >> 4, g = lane >> 4;
+    const int j = x;
+    e16_lcd* const wrec = (e16_lcd*)(lds_all + wv * E16_WAVE_LDS);     // [4][E16_REC]
+    e16_lcd* const wxch = wrec + 4 * E16_REC;                                          // [E16_XCH]
+    e16_lcd* const rec = wrec + mat * E16_REC;
+    const int64_t wslot0 = ((int64_t)blockIdx.x * 4 + wv) * 4;                          // first matrix of this wavefront
+    if (wslot0 >= nc) return;                                                           // (wave-uniform)
+    const int64_t slot_u = wslot0 + mat;
+    const bool live = slot_u < nc;
+    const int64_t slot = live ? slot_u : nc - 1;                                        // idle tail rows shadow the last matrix
+    const int64_t id = id0 + slot;
+    const int n = mv.nsta;
+    const bool real_row = x < n;
+
+    // ---- H(k), lane x = row x
+    cd a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = cd{0.0, 0.0};
+    if constexpr (MODE == 2) {
+        const cd* h = Lst.ham + id * (int64_t)n * n;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (real_row && c < n) {   // upper triangle, mirrored (the reference's eigh reads one triangle)
+                cd t = c >= x ? h[x * n + c] : cconj(h[c * n + x]);
+                if (c == x) t.y = 0.0;
+                a[c] = t;
+            }
+        }
+    } else {
+        cd zk[4] = {cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}};
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d < mv.dim_k) zk[d] = expi2pi(Lst.k[id * mv.dim_k + d]);
+        } else {
+            // exp(2 pi i k_d) of a mesh point: the per-axis tables (k_grid_tables: the same expression as grid_point + expi2pi,
+            // so the same bits whichever window the point is solved in)
+            int64_t rem = id;
+#pragma unroll
+            for (int d = 3; d >= 0; --d) {
+                if (d < G.wv.dim_arr) {
+                    const int64_t md = G.wv.mesh[d];
+                    const int64_t qd = d > 0 ? rem / md : 0;
+                    zk[d] = G.tz[d][d > 0 ? rem - qd * md : rem];
+                    rem = qd;
+                }
+            }
+        }
+        // S[x][c] = sum_R U_R[slot(min,max)] e^{2 pi i k.R}  (conjugated below the diagonal)
+        int sidx[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int lo = x < c ? x : c, hi = x < c ? c : x;
+            sidx[c] = real_row && c < n ? lo * n - lo * (lo - 1) / 2 + (hi - lo) : -1;
+        }
+        for (int r = 0; r < mv.nR; ++r) {
+            const cd ph = phase_of_R(zk, mv.rvec[r]);
+            const cd* u = mv.rblock + (size_t)r * mv.nslot;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (sidx[c] >= 0) cfma(a[c], u[sidx[c]], ph);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < x) a[c].y = -a[c].y;
+            if (c == x) a[c].y = 0.0;
+        }
+    }
+
+    E16_MARK(1);
+    // ---- 1. tridiagonalisation; lane x ends up with d_x and e_x = |T[x+1][x]|, and with the phase of column x of D
+    double ee = 0.0;
+    cd delta{1.0, 0.0}, dx{1.0, 0.0};
+    auto step_phase = [&](const cd t, const int col) {
+        const double t2 = cabs2(t);
+        double mag = 0.0;
+        if (t2 > 0.0) {
+            const double inv = rsqrt_full(t2);
+            mag = t2 * inv;
+            delta = cmul(delta, cd{t.x * inv, t.y * inv});
+        }
+        if (x == col - 1) ee = mag;
+        if (x == col) dx = delta;
+    };
+    {
+        e16_lcd* const lq = wxch + mat * 17;
+#define TBK_E16_HOUSE(KK)                                     \
+    {                                                         \
+        const cd t = e16_house<KK>(a, x, rec, lq);            \
+        step_phase(t, KK + 1);                                \
+    }
+        TBK_E16_HOUSE(0) TBK_E16_HOUSE(1) TBK_E16_HOUSE(2) TBK_E16_HOUSE(3) TBK_E16_HOUSE(4) TBK_E16_HOUSE(5) TBK_E16_HOUSE(6)
+        TBK_E16_HOUSE(7) TBK_E16_HOUSE(8) TBK_E16_HOUSE(9) TBK_E16_HOUSE(10) TBK_E16_HOUSE(11) TBK_E16_HOUSE(12) TBK_E16_HOUSE(13)
+#undef TBK_E16_HOUSE
+    }
+    const cd t14 = rowbcast_c<15>(a[14]);                // T[15][14]: never reflected
+    step_phase(t14, 15);
+    const double dd = sel16<0>(a, x, cd{0.0, 0.0}).x;    // d_x = A[x][x]
+    e16_put(rec + 119 + x, dx);
+    E16_MARK(2);
+    // (d, e) of T to every lane of the matrix
+    double d[16], e[16];
+    {
+        e16_lcd* const xd = wxch + mat * 16;
+        E16_ORDER();
+        xd[x] = e16_d2{dd, x < 15 ? ee : 0.0};
+        E16_ORDER();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const e16_d2 t = xd[i];
+            d[i] = t.x;
+            e[i] = t.y;
+        }
+        E16_ORDER();
+    }
+
+    // ---- 2. eigenvalue j (scaled T), 3. its eigenvector of T
+    double scale = 1.0, lam = 0.0;
+    int bl = 0, bh = 15;
+    unsigned split = 0;
+    bool flag = false;
+    e16_eigenvalue(d, e, n, j, reinterpret_cast<e16_lu2*>(wxch) + mat * 16, scale, lam, bl, bh, split, flag, slot_u);
+    E16_MARK(3);
+    double v[16], dlam = 0.0;
+    const bool bad = e16_twisted(d, e, lam, bl, bh, v, dlam) && j < n;
+    E16_MARK(4);
+    const double lam_s = lam + dlam;                    // Rayleigh-quotient correction
+    E16_DBG(slot_u, j, 13, dlam);
+    E16_DBG(slot_u, j, 14, bad ? 1.0 : 0.0);
+    E16_DBG(slot_u, j, 15, scale);
+    // |T| = the largest eigenvalue in magnitude, as in round 3's kernels
+    double tmax = j < n ? fabs(lam_s) : 0.0;
+    tmax = fmax(tmax, row_ror_d<8>(tmax));
+    tmax = fmax(tmax, row_ror_d<4>(tmax));
+    tmax = fmax(tmax, row_ror_d<2>(tmax));
+    tmax = fmax(tmax, row_ror_d<1>(tmax));
+    // Eigenvalues of DIFFERENT blocks that agree to rounding (Kramers pairs of a cleanly split T) may come out in either order:
+    // neighbours exchange their values (not their vectors) so that the bands ascend; a disorder beyond rounding lists the matrix
+    double lam_o = lam_s;
+    bool disorder = false;
+    {
+        const double tol = 1.4210854715202004e-14 * tmax;   // 64 eps |T|
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const double up = e16_next(lam_o), dn = e16_prev(lam_o);   // lanes j + 1 and j - 1
+            const bool lead = (j & 1) == pass;
+            if (lead) {
+                if (j + 1 < n && up < lam_o) {
+                    disorder = disorder || lam_o - up > tol;
+                    lam_o = up;
+                }
+            } else {
+                if (j >= 1 && j < n && dn > lam_o) {
+                    disorder = disorder || dn - lam_o > tol;
+                    lam_o = dn;
+                }
+            }
+        }
+    }
+    const double lam_out = lam_o * e16_rcp(scale);      // (scale is a power of two: exact)
+    // two eigenvalues of ONE block closer than gaptol |T| (the Newton-Schulz step below would not reach rounding level)
+    bool close_pair = disorder;
+    {
+        const double up = e16_next(lam_o);              // eigenvalue j + 1 (lane 15: excluded)
+        const int bl_up = __builtin_amdgcn_update_dpp(0, bl, 0x101, 0xf, 0xf, true);
+        close_pair = close_pair || (j + 1 < n && ((bl_up == bl && !(up - lam_o >= gaptol * tmax)) || up < lam_o));
+    }
+    const unsigned long long fb = __builtin_amdgcn_ballot_w64((flag || bad || close_pair) && live && j < n);
+    const bool listed = ((unsigned)(fb >> (lane & 48)) & 0xffffu) != 0;
+    if (listed && j == 0 && live) list[atomicAdd(count, 1)] = (int)slot;
+
+    // eigenvalues out / minimal gaps of the mesh (listed matrices: the QL-replay kernels report theirs)
+    if constexpr (MODE == 1) {
+        double gap = e16_next(lam_out) - lam_out;
+        gap = (j + 1 < n && live && !listed) ? gap : INFINITY;
+        gap = fmin(gap, __shfl_xor(gap, 16));
+        gap = fmin(gap, __shfl_xor(gap, 32));
+        if (lane < 15 && lane + 1 < n) {
+            unsigned long long* slotp = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * n + lane;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(fmax(gap, 0.0));
+            if (bits < __hip_atomic_load(slotp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slotp, bits);
+        }
+    } else {
+        if (live && j < n) Lst.eval[(int64_t)j * nk + id] = lam_out;
+    }
+
+    E16_MARK(5);
+    // ---- 4. one Newton-Schulz step V <- V (1.5 I - 0.5 V^T V), per matrix two 16 x 16 x 16 real products on the matrix cores
+    // v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][4 kb + (l >> 4)] and B[4 kb + (l >> 4)][l & 15], and holds
+    // D[(l >> 4) + 4 r][l & 15] in register r (profiles/microbench/mfma_f64_layout.hip).  One matrix at a time through the
+    // exchange region (16 x 18 doubles).
+    {
+        e16_ld* const Vm = reinterpret_cast<e16_ld*>(wxch);
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            E16_ORDER();
+            if (mat == m4) {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) *reinterpret_cast<e16_lcd*>(Vm + j * 18 + i) = e16_d2{v[i], v[i + 1]};
+            }
+            E16_ORDER();
+            e16_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const double av = Vm[j * 18 + 4 * kb + g];               // V[4 kb + g][j] = A^T and B alike: G = V^T V
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, av, acc, 0, 0, 0);
+            }
+            e16_d4 xr;                                                    // X[g + 4 r][j] = 1.5 delta - 0.5 G
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xr[r] = fma(-0.5, acc[r], (g + 4 * r) == j ? 1.5 : 0.0);
+            e16_d4 vn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const double av = Vm[(4 * kb + g) * 18 + j];              // A[x = j][k = 4 kb + g] = V[j][4 kb + g]
+                vn = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xr[kb], vn, 0, 0, 0);   // B[k][col] = X[4 kb + g][col]: own register kb
+            }
+            // vn[r] = V'[x = g + 4 r][column j]: back into the column-major image, in place (all reads of this matrix are done)
+            E16_ORDER();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vm[j * 18 + g + 4 * r] = vn[r];
+            E16_ORDER();
+            if (mat == m4) {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const e16_d2 t = *reinterpret_cast<const e16_lcd*>(Vm + j * 18 + i);
+                    v[i] = t.x;
+                    v[i + 1] = t.y;
+                }
+            }
+        }
+        E16_ORDER();
+    }
+
+    E16_MARK(6);
+    // ---- 5. z = H_0 ( H_1 ( ... H_13 (D v))), H_K = I - beta_K u_K u_K^+; the reflectors are read from LDS by broadcast
+    cd y[16];
+#pragma unroll
+    for (int xx = 0; xx < 16; ++xx) {
+        const cd ph = e16_get(rec + 119 + xx);
+        y[xx] = cd{ph.x * v[xx], ph.y * v[xx]};
+    }
+    {
+        const e16_ld* const betas = reinterpret_cast<const e16_ld*>(rec + 135);
+        auto reflect = [&](auto KC) {
+            constexpr int K = decltype(KC)::value;
+            const e16_lcd* const ru = rec + (e16_off(K) - (K + 1));
+            cd u[16];
+            cd w{0.0, 0.0};
+#pragma unroll
+            for (int xx = K + 1; xx < 16; ++xx) {
+                u[xx] = e16_get(ru + xx);
+                // w += conj(u_x) y_x
+                w.x = fma(u[xx].x, y[xx].x, w.x);
+                w.x = fma(u[xx].y, y[xx].y, w.x);
+                w.y = fma(u[xx].x, y[xx].y, w.y);
+                w.y = fma(-u[xx].y, y[xx].x, w.y);
+            }
+            const double beta = betas[K];
+            w = cd{w.x * beta, w.y * beta};
+#pragma unroll
+            for (int xx = K + 1; xx < 16; ++xx) {
+                // y_x -= u_x w
+                y[xx].x = fma(-u[xx].x, w.x, y[xx].x);
+                y[xx].x = fma(u[xx].y, w.y, y[xx].x);
+                y[xx].y = fma(-u[xx].x, w.y, y[xx].y);
+                y[xx].y = fma(-u[xx].y, w.x, y[xx].y);
+            }
+        };
+        reflect(std::integral_constant<int, 13>{});
+        reflect(std::integral_constant<int, 12>{});
+        reflect(std::integral_constant<int, 11>{});
+        reflect(std::integral_constant<int, 10>{});
+        reflect(std::integral_constant<int, 9>{});
+        reflect(std::integral_constant<int, 8>{});
+        reflect(std::integral_constant<int, 7>{});
+        reflect(std::integral_constant<int, 6>{});
+        reflect(std::integral_constant<int, 5>{});
+        reflect(std::integral_constant<int, 4>{});
+        reflect(std::integral_constant<int, 3>{});
+        reflect(std::integral_constant<int, 2>{});
+        reflect(std::integral_constant<int, 1>{});
+        reflect(std::integral_constant<int, 0>{});
+    }
+    E16_ORDER();
+
+    E16_MARK(7);
+    // ---- 6. transpose through LDS (row stride 17 doubles, over the records: all reads of them are done): lane c of a matrix
+    // receives component c of every vector
+    e16_ld* const Ts = reinterpret_cast<e16_ld*>(wrec);                                 // [4][16][17]
+    cd zt[16];
+#pragma unroll
+    for (int xx = 0; xx < 16; ++xx) Ts[(mat * 16 + j) * 17 + xx] = y[xx].x;
+    E16_ORDER();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) zt[b].x = Ts[(mat * 16 + b) * 17 + j];
+    E16_ORDER();
+#pragma unroll
+    for (int xx = 0; xx < 16; ++xx) Ts[(mat * 16 + j) * 17 + xx] = y[xx].y;
+    E16_ORDER();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) zt[b].y = Ts[(mat * 16 + b) * 17 + j];
+
+    const int c = j;                                   // from here on the lane owns orbital component c
+    if (!live || c >= n) return;
+    cd f{1.0, 0.0};
+    if constexpr (MODE != 2) {
+        double kk[4] = {0.0, 0.0, 0.0, 0.0};
+        bool wrap[4] = {false, false, false, false};
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int dd2 = 0; dd2 < 4; ++dd2)
+                if (dd2 < mv.dim_k) kk[dd2] = Lst.k[id * mv.dim_k + dd2];
+        } else {
+            grid_point(G, id, kk, wrap);
+        }
+        f = cconj(expi2pi(kdot(kk, mv.orb[c])));
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int dd2 = 0; dd2 < 4; ++dd2)
+                if (wrap[dd2]) f = cmul(f, G.pbc[dd2 * n + c]);
+        }
+    }
+    // (lane b of the matrix computed eigenvalue b: the bands are in ascending order by construction)
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        if (b < n) {
+            const cd val = cmul(zt[b], f);
+            if constexpr (MODE == 1) wf_at(G.wv, b, id)[c] = val;
+            else Lst.evec[((int64_t)b * nk + id) * n + c] = val;
+        }
+    }
+}

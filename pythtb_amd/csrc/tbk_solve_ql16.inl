@@ -240,7 +240,7 @@ template <int MODE>
 __device__ __forceinline__ void ql16_lanes_body(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
                                                 const double2* __restrict__ de, double* __restrict__ eval, const GridArgs& G,
                                                 const Ql16Rec& R, int* flags, const int* __restrict__ list, const int64_t nhave,
-                                                const int64_t idc) {
+                                                const int64_t idc, const bool list_gaps = false) {
     const bool has = idc < nhave;
     const int64_t ic = has ? idc : nhave - 1;
     const int64_t mat_out = id0 + (list ? (int64_t)list[ic] : idc);
@@ -319,7 +319,7 @@ __device__ __forceinline__ void ql16_lanes_body(const int n, const int64_t nk, c
 #pragma unroll
         for (int a = 0; a < 16; ++a) v = (a < n && rk[a] == r) ? d[a] : v;
         if constexpr (MODE == 1) {
-            if (r > 0 && list == nullptr) {
+            if (r > 0 && (list == nullptr || list_gaps)) {   // (list_gaps: the caller left the listed matrices' gaps to this kernel -- k_e16)
                 double gap = has ? v - prev : INFINITY;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) gap = fmin(gap, __shfl_xor(gap, o));
@@ -340,14 +340,14 @@ template <int MODE, bool LIST = false>
 __global__ __launch_bounds__(256) void k_ql16_lanes(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
                                                     const double2* __restrict__ de, double* __restrict__ eval, const GridArgs G,
                                                     const Ql16Rec R, int* flags, const int* __restrict__ list = nullptr,
-                                                    const int* __restrict__ count = nullptr) {
+                                                    const int* __restrict__ count = nullptr, const bool list_gaps = false) {
     if constexpr (!LIST) {
         ql16_lanes_body<MODE>(n, nk, id0, nc, de, eval, G, R, flags, nullptr, nc, (int64_t)blockIdx.x * 256 + threadIdx.x);
         return;
     }
     const int64_t nhave = *count;
     for (int64_t base = (int64_t)blockIdx.x * 256; base < nhave; base += (int64_t)gridDim.x * 256)
-        ql16_lanes_body<MODE>(n, nk, id0, nc, de, eval, G, R, flags, list, nhave, base + threadIdx.x);
+        ql16_lanes_body<MODE>(n, nk, id0, nc, de, eval, G, R, flags, list, nhave, base + threadIdx.x, list_gaps);
 }
 
 // position I of a recorded sweep over [lo, m): lane x of the matrix loaded the rotation of position x into `mine`

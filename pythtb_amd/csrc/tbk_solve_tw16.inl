@@ -596,6 +596,7 @@ __global__ __launch_bounds__(256, 3) void k_tw16_vectors(const int n, const int6
     }
 }
 
+#ifndef TBK_TW16_KERNELS_ONLY   // (profiles/microbench/e16_bench.hip times the three kernels beside the fused one)
 // ---- host side: chunks of the batch through the three kernels, then the listed matrices through the QL-replay kernels.
 // Up to three chunks are in flight, each on a stream and a workspace of its own: the eigenvalue kernel is a dependent chain
 // per lane (2 wavefronts per SIMD's worth of work at 43 % of the VALU issue rate, profiles/r03*), the other two are
@@ -619,10 +620,14 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     // per matrix: (d, e) | reflector record | eigenvalues by position | meta | list entry  +  the fallback's rotation record,
     // sweep words, sweep count and ranks (touched for listed matrices only)
-    const size_t per_main = 16 * sizeof(double2) + TW16_REC * sizeof(cd) + 16 * sizeof(double) + sizeof(uint4) + sizeof(int);
+    const bool fused = K.e16 != 0;   // TBK_E16 (default): the three main kernels are ONE, k_e16 (tbk_solve_e16.hip)
+    // (fused: no reflector record, eigenvalue or meta array -- only the fallback's (d, e), list entry and rotation record)
+    const size_t per_main = 16 * sizeof(double2) + (fused ? 0 : TW16_REC * sizeof(cd) + 16 * sizeof(double) + sizeof(uint4)) + sizeof(int);
     const size_t per_fb = (size_t)scap * 16 * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + 16;
     const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 8192) << 20;
-    int ns = K.tw16_streams >= 1 ? std::min(K.tw16_streams, 3) : 3;
+    // fused: no (d, e) / reflector / eigenvalue arrays between kernels and no latency-bound lane-per-matrix kernel to hide behind
+    // its neighbours, so one chunk in flight unless asked
+    int ns = K.tw16_streams >= 1 ? std::min(K.tw16_streams, 3) : (fused ? 1 : 3);
     // (per-kernel HIP-event brackets exist with TBK_TW16_STREAMS=1 only; otherwise the caller's bracket on the context's
     // stream covers the fork and the join)
     if (nk < 4 * 16384) ns = 1;
@@ -634,8 +639,9 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
     }
     chunk = (chunk + 3) & ~(int64_t)3;                                               // whole wavefronts of four matrices
     TBK_REQUIRE(chunk < (int64_t)0x7fffffff / 16, TBK_EUNSUPPORTED, "chunk of %lld matrices", (long long)chunk);
-    const size_t wone = al((size_t)chunk * 16 * sizeof(double2)) + al((size_t)chunk * TW16_REC * sizeof(cd)) +
-                        al((size_t)chunk * 16 * sizeof(double)) + al((size_t)chunk * sizeof(uint4)) + al((size_t)chunk * sizeof(int)) + 256 +
+    const size_t nmain = fused ? 0 : (size_t)chunk;     // entries of the arrays only the three-kernel form passes between its kernels
+    const size_t wone = al((size_t)chunk * 16 * sizeof(double2)) + al(nmain * TW16_REC * sizeof(cd)) +
+                        al(nmain * 16 * sizeof(double)) + al(nmain * sizeof(uint4)) + al((size_t)chunk * sizeof(int)) + 256 +
                         al((size_t)chunk * scap * 16 * sizeof(double2)) + al((size_t)chunk * scap * sizeof(unsigned)) +
                         al((size_t)chunk * sizeof(int)) + al((size_t)chunk * 16) + 1024;
     const size_t wbytes = wone * ns;
@@ -654,11 +660,11 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
         W[s].de = (double2*)p;
         p += al((size_t)chunk * 16 * sizeof(double2));
         W[s].refl = (cd*)p;
-        p += al((size_t)chunk * TW16_REC * sizeof(cd));
+        p += al(nmain * TW16_REC * sizeof(cd));
         W[s].lam = (double*)p;
-        p += al((size_t)chunk * 16 * sizeof(double));
+        p += al(nmain * 16 * sizeof(double));
         W[s].meta = (uint4*)p;
-        p += al((size_t)chunk * sizeof(uint4));
+        p += al(nmain * sizeof(uint4));
         W[s].list = (int*)p;
         p += al((size_t)chunk * sizeof(int));
         W[s].count = (int*)p;
@@ -696,6 +702,11 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
             hipStream_t sq = st[which];
             const bool brackets = ns == 1;
             TBK_HIP(hipMemsetAsync(w.count, 0, sizeof(int), sq));
+            if (fused) {
+                ProfScope ps(brackets ? ctx : nullptr, "e16");
+                const int rc = tbk_e16_launch(MODE, sq, mv, nk, L, G, id0, nc, w.list, w.count, K.tw16_gaptol);
+                if (rc) return rc;
+            } else {
             {
                 ProfScope ps(brackets ? ctx : nullptr, "tw16_tridiag");
                 hipLaunchKernelGGL((k_tw16_tridiag<MODE>), dim3(b16), dim3(256), 0, sq, mv, nk, L, G, w.de, w.refl, id0, nc);
@@ -710,6 +721,7 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
                 hipLaunchKernelGGL((k_tw16_vectors<MODE>), dim3(b16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, mv, L, G, (const double2*)w.de,
                                    (const double*)w.lam, (const uint4*)w.meta, (const cd*)w.refl, w.list, w.count);
             }
+            }
             // the listed matrices once more, by QL with replayed rotations: the count stays on the device, so these are small fixed
             // grids whose blocks stride over the list (an empty list costs three launches of idle blocks)
             {
@@ -717,8 +729,9 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
                 const unsigned f16 = std::min<unsigned>(b16, 4u * (unsigned)ctx->cus), f1 = std::min<unsigned>(b1, 4u * (unsigned)ctx->cus);
                 hipLaunchKernelGGL((k_solve_ql16<MODE, true, 2, true>), dim3(f16), dim3(256), 0, sq, mv, nk, L, G, ctx->flags_dev, w.de, id0, nc,
                                    (const int*)w.list, (const int*)w.count);
+                // (the fused kernel leaves the minimal gaps of the matrices it lists to this kernel; round 3's eigenvalue kernel took them itself)
                 hipLaunchKernelGGL((k_ql16_lanes<MODE, true>), dim3(f1), dim3(256), 0, sq, mv.nsta, nk, id0, nc, (const double2*)w.de, L.eval, G, w.R,
-                                   ctx->flags_dev, (const int*)w.list, (const int*)w.count);
+                                   ctx->flags_dev, (const int*)w.list, (const int*)w.count, fused);
                 hipLaunchKernelGGL((k_ql16_replay<MODE, true>), dim3(f16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, w.R, evec, G.wv, (const int*)w.list,
                                    (const int*)w.count);
             }
@@ -743,3 +756,4 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
+#endif  // TBK_TW16_KERNELS_ONLY
