@@ -11,6 +11,7 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include "tbk_solve_dev.h"
 #define TBK_TW16_KERNELS_ONLY
@@ -131,7 +132,148 @@ static Quality check(const std::vector<cd>& H, const std::vector<double>& ev, co
     return q;
 }
 
+// ---- MODE 1 (mesh): a synthetic cubic16-like model (R-grouped table of 7 lattice vectors x 136 slots, random orbital positions)
+// on a side^3 mesh, per-axis phase tables computed here: times k_e16<1> (and k_tw16_*<1>), no quality check (the GPU tests do that)
+static void mesh_leg(int side, int reps) {
+    const int n = 16, nslot = 136, nR = 7;
+    const int64_t npts = (int64_t)side * side * side;
+    std::vector<int4> rvec = {{0, 0, 0, 0}, {1, 0, 0, 0}, {-1, 0, 0, 0}, {0, 1, 0, 0}, {0, -1, 0, 0}, {0, 0, 1, 0}, {0, 0, -1, 0}};
+    std::vector<cd> rblock(nR * nslot);
+    std::vector<double4> orb(n);
+    srand(1);
+    auto rnd = []() { return 2.0 * rand() / RAND_MAX - 1.0; };
+    for (int r = 0; r < nR; ++r)
+        for (int sidx = 0, a = 0; a < n; ++a)
+            for (int b = a; b < n; ++b, ++sidx) {
+                cd v{0.1 * rnd(), 0.1 * rnd()};
+                if (r == 0 && a == b) v = cd{(a < 8 ? -2.0 : 2.0) + 0.2 * rnd(), 0.0};
+                rblock[r * nslot + sidx] = v;
+            }
+    // (hermiticity of S(k) = sum_R U_R e^{ikR} on the diagonal slots needs U_{-R} = conj U_R there)
+    for (int r = 1; r < nR; r += 2)
+        for (int sidx = 0, a = 0; a < n; ++a)
+            for (int b = a; b < n; ++b, ++sidx)
+                if (a == b) rblock[(r + 1) * nslot + sidx] = cd{rblock[r * nslot + sidx].x, -rblock[r * nslot + sidx].y};
+    for (int o = 0; o < n; ++o) orb[o] = double4{0.5 * (rnd() + 1), 0.5 * (rnd() + 1), 0.5 * (rnd() + 1), 0.0};
+    std::vector<cd> tz(3 * side), tf(3 * side * n), pbc(4 * n, cd{1, 0});
+    for (int d = 0; d < 3; ++d)
+        for (int i = 0; i < side; ++i) {
+            const int g = i == side - 1 ? 0 : i;
+            const double kd = (double)g / (side - 1);
+            tz[d * side + i] = cd{cos(2 * M_PI * kd), sin(2 * M_PI * kd)};
+            for (int o = 0; o < n; ++o) {
+                const double td = d == 0 ? orb[o].x : d == 1 ? orb[o].y : orb[o].z;
+                tf[(d * side + i) * n + o] = cd{cos(2 * M_PI * kd * td), -sin(2 * M_PI * kd * td)};
+            }
+        }
+    int4* d_rvec;
+    cd *d_rblock, *d_tz, *d_tf, *d_pbc, *d_wf, *refl;
+    double4* d_orb;
+    unsigned long long* d_gaps;
+    int *list, *cnt, *flags;
+    double2* de;
+    double* lam;
+    uint4* meta;
+    CK(hipMalloc(&d_rvec, sizeof(int4) * nR));
+    CK(hipMalloc(&d_rblock, sizeof(cd) * rblock.size()));
+    CK(hipMalloc(&d_orb, sizeof(double4) * n));
+    CK(hipMalloc(&d_tz, sizeof(cd) * tz.size()));
+    CK(hipMalloc(&d_tf, sizeof(cd) * tf.size()));
+    CK(hipMalloc(&d_pbc, sizeof(cd) * pbc.size()));
+    CK(hipMalloc(&d_wf, sizeof(cd) * npts * n * n));
+    CK(hipMalloc(&d_gaps, 8 * 2 * TBK_GAP_SHARDS * n));
+    CK(hipMalloc(&list, npts * sizeof(int)));
+    CK(hipMalloc(&cnt, 256));
+    CK(hipMalloc(&flags, 256));
+    CK(hipMalloc(&de, npts * 16 * sizeof(double2)));
+    CK(hipMalloc(&refl, npts * TW16_REC * sizeof(cd)));
+    CK(hipMalloc(&lam, npts * 16 * sizeof(double)));
+    CK(hipMalloc(&meta, npts * sizeof(uint4)));
+    CK(hipMemset(d_gaps, 0x7f, 8 * 2 * TBK_GAP_SHARDS * n));
+    CK(hipMemset(flags, 0, 256));
+    CK(hipMemcpy(d_rvec, rvec.data(), sizeof(int4) * nR, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_rblock, rblock.data(), sizeof(cd) * rblock.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_orb, orb.data(), sizeof(double4) * n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_tz, tz.data(), sizeof(cd) * tz.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_tf, tf.data(), sizeof(cd) * tf.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_pbc, pbc.data(), sizeof(cd) * pbc.size(), hipMemcpyHostToDevice));
+    ModelView mv{};
+    mv.dim_k = 3;
+    mv.nsta = n;
+    mv.nspin = 1;
+    mv.nslot = nslot;
+    mv.orb = d_orb;
+    mv.nR = nR;
+    mv.rvec = d_rvec;
+    mv.rblock = d_rblock;
+    GridArgs G{};
+    G.wv.dim_arr = 3;
+    G.wv.nsta = n;
+    G.wv.ncomp = n;
+    G.wv.npts = npts;
+    G.wv.data = d_wf;
+    for (int d = 0; d < 3; ++d) {
+        G.wv.mesh[d] = side;
+        G.gmesh[d] = side;
+        G.off[d] = 0;
+        G.start_k[d] = 0.0;
+        G.tz[d] = d_tz + d * side;
+        G.tf[d] = d_tf + (size_t)d * side * n;
+    }
+    G.wv.mesh[3] = 1;
+    G.wv.stride[0] = (int64_t)side * side;
+    G.wv.stride[1] = side;
+    G.wv.stride[2] = 1;
+    G.pbc = d_pbc;
+    G.gaps = d_gaps;
+    G.gaps_next = d_gaps + TBK_GAP_SHARDS * n;
+    G.last = 2;
+    G.flags = flags;
+    ListArgs L{};
+    L.flags = flags;
+    const int64_t nc = npts;
+    const unsigned b16 = (unsigned)((nc * 16 + 255) / 256), b1 = (unsigned)((nc + 255) / 256);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto time_it = [&](auto&& fn, const char* name) {
+        fn();
+        CK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0, 0));
+            fn();
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+        }
+        printf("%-34s %9.1f us   (%.3g matrices/s, %.1f us per 137312)\n", name, best * 1e3, nc / (best * 1e-3), best * 1e3 * 137312.0 / nc);
+        return best;
+    };
+    printf("mesh %d^3 = %lld points, synthetic 16-orbital model, 7 lattice vectors\n", side, (long long)npts);
+    time_it([&]() {
+        CK(hipMemsetAsync(cnt, 0, 4, 0));
+        hipLaunchKernelGGL((k_tw16_tridiag<1>), dim3(b16), dim3(256), 0, 0, mv, nc, L, G, de, refl, (int64_t)0, nc);
+        hipLaunchKernelGGL((k_tw16_eigvals<1>), dim3(b1), dim3(256), 0, 0, n, nc, (int64_t)0, nc, (const double2*)de, (double*)nullptr, G, lam, meta, list, cnt, flags, 1e-5);
+        hipLaunchKernelGGL((k_tw16_vectors<1>), dim3(b16), dim3(256), 0, 0, n, nc, (int64_t)0, nc, mv, L, G, (const double2*)de, (const double*)lam,
+                           (const uint4*)meta, (const cd*)refl, list, cnt);
+    }, "three kernels <1> back to back");
+    time_it([&]() {
+        CK(hipMemsetAsync(cnt, 0, 4, 0));
+        hipLaunchKernelGGL((k_e16<1>), dim3(b16), dim3(256), 0, 0, mv, nc, L, G, (int64_t)0, nc, list, cnt, 1e-5);
+    }, "k_e16<1>");
+    int c0;
+    CK(hipMemcpy(&c0, cnt, 4, hipMemcpyDeviceToHost));
+    printf("listed by k_e16<1>: %d\n", c0);
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "mesh") {
+        mesh_leg(argc > 2 ? atoi(argv[2]) : 65, argc > 3 ? atoi(argv[3]) : 5);
+        return 0;
+    }
     const int64_t nk = argc > 1 ? atoll(argv[1]) : 137312;
     const int n = argc > 2 ? atoi(argv[2]) : 16;
     const int kind = argc > 3 ? atoi(argv[3]) : 0;
