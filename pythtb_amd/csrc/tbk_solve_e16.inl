@@ -53,6 +53,29 @@ __device__ __forceinline__ void e16_put(e16_lcd* p, const cd v) { *p = e16_d2{v.
 // compiler has to keep the order (the views of a region differ in type)
 #define E16_ORDER() asm volatile("" ::: "memory")
 
+// Complex multiply-add and the phase e^{2 pi i k.R} with every rounding spelled out: H(k) is accumulated at two places of the
+// kernel (by the lanes together for the part that is constant along a mesh row, lane by lane otherwise) and both must give the
+// same bits -- the shared helpers' `a * b - c * d` leaves the choice of which product is fused to the compiler, site by site.
+__device__ __forceinline__ void e16_cfma(cd& acc, const cd a, const cd b) {
+    acc.x = fma(-a.y, b.y, fma(a.x, b.x, acc.x));
+    acc.y = fma(a.y, b.x, fma(a.x, b.y, acc.y));
+}
+__device__ __forceinline__ cd e16_phase_of_R(const cd (&z)[4], const int4 R) {
+    cd e{1.0, 0.0};
+    const int r[4] = {R.x, R.y, R.z, R.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        int m = r[d];
+        cd zz = z[d];
+        if (m < 0) {
+            m = -m;
+            zz.y = -zz.y;
+        }
+        for (int q = 0; q < m; ++q) e = cd{fma(e.x, zz.x, -(e.y * zz.y)), fma(e.x, zz.y, e.y * zz.x)};
+    }
+    return e;
+}
+
 // ---------------------------------------------------------------- 1. Householder tridiagonalisation, reflectors into LDS
 // acc += (value of `src` in lane C of this 16-lane row) * mul, one instruction: the fp64 ALU takes a DPP row broadcast on its
 // first operand (v_fmac_f64_dpp ... row_newbcast:C; the only DPP control the 64-bit ALU has).  u and q of a reflection reach
@@ -626,26 +649,64 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         // the kernel (profiles/microbench/e16_bench mesh, E16_SKIP=64)
         const int nsl = mv.nslot;
         const int nRr = (E16_SKIP & 64) ? 1 : mv.nR;
-        cd nx[3];
+        // On a mesh the lattice vectors with NO component along the last axis give the same sum for every point of a mesh row:
+        // S = C(k_0 .. k_{last-1}) + sum over the others of U_R e^{2 pi i k.R}.  When the four points of the wavefront lie in one
+        // row, the lanes form C together -- slot t, t + 64, t + 128 each, every U_R read once, coalesced -- and pick their 16
+        // entries of it from the exchange region; for cubic16 that is 3 passes over the slots instead of 7.  A wavefront that
+        // straddles two rows accumulates the same terms in the same order lane by lane: C first, then the others, each term one
+        // complex multiply-add from zero -- the same bits either way, so windows and halo planes stay bit-identical.
+        const int lastax = MODE == 1 ? G.last : -1;
+        auto in_row_part = [&](const int4 R) {             // (wave-uniform)
+            return lastax >= 0 && (lastax == 0 ? R.x : lastax == 1 ? R.y : lastax == 2 ? R.z : R.w) == 0;
+        };
+        bool shared = false;
+        if constexpr (MODE == 1) {
+            bool same = true;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) nx[t] = nRr > 0 && t * 64 + lane < nsl ? mv.rblock[t * 64 + lane] : cd{0.0, 0.0};
-        for (int r = 0; r < nRr; ++r) {
-            const cd ph = phase_of_R(zk, mv.rvec[r]);
+            for (int d = 0; d < 3; ++d)
+                if (d < lastax) same = same && mi[d] == __builtin_amdgcn_readfirstlane(mi[d]);
+            shared = lastax >= 1 && __builtin_amdgcn_ballot_w64(!same && live) == 0;
+        }
+        auto stage_and_add = [&](const int r) {            // a[c] += U_r[slot(x, c)] e^{2 pi i k.R_r}, U_r through the exchange region
+            const cd ph = e16_phase_of_R(zk, mv.rvec[r]);
+            const cd* un = mv.rblock + (size_t)r * nsl;
+            cd nx[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) nx[t] = t * 64 + lane < nsl ? un[t * 64 + lane] : cd{0.0, 0.0};
             E16_ORDER();
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 if (t * 64 + lane < nsl) e16_put(wxch + t * 64 + lane, nx[t]);
             E16_ORDER();
-            if (r + 1 < nRr) {
-                const cd* un = mv.rblock + (size_t)(r + 1) * nsl;
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    if (t * 64 + lane < nsl) nx[t] = un[t * 64 + lane];
-            }
 #pragma unroll
             for (int c = 0; c < 16; ++c)
-                if (sidx[c] >= 0) cfma(a[c], e16_get(wxch + sidx[c]), ph);
+                if (sidx[c] >= 0) e16_cfma(a[c], e16_get(wxch + sidx[c]), ph);
+        };
+        if (shared) {
+            cd cs[3] = {cd{0.0, 0.0}, cd{0.0, 0.0}, cd{0.0, 0.0}};
+            for (int r = 0; r < nRr; ++r) {
+                const int4 R = mv.rvec[r];
+                if (!in_row_part(R)) continue;
+                const cd ph = e16_phase_of_R(zk, R);        // (no factor of the last axis: the same in every lane)
+                const cd* un = mv.rblock + (size_t)r * nsl;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (t * 64 + lane < nsl) e16_cfma(cs[t], un[t * 64 + lane], ph);
+            }
+            E16_ORDER();
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (t * 64 + lane < nsl) e16_put(wxch + t * 64 + lane, cs[t]);
+            E16_ORDER();
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (sidx[c] >= 0) a[c] = e16_get(wxch + sidx[c]);
+        } else {
+            for (int r = 0; r < nRr; ++r)
+                if (in_row_part(mv.rvec[r])) stage_and_add(r);
         }
+        for (int r = 0; r < nRr; ++r)
+            if (!in_row_part(mv.rvec[r])) stage_and_add(r);
         E16_ORDER();
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
