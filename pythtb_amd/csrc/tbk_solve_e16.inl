@@ -186,12 +186,10 @@ __device__ __forceinline__ void e16_house(cd (&a)[16], const int x, e16_lcd* rec
 template <int I>
 __device__ __forceinline__ void e16_count_step(const double (&d)[16], const double (&e2)[16], const int n, const double x, double& q,
                                                unsigned& acc) {
-    if (I < n) {                                         // (wave-uniform)
+    {
         const double r = __builtin_amdgcn_rcp(q);
         q = I == 0 ? d[0] - x : fma(-e2[I > 0 ? I - 1 : 0], r, d[I] - x);
         acc = __builtin_amdgcn_alignbit(acc, __double2hiint(q), 31);   // (acc << 1) | sign(q)
-    } else {
-        acc <<= 1;
     }
     if constexpr (I + 1 < 16) e16_count_step<I + 1>(d, e2, n, x, q, acc);
 }
@@ -210,13 +208,11 @@ __device__ __forceinline__ unsigned e16_signs(const double (&d)[16], const doubl
 template <int I>
 __device__ __forceinline__ void e16_count_poly_step(const double (&d)[16], const double (&e2)[16], const int n, const double x, double& p1,
                                                     double& p2, unsigned& acc) {
-    if (I < n) {                                         // (wave-uniform)
+    {
         const double p = I == 0 ? d[0] - x : fma(d[I] - x, p1, -e2[I > 0 ? I - 1 : 0] * p2);
         acc = __builtin_amdgcn_alignbit(acc, (unsigned)(__double2hiint(p) ^ __double2hiint(p1)), 31);
         p2 = p1;
         p1 = p;
-    } else {
-        acc <<= 1;
     }
     if constexpr (I + 1 < 16) e16_count_poly_step<I + 1>(d, e2, n, x, p1, p2, acc);
 }
@@ -234,7 +230,7 @@ __device__ __forceinline__ unsigned e16_signs_poly(const double (&d)[16], const 
 template <int I, bool BLOCK>
 __device__ __forceinline__ void e16_poly_step(const double (&d)[16], const double (&e2)[16], const int n, const int bl, const int bh,
                                               const double x, double& p1, double& p2, double& dp1, double& dp2, unsigned& sgn, unsigned& len) {
-    if (BLOCK ? (I >= bl && I <= bh) : I < n) {
+    if (!BLOCK || (I >= bl && I <= bh)) {
         const double t = d[I] - x;
         const double ee = I > 0 ? ((!BLOCK || I > bl) ? e2[I > 0 ? I - 1 : 0] : 0.0) : 0.0;
         const double p = fma(t, p1, -ee * p2);
@@ -292,47 +288,55 @@ __device__ double e16_dbg[64 * 16];
 // d, e: T of this lane's matrix (replicated over its 16 lanes); on return scaled by `scale` (a power of two: exact) with the
 // negligible couplings zeroed, lam = eigenvalue j of the scaled T, [bl, bh] its unreduced block.  flag: this lane could not do
 // its part (no convergence).  n: real states (rows n.. of T are decoupled padding and take no part).
-__device__ __forceinline__ void e16_eigenvalue(double (&d)[16], double (&e)[16], const int n, const int j, e16_lu2* xch /* [16] of this matrix */,
-                                               double& scale, double& lam, int& bl, int& bh, unsigned& split, bool& flag, const int64_t dbg_slot = -1) {
-    // ---- splits and scale
-    split = 0x8000u;
-    double tn = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (i < 15) {
-            const bool ng = !(fabs(e[i]) > 2.220446049250313e-16 * (fabs(d[i]) + fabs(d[i + 1]))) || i >= n - 1;
-            split |= ng ? (1u << i) : 0u;
-            e[i] = ng ? 0.0 : e[i];
-        }
-    }
-    e[15] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < n) tn = fmax(tn, fabs(d[i]) + (i > 0 ? fabs(e[i - 1]) : 0.0) + fabs(e[i]));
+__device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_in, double (&d)[16], double (&e)[16], const int n, const int j,
+                                               e16_lcd* xd /* [16] of this matrix */, double& scale, double& lam, int& bl, int& bh, unsigned& split,
+                                               bool& flag, const int64_t dbg_slot = -1) {
+    // ---- splits, scale and Gershgorin bounds, each lane for its own position j of T (then row reductions), the scaled
+    // (d_j, e_j) to every lane of the matrix through LDS.  (Every lane doing all 16 positions was 465 instructions.)
+    const int lane = threadIdx.x & 63;
+    const double dnext = e16_next(dd);                   // d_{j+1} (0 in lane 15)
+    const bool ng = !(fabs(ee_in) > 2.220446049250313e-16 * (fabs(dd) + fabs(dnext))) || j >= n - 1 || j >= 15;
+    split = (unsigned)(__builtin_amdgcn_ballot_w64(ng) >> (lane & 48)) & 0xffffu;   // bit i: e_i negligible in T (bit 15 always)
+    const double ee = ng ? 0.0 : ee_in;
+    const double rad = fabs(e16_prev(ee)) + fabs(ee);    // |e_{j-1}| + |e_j|
+    double tn = j < n ? fabs(dd) + rad : 0.0;
+    tn = fmax(tn, row_ror_d<8>(tn));
+    tn = fmax(tn, row_ror_d<4>(tn));
+    tn = fmax(tn, row_ror_d<2>(tn));
+    tn = fmax(tn, row_ror_d<1>(tn));
     {
         int ex = 0;
         (void)frexp(tn, &ex);                            // tn = m 2^ex, m in [1/2, 1)
         scale = tn > 0.0 && tn < INFINITY ? ldexp(1.0, -ex) : 1.0;
     }
-    double e2[16];
-    double gl = INFINITY, gu = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        d[i] *= scale;
-        e[i] *= scale;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        e2[i] = (split >> i) & 1u ? 1e-300 : e[i] * e[i];
-        if (i < n) {
-            const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + fabs(e[i]);
-            gl = fmin(gl, d[i] - rad);
-            gu = fmax(gu, d[i] + rad);
-        }
-    }
+    // (the padding rows of a matrix smaller than 16 sit at 2, above the scaled spectrum: decoupled, they never add to a
+    // count below 2 and the recurrences run over all 16 positions without asking)
+    const double ds = j < n ? dd * scale : 2.0, es = ee * scale;
+    double gl = j < n ? ds - rad * scale : INFINITY, gu = j < n ? ds + rad * scale : -INFINITY;
+    gl = fmin(gl, row_ror_d<8>(gl));
+    gu = fmax(gu, row_ror_d<8>(gu));
+    gl = fmin(gl, row_ror_d<4>(gl));
+    gu = fmax(gu, row_ror_d<4>(gu));
+    gl = fmin(gl, row_ror_d<2>(gl));
+    gu = fmax(gu, row_ror_d<2>(gu));
+    gl = fmin(gl, row_ror_d<1>(gl));
+    gu = fmax(gu, row_ror_d<1>(gu));
     // (a hair wider than Gershgorin's discs, so that the counts at the ends are 0 and n whatever the rounding)
     gl -= 1e-13;
     gu += 1e-13;
+    double e2[16];
+    E16_ORDER();
+    xd[j] = e16_d2{ds, es};
+    E16_ORDER();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const e16_d2 t = xd[i];
+        d[i] = t.x;
+        e[i] = t.y;
+        e2[i] = fmax(t.y * t.y, 1e-300);                 // (1e-300 at the splits: 0 x inf never appears among the pivots)
+    }
+    E16_ORDER();
+    e16_lu2* const xch = reinterpret_cast<e16_lu2*>(xd);
 
     E16_MARK(21);
     // ---- one multisection shared by the 16 lanes: lane j looks at point j of 16 inside (gl, gu)
@@ -344,7 +348,7 @@ __device__ __forceinline__ void e16_eigenvalue(double (&d)[16], double (&e)[16],
     xch[j] = e16_u2{(unsigned)__builtin_popcount(sj), sj};
     E16_ORDER();
     double lo = gl, hi = gu;
-    unsigned clo = 0, chi = (unsigned)n, slo = 0, shi = n >= 16 ? 0xffffu : (((1u << n) - 1u) << (16 - n));
+    unsigned clo = 0, chi = (unsigned)n, slo = 0, shi = n >= 16 ? 0xffffu : (((1u << n) - 1u) << (16 - n));   // (pivot i negative: bit 15 - i)
     {
         // m = points whose count is <= j (the counts do not decrease): eigenvalue j lies between points m-1 and m
         int m = 0;
@@ -443,7 +447,7 @@ __device__ __forceinline__ void e16_eigenvalue(double (&d)[16], double (&e)[16],
     for (int it = 0; it < E16_NEWTON_MAX; ++it) {
         if (__builtin_amdgcn_ballot_w64(!conv) == 0) break;
         double p1 = 1.0, p2 = 0.0, dp1 = 0.0, dp2 = 0.0;
-        unsigned sgn = 0, len = (unsigned)n;
+        unsigned sgn = 0, len = 16u;                      // (unsplit: all 16 positions, the padding ones never change sign)
         if (splits) {
             len = 0;
             e16_poly_step<0, true>(d, e2, n, bl, bh, x, p1, p2, dp1, dp2, sgn, len);
@@ -752,29 +756,14 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     const double dd = sel16<0>(a, x, cd{0.0, 0.0}).x;    // d_x = A[x][x]
     e16_put(rec + 119 + x, dx);
     E16_MARK(2);
-    // (d, e) of T to every lane of the matrix
     double d[16], e[16];
-    {
-        e16_lcd* const xd = wxch + mat * 16;
-        E16_ORDER();
-        xd[x] = e16_d2{dd, x < 15 ? ee : 0.0};
-        E16_ORDER();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const e16_d2 t = xd[i];
-            d[i] = t.x;
-            e[i] = t.y;
-        }
-        E16_ORDER();
-    }
-
+    E16_ORDER();
     // ---- 2. eigenvalue j (scaled T), 3. its eigenvector of T
     double scale = 1.0, lam = 0.0;
     int bl = 0, bh = 15;
     unsigned split = 0;
     bool flag = false;
-    if constexpr (!(E16_SKIP & 2)) e16_eigenvalue(d, e, n, j, reinterpret_cast<e16_lu2*>(wxch) + mat * 16, scale, lam, bl, bh, split, flag, slot_u);
-    else lam = qle_pick<0>(d, j, 0.0);
+    e16_eigenvalue(dd, x < 15 ? ee : 0.0, d, e, n, j, wxch + mat * 16, scale, lam, bl, bh, split, flag, slot_u);
     E16_MARK(3);
     double v[16], dlam = 0.0;
     bool bad = false;
