@@ -1223,11 +1223,56 @@ __global__ __launch_bounds__(64, 1) void k_chain_lu_wave(const ChainArgs A, cons
     if (lane == 0 && !dets_out) A.partial[seg * A.nstrings + s] = acc;
 }
 
+#include "tbk_berry_prod.inl"   // 5..8 bands, berry_phase: the ordered product of a string's link matrices on the matrix cores, no workspace
+
 // 5..8 bands of wide states: link matrices of a batch of strings -> workspace (nocc^2 c128 per link, at most ~1 GiB per
 // batch), then their determinants -- multiplied per (string, segment) into A.partial (dets_out == null: berry_phase) or
 // filed one by one under the link's first point (berry_flux).  A.seg_len / A.nseg must be set.
 static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A, int nocc, cd* dets_out) {
     const int nn = nocc * nocc;
+    // berry_phase of 5..8 bands (no per-link determinants wanted): the product form -- one nocc x nocc matrix per (string, segment)
+    // instead of one per link, no link-matrix workspace (TBK_CHAIN_PROD=0: the two kernels below)
+    {
+        const size_t lds_p1 = (size_t)(TBK_CHAINP_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd) + (size_t)TBK_CHAINP_G * 256 * sizeof(double);
+        if (!dets_out && nocc >= 5 && nocc <= 8 && tbk_knobs().chain_prod != 0 && 2 * lds_p1 <= 64 * 1024) {
+            const int64_t nw = A.nstrings * A.nseg;
+            const size_t wbytes = (size_t)nw * 64 * sizeof(cd);
+            if (wbytes > ctx->work_bytes) {
+                TBK_HIP(hipStreamSynchronize(ctx->stream));
+                if (ctx->work) TBK_HIP(hipFree(ctx->work));
+                ctx->work = nullptr;
+                ctx->work_bytes = 0;
+                hipError_t e = hipMalloc(&ctx->work, wbytes);
+                TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "string-product workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
+                ctx->work_bytes = wbytes;
+            }
+            cd* pw = (cd*)ctx->work;
+            const int nld = (nocc * v.ncomp + 63) / 64;
+            const dim3 gp((unsigned)((nw + 1) / 2)), gd((unsigned)((nw + 63) / 64));
+#define TBK_CHAINP(NN, LL)                                                                                                       \
+    {                                                                                                                            \
+        { ProfScope p1(ctx, "chain_prod"); hipLaunchKernelGGL((k_chain_prod_tile<NN, LL>), gp, dim3(128), 2 * lds_p1, ctx->stream, A, (int64_t)0, A.nstrings, pw); } \
+        { ProfScope p2(ctx, "chain_prod_det"); hipLaunchKernelGGL((k_chain_prod_det<NN>), gd, dim3(64), 0, ctx->stream, A, (int64_t)0, A.nstrings, (const cd*)pw); } \
+    }
+#define TBK_CHAINP_N(NN)                                  \
+    switch (nld) {                                        \
+        case 1: TBK_CHAINP(NN, 1) break;                  \
+        case 2: TBK_CHAINP(NN, 2) break;                  \
+        case 3: TBK_CHAINP(NN, 3) break;                  \
+        default: TBK_CHAINP(NN, 4) break;                 \
+    }
+            switch (nocc) {
+                case 5: TBK_CHAINP_N(5) break;
+                case 6: TBK_CHAINP_N(6) break;
+                case 7: TBK_CHAINP_N(7) break;
+                default: TBK_CHAINP_N(8) break;
+            }
+#undef TBK_CHAINP_N
+#undef TBK_CHAINP
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
+    }
     const size_t per_string = (size_t)A.nlinks * nn * sizeof(cd);
     const size_t ws_cap = (size_t)std::max(1, tbk_knobs().chain_ws_mb) << 20;
     const int64_t nsb = std::max<int64_t>(1, std::min<int64_t>(A.nstrings, (int64_t)(ws_cap / per_string)));

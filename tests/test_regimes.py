@@ -215,17 +215,30 @@ def test_links_four_per_step_equal_one_per_step(tb, norb, mesh):
     m = hp.random_model(tb.tb_model, norb, 3, 1, seed=norb, nhop=5 * norb, rmax=1)
     w = tb.wf_array(m, list(mesh))
     w.solve_on_grid([0.1, -0.2, 0.05])
+    host = w.to_host()
     for nocc in (5, 6, 7, 8):
         for d in (0, 1, 2):
             got = {}
-            for tile in (1, 0):
-                with _lib.knob("TBK_CHAIN_TILE", tile):
-                    got[tile] = np.asarray(w.berry_phase(range(nocc), d, contin=False))
+            with _lib.knob("TBK_CHAIN_PROD", 0):       # (the link-determinant form: the two link kernels)
+                for tile in (1, 0):
+                    with _lib.knob("TBK_CHAIN_TILE", tile):
+                        got[tile] = np.asarray(w.berry_phase(range(nocc), d, contin=False))
             assert np.array_equal(got[1], got[0]), (nocc, d)
-            if nocc == 6 and d == 2:
-                ref = np.asarray(orc.berry_phase(w.to_host(), 3, list(range(nocc)), d, contin=False))
-                dphi = (got[1] - ref + np.pi) % (2 * np.pi) - np.pi
+            # round 4's default: the string's matrix product on the matrix cores, ONE determinant per string like the reference
+            # (pythtb.py:3813-3831) -- the same phases to rounding, run to run the same bits
+            prod = np.asarray(w.berry_phase(range(nocc), d, contin=False))
+            assert np.array_equal(prod, np.asarray(w.berry_phase(range(nocc), d, contin=False)))
+            dphi = (prod - got[1] + np.pi) % (2 * np.pi) - np.pi
+            assert np.max(np.abs(dphi)) < 1e-12, (nocc, d, np.max(np.abs(dphi)))
+            if nocc in (5, 6, 8) and d in (0, 2):
+                ref = np.asarray(orc.berry_phase(host, 3, list(range(nocc)), d, contin=False))
+                dphi = (prod - ref + np.pi) % (2 * np.pi) - np.pi
                 assert np.max(np.abs(dphi)) < 1e-10
+    # bands that are not the lowest ones, in another order (the determinant does not care, the kernels index by occ[])
+    sel = [7, 2, 5, 0, 3]
+    a = np.asarray(w.berry_phase(sel, 1, contin=False))
+    ref = np.asarray(orc.berry_phase(host, 3, sel, 1, contin=False))
+    assert np.max(np.abs((a - ref + np.pi) % (2 * np.pi) - np.pi)) < 1e-10
 
 
 # ---------------------------------------------------------------------------------------------- input nobody can solve
