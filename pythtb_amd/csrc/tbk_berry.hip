@@ -761,12 +761,13 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     TBK_REQUIRE(nslices * A.bps < (int64_t)0x7fffffff, TBK_EUNSUPPORTED, "too many plaquette blocks");
     if (w->flux_nslices_cap < nslices) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
-        if (w->flux_totals_dev) TBK_HIP(hipFree(w->flux_totals_dev));
         if (w->flux_cnt_dev) TBK_HIP(hipFree(w->flux_cnt_dev));
-        w->flux_totals_dev = nullptr;
         w->flux_cnt_dev = nullptr;
         w->flux_nslices_cap = 0;
-        TBK_HIP(hipMalloc((void**)&w->flux_totals_dev, nslices * sizeof(double)));
+        {
+            const int rct = tbk_wfs_totals_alloc(w, nslices);
+            if (rct) return rct;
+        }
         TBK_HIP(hipMalloc((void**)&w->flux_cnt_dev, nslices * 16 * sizeof(unsigned)));
         TBK_HIP(hipMemsetAsync(w->flux_cnt_dev, 0, nslices * 16 * sizeof(unsigned), ctx->stream));
         w->flux_nslices_cap = nslices;
@@ -902,6 +903,11 @@ extern "C" int tbk_berry_flux_result(tbk_wfs* w, double* totals, double* plaq) {
         TBK_REQUIRE(w->flux_plaq_n > 0, TBK_EINVAL, "tbk_berry_flux_result: plaquettes were not requested");
         TBK_HIP(hipMemcpyAsync(plaq, w->flux_plaq_dev, w->flux_plaq_n * sizeof(double), hipMemcpyDeviceToHost,
                                ctx->stream));
+    }
+    if (w->flux_totals_host) {                       // mapped host memory: the kernel's stores were the transfer
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(totals, w->flux_totals_host, w->flux_nslices * sizeof(double));
+        return TBK_OK;
     }
     return tbk_small_d2h(ctx, totals, w->flux_totals_dev, w->flux_nslices * sizeof(double));
 }

@@ -191,6 +191,33 @@ int tbk_small_d2h(tbk_ctx* c, void* dst, const void* src_dev, size_t bytes) {
     return TBK_OK;
 }
 
+// The totals of a berry_flux launch (one double per slice): small ones live in mapped host memory, so that the kernel's own
+// stores are the transfer and tbk_berry_flux_result is one synchronisation and a read (a hipMemcpyAsync of 8 bytes is 10 us of
+// the 125 us two-call step at 2048^2)
+void tbk_wfs_totals_free(tbk_wfs* w) {
+    if (w->flux_totals_host) hipHostFree(w->flux_totals_host);
+    else if (w->flux_totals_dev) hipFree(w->flux_totals_dev);
+    w->flux_totals_host = nullptr;
+    w->flux_totals_dev = nullptr;
+}
+int tbk_wfs_totals_alloc(tbk_wfs* w, int64_t nslices) {
+    tbk_wfs_totals_free(w);
+    const size_t bytes = (size_t)std::max<int64_t>(nslices, 1) * sizeof(double);
+    if (bytes <= 64 * 1024 && tbk_knobs().zero_copy_kb > 0) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, bytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            w->flux_totals_host = (double*)h;
+            w->flux_totals_dev = (double*)d;
+            return TBK_OK;
+        }
+        (void)hipGetLastError();
+        if (h) hipHostFree(h);
+    }
+    TBK_HIP(hipMalloc((void**)&w->flux_totals_dev, bytes));
+    return TBK_OK;
+}
+
 int tbk_ctx_scratch(tbk_ctx* c, size_t bytes, void** out) {
     if (bytes > c->scratch_bytes) {
         TBK_HIP(hipStreamSynchronize(c->stream));
@@ -846,7 +873,7 @@ extern "C" int tbk_wfs_free(tbk_wfs* w) {
     if (w->gap_part_dev) hipFree(w->gap_part_dev);
     if (w->pbc_dev) hipFree(w->pbc_dev);
     if (w->tab_dev) hipFree(w->tab_dev);
-    if (w->flux_totals_dev) hipFree(w->flux_totals_dev);
+    tbk_wfs_totals_free(w);
     if (w->flux_cnt_dev) hipFree(w->flux_cnt_dev);
     if (w->flux_plaq_dev) hipFree(w->flux_plaq_dev);
     if (w->flux_partial_dev) hipFree(w->flux_partial_dev);

@@ -308,7 +308,8 @@ struct tbk_wfs {
     int64_t tab_cap = 0;
     std::vector<double> tab_key;
     // flux results
-    double* flux_totals_dev = nullptr;
+    double* flux_totals_dev = nullptr;   // device pointer of the per-slice totals; mapped HOST memory when small (flux_totals_host != null)
+    double* flux_totals_host = nullptr;  // ... its host address: the result is read after one synchronisation, no copy operation
     unsigned* flux_cnt_dev = nullptr;        // [slices][16] arrival tickets of the row kernel
     int64_t flux_nslices = 0, flux_nslices_cap = 0;
     double* flux_plaq_dev = nullptr;
@@ -316,6 +317,10 @@ struct tbk_wfs {
     double* flux_partial_dev = nullptr;
     int64_t flux_partial_cap = 0;
 };
+
+// tbk_core.hip: (re)allocate / release the per-slice flux totals (mapped host memory up to 64 KB, device memory beyond)
+int tbk_wfs_totals_alloc(struct tbk_wfs* w, int64_t nslices);
+void tbk_wfs_totals_free(struct tbk_wfs* w);
 
 // implemented in tbk_solve.hip: batched Hermitian eigen-solve, all pointers on the device
 // (eval[n][nk], evec[n][nk][n]); tbk_eigh_check reports Jacobi non-convergence

@@ -2061,11 +2061,12 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         w->gap_part_n = G.ntiles;
         if (w->flux_nslices_cap < 1) {
             TBK_HIP(hipStreamSynchronize(ctx->stream));
-            if (w->flux_totals_dev) TBK_HIP(hipFree(w->flux_totals_dev));
             if (w->flux_cnt_dev) TBK_HIP(hipFree(w->flux_cnt_dev));
-            w->flux_totals_dev = nullptr;
             w->flux_cnt_dev = nullptr;
-            TBK_HIP(hipMalloc((void**)&w->flux_totals_dev, sizeof(double)));
+            {
+                const int rct = tbk_wfs_totals_alloc(w, 1);
+                if (rct) return rct;
+            }
             TBK_HIP(hipMalloc((void**)&w->flux_cnt_dev, 16 * sizeof(unsigned)));
             TBK_HIP(hipMemsetAsync(w->flux_cnt_dev, 0, 16 * sizeof(unsigned), ctx->stream));
             w->flux_nslices_cap = 1;
@@ -2202,15 +2203,30 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
 static int solve_grid_result_once(tbk_wfs* w, double* min_gaps, bool can_retry) {
     tbk_ctx* ctx = w->ctx;
     if (w->gap_part_n > 0 && w->gaps_n > 0 && min_gaps) {   // the row kernel left per-tile minima
-        void* base = nullptr;
-        int rc = tbk_ctx_scratch(ctx, 256 + (size_t)w->gaps_n * sizeof(double), &base);
+        // the reduced gaps go straight into the context's mapped host buffer when there is one: the kernel's stores are the
+        // transfer, one synchronisation, no copy operation
+        const size_t gb = (size_t)w->gaps_n * sizeof(double);
+        void* zh = nullptr;
+        void* zd = nullptr;
+        int rc = tbk_knobs().zero_copy_kb > 0 ? tbk_ctx_zero_copy(ctx, gb, &zh, &zd) : TBK_OK;
         if (rc) return rc;
-        double* out_dev = (double*)((unsigned char*)base + 256);
+        double* out_dev = (double*)zd;
+        if (!zh) {
+            void* base = nullptr;
+            rc = tbk_ctx_scratch(ctx, 256 + gb, &base);
+            if (rc) return rc;
+            out_dev = (double*)((unsigned char*)base + 256);
+        }
         hipLaunchKernelGGL(k_gap_part_reduce, dim3(w->gaps_n), dim3(1024), 0, ctx->stream, w->gap_part_dev, w->gap_part_n,
                            w->gaps_n, out_dev);
         TBK_HIP(hipGetLastError());
-        rc = tbk_small_d2h(ctx, min_gaps, out_dev, (size_t)w->gaps_n * sizeof(double));
-        if (rc) return rc;
+        if (zh) {
+            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            memcpy(min_gaps, zh, gb);
+        } else {
+            rc = tbk_small_d2h(ctx, min_gaps, out_dev, gb);
+            if (rc) return rc;
+        }
         return check_noconv(ctx, w->view.nsta);
     }
     const size_t half = (size_t)TBK_GAP_SHARDS * w->view.ncomp;

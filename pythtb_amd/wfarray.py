@@ -288,10 +288,7 @@ class wf_array(object):
         if start.shape != (self._dim_arr,):
             raise Exception("\n\nk-vector of wrong shape!")
         n = m._nsta
-        pbc = np.zeros((self._dim_arr, n), dtype=complex)
-        for d in range(self._dim_arr):
-            fac = np.exp(-2.j * np.pi * self._orb[:, m._per[d]])     # pythtb.py:2729
-            pbc[d] = np.repeat(fac, self._nspin)
+        pbc = self._pbc_phases()
         h = self._dev_handle(self._shape())
         gaps = np.zeros(max(n - 1, 1), dtype=float)
         n0 = int(self._mesh_arr[0])
@@ -301,6 +298,20 @@ class wf_array(object):
         if n <= 1:
             return None
         return gaps[:n - 1]
+
+    def _pbc_phases(self):
+        """exp(-2 pi i orb[:, per[d]]) per mesh axis and state (pythtb.py:2729), kept between calls (the orbital positions of
+        a wf_array are copied at construction; `_per` and the positions are compared)."""
+        m = self._model
+        key = (tuple(int(x) for x in m._per[:self._dim_arr]), self._orb.tobytes(), self._nspin)
+        c = getattr(self, "_pbc_cache", None)
+        if c is not None and c[0] == key:
+            return c[1]
+        pbc = np.zeros((self._dim_arr, m._nsta), dtype=complex)
+        for d in range(self._dim_arr):
+            pbc[d] = np.repeat(np.exp(-2.j * np.pi * self._orb[:, m._per[d]]), self._nspin)
+        self._pbc_cache = (key, pbc)
+        return pbc
 
     def solve_on_grid_flux(self, start_k, occ="All"):
         """Extension (not in the reference): `solve_on_grid(start_k)` and `berry_flux(occ)` of a 2-D array in ONE pass over

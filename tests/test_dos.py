@@ -143,3 +143,34 @@ def test_dos_argument_checks(tb):
         m.solve_all_mesh([0, 4])
     with pytest.raises(Exception, match="bins"):
         m.dos_mesh([4, 4], 0)
+
+
+def test_solve_all_on_the_untouched_uniform_mesh_uploads_nothing(tb):
+    """configs[1]'s drop-in call `m.solve_all(m.k_uniform_mesh([N, N]))` (examples/haldane.py:96-100): the k list is generated
+    on the device -- no 16-bytes-per-k upload, the same eigenvalues as the list path bit for bit -- while
+    a copy of the mesh, or the mesh after any write, takes the list path."""
+    from pythtb_amd import _lib
+    ctx = _lib.default_context()
+    for m, mesh in ((hp.haldane(tb.tb_model, 0.2), [300, 200]), (hp.kane_mele(tb.tb_model, "odd"), [64, 48]),
+                    (hp.chain3(tb.tb_model, -1.0, 2.0, 0.3), [501]), (hp.cubic16(tb.tb_model), [6, 5, 7])):
+        k = m.k_uniform_mesh(mesh)
+        plain = np.array(k)                                # an ordinary copy: the list path
+        m.solve_all(plain[:3])                             # (model tables on the device before the counters are read)
+        ctx.transfer_stats(reset=True)
+        ev = m.solve_all(k)
+        st = ctx.transfer_stats(reset=True)
+        assert st["h2d_bytes"] < 1024, st
+        ev_list = m.solve_all(plain)
+        st2 = ctx.transfer_stats(reset=True)
+        assert st2["h2d_bytes"] >= plain.nbytes
+        assert ev.shape == ev_list.shape and np.array_equal(ev, ev_list)
+        ev2, vec2 = m.solve_all(k, eig_vectors=True)
+        evl, vecl = m.solve_all(plain, eig_vectors=True)
+        assert np.array_equal(ev2, evl) and vec2.shape == vecl.shape and np.array_equal(vec2, vecl)
+        # a write drops the note: the (shifted) list is uploaded and solved as a list
+        k[1] += 0.25
+        ctx.transfer_stats(reset=True)
+        ev3 = m.solve_all(k)
+        assert ctx.transfer_stats()["h2d_bytes"] >= plain.nbytes
+        plain[1] += 0.25
+        assert np.array_equal(ev3, m.solve_all(plain)) and not np.array_equal(ev3[:, 1], ev[:, 1])

@@ -229,6 +229,46 @@ def test_wf_array_host_side():
     assert w[1, 2][0, 1] == 4 and w._wfs[1, 2, 0, 0] == 2 and w[2, 3][1, 0] == 7 and w._wfs[2, 3, 1, 0] == 7
 
 
+def test_uniform_mesh_array_remembers_its_mesh_until_it_may_have_changed():
+    """k_uniform_mesh returns the reference's array (pythtb.py:1792-1861) with a note of which mesh it is, so that
+    solve_all(k_uniform_mesh(mesh)) can generate the list on the device; every way of changing the array drops the note
+    (host-side logic only: no device call here)."""
+    import copy
+    import pickle
+    from pythtb_amd.model import _UniformMeshArray as U
+    m = hp.haldane(tb.tb_model, 0.2)
+    ref = np.divide(np.indices((4, 6)).reshape(2, -1).T, np.array([4.0, 6.0]))
+    k = m.k_uniform_mesh([4, 6])
+    assert isinstance(k, np.ndarray) and k.flags.writeable and k.flags["C_CONTIGUOUS"] and np.array_equal(k, ref)
+    assert repr(k) == repr(ref) and str(k) == str(ref)
+    assert U._untouched_mesh(k, 2) == (4, 6) and U._untouched_mesh(k, 3) is None
+    # derived arrays are ordinary arrays / carry no note
+    assert type(k + 1.0) is np.ndarray and type(k.sum()) is np.float64 and type(np.mean(k, axis=0)) is np.ndarray
+    for derived in (k.copy(), k[3:], k.T, k.reshape(4, 6, 2), copy.deepcopy(k), pickle.loads(pickle.dumps(k)), np.array(k)):
+        assert U._untouched_mesh(derived, 2) is None
+    assert U._untouched_mesh(k, 2) == (4, 6)                         # ... and looking at them changed nothing
+    # every write drops the note
+    def fresh():
+        return m.k_uniform_mesh([4, 6])
+    cases = []
+    a = fresh(); a[2, 0] = 0.9; cases.append(a)
+    a = fresh(); b = a; b += 0.0; cases.append(a)
+    a = fresh(); v = a[1:3]; v[0, 0] = 5.0; cases.append(a)          # through a view
+    a = fresh(); a.T[0, 5] = 7.0; cases.append(a)
+    a = fresh(); np.copyto(a, 0.0); cases.append(a)
+    a = fresh(); a.fill(0.5); cases.append(a)
+    a = fresh(); np.add(a, 1.0, out=a); cases.append(a)
+    a = fresh(); np.multiply(a[::2], 2.0, out=a[::2]); cases.append(a)
+    a = fresh(); a.sort(axis=0); cases.append(a)
+    a = fresh(); np.put(a, [3], [9.0]); cases.append(a)
+    a = fresh(); np.asarray(a)[0, 1] = 3.0; cases.append(a)         # a base-class alias: caught by the sampled rows
+    for c in cases:
+        assert U._untouched_mesh(c, 2) is None
+    assert U._untouched_mesh(m.k_uniform_mesh([3, 5]), 2) == (3, 5)
+    m1 = hp.chain3(tb.tb_model, -1.0, 2.0, 0.3)
+    assert U._untouched_mesh(m1.k_uniform_mesh([7]), 1) == (7,)
+
+
 def test_z2_index_from_the_reference_wannier_centres():
     """Z2 from the `wan_cent` arrays the reference's own kane_mele test holds (tests/test_examples/kane_mele: index 0
     "even", 1 "odd"; centres in units of 2 pi on 41 strings) and from the full-size configs[3] array captured from
