@@ -82,13 +82,22 @@ def single_gpu(which, reps):
                 fn()
                 best = min(best, time.perf_counter() - t0)
             return best
-        t_host = wall(lambda: m.solve_all(k))                          # k uploaded, eigenvalues downloaded
+        t_host = wall(lambda: m.solve_all(k))                          # the drop-in call: k is the untouched k_uniform_mesh array, so the list is generated on the device
+        ctx.prof_enable(1)
+        ctx.prof_reset()
+        m.solve_all(k)
+        prof_mesh = {kk: v["total_ms"] / max(v["launches"], 1) for kk, v in ctx.prof_report().items()}
+        ctx.prof_enable(0)
+        kplain = np.array(k)
+        t_list = wall(lambda: m.solve_all(kplain))                     # the same through the list path (k uploaded)
         t_mesh = wall(lambda: m.solve_all_mesh([1024, 1024]))          # k generated on the device
         t_dos = wall(lambda: m.dos_mesh([1024, 1024], 50, range=(-4.0, 4.0)))   # nothing bulky crosses PCIe
         out.append({"config": "B: Haldane solve_all 1024^2", "nk": nk, "eval_only_ms": t_val, "with_vectors_ms": t_vec,
                     "kpts_per_s_eval": nk / t_val * 1e3, "kpts_per_s_vec": nk / t_vec * 1e3,
                     "hbm_GBs_eval": 32 * nk / t_val / 1e6, "hbm_GBs_vec": 96 * nk / t_vec / 1e6,
                     "python_call_incl_pcie_s": t_host, "kpts_per_s_python_call": nk / t_host,
+                    "python_call_list_path_s": t_list, "mesh_path_kernels_ms": prof_mesh,
+                    "mesh_evals_hbm_GBs": 32 * nk / prof_mesh["mesh_evals"] / 1e6 if "mesh_evals" in prof_mesh else None,
                     "solve_all_mesh_call_s": t_mesh, "dos_mesh_call_s": t_dos, "kpts_per_s_dos_call": nk / t_dos})
     if "C" in which or "D" in which:
         for tag, model, mesh, occ in (("C: Haldane 2048^2", hp.haldane(tb.tb_model, 0.0), [2049, 2049], [0]),

@@ -70,6 +70,7 @@ static void knobs_parse() {
     geti("TBK_CHAIN_WAVE", k.chain_wave);
     geti("TBK_CHAIN_TILE", k.chain_tile);
     geti("TBK_CHAIN_PROD", k.chain_prod);
+    geti("TBK_MESH_ROWS", k.mesh_rows);
     geti("TBK_TRIGV_FROM", k.trigv_from);
     geti("TBK_CHAIN_WS_MB", k.chain_ws_mb);
     geti("TBK_CHAIN_WAVE_FROM", k.chain_wave_from);

@@ -190,6 +190,12 @@ static int mesh_solve_dev(tbk_model* m, const int32_t* mesh, bool vec, size_t ex
     *v_dev = vec ? (double*)(p + al(kb) + al(eb)) : nullptr;
     if (extra_dev) *extra_dev = p + al(kb) + al(eb) + al(vb);
     *nk_out = nk;
+    if (!vec) {          // eigenvalues only, up to 4 states: straight from the mesh (k_mesh_evals), no k list at all
+        bool done = false;
+        rc = tbk_mesh_evals_rows(m, mesh, *e_dev, &done);
+        if (rc) return rc;
+        if (done) return tbk_eigh_check(ctx, n);
+    }
     rc = tbk_k_uniform_mesh_dev(ctx, d, mesh, *k_dev);
     if (rc) return rc;
     return tbk_solve_list_dev_checked(m, *k_dev, nk, *e_dev, *v_dev);

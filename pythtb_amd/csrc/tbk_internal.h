@@ -73,6 +73,7 @@ struct TbkKnobs {
     int flux_fused = 0;         // TBK_FLUX_FUSED    1: final flux sum inside the kernel
     int trigv_from = -1;        // TBK_TRIGV_FROM    smallest n of the workgroup-scale direct eigenvector path (default 65; A/B runs down to 17)
     int chain_ws_mb = 1024;     // TBK_CHAIN_WS_MB   link-matrix workspace per batch of strings, MiB
+    int mesh_rows = 1;          // TBK_MESH_ROWS     0: eigenvalues on a generated uniform mesh by the list kernel on the generated list instead of the row kernel k_mesh_evals
     int chain_prod = 1;         // TBK_CHAIN_PROD    0: det-type berry_phase of 5..8 wide bands by link determinants (k_chain_links_tile + k_chain_lu_wave, a link-matrix workspace) instead of the string's matrix product on the matrix cores
     int chain_tile = 1;         // TBK_CHAIN_TILE    0: one link per wavefront step (k_chain_links_wave) also for 5..8 bands
     int chain_wave = 1;         // TBK_CHAIN_WAVE    0: thread-per-string link determinants also for 1..8 bands of wide (>= 8 component) states
@@ -318,6 +319,8 @@ struct tbk_wfs {
     int64_t flux_partial_cap = 0;
 };
 
+// tbk_solve.hip: eigenvalues on k_uniform_mesh(mesh) by the row kernel (n <= 4); *done = false where it does not apply
+int tbk_mesh_evals_rows(struct tbk_model* m, const int32_t* mesh, double* e_dev, bool* done);
 // tbk_core.hip: (re)allocate / release the per-slice flux totals (mapped host memory up to 64 KB, device memory beyond)
 int tbk_wfs_totals_alloc(struct tbk_wfs* w, int64_t nslices);
 void tbk_wfs_totals_free(struct tbk_wfs* w);

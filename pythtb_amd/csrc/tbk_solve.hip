@@ -911,6 +911,180 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     }
 }
 
+// ---- eigenvalues of the model on k_uniform_mesh(mesh) (solve_all on the mesh the model itself generated, configs[1]): the
+// tile scheme and the row-polynomial assembly of k_grid_rows with nothing but the eigenvalues going out -- eval[band][point],
+// 8 bytes per lane and band, coalesced.  No k list is read (the list kernel read 8 d bytes per point of a list the device had
+// just generated) and no exp(2 pi i x) is evaluated per point (the per-axis tables).  k_d = i / N_d comes out of the tables as
+// the window [0, N_d) of a global mesh of N_d + 1 points anchored at 0: (double)g / (double)N_d, the generator's own expression.
+template <int N, int PM>
+__global__ __launch_bounds__(256) void k_mesh_evals(const ModelView mv, const GridArgs G, double* __restrict__ eval) {
+    extern __shared__ __align__(16) unsigned char lds_rows[];
+    constexpr int NSLOT = N * (N + 1) / 2;
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pmax = PM >= 0 ? PM : mv.pmax;
+    const int npow = 2 * pmax + 1;
+    const int ncell = NSLOT * npow;
+    cd* C = reinterpret_cast<cd*>(lds_rows) + wib * ncell;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wib;
+    const bool live = tile < G.ntiles;
+    const int last = G.last;
+    const int nlast = G.wv.mesh[last];
+    unsigned row = 0;
+    int jc0 = 0, jc1 = 0;
+    if (live) {
+        row = (unsigned)(tile / G.tpr);
+        const int ts = (int)(tile - (int64_t)row * G.tpr);
+        jc0 = ts * G.seg;
+        jc1 = min(jc0 + G.seg, G.cpr);
+        cd z[4] = {cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}, cd{1.0, 0.0}};
+        unsigned rem = row;
+#pragma unroll
+        for (int d = 2; d >= 0; --d) {
+            if (d < last) {
+                const unsigned md = (unsigned)G.wv.mesh[d];
+                const unsigned q = rem / md;
+                z[d] = G.tz[d][rem - q * md];
+                rem = q;
+            }
+        }
+        for (int cell = lane; cell < ncell; cell += 64) {
+            const int t0 = mv.cell_ptr[cell], t1 = mv.cell_ptr[cell + 1];
+            cd acc{0.0, 0.0};
+            for (int t = t0; t < t1; ++t) {
+                int4 R = mv.term_R[t];
+                if (last == 0) R.x = 0; else if (last == 1) R.y = 0; else if (last == 2) R.z = 0; else R.w = 0;
+                cfma(acc, mv.term_amp[t], phase_of_R(z, R));
+            }
+            C[cell] = acc;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    for (int jc = jc0; jc < jc1; ++jc) {
+        const int j = jc * 64 + lane;
+        const cd zl = G.tz[last][min(j, nlast - 1)];
+        SmallMat<N> M;
+        int slot = 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+#pragma unroll
+            for (int b = a; b < N; ++b, ++slot) {
+                const cd* Cs = C + slot * npow + pmax;
+                cd acc = Cs[0];
+                cd zp = zl;
+                if constexpr (PM >= 0) {
+#pragma unroll
+                    for (int p = 1; p <= PM; ++p) {
+                        cfma(acc, Cs[p], zp);
+                        cfma(acc, Cs[-p], cconj(zp));
+                        if (p < PM) zp = cmul(zp, zl);
+                    }
+                } else {
+                    for (int p = 1; p <= pmax; ++p) {
+                        cfma(acc, Cs[p], zp);
+                        cfma(acc, Cs[-p], cconj(zp));
+                        zp = cmul(zp, zl);
+                    }
+                }
+                if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
+            }
+        }
+        if constexpr (N > 2) {
+            if (!jacobi_small<N, false>(M) && G.flags) G.flags[0] = 1;
+            sort_small<N>(M);
+        } else {
+            jacobi_small<N, false>(M);
+        }
+        if (j < nlast) {
+            const int64_t point = (int64_t)row * nlast + j;
+#pragma unroll
+            for (int b = 0; b < N; ++b) eval[(int64_t)b * G.wv.npts + point] = M.dg[b];
+        }
+    }
+}
+
+// eigenvalues of `m` on k_uniform_mesh(mesh) into e_dev[nsta][nk] by k_mesh_evals; *done = false (and nothing launched) where it
+// does not apply (more than 4 states, a cell table beyond 48 KB of LDS, TBK_MESH_ROWS=0): the caller solves the generated list
+int tbk_mesh_evals_rows(tbk_model* m, const int32_t* mesh, double* e_dev, bool* done) {
+    *done = false;
+    tbk_ctx* ctx = m->ctx;
+    const int n = m->nsta, D = m->dim_k;
+    if (n < 1 || n > 4 || D < 1 || D > 3 || tbk_knobs().mesh_rows == 0) return TBK_OK;
+    const size_t lds = (size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) * sizeof(cd);
+    if (lds > 48 * 1024) return TBK_OK;
+    GridArgs G{};
+    WfsView& v = G.wv;
+    v.dim_arr = D;
+    v.nsta = n;
+    v.ncomp = n;
+    v.npts = 1;
+    int64_t ntab = 0;
+    for (int d = 0; d < D; ++d) {
+        v.mesh[d] = mesh[d];
+        G.gmesh[d] = mesh[d] + 1;              // k_d = g / N_d: the first N_d points of a global mesh of N_d + 1 anchored at 0
+        G.off[d] = 0;
+        G.start_k[d] = 0.0;
+        v.npts *= mesh[d];
+        ntab += mesh[d];
+    }
+    for (int d = D; d < TBK_MAX_DIM; ++d) v.mesh[d] = 1;
+    if (v.npts / mesh[D - 1] >= (int64_t)0xffffffffu) return TBK_OK;
+    // per-axis tables in the context's work area (tz | tf); tf (orbital phases) is written by k_grid_tables and not used here
+    const size_t tbytes = (size_t)ntab * (1 + n) * sizeof(cd) + (size_t)TBK_MAX_DIM * n * sizeof(cd);
+    if (tbytes > ctx->work_bytes) {
+        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->work) TBK_HIP(hipFree(ctx->work));
+        ctx->work = nullptr;
+        ctx->work_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->work, std::max(tbytes, (size_t)1 << 20));
+        TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "mesh tables of %zu bytes: %s", tbytes, hipGetErrorString(e));
+        ctx->work_bytes = std::max(tbytes, (size_t)1 << 20);
+    }
+    cd* tab = (cd*)ctx->work;
+    cd* pbc = tab + ntab * (1 + n);
+    TBK_HIP(hipMemsetAsync(pbc, 0, (size_t)TBK_MAX_DIM * n * sizeof(cd), ctx->stream));
+    G.pbc = pbc;
+    {
+        int64_t zo = 0, fo = ntab;
+        for (int d = 0; d < D; ++d) {
+            G.tz[d] = tab + zo;
+            G.tf[d] = tab + fo;
+            zo += mesh[d];
+            fo += (int64_t)mesh[d] * n;
+        }
+    }
+    G.flags = ctx->flags_dev;
+    G.last = D - 1;
+    G.cpr = (mesh[D - 1] + 63) / 64;
+    const int64_t nrows = v.npts / mesh[D - 1];
+    G.nchunks = nrows * G.cpr;
+    const int64_t want = (int64_t)ctx->cus * 32;
+    G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, G.cpr), G.nchunks / want));
+    G.tpr = (G.cpr + G.seg - 1) / G.seg;
+    G.seg = (G.cpr + G.tpr - 1) / G.tpr;
+    G.ntiles = nrows * G.tpr;
+    {
+        ProfScope ps(ctx, "grid_tables");
+        hipLaunchKernelGGL(k_grid_tables, dim3((unsigned)((ntab + 255) / 256)), dim3(256), 0, ctx->stream, m->view, G, tab, tab + ntab);
+    }
+    const unsigned blocks = (unsigned)((G.ntiles + 3) / 4);
+    const int pm = m->view.pmax;
+    {
+        ProfScope ps(ctx, "mesh_evals");
+#define TBK_MEV(NN, PP) hipLaunchKernelGGL((k_mesh_evals<NN, PP>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G, e_dev)
+        switch (n) {
+            case 1: if (pm == 0) TBK_MEV(1, 0); else if (pm == 1) TBK_MEV(1, 1); else TBK_MEV(1, -1); break;
+            case 2: if (pm == 0) TBK_MEV(2, 0); else if (pm == 1) TBK_MEV(2, 1); else TBK_MEV(2, -1); break;
+            case 3: if (pm == 1) TBK_MEV(3, 1); else TBK_MEV(3, -1); break;
+            default: if (pm == 1) TBK_MEV(4, 1); else TBK_MEV(4, -1); break;
+        }
+#undef TBK_MEV
+    }
+    TBK_HIP(hipGetLastError());
+    *done = true;
+    return TBK_OK;
+}
+
 // ---------------------------------------------------------------------------
 // S(k) of one point (or the supplied matrix, MODE 2) into the LDS matrix A[n][ld], by the NT threads of a
 // workgroup; `ph` is scratch for max(nR, 1) phases.  The last writes are NOT followed by a barrier.

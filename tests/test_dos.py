@@ -160,17 +160,27 @@ def test_solve_all_on_the_untouched_uniform_mesh_uploads_nothing(tb):
         ev = m.solve_all(k)
         st = ctx.transfer_stats(reset=True)
         assert st["h2d_bytes"] < 1024, st
+        ctx.prof_enable(1)
+        ctx.prof_reset()
         ev_list = m.solve_all(plain)
-        st2 = ctx.transfer_stats(reset=True)
-        assert st2["h2d_bytes"] >= plain.nbytes
-        assert ev.shape == ev_list.shape and np.array_equal(ev, ev_list)
+        names = set(ctx.prof_report())
+        assert not any(nm.startswith("mesh_evals") or nm == "k_mesh" for nm in names), names     # the list path: no mesh kernels
+        ctx.prof_reset()
+        m.solve_all(m.k_uniform_mesh(mesh))
+        names = set(ctx.prof_report())
+        ctx.prof_enable(0)
+        assert ("mesh_evals" in names) == (m._nsta <= 4) and not any(nm.startswith("solve_list") for nm in names) == (m._nsta <= 4), names
+        # (eigenvalues alone of up to 4 states come from the row kernel k_mesh_evals -- the mesh's separable phases, no k list at
+        # all: equal to the list kernel's to rounding; everything else is the list kernel on the generated list: the same bits)
+        assert ev.shape == ev_list.shape and np.max(np.abs(ev - ev_list)) < 1e-13
+        assert m._nsta <= 4 or np.array_equal(ev, ev_list)
+        with _lib.knob("TBK_MESH_ROWS", 0):
+            assert np.array_equal(m.solve_all(m.k_uniform_mesh(mesh)), ev_list)
         ev2, vec2 = m.solve_all(k, eig_vectors=True)
         evl, vecl = m.solve_all(plain, eig_vectors=True)
         assert np.array_equal(ev2, evl) and vec2.shape == vecl.shape and np.array_equal(vec2, vecl)
         # a write drops the note: the (shifted) list is uploaded and solved as a list
         k[1] += 0.25
-        ctx.transfer_stats(reset=True)
         ev3 = m.solve_all(k)
-        assert ctx.transfer_stats()["h2d_bytes"] >= plain.nbytes
         plain[1] += 0.25
         assert np.array_equal(ev3, m.solve_all(plain)) and not np.array_equal(ev3[:, 1], ev[:, 1])
