@@ -2,7 +2,8 @@
 """Secondary measurements: the other BASELINE.json configs (device-resident timings from HIP events on the
 library's stream; not the driver's headline line -- that is bench.py).  One JSON object per config.
 
-    python bench_configs.py [B] [C] [D] [E] [R] [--reps 5]             one GPU (R: ribbons / mid-size meshes, not in BASELINE.json)
+    python bench_configs.py [B] [C] [D] [E] [R] [W] [H] [--reps 5]     one GPU (not in BASELINE.json: R ribbons / mid-size meshes, W the
+                                                                        Wannier90 silicon model, H hybrid Wannier centres (8f-1))
     python bench_configs.py --gpus N [B] [D] [E] [--side 257]           N GPUs, one process each (starts its own ranks; the
                                                                         same under torch.distributed.run --nproc-per-node N)
 
@@ -154,6 +155,84 @@ def single_gpu(which, reps):
                     "kpts_per_s": nk / t_solve * 1e3, "berry_phase_8band_call_ms": t_phase * 1e3,
                     "links_per_s": 65 * 65 * 64 / t_phase})
         _lib.check(lib.tbk_wfs_free(hw))
+    if "W" in which:
+        # (not a BASELINE config) SURVEY.md 8f-4: the Wannier90 importer's regime -- silicon, 8 Wannier functions, 2972 hopping terms
+        # (website/local/w90_example/example_a, committed under tests/golden/w90_silicon): the long hopping table is where H(k)
+        # assembly dominates.  solve_all eigenvalues on a 48^3 uniform mesh (k generated on the device) and solve_on_grid on 65^3.
+        HBM, VALU = 8000.0, 256 * 4 * 2.4e9 / 4.0
+        with contextlib.redirect_stdout(io.StringIO()):
+            si = tb.w90(os.path.join(_ROOT, "tests", "golden", "w90_silicon"), "silicon")
+            m = si.model()
+        hm = m._device_model()
+        nterm = len(m._hoppings)
+        mesh = np.array([48, 48, 48], dtype=np.int32)
+        nk = int(np.prod(mesh))
+        kd, ed = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 3 * 8, C.byref(kd)))
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 8 * 8, C.byref(ed)))
+        _lib.check(lib.tbk_k_uniform_mesh_dev(ctx.handle, 3, _lib.iptr(mesh), kd))
+        t_list = timed(ctx, lambda: _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None)), reps)
+        G = 65
+        hw, pbc = grid_handle(_lib, lib, ctx, m, [G, G, G])
+        start = np.zeros(3)
+        t_grid = timed(ctx, lambda: _lib.check(lib.tbk_wfs_solve_grid_async(hw, hm, _lib.dptr(start), _lib.dptr(pbc.view(float)), 0, G)), max(1, reps // 2))
+        ctx.prof_enable(1)
+        ctx.prof_reset()
+        _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None))
+        _lib.check(lib.tbk_wfs_solve_grid_async(hw, hm, _lib.dptr(start), _lib.dptr(pbc.view(float)), 0, G))
+        ctx.sync()
+        kern = {kk: v["total_ms"] for kk, v in ctx.prof_report().items()}
+        ctx.prof_enable(0)
+        # the assembly: one complex multiply-add (8 flops) per merged (slot, R) term and k-point; the R-grouped table holds
+        # nR x 36 slots of 16 bytes and is read once per k-point through scalar loads (L2)
+        out.append({"config": "W: w90 silicon (8 Wannier functions, %d hopping terms): solve_all 48^3 (eigenvalues) + solve_on_grid 65^3" % nterm,
+                    "nterm": nterm, "nk_list": nk, "solve_list_eval_ms": t_list, "kpts_per_s_list": nk / t_list * 1e3,
+                    "term_evals_per_s_list": nk / t_list * 1e3 * nterm,
+                    "grid": G, "solve_on_grid_ms": t_grid, "kpts_per_s_grid": G ** 3 / t_grid * 1e3,
+                    "term_evals_per_s_grid": G ** 3 / t_grid * 1e3 * nterm, "kernels_ms": kern,
+                    "roofline": {"solve_list": {"bound": "fp64 VALU issue (the assembly's multiply-adds and the 8 x 8 Jacobi); the table streams from L2 by scalar loads",
+                                                "hbm_frac": 8 * (3 + 8) * nk / (t_list * 1e-3) / 1e9 / HBM, "algorithmic_bytes_per_k": 8 * (3 + 8),
+                                                "assembly_useful_tflops": 8.0 * nterm * nk / (t_list * 1e-3) / 1e12},
+                                 "solve_grid": {"bound": "fp64 VALU issue", "hbm_frac": 16 * 64 * G ** 3 / (t_grid * 1e-3) / 1e9 / HBM,
+                                                "algorithmic_bytes_per_k": 16 * 64,
+                                                "assembly_useful_tflops": 8.0 * nterm * G ** 3 / (t_grid * 1e-3) / 1e12}}})
+        _lib.check(lib.tbk_wfs_free(hw))
+        _lib.check(lib.tbk_dev_free(ctx.handle, kd))
+        _lib.check(lib.tbk_dev_free(ctx.handle, ed))
+    if "H" in which:
+        # (not a BASELINE config) SURVEY.md 8f-1: hybrid Wannier centres of a cubic slab on a 2-D mesh (examples/cubic_slab_hwf.py's loop as
+        # ONE batched call on the resident array): position matrix of the occupied block + its small eigen-solve per mesh point
+        HBM = 8000.0
+        with contextlib.redirect_stdout(io.StringIO()):
+            m3 = tb.tb_model(3, 3, np.identity(3), [[0, 0, 0]])
+            for Rv in ([1, 0, 0], [0, 1, 0], [0, 0, 1]):
+                m3.set_hop(-1.0, 0, 0, Rv)
+            slab = m3.cut_piece(16, 2, glue_edgs=False)
+        mesh2 = [513, 513]
+        w = tb.wf_array(slab, mesh2)
+        w.solve_on_grid([0.0, 0.0])
+        nocc = 8
+        w.position_hwf_mesh(range(nocc), 2)
+        ctx.sync()
+        best = 1e9
+        for _ in range(max(1, reps)):
+            t0 = time.perf_counter()
+            hwfc = w.position_hwf_mesh(range(nocc), 2)
+            best = min(best, time.perf_counter() - t0)
+        ctx.prof_enable(1)
+        ctx.prof_reset()
+        w.position_hwf_mesh(range(nocc), 2)
+        kern = {kk: v["total_ms"] for kk, v in ctx.prof_report().items()}
+        ctx.prof_enable(0)
+        npt = mesh2[0] * mesh2[1]
+        dev_ms = sum(kern.values())
+        out.append({"config": "H: hybrid Wannier centres, 16-layer cubic slab, wf_array([513,513]), position_hwf_mesh(range(8), dir=2)",
+                    "points": npt, "nocc": nocc, "n": 16, "call_ms_incl_download": best * 1e3, "points_per_s_call": npt / best,
+                    "kernels_ms": kern, "device_ms": dev_ms, "points_per_s_device": npt / (dev_ms * 1e-3) if dev_ms > 0 else None,
+                    "roofline": {"bound": "fp64 VALU issue / latency of the batched 8 x 8 eigen-solve (k_solve_reg)",
+                                 "algorithmic_bytes_per_point": 16 * nocc * 16 + 8 * nocc,
+                                 "hbm_frac": (16 * nocc * 16 + 8 * nocc) * npt / (dev_ms * 1e-3) / 1e9 / HBM if dev_ms > 0 else None},
+                    "check": {"centres_in_slab": bool(np.all((hwfc > -0.5) & (hwfc < 16.5))), "mean_centre": float(hwfc.mean())}})
     if "R" in which:
         # (not a BASELINE config) the widening rows of SURVEY.md 8f-2: ribbon band structures and a mid-size mesh solve, to keep
         # the direct paths for 17..1024 states under measurement.  Wall-clock of the Python calls, PCIe included.

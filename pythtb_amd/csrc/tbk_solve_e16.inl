@@ -328,15 +328,16 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     E16_ORDER();
     xd[j] = e16_d2{ds, es};
     E16_ORDER();
+    // (the scaled e_i themselves stay in LDS until the eigenvalue is known: 32 registers the isolation and the Newton steps do not
+    // need -- they work on d and e^2 -- and that were being spilled to scratch here)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const e16_d2 t = xd[i];
         d[i] = t.x;
-        e[i] = t.y;
         e2[i] = fmax(t.y * t.y, 1e-300);                 // (1e-300 at the splits: 0 x inf never appears among the pivots)
     }
     E16_ORDER();
-    e16_lu2* const xch = reinterpret_cast<e16_lu2*>(xd);
+    e16_lu2* const xch = reinterpret_cast<e16_lu2*>(xd - 16 * ((threadIdx.x & 63) >> 4) + 64) + 16 * ((threadIdx.x & 63) >> 4);   // counts: past the four (d, e) blocks
 
     E16_MARK(21);
     // ---- one multisection shared by the 16 lanes: lane j looks at point j of 16 inside (gl, gu)
@@ -483,6 +484,10 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     }
     flag = flag || !conv;
     lam = x;
+    E16_ORDER();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = xd[i].y;         // (the couplings, for the twisted factorisation)
+    E16_ORDER();
     if (j >= n) {                                        // a padding row: decoupled, its eigenvector is e_j (V stays orthogonal)
         bl = j;
         bh = j;
@@ -583,35 +588,38 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     const int n = mv.nsta;
     const bool real_row = x < n;
 
-    // mesh indices of the point (MODE 1): decoded once, for the tables of exp(2 pi i k_d) here and of the orbital phases at the end
-    int mi[4] = {0, 0, 0, 0};
-    if constexpr (MODE == 1) {
+    // mesh indices of a point (MODE 1), for the tables of exp(2 pi i k_d) here and of the orbital phases at the end
+    auto mesh_indices = [&](const int64_t pid, int (&mi_)[4]) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) mi_[d] = 0;
         if (G.wv.npts < (int64_t)0xffffffffu) {
-            unsigned rem = (unsigned)id;
+            unsigned rem = (unsigned)pid;
 #pragma unroll
             for (int d = 3; d >= 1; --d) {
                 const unsigned md = (unsigned)G.wv.mesh[d];
                 if (d < G.wv.dim_arr && md > 1) {
                     const unsigned q = rem / md;
-                    mi[d] = (int)(rem - q * md);
+                    mi_[d] = (int)(rem - q * md);
                     rem = q;
                 }
             }
-            mi[0] = (int)rem;
+            mi_[0] = (int)rem;
         } else {
-            int64_t rem = id;
+            int64_t rem = pid;
 #pragma unroll
             for (int d = 3; d >= 1; --d) {
                 const int64_t md = G.wv.mesh[d];
                 if (d < G.wv.dim_arr && md > 1) {
                     const int64_t q = rem / md;
-                    mi[d] = (int)(rem - q * md);
+                    mi_[d] = (int)(rem - q * md);
                     rem = q;
                 }
             }
-            mi[0] = (int)rem;
+            mi_[0] = (int)rem;
         }
-    }
+    };
+    int mi[4] = {0, 0, 0, 0};
+    if constexpr (MODE == 1) mesh_indices(id, mi);
     // ---- H(k), lane x = row x
     cd a[16];
 #pragma unroll
@@ -773,6 +781,16 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         for (int i = 0; i < 16; ++i) v[i] = i == j ? 1.0 : d[i] * 1e-3;
     }
     E16_MARK(4);
+    // From here on the matrix this lane works for, whether it exists, and its mesh indices are derived AGAIN from the thread
+    // index (through a register the compiler cannot see through): held from the top of the kernel, those eight registers were
+    // spilled to scratch across the eigenvalue and eigenvector stages -- 72 bytes per lane, 0.3 GB of stores and 0.2 GB of loads per
+    // 65^3 points on a kernel whose whole output is 1.1 GB (profiles/r04acfg).
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int64_t slot_u2 = ((int64_t)blockIdx.x * 4 + (tid2 >> 6)) * 4 + ((tid2 & 63) >> 4);
+    const bool live2 = slot_u2 < nc;
+    const int64_t slot2 = live2 ? slot_u2 : nc - 1;
+    const int64_t id2 = id0 + slot2;
     const double lam_s = lam + dlam;                    // Rayleigh-quotient correction
     E16_DBG(slot_u, j, 13, dlam);
     E16_DBG(slot_u, j, 14, bad ? 1.0 : 0.0);
@@ -814,14 +832,14 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         const int bl_up = __builtin_amdgcn_update_dpp(0, bl, 0x101, 0xf, 0xf, true);
         close_pair = close_pair || (j + 1 < n && ((bl_up == bl && !(up - lam_o >= gaptol * tmax)) || up < lam_o));
     }
-    const unsigned long long fb = __builtin_amdgcn_ballot_w64((flag || bad || close_pair) && live && j < n);
+    const unsigned long long fb = __builtin_amdgcn_ballot_w64((flag || bad || close_pair) && live2 && j < n);
     const bool listed = ((unsigned)(fb >> (lane & 48)) & 0xffffu) != 0;
-    if (listed && j == 0 && live) list[atomicAdd(count, 1)] = (int)slot;
+    if (listed && j == 0 && live2) list[atomicAdd(count, 1)] = (int)slot2;
 
     // eigenvalues out / minimal gaps of the mesh (listed matrices: the QL-replay kernels report theirs)
     if constexpr (MODE == 1) {
         double gap = e16_next(lam_out) - lam_out;
-        gap = (j + 1 < n && live && !listed) ? gap : INFINITY;
+        gap = (j + 1 < n && live2 && !listed) ? gap : INFINITY;
         gap = fmin(gap, __shfl_xor(gap, 16));
         gap = fmin(gap, __shfl_xor(gap, 32));
         if (lane < 15 && lane + 1 < n) {
@@ -830,7 +848,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
             if (bits < __hip_atomic_load(slotp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slotp, bits);
         }
     } else {
-        if (live && j < n) Lst.eval[(int64_t)j * nk + id] = lam_out;
+        if (live2 && j < n) Lst.eval[(int64_t)j * nk + id2] = lam_out;
     }
 
     E16_MARK(5);
@@ -950,21 +968,23 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     for (int b = 0; b < 16; ++b) zt[b].y = Ts[(mat * 16 + b) * 17 + j];
 
     const int c = j;                                   // from here on the lane owns orbital component c
-    if (!live || c >= n) return;
+    if (!live2 || c >= n) return;
     cd f{1.0, 0.0};
     if constexpr (MODE == 0) {
         double kk[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int dd2 = 0; dd2 < 4; ++dd2)
-            if (dd2 < mv.dim_k) kk[dd2] = Lst.k[id * mv.dim_k + dd2];
+            if (dd2 < mv.dim_k) kk[dd2] = Lst.k[id2 * mv.dim_k + dd2];
         f = cconj(expi2pi(kdot(kk, mv.orb[c])));
     } else if constexpr (MODE == 1) {
         // exp(-2 pi i k.tau_c) x (pbc phase on the periodic images) as the product of the per-axis tables k_grid_tables wrote for
         // this window (one entry per axis and orbital, computed from the GLOBAL index: the same bits in every window)
-        f = G.tf[0][(int64_t)mi[0] * n + c];
+        int mj[4];
+        mesh_indices(id2, mj);
+        f = G.tf[0][(int64_t)mj[0] * n + c];
 #pragma unroll
         for (int dd2 = 1; dd2 < 4; ++dd2)
-            if (dd2 < G.wv.dim_arr) f = cmul(f, G.tf[dd2][(int64_t)mi[dd2] * n + c]);
+            if (dd2 < G.wv.dim_arr) f = cmul(f, G.tf[dd2][(int64_t)mj[dd2] * n + c]);
     }
     // (lane b of the matrix computed eigenvalue b: the bands are in ascending order by construction)
 #pragma unroll
@@ -973,8 +993,8 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
             const cd val = cmul(zt[b], f);
             if constexpr (E16_SKIP & 32) {
                 if (val.x == 1.2345e-300) Lst.evec[0] = val;     // (keeps the value alive)
-            } else if constexpr (MODE == 1) wf_at(G.wv, b, id)[c] = val;
-            else Lst.evec[((int64_t)b * nk + id) * n + c] = val;
+            } else if constexpr (MODE == 1) wf_at(G.wv, b, id2)[c] = val;
+            else Lst.evec[((int64_t)b * nk + id2) * n + c] = val;
         }
     }
 }
