@@ -179,3 +179,38 @@ def test_padded_sizes_on_a_mesh_against_the_oracle(tb):
     oph = orc.berry_phase(owfs, 2, list(range(5)), 1, contin=False)
     if np.min(ogaps[4]) > 1e-3:                       # (the occupied set must be separated for its phase to be defined)
         assert np.max(np.abs(np.angle(np.exp(1j * (np.asarray(ph) - np.asarray(oph)))))) < 1e-9
+
+
+def test_spin_degenerate_bands_on_a_mesh(tb):
+    """An 8-orbital model with two spin components and no spin-orbit coupling: EVERY level of every H(k) is exactly twice
+    degenerate (Kramers-like pairs), T splits -- or nearly so -- at every point.  The fused kernel has to put the two members of a
+    pair into different unreduced blocks (or list the matrix): eigenvalues against numpy, residuals and orthonormality of what
+    comes out, ascending bands, on a k list and on a mesh with its windows."""
+    rng = np.random.default_rng(17)
+    m = hp.quiet(tb.tb_model, 2, 2, [[1.0, 0.0], [0.3, 0.9]], rng.random((8, 2)), nspin=2)
+    m.set_onsite(list(rng.standard_normal(8)))
+    for i in range(8):
+        for j in range(i + 1, 8):
+            m.set_hop(0.3 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, [0, 0])
+    for R in ([1, 0], [0, 1], [1, 1]):
+        for i in range(8):
+            for j in range(8):
+                if rng.random() < 0.4:
+                    m.set_hop(0.2 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, R)
+    k = rng.random((900, 2))
+    with _forced():
+        ev, vec = m.solve_all(k, eig_vectors=True)
+        w = tb.wf_array(m, [21, 18])
+        gaps = w.solve_on_grid([0.05, -0.1])
+        host = w.to_host().copy()
+        ww = tb.wf_array(m, [7, 9])
+        ww.solve_on_grid_window([0.05, -0.1], [5, 4], [21, 18])
+        assert np.array_equal(ww.to_host(), host[5:12, 4:13])
+    H = np.array([m._gen_ham(kk).reshape(16, 16) for kk in k[::9]])
+    q = _quality(H, ev[:, ::9], vec.reshape(16, len(k), 16)[:, ::9, :])
+    assert max(q) < 2e-14, q
+    assert np.all(np.diff(ev, axis=0) >= 0.0)
+    assert np.max(np.abs(ev[0::2] - ev[1::2])) < 1e-13                    # the pairs
+    assert np.max(gaps[0::2]) < 1e-13 and np.min(gaps[1::2]) >= 0.0       # gaps inside the pairs vanish
+    V = host.reshape(-1, 16, 16)
+    assert max(np.max(np.abs(v.conj() @ v.T - np.identity(16))) for v in V) < 1e-13
