@@ -11,65 +11,26 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
 # (a key "a+b+c" sums the per-dispatch counts of several kernels that each cover the same points)
 SOURCES = [
-    # round 3, final build (+ expi2pi, two k-points per lane on eigenvalue-only lists, four links per step): r03l, r03l2, r03lcfg (r03k* = the same a few commits earlier)
+    # round 4, final build: r04b (the two-call step), r04c (--fused-headline), r04bcfg (bench_configs.py B D E under TBK_TW16_STREAMS=1)
+    ("k_grid_rows_flux<2,1,1>", "r04c/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
+    ("k_grid_rows<2,1>", "r04b/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r04b/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r04bcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r04bcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_e16<1>", "r04bcfg/pmc_per_dispatch.json", "k_e16<1>", 65 ** 3),
+    ("k_mesh_evals<2,1>", "r04bcfg/pmc_per_dispatch.json", "k_mesh_evals<2,1>", 1024 * 1024),
+    ("k_chain_prod_tile<8,2>", "r04bcfg/pmc_per_dispatch.json", "k_chain_prod_tile<8,2>", 65 ** 3),
+    ("k_solve_small_multi<2,false,2>", "r04bcfg/pmc_per_dispatch.json", "k_solve_small_multi<2,false,2>", 1024 * 1024),
+    ("k_solve_small<2,0,true>", "r04bcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
+    # round 3, final build (the three-kernel n = 9..16 path, TBK_E16=0, is still counted from here)
+    ("k_tw16<1>", "r03lcfg/pmc_per_dispatch.json", "k_tw16_tridiag<1>+k_tw16_eigvals<1>+k_tw16_vectors<1>", 65 ** 3),
     ("k_grid_rows_flux<2,1,1>", "r03l/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
     ("k_grid_rows<2,1>", "r03l2/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
     ("k_flux_rows<1,2>", "r03l2/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
     ("k_grid_rows<4,1>", "r03lcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
     ("k_flux_rows<2,4>", "r03lcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_tw16<1>", "r03lcfg/pmc_per_dispatch.json", "k_tw16_tridiag<1>+k_tw16_eigvals<1>+k_tw16_vectors<1>", 65 ** 3),
-    ("k_solve_small_multi<2,false,2>", "r03lcfg/pmc_per_dispatch.json", "k_solve_small_multi<2,false,2>", 1024 * 1024),
-    ("k_solve_small<2,0,true>", "r03lcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
-    # the same before those three changes (tbk_solve / tbk_berry compiled without MachineLICM, seams + total in one kernel): r03j, r03j2, r03jcfg
-    ("k_grid_rows_flux<2,1,1>", "r03j/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
-    ("k_grid_rows<2,1>", "r03j2/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r03j2/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r03jcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r03jcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_tw16<1>", "r03jcfg/pmc_per_dispatch.json", "k_tw16_tridiag<1>+k_tw16_eigvals<1>+k_tw16_vectors<1>", 65 ** 3),
-    ("k_solve_small<2,0,false>", "r03jcfg/pmc_per_dispatch.json", "k_solve_small<2,0,false>", 1024 * 1024),
-    ("k_solve_small<2,0,true>", "r03jcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
-    # round 3: the fused headline kernel, the two-launch step's kernels, configs[1] / [3] / [4] (r03hcfg: TBK_TW16_STREAMS=1, so
-    # that every kernel's counters belong to it alone)
-    ("k_grid_rows_flux<2,1,1>", "r03h/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
-    ("k_grid_rows<2,1>", "r03h2/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r03h2/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r03hcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r03hcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_tw16<1>", "r03hcfg/pmc_per_dispatch.json", "k_tw16_tridiag<1>+k_tw16_eigvals<1>+k_tw16_vectors<1>", 65 ** 3),
-    ("k_solve_small<2,0,false>", "r03hcfg/pmc_per_dispatch.json", "k_solve_small<2,0,false>", 1024 * 1024),
-    ("k_solve_small<2,0,true>", "r03hcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
-    ("k_grid_rows<4,1>", "r02hcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r02hcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    # the 65^3 mesh of the collection goes through the three kernels in two chunks
+    # round 2: the single-kernel and first three-kernel forms of the n = 16 solve (history; bench.py does not name them any more)
     ("k_solve_ql16<1,true>", "r02hcfg/pmc_per_dispatch.json", "k_solve_ql16<1,true,2>+k_ql16_lanes<1>+k_ql16_replay<1>", 65 ** 3 // 2),
-    ("k_grid_rows<2,1>", "r02i/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r02i/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<2,1>", "r02g/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r02g/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r02gcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r02gcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_solve_ql16<1,true>", "r02gcfg/pmc_per_dispatch.json", "k_solve_ql16<1,true,0>", 65 ** 3),
-    ("k_grid_rows<2,1>", "r02f/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r02f/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r02fcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r02fcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_solve_ql16<1,true>", "r02fcfg/pmc_per_dispatch.json", "k_solve_ql16<1,true,0>", 65 ** 3),
-    ("k_grid_rows<2,1>", "r02e/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r02e/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r02ecfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r02ecfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_solve_ql16<1,true>", "r02ecfg/pmc_per_dispatch.json", "k_solve_ql16<1,true>", 65 ** 3),
-    ("k_grid_rows<2,1>", "r02c/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r02c/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r02ccfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r02ccfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_solve_ql16<1,true>", "r02ccfg/pmc_per_dispatch.json", "k_solve_ql16<1,true>", 65 ** 3),
-    # fallbacks from earlier collections (used only while the entry above is missing)
-    ("k_grid_rows<2,1>", "r01g/pmc_per_dispatch.json", "k_grid_rows", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r01g/pmc_per_dispatch.json", "k_flux_rows", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r02a/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r02a/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
 ]
 # ---- the flop model behind bench.py's `useful_flop_frac` (SURVEY.md 8d "ALGORITHMIC flops per k-point").
 # Real fp64 flops per mesh point of the ALGORITHM (not of the instruction stream: masked lanes, moves, cross-lane reductions and
@@ -99,6 +60,8 @@ FLOPS = {
     # cubic16: 136 slots x 4 lattice vectors (R-grouped) = 544 complex multiply-adds
     "k_tw16<1>": (544 * 8 + _eig16(16) + 6 * 256, "mesh solve n=16: 544 cmadd assembly + tridiagonalise 21.8k + QL 7.7k + twisted 2.6k + Newton-Schulz 16.4k + back-transform 16.4k + phases 1.5k"),
     "k_e16<1>": (544 * 8 + _eig16(16) + 6 * 256, "mesh solve n=16 (one fused kernel): same algorithm as k_tw16<1>"),
+    "k_mesh_evals<2,1>": (15 * 8 + 30, "mesh eigenvalues n=2: 15 terms x 8 + closed form 30 (phases from the per-axis tables)"),
+    "k_chain_prod_tile<8,2>": (8 * 8 * 16 * 8 + 8 * 8 * 8 * 8, "link of 8 of 16 bands: overlap matrix 8x8x16 cmadd + running product 8^3 cmadd (the determinant is once per string)"),
     "k_solve_small_multi<2,false,2>": (4 * 40 + 15 * 8 + 30, "k list n=2 eigenvalues: 4 sincos + 15 terms x 8 + closed form 30"),
     "k_solve_small<2,0,false>": (4 * 40 + 15 * 8 + 30, "k list n=2 eigenvalues: 4 sincos + 15 terms x 8 + closed form 30"),
     "k_solve_small<2,0,true>": (4 * 40 + 15 * 8 + 60 + 24, "k list n=2 with vectors: 4 sincos + 15 terms x 8 + closed form 60 + phases 24"),
