@@ -616,17 +616,21 @@ __global__ __launch_bounds__(256) void k_flux(const FluxArgs A) {
 // one block per slice: fixed-shape sum (4 interleaved accumulators per thread so the
 // loads overlap, then an LDS tree) -- the same order every run, no atomics
 __global__ __launch_bounds__(1024) void k_flux_reduce(const double* __restrict__ partial, int bps,
-                                                      double* __restrict__ totals) {
+                                                      double* __restrict__ totals, const DoneArgs done) {
     const double* p = partial + (int64_t)blockIdx.x * bps;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int i = threadIdx.x;
-    for (; i + 3 * 1024 < bps; i += 4 * 1024) {
-        s0 += p[i];
-        s1 += p[i + 1024];
-        s2 += p[i + 2048];
-        s3 += p[i + 3072];
+    // (four loads in flight per thread, the tail included: the 2112 partials of a 2048^2 mesh are one round of loads -- this kernel
+    // is pure latency in front of every berry_flux return; the shape of the sum depends on bps alone)
+    for (int i = threadIdx.x; i < bps; i += 4 * 1024) {
+        const double v0 = p[i];
+        const double v1 = i + 1024 < bps ? p[i + 1024] : 0.0;
+        const double v2 = i + 2048 < bps ? p[i + 2048] : 0.0;
+        const double v3 = i + 3072 < bps ? p[i + 3072] : 0.0;
+        s0 += v0;
+        s1 += v1;
+        s2 += v2;
+        s3 += v3;
     }
-    for (; i < bps; i += 1024) s0 += p[i];
     // fixed-shape tree: xor-butterfly inside each wavefront (the same bits in every lane), then the 16 wavefront sums in
     // index order -- two barriers instead of the ten of an LDS tree over 1024 entries
     double s = (s0 + s1) + (s2 + s3);
@@ -641,7 +645,10 @@ __global__ __launch_bounds__(1024) void k_flux_reduce(const double* __restrict__
         for (int i = 1; i < 16; ++i) t += red[i];
         red[0] = t;
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) {
+        totals[blockIdx.x] = red[0];
+        tbk_signal_done(done);      // (the call's last kernel: tbk_berry_flux_result may be polling the completion word)
+    }
 }
 
 static int check_occ(const tbk_wfs* w, const int32_t* occ, int nocc) {
@@ -888,9 +895,14 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     }
     if (!rows || !A.fused) {
         ProfScope ps(ctx, "flux_reduce");
+        // totals in mapped host memory and no per-plaquette output: this is the call's last kernel, the result call polls its
+        // completion word instead of synchronising the stream
+        w->flux_done = (w->flux_totals_host && !want_plaq) ? tbk_done_arm(ctx, false) : DoneArgs{nullptr, nullptr, nullptr, 0u};
         hipLaunchKernelGGL(k_flux_reduce, dim3((unsigned)nslices), dim3(1024), 0, ctx->stream,
-                           (const double*)w->flux_partial_dev, rows ? A.bpb : A.bps, w->flux_totals_dev);
+                           (const double*)w->flux_partial_dev, rows ? A.bpb : A.bps, w->flux_totals_dev, w->flux_done);
         TBK_HIP(hipGetLastError());
+    } else {
+        w->flux_done = DoneArgs{nullptr, nullptr, nullptr, 0u};
     }
     return TBK_OK;
 }
@@ -905,7 +917,10 @@ extern "C" int tbk_berry_flux_result(tbk_wfs* w, double* totals, double* plaq) {
                                ctx->stream));
     }
     if (w->flux_totals_host) {                       // mapped host memory: the kernel's stores were the transfer
-        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        const DoneArgs done = plaq ? DoneArgs{nullptr, nullptr, nullptr, 0u} : w->flux_done;
+        w->flux_done = DoneArgs{nullptr, nullptr, nullptr, 0u};
+        const int rc = tbk_done_wait(ctx, done);
+        if (rc) return rc;
         memcpy(totals, w->flux_totals_host, w->flux_nslices * sizeof(double));
         return TBK_OK;
     }
@@ -1239,7 +1254,8 @@ static int launch_chain_wave(tbk_ctx* ctx, const WfsView& v, const ChainArgs& A,
     // berry_phase of 5..8 bands (no per-link determinants wanted): the product form -- one nocc x nocc matrix per (string, segment)
     // instead of one per link, no link-matrix workspace (TBK_CHAIN_PROD=0: the two kernels below)
     {
-        const size_t lds_p1 = (size_t)(TBK_CHAINP_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd) + (size_t)TBK_CHAINP_G * 256 * sizeof(double);
+        const size_t lds_pts = (size_t)(TBK_CHAINP_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd), lds_img = (size_t)TBK_CHAINP_G * 256 * sizeof(double);
+        const size_t lds_p1 = nocc == 8 ? std::max(lds_pts, lds_img) : lds_pts + lds_img;   // (8 bands: the images lie over the points)
         if (!dets_out && nocc >= 5 && nocc <= 8 && tbk_knobs().chain_prod != 0 && 2 * lds_p1 <= 64 * 1024) {
             const int64_t nw = A.nstrings * A.nseg;
             const size_t wbytes = (size_t)nw * 64 * sizeof(cd);

@@ -5,6 +5,7 @@
 #include <string.h>
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <map>
 #include <new>
 #include "tbk_internal.h"
@@ -67,6 +68,7 @@ static void knobs_parse() {
     geti("TBK_GRID_KERNEL", k.grid_kernel);
     geti("TBK_FLUX_TI", k.flux_ti);
     geti("TBK_FLUX_FUSED", k.flux_fused);
+    geti("TBK_POLL_DONE", k.poll_done);
     geti("TBK_CHAIN_WAVE", k.chain_wave);
     geti("TBK_CHAIN_TILE", k.chain_tile);
     geti("TBK_CHAIN_PROD", k.chain_prod);
@@ -130,6 +132,21 @@ extern "C" int tbk_ctx_create(int device, tbk_ctx** out) {
     if (hipHostMalloc(&c->pinned, 64 * 1024, hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;   // (optional: falls back to plain copies)
     TBK_HIP(hipMalloc((void**)&c->flags_dev, 64 * sizeof(int)));
     TBK_HIP(hipMemsetAsync(c->flags_dev, 0, 64 * sizeof(int), c->stream));
+    {   // completion word (tbk_done_arm): optional -- without it small calls synchronise the stream
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess &&
+            hipMalloc((void**)&c->done_cnt_dev, 64) == hipSuccess) {
+            memset(h, 0, 64);
+            c->done_host = (unsigned*)h;
+            c->done_dev = (unsigned*)d;
+            TBK_HIP(hipMemsetAsync(c->done_cnt_dev, 0, 64, c->stream));
+        } else {
+            (void)hipGetLastError();
+            if (h) hipHostFree(h);
+            c->done_cnt_dev = nullptr;
+        }
+    }
     TBK_HIP(hipStreamSynchronize(c->stream));
     *out = c;
     return TBK_OK;
@@ -150,6 +167,8 @@ extern "C" int tbk_ctx_destroy(tbk_ctx* c) {
     for (auto& b : c->blob_pool) hipFree(b.p);
     c->blob_pool.clear();
     if (c->flags_dev) hipFree(c->flags_dev);
+    if (c->done_host) hipHostFree(c->done_host);
+    if (c->done_cnt_dev) hipFree(c->done_cnt_dev);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->work) hipFree(c->work);
     hipEventDestroy(c->timer0);
@@ -189,6 +208,35 @@ int tbk_small_d2h(tbk_ctx* c, void* dst, const void* src_dev, size_t bytes) {
     TBK_HIP(hipMemcpyAsync(c->pinned, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     TBK_HIP(hipStreamSynchronize(c->stream));
     memcpy(dst, c->pinned, bytes);
+    return TBK_OK;
+}
+
+DoneArgs tbk_done_arm(tbk_ctx* c, bool with_flags) {
+    DoneArgs d{nullptr, nullptr, nullptr, 0u};
+    // (profiling brackets the launch with events and reads them back after a synchronisation: keep that path as it was)
+    if (!c->done_host || tbk_knobs().poll_done == 0 || c->prof_period != 0) return d;
+    c->done_seq += 1u;
+    if (c->done_seq == 0u) c->done_seq = 1u;
+    d.word = c->done_dev;
+    d.cnt = c->done_cnt_dev;
+    d.flags_src = with_flags ? c->flags_dev : nullptr;
+    d.seq = c->done_seq;
+    return d;
+}
+
+int tbk_done_wait(tbk_ctx* c, const DoneArgs& d) {
+    if (d.word) {
+        const volatile unsigned* w = c->done_host;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 512; ++i) {
+                if ((int)(__atomic_load_n(w, __ATOMIC_ACQUIRE) - d.seq) >= 0) return TBK_OK;   // (launches complete in stream order)
+                __builtin_ia32_pause();
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;   // a long launch: sleep on the signal
+        }
+    }
+    TBK_HIP(hipStreamSynchronize(c->stream));
     return TBK_OK;
 }
 

@@ -70,6 +70,7 @@ struct TbkKnobs {
     int grid_seg = -1;          // TBK_GRID_SEG      chunks per wave tile of k_grid_rows
     int grid_kernel = 0;        // TBK_GRID_KERNEL   1: term-walking mesh kernel instead of the row-polynomial one
     int flux_ti = -1;           // TBK_FLUX_TI       rows per flux tile
+    int poll_done = 1;          // TBK_POLL_DONE     0: small calls wait with hipStreamSynchronize instead of polling the completion word
     int flux_fused = 0;         // TBK_FLUX_FUSED    1: final flux sum inside the kernel
     int trigv_from = -1;        // TBK_TRIGV_FROM    smallest n of the workgroup-scale direct eigenvector path (default 65; A/B runs down to 17)
     int chain_ws_mb = 1024;     // TBK_CHAIN_WS_MB   link-matrix workspace per batch of strings, MiB
@@ -205,6 +206,13 @@ struct tbk_ctx {
     size_t zc_bytes = 0;
     void* pinned = nullptr;    // 64 KiB of pinned host memory for small results
     int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
+    // completion word of small calls (tbk_done_arm / tbk_done_wait): 64 B of mapped host memory -- [0] the sequence number the last
+    // kernel of the call stores after its results, [4..7] a copy of flags_dev[0..3] taken by that kernel; and its device-side
+    // arrival counter.  Null when the mapped allocation failed or TBK_POLL_DONE=0: callers then synchronise the stream.
+    unsigned* done_host = nullptr;
+    unsigned* done_dev = nullptr;
+    unsigned* done_cnt_dev = nullptr;
+    unsigned done_seq = 0;
     void* work = nullptr;      // workspace of the workgroup-per-matrix eigen-solver (n > 64)
     size_t work_bytes = 0;
     // whole-array / per-point wf_array transfers across PCIe (tbk_ctx_transfer_stats)
@@ -220,6 +228,39 @@ int tbk_ctx_zero_copy(tbk_ctx* ctx, size_t bytes, void** host, void** dev);
 // small device-to-host result (min gaps, flux totals, status words): through a pinned staging buffer -- an async copy into
 // pageable memory is staged by the runtime and cost ~10 us more per call on the Python-API path -- then stream sync
 int tbk_small_d2h(tbk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
+
+// ---- "the call is finished" without hipStreamSynchronize.  Waiting on the runtime's completion signal costs ~12 us for a kernel
+// of ~2 us; polling a word of mapped host memory that the call's LAST kernel stores after its results costs ~6.6 us
+// (profiles/microbench/sync_latency.hip; hipDeviceScheduleSpin does not change the former).  The pair of calls of the headline
+// step waits twice.  Use: `DoneArgs d = tbk_done_arm(ctx)` -> pass d to the last kernel, which calls tbk_signal_done(d) from ONE
+// thread per workgroup after that workgroup's result stores -> `tbk_done_wait(ctx, d)` on the host (polls for at most ~1 ms,
+// then falls back to hipStreamSynchronize, which is also what happens when d.word is null).  Results the host reads after the
+// wait must have been stored by that last kernel (or sit in device memory).
+struct DoneArgs {
+    unsigned* word;        // device pointer of done_host[0]; null = not armed
+    unsigned* cnt;         // arrival counter (device memory), zero between launches
+    const int* flags_src;  // ctx->flags_dev, or null: copied to word[4..7] by the last workgroup
+    unsigned seq;
+};
+DoneArgs tbk_done_arm(tbk_ctx* ctx, bool with_flags);
+int tbk_done_wait(tbk_ctx* ctx, const DoneArgs& d);
+#ifdef __HIPCC__
+__device__ inline void tbk_signal_done(const DoneArgs& d) {
+    if (!d.word) return;
+    __threadfence_system();                       // this workgroup's results (mapped host memory or HBM) before its ticket
+    const unsigned t = atomicAdd(d.cnt, 1u);
+    if (t == gridDim.x * gridDim.y * gridDim.z - 1u) {
+        __hip_atomic_store(d.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d.flags_src) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                d.word[4 + i] = (unsigned)__hip_atomic_load(d.flags_src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence_system();
+        __hip_atomic_store(d.word, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#endif
 
 // RAII bracket recording HIP events around one kernel launch when profiling.
 struct ProfScope {
@@ -311,6 +352,7 @@ struct tbk_wfs {
     // flux results
     double* flux_totals_dev = nullptr;   // device pointer of the per-slice totals; mapped HOST memory when small (flux_totals_host != null)
     double* flux_totals_host = nullptr;  // ... its host address: the result is read after one synchronisation, no copy operation
+    DoneArgs flux_done{nullptr, nullptr, nullptr, 0u};   // completion word armed by the pending berry_flux launch (word null: synchronise)
     unsigned* flux_cnt_dev = nullptr;        // [slices][16] arrival tickets of the row kernel
     int64_t flux_nslices = 0, flux_nslices_cap = 0;
     double* flux_plaq_dev = nullptr;

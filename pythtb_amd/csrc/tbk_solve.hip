@@ -1486,19 +1486,29 @@ __global__ __launch_bounds__(256) void k_gen_ham(const ModelView mv, const int64
     }
 }
 
-// min over the per-tile partial gaps of k_grid_rows: one 1024-thread workgroup per band pair, four loads in flight per thread
+// min over the per-tile partial gaps of k_grid_rows: one 1024-thread workgroup per band pair
 __global__ __launch_bounds__(1024) void k_gap_part_reduce(const double* __restrict__ part, const int64_t ntiles, const int ng,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, const DoneArgs done) {
     const int b = blockIdx.x;
+    // (twelve loads in flight per thread: the 10 245 tiles of a 2048^2 mesh are ONE round of loads, not three dependent ones --
+    // this kernel is pure latency and sits in front of every solve_on_grid return)
     double g0 = INFINITY, g1 = INFINITY, g2 = INFINITY, g3 = INFINITY;
     int64_t t = threadIdx.x;
-    for (; t + 3 * 1024 < ntiles; t += 4 * 1024) {
-        g0 = fmin(g0, part[t * ng + b]);
-        g1 = fmin(g1, part[(t + 1024) * ng + b]);
-        g2 = fmin(g2, part[(t + 2048) * ng + b]);
-        g3 = fmin(g3, part[(t + 3072) * ng + b]);
+    for (; t < ntiles; t += 12 * 1024) {
+        double v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int64_t idx = t + (int64_t)i * 1024;
+            v[i] = idx < ntiles ? part[idx * ng + b] : INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i += 4) {
+            g0 = fmin(g0, v[i]);
+            g1 = fmin(g1, v[i + 1]);
+            g2 = fmin(g2, v[i + 2]);
+            g3 = fmin(g3, v[i + 3]);
+        }
     }
-    for (; t < ntiles; t += 1024) g0 = fmin(g0, part[t * ng + b]);
     double g = fmin(fmin(g0, g1), fmin(g2, g3));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) g = fmin(g, __shfl_xor(g, off));
@@ -1510,6 +1520,7 @@ __global__ __launch_bounds__(1024) void k_gap_part_reduce(const double* __restri
 #pragma unroll
         for (int i = 1; i < 16; ++i) m = fmin(m, red[i]);
         out[b] = fmax(m, 0.0);
+        tbk_signal_done(done);      // (the call's last kernel: the host may be polling the completion word)
     }
 }
 
@@ -2391,12 +2402,22 @@ static int solve_grid_result_once(tbk_wfs* w, double* min_gaps, bool can_retry) 
             if (rc) return rc;
             out_dev = (double*)((unsigned char*)base + 256);
         }
+        // with the gaps in mapped memory the reduction is the call's last kernel: it also copies the status words and stores the
+        // completion word the host polls (tbk_done_wait) -- no hipStreamSynchronize, no second round trip for the status
+        const DoneArgs done = zh ? tbk_done_arm(ctx, w->view.nsta > 2) : DoneArgs{nullptr, nullptr, nullptr, 0u};
         hipLaunchKernelGGL(k_gap_part_reduce, dim3(w->gaps_n), dim3(1024), 0, ctx->stream, w->gap_part_dev, w->gap_part_n,
-                           w->gaps_n, out_dev);
+                           w->gaps_n, out_dev, done);
         TBK_HIP(hipGetLastError());
         if (zh) {
-            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            rc = tbk_done_wait(ctx, done);
+            if (rc) return rc;
             memcpy(min_gaps, zh, gb);
+            if (done.word && done.flags_src) {   // status words as the last kernel saw them: the usual case is "all clear"
+                const volatile unsigned* f = ctx->done_host + 4;
+                if (f[0] == 0u && f[2] == 0u) return TBK_OK;
+            } else if (done.word) {
+                return TBK_OK;                   // (n <= 2: closed forms, nothing iterates)
+            }
         } else {
             rc = tbk_small_d2h(ctx, min_gaps, out_dev, gb);
             if (rc) return rc;

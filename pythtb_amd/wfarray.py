@@ -257,6 +257,8 @@ class wf_array(object):
         st["_host_exported"] = False
         st["_pt_views"] = {}
         st["_pt_copies"] = []
+        st.pop("_bufs", None)          # (ctypes pointers of the per-call buffers: rebuilt on first use)
+        st.pop("_pbc_cache", None)
         return st
 
     def __del__(self):
@@ -284,34 +286,42 @@ class wf_array(object):
         for d in range(self._dim_arr):                       # impose_pbc's guard (pythtb.py:2725)
             if m._per[d] not in m._per:
                 raise Exception("Periodic boundary condition can be specified only along periodic directions!")
-        start = np.ascontiguousarray(np.array(start_k, dtype=float).reshape(-1))
-        if start.shape != (self._dim_arr,):
+        sk = np.array(start_k, dtype=float)
+        if sk.size != self._dim_arr:
             raise Exception("\n\nk-vector of wrong shape!")
         n = m._nsta
-        pbc = self._pbc_phases()
+        # (the small argument / result buffers of this call and their ctypes pointers live with the array: building the
+        # pointer objects anew was 4 us of every call, profiles/api_call_profile.py)
+        b = self._call_bufs(n)
+        b["start"][:] = sk.reshape(-1)
+        pbc_p = self._pbc_phases(True)
         h = self._dev_handle(self._shape())
-        gaps = np.zeros(max(n - 1, 1), dtype=float)
-        n0 = int(self._mesh_arr[0])
-        _lib.check(_lib.lib.tbk_wfs_solve_grid(h, m._device_model(), _lib.dptr(start),
-                                               _lib.dptr(pbc.view(float)), 0, n0, _lib.dptr(gaps)))
+        _lib.check(_lib.lib.tbk_wfs_solve_grid(h, m._device_model(), b["start_p"], pbc_p, 0, int(self._mesh_arr[0]), b["gaps_p"]))
         self._device_wrote()
         if n <= 1:
             return None
-        return gaps[:n - 1]
+        return b["gaps"][:n - 1].copy()
 
-    def _pbc_phases(self):
+    def _call_bufs(self, n):
+        b = getattr(self, "_bufs", None)
+        if b is None or b["n"] != n:
+            start, gaps = np.zeros(self._dim_arr, dtype=float), np.zeros(max(n - 1, 1), dtype=float)
+            b = self._bufs = {"n": n, "start": start, "gaps": gaps, "start_p": _lib.dptr(start), "gaps_p": _lib.dptr(gaps),
+                              "totals": {}, "occ": {}}
+        return b
+
+    def _pbc_phases(self, pointer=False):
         """exp(-2 pi i orb[:, per[d]]) per mesh axis and state (pythtb.py:2729), kept between calls (the orbital positions of
         a wf_array are copied at construction; `_per` and the positions are compared)."""
         m = self._model
-        key = (tuple(int(x) for x in m._per[:self._dim_arr]), self._orb.tobytes(), self._nspin)
         c = getattr(self, "_pbc_cache", None)
-        if c is not None and c[0] == key:
-            return c[1]
+        if c is not None and c[0] == tuple(m._per[:self._dim_arr]) and c[1] == self._orb.tobytes() and c[2] == self._nspin:
+            return c[4] if pointer else c[3]
         pbc = np.zeros((self._dim_arr, m._nsta), dtype=complex)
         for d in range(self._dim_arr):
             pbc[d] = np.repeat(np.exp(-2.j * np.pi * self._orb[:, m._per[d]]), self._nspin)
-        self._pbc_cache = (key, pbc)
-        return pbc
+        self._pbc_cache = (tuple(m._per[:self._dim_arr]), self._orb.tobytes(), self._nspin, pbc, _lib.dptr(pbc.view(float)))
+        return self._pbc_cache[4] if pointer else pbc
 
     def solve_on_grid_flux(self, start_k, occ="All"):
         """Extension (not in the reference): `solve_on_grid(start_k)` and `berry_flux(occ)` of a 2-D array in ONE pass over
@@ -394,7 +404,7 @@ class wf_array(object):
         resident array -- 69.5 GB for BASELINE configs[4] -- only to throw the copy away)."""
         new = wf_array.__new__(wf_array)
         for k, v in self.__dict__.items():
-            if k in ("_host", "_dev", "_dev_shape", "_pt_views", "_pt_copies"):
+            if k in ("_host", "_dev", "_dev_shape", "_pt_views", "_pt_copies", "_bufs", "_pbc_cache"):
                 continue
             new.__dict__[k] = copy.deepcopy(v)
         new._host = None
@@ -675,15 +685,28 @@ class wf_array(object):
         if self._dim_arr not in (2, 3, 4):
             raise Exception("\n\nWrong dimensionality!")
         h = self._ensure_dev()
-        rest = [int(self._mesh_arr[d]) for d in range(self._dim_arr) if d not in (dirs[0], dirs[1])]
-        nsl = int(np.prod(rest)) if rest else 1
+        if self._dim_arr == 2:
+            rest, nsl = [], 1
+        else:
+            rest = [int(self._mesh_arr[d]) for d in range(self._dim_arr) if d not in (dirs[0], dirs[1])]
+            nsl = int(np.prod(rest)) if rest else 1
         n0 = int(self._mesh_arr[dirs[0]]) - 1
         n1 = int(self._mesh_arr[dirs[1]]) - 1
-        totals = np.zeros(nsl, dtype=float)
+        b = self._call_bufs(self._nsta_arr)
+        t = b["totals"].get(nsl)
+        if t is None:
+            t = np.zeros(nsl, dtype=float)
+            t = b["totals"][nsl] = (t, _lib.dptr(t))
         plaq = np.zeros((nsl, n0, n1), dtype=float) if individual_phases else None
-        occ32 = np.ascontiguousarray(occ, dtype=np.int32)
-        _lib.check(_lib.lib.tbk_berry_flux(h, _lib.iptr(occ32), len(occ32), int(dirs[0]), int(dirs[1]),
-                                           _lib.dptr(totals), _lib.dptr(plaq)))
+        okey = (occ.dtype.char, occ.tobytes())
+        o = b["occ"].get(okey)
+        if o is None:
+            if len(b["occ"]) > 64:
+                b["occ"].clear()
+            occ32 = np.ascontiguousarray(occ, dtype=np.int32)
+            o = b["occ"][okey] = (occ32, _lib.iptr(occ32), len(occ32))
+        _lib.check(_lib.lib.tbk_berry_flux(h, o[1], o[2], int(dirs[0]), int(dirs[1]), t[1], _lib.dptr(plaq)))
+        totals = t[0].copy()
         if self._dim_arr == 2:
             return plaq[0] if individual_phases else np.float64(totals[0])
         if individual_phases:

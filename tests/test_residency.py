@@ -355,3 +355,29 @@ def test_parked_model_blobs_survive_the_first_small_solve():
         _lib.check(lib.tbk_solve_list(h, _lib.dptr(k), 2, _lib.dptr(ev), None))   # the first one allocates the mapped buffer
         assert np.array_equal(ev, ref)
         _lib.check(lib.tbk_model_free(h))
+
+
+def test_copies_and_pickles_after_the_per_call_buffers_exist(tb):
+    """solve_on_grid / berry_flux keep their small argument buffers and ctypes pointers on the array (round 4): a deepcopy, a
+    pickle round trip and choose_states after such calls must still work, and give an array that answers like the original
+    -- with TBK_POLL_DONE=0 (hipStreamSynchronize instead of the polled completion word) the same bits."""
+    import copy
+    import pickle
+    from pythtb_amd import _lib
+    m = hp.haldane(tb.tb_model)
+    w = tb.wf_array(m, [31, 29])
+    gaps = w.solve_on_grid([-0.5, -0.5])
+    flux = w.berry_flux([0])
+    for other in (copy.deepcopy(w), pickle.loads(pickle.dumps(w)), w.choose_states([0, 1])):
+        assert other.berry_flux([0]) == flux
+        assert np.array_equal(other.solve_on_grid([-0.5, -0.5]), gaps)
+        assert other.berry_flux([0]) == flux
+    with _lib.knob("TBK_POLL_DONE", 0):
+        w2 = tb.wf_array(m, [31, 29])
+        assert np.array_equal(w2.solve_on_grid([-0.5, -0.5]), gaps) and w2.berry_flux([0]) == flux
+    for _ in range(50):       # many completions in a row: each wait returns THIS call's result
+        s = [-0.5 + 0.01 * _, -0.5]
+        g = w.solve_on_grid(s)
+        f = w.berry_flux([0])
+        with _lib.knob("TBK_POLL_DONE", 0):
+            assert np.array_equal(w2.solve_on_grid(s), g) and w2.berry_flux([0]) == f
