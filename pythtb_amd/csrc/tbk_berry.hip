@@ -1708,9 +1708,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             hipLaunchKernelGGL(k_string_from_dets, dim3((unsigned)((A.nstrings + 255) / 256)), dim3(256), 0, ctx->stream, S);
             TBK_HIP(hipGetLastError());
         }
-        TBK_HIP(hipMemcpyAsync(out, out_dev, (size_t)A.nstrings * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        TBK_HIP(hipStreamSynchronize(ctx->stream));
-        return TBK_OK;
+        return tbk_small_result(ctx, out, out_dev, (size_t)A.nstrings * sizeof(double), nullptr);
     }
     if (big_ev) {
         // workgroup-level pipeline (tbk_berry_big.inl): link polar factors, pairwise product tree, Cayley
@@ -1902,19 +1900,13 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     }
     int flag = 0;
     const size_t outb = (size_t)nout * sizeof(double);
-    if (ctx->pinned && outb + 64 <= 64 * 1024) {
-        // small result: phases and the status word land in the context's pinned buffer, one synchronisation, no staging
-        // copies through pageable memory (a berry_phase call on a 31 x 31 array is 50 us, two of these copies 15 of them)
-        unsigned char* pin = (unsigned char*)ctx->pinned;
-        TBK_HIP(hipMemcpyAsync(pin + 64, A.out, outb, hipMemcpyDeviceToHost, ctx->stream));
-        TBK_HIP(hipMemcpyAsync(pin, ctx->flags_dev + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        TBK_HIP(hipStreamSynchronize(ctx->stream));
-        memcpy(out, pin + 64, outb);
-        memcpy(&flag, pin, sizeof(int));
-    } else {
-        TBK_HIP(hipMemcpyAsync(out, A.out, outb, hipMemcpyDeviceToHost, ctx->stream));
-        TBK_HIP(hipMemcpyAsync(&flag, ctx->flags_dev + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        TBK_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        // phases and status words in one round trip (small results: one copy kernel that also stores the completion word the
+        // host polls -- a berry_phase call on a 31 x 31 array was 34 us, two hipMemcpyAsync and a synchronisation 17 of them)
+        int fl[4] = {0, 0, 0, 0};
+        const int rcr = tbk_small_result(ctx, out, A.out, outb, fl);
+        if (rcr) return rcr;
+        flag = fl[1];
     }
     if (flag) {
         TBK_HIP(hipMemsetAsync(ctx->flags_dev + 1, 0, sizeof(int), ctx->stream));

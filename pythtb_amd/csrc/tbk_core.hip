@@ -129,7 +129,11 @@ extern "C" int tbk_ctx_create(int device, tbk_ctx** out) {
     TBK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     TBK_HIP(hipEventCreate(&c->timer0));
     TBK_HIP(hipEventCreate(&c->timer1));
-    if (hipHostMalloc(&c->pinned, 64 * 1024, hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;   // (optional: falls back to plain copies)
+    if (hipHostMalloc(&c->pinned, 64 * 1024, hipHostMallocMapped) != hipSuccess) c->pinned = nullptr;   // (optional: falls back to plain copies)
+    if (c->pinned && hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        c->pinned_dev = nullptr;
+    }
     TBK_HIP(hipMalloc((void**)&c->flags_dev, 64 * sizeof(int)));
     TBK_HIP(hipMemsetAsync(c->flags_dev, 0, 64 * sizeof(int), c->stream));
     {   // completion word (tbk_done_arm): optional -- without it small calls synchronise the stream
@@ -198,18 +202,56 @@ extern "C" int tbk_ctx_device_info(tbk_ctx* c, char* name, int cap, int* cus, in
     return TBK_OK;
 }
 
-int tbk_small_d2h(tbk_ctx* c, void* dst, const void* src_dev, size_t bytes) {
-    if (bytes == 0) return TBK_OK;
-    if (bytes > 64 * 1024 || !c->pinned) {
-        TBK_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+// a small result out of device memory: ONE kernel copies it into the context's pinned (device-visible) buffer, takes the status
+// words along and stores the completion word; the host polls that (a hipMemcpyAsync + hipStreamSynchronize pair is ~17 us, this is
+// ~9).  flags_out (nullable): ctx->flags_dev[0..3] as that kernel saw them.
+__global__ __launch_bounds__(256) void k_copy_small_signal(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                           const unsigned bytes, const DoneArgs done) {
+    if ((((size_t)src | (size_t)dst) & 7) == 0) {
+        const unsigned n8 = bytes >> 3;
+        for (unsigned i = threadIdx.x; i < n8; i += 256)
+            reinterpret_cast<unsigned long long*>(dst)[i] = reinterpret_cast<const unsigned long long*>(src)[i];
+        for (unsigned i = (n8 << 3) + threadIdx.x; i < bytes; i += 256) dst[i] = src[i];
+    } else {
+        for (unsigned i = threadIdx.x; i < bytes; i += 256) dst[i] = src[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) tbk_signal_done(done);
+}
+
+int tbk_small_result(tbk_ctx* c, void* dst, const void* src_dev, size_t bytes, int* flags_out) {
+    if (bytes == 0 && !flags_out) return TBK_OK;
+    if (c->pinned && c->pinned_dev && bytes + 64 <= 64 * 1024) {
+        const DoneArgs d = tbk_done_arm(c, flags_out != nullptr);
+        if (d.word) {
+            hipLaunchKernelGGL(k_copy_small_signal, dim3(1), dim3(256), 0, c->stream, (const unsigned char*)src_dev,
+                               (unsigned char*)c->pinned_dev + 64, (unsigned)bytes, d);
+            TBK_HIP(hipGetLastError());
+            const int rc = tbk_done_wait(c, d);
+            if (rc) return rc;
+            memcpy(dst, (unsigned char*)c->pinned + 64, bytes);
+            if (flags_out)
+                for (int i = 0; i < 4; ++i) flags_out[i] = (int)c->done_host[4 + i];
+            return TBK_OK;
+        }
+    }
+    if (c->pinned && bytes + 64 <= 64 * 1024) {
+        unsigned char* pin = (unsigned char*)c->pinned;
+        if (bytes) TBK_HIP(hipMemcpyAsync(pin + 64, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (flags_out) TBK_HIP(hipMemcpyAsync(pin, c->flags_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         TBK_HIP(hipStreamSynchronize(c->stream));
+        memcpy(dst, pin + 64, bytes);
+        if (flags_out) memcpy(flags_out, pin, 4 * sizeof(int));
         return TBK_OK;
     }
-    TBK_HIP(hipMemcpyAsync(c->pinned, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (bytes) TBK_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (flags_out) TBK_HIP(hipMemcpyAsync(flags_out, c->flags_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     TBK_HIP(hipStreamSynchronize(c->stream));
-    memcpy(dst, c->pinned, bytes);
     return TBK_OK;
 }
+
+int tbk_small_d2h(tbk_ctx* c, void* dst, const void* src_dev, size_t bytes) { return tbk_small_result(c, dst, src_dev, bytes, nullptr); }
 
 DoneArgs tbk_done_arm(tbk_ctx* c, bool with_flags) {
     DoneArgs d{nullptr, nullptr, nullptr, 0u};

@@ -205,6 +205,7 @@ struct tbk_ctx {
     void* zc_dev = nullptr;
     size_t zc_bytes = 0;
     void* pinned = nullptr;    // 64 KiB of pinned host memory for small results
+    void* pinned_dev = nullptr;  // ... its device address (k_copy_small_signal writes small results there itself)
     int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
     // completion word of small calls (tbk_done_arm / tbk_done_wait): 64 B of mapped host memory -- [0] the sequence number the last
     // kernel of the call stores after its results, [4..7] a copy of flags_dev[0..3] taken by that kernel; and its device-side
@@ -228,6 +229,8 @@ int tbk_ctx_zero_copy(tbk_ctx* ctx, size_t bytes, void** host, void** dev);
 // small device-to-host result (min gaps, flux totals, status words): through a pinned staging buffer -- an async copy into
 // pageable memory is staged by the runtime and cost ~10 us more per call on the Python-API path -- then stream sync
 int tbk_small_d2h(tbk_ctx* ctx, void* dst, const void* src_dev, size_t bytes);
+// the same with the status words (flags_out[4] = ctx->flags_dev[0..3], nullable) in the same round trip
+int tbk_small_result(tbk_ctx* ctx, void* dst, const void* src_dev, size_t bytes, int* flags_out);
 
 // ---- "the call is finished" without hipStreamSynchronize.  Waiting on the runtime's completion signal costs ~12 us for a kernel
 // of ~2 us; polling a word of mapped host memory that the call's LAST kernel stores after its results costs ~6.6 us

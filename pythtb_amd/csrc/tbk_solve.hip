@@ -459,11 +459,18 @@ __device__ __forceinline__ void gap_min_wave(unsigned long long* shard_row, int 
     }
 }
 
+// a call's last kernel did not take the completion word itself: one more launch that only stores it
+__global__ void k_signal_only(const DoneArgs done) {
+    if (threadIdx.x == 0) tbk_signal_done(done);
+}
+
 // ---- k list (MODE 0) or supplied matrices (MODE 2) -> eval[b][k], evec[b][k][o]
 template <int N, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const int64_t nk, const ListArgs L) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nk) return;
+    // (the point's work stays INLINE under this test: moved into a function of its own the compiler fused other products and
+    // the eigenvectors differed from k_solve_small_multi's by an ulp -- tests/test_regimes.py::test_two_points_per_lane_...)
+    if (idx < nk) {
     double kk[4] = {0.0, 0.0, 0.0, 0.0};
     SmallMat<N> M;
     if constexpr (MODE == 2) {
@@ -509,6 +516,12 @@ __global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const i
 #pragma unroll
             for (int o = 0; o < N; ++o) out[o] = cmul(M.v[o][b], fo[o]);
         }
+    }
+    }
+    if (L.done.word) {               // (kernel-uniform; small calls only: every lane's results reach the host before the ticket)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) tbk_signal_done(L.done);
     }
 }
 
@@ -1455,11 +1468,8 @@ static size_t wave_lds_bytes(int n, bool with_t, int nR = 0) {
 // ---------------------------------------------------------------------------
 // _gen_ham parity hook: H_ab(k) = conj(e_a) e_b S_ab(k), one thread per (k,slot)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gen_ham(const ModelView mv, const int64_t nk,
-                                                 const double* __restrict__ k, cd* __restrict__ ham) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = nk * mv.nslot;
-    if (idx >= total) return;
+__device__ __forceinline__ void gen_ham_entry(const ModelView& mv, const int64_t nk, const double* __restrict__ k,
+                                              cd* __restrict__ ham, const int64_t idx) {
     const int64_t ik = idx / mv.nslot;
     const int slot = (int)(idx - ik * mv.nslot);
     double kk[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1483,6 +1493,16 @@ __global__ __launch_bounds__(256) void k_gen_ham(const ModelView mv, const int64
         const cd v = cmul(cmulc(ea, eb), s);
         h[a * n + b] = v;
         h[b * n + a] = cconj(v);
+    }
+}
+__global__ __launch_bounds__(256) void k_gen_ham(const ModelView mv, const int64_t nk,
+                                                 const double* __restrict__ k, cd* __restrict__ ham, const DoneArgs done) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < nk * mv.nslot) gen_ham_entry(mv, nk, k, ham, idx);
+    if (done.word) {                 // (small calls: H(k) lies in mapped host memory and the host polls the completion word)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) tbk_signal_done(done);
     }
 }
 
@@ -1556,6 +1576,7 @@ static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
             if (n == 2) hipLaunchKernelGGL((k_solve_small_multi<2, VEC, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
             else if (n == 3) hipLaunchKernelGGL((k_solve_small_multi<3, false, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
             else hipLaunchKernelGGL((k_solve_small_multi<4, false, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
+            if (L.done.word) hipLaunchKernelGGL(k_signal_only, dim3(1), dim3(64), 0, ctx->stream, L.done);   // (TBK_SMALL_KPT=2 on a small call)
             TBK_HIP(hipGetLastError());
             return TBK_OK;
         }
@@ -1926,9 +1947,27 @@ extern "C" int tbk_solve_list(tbk_model* m, const double* k, int64_t nk, double*
                 TBK_REQUIRE(k, TBK_EINVAL, "tbk_solve_list: null k");
                 memcpy(hp_, k, kb);
             }
-            rcz = tbk_solve_list_dev_checked(m, (const double*)dp_, nk, (double*)(dp_ + al(kb)), evec ? (double*)(dp_ + al(kb) + al(eb)) : nullptr);
-            if (rcz) return rcz;
-            TBK_HIP(hipStreamSynchronize(ctx->stream));
+            double* const e_zd = (double*)(dp_ + al(kb));
+            double* const v_zd = evec ? (double*)(dp_ + al(kb) + al(eb)) : nullptr;
+            // up to 4 states: ONE kernel (k_solve_small), which stores the completion word after its results -- the host polls that
+            // instead of synchronising the stream (tbk_done_wait), and the status words come back beside it
+            const DoneArgs done = n <= 4 ? tbk_done_arm(ctx, n > 2) : DoneArgs{nullptr, nullptr, nullptr, 0u};
+            if (done.word) {
+                ListArgs L{(const double*)dp_, nullptr, e_zd, (cd*)v_zd};
+                L.done = done;
+                rcz = launch_solve<0>(ctx, m->view, n, nk, evec != nullptr, L, evec ? "solve_list_vec" : "solve_list_val");
+                if (rcz) return rcz;
+                rcz = tbk_done_wait(ctx, done);
+                if (rcz) return rcz;
+                if (done.flags_src && ctx->done_host[4] != 0u) {     // an eigen-solver ran into its iteration cap: the usual report
+                    rcz = check_noconv(ctx, n);
+                    if (rcz) return rcz;
+                }
+            } else {
+                rcz = tbk_solve_list_dev_checked(m, (const double*)dp_, nk, e_zd, v_zd);
+                if (rcz) return rcz;
+                TBK_HIP(hipStreamSynchronize(ctx->stream));
+            }
             memcpy(eval, hp_ + al(kb), eb);
             if (evec) memcpy(evec, hp_ + al(kb) + al(eb), vb);
             return TBK_OK;
@@ -2047,15 +2086,18 @@ extern "C" int tbk_gen_ham(tbk_model* m, const double* k, int64_t nk, double* ha
     }
     if (zh) memset((unsigned char*)zh + al(kb), 0, hb);
     else TBK_HIP(hipMemsetAsync(h_dev, 0, hb, ctx->stream));
+    DoneArgs done{nullptr, nullptr, nullptr, 0u};
     {
         ProfScope ps(ctx, "gen_ham");
         const int64_t total = nk * m->nslot;
+        done = zh ? tbk_done_arm(ctx, false) : DoneArgs{nullptr, nullptr, nullptr, 0u};
         hipLaunchKernelGGL(k_gen_ham, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                           m->view, nk, k_dev, h_dev);
+                           m->view, nk, k_dev, h_dev, done);
         TBK_HIP(hipGetLastError());
     }
     if (zh) {
-        TBK_HIP(hipStreamSynchronize(ctx->stream));
+        const int rcw = tbk_done_wait(ctx, done);
+        if (rcw) return rcw;
         memcpy(ham_out, (unsigned char*)zh + al(kb), hb);
         return TBK_OK;
     }

@@ -49,6 +49,8 @@ struct ListArgs {
     int* flags;       // the context's sticky status words ([0]: an eigen-solver ran into its iteration cap); null: not reported
     int natural;      // k_solve_row16 only: leave the eigenpairs in Jacobi's own order (column j grown out of e_j, so the
                       // eigenvector matrix stays as close to the identity as the rotations allow) instead of sorting
+    DoneArgs done;    // k_solve_small only (k lists of <= 4 states whose results lie in mapped host memory): completion word for
+                      // the host to poll (tbk_done_wait); word == null: not armed
 };
 
 // "entry j (value o) comes before entry x (value mine)" in an ascending order that is TOTAL even with NaNs (they sort last,

@@ -381,3 +381,30 @@ def test_copies_and_pickles_after_the_per_call_buffers_exist(tb):
         f = w.berry_flux([0])
         with _lib.knob("TBK_POLL_DONE", 0):
             assert np.array_equal(w2.solve_on_grid(s), g) and w2.berry_flux([0]) == f
+
+
+def test_small_calls_polled_completion_equals_stream_synchronisation(tb):
+    """Small calls (band-structure paths, solve_one, _gen_ham, Berry phases of small arrays) wait on a completion word that the
+    call's last kernel stores in mapped host memory (tbk_done_wait) instead of hipStreamSynchronize: the same bits either way,
+    call after call, for every model size that takes the small-list kernel and one that does not."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(4)
+    models = [hp.haldane(tb.tb_model), hp.kane_mele(tb.tb_model), hp.random_model(tb.tb_model, 3, 2, 1, seed=3, nhop=9, rmax=1),
+              hp.random_model(tb.tb_model, 6, 2, 1, seed=6, nhop=20, rmax=1)]
+    for m in models:
+        k = rng.random((121, m._dim_k))
+        ref = {}
+        for poll in (0, 1, 1, 0):
+            with _lib.knob("TBK_POLL_DONE", poll):
+                got = (m.solve_all(k), m.solve_all(k, eig_vectors=True), m.solve_one(k[7]), m._gen_ham(k[5]),
+                       m.solve_one(k[9], eig_vectors=True))
+                w = tb.wf_array(m, [13, 11])
+                gaps = w.solve_on_grid([0.1, -0.2])
+                occ = list(range(max(1, m._nsta // 2)))
+                ph = (w.berry_phase(occ, 1, contin=False), w.berry_phase(occ, 0, contin=False, berry_evals=len(occ) > 1),
+                      w.berry_flux(occ), w.berry_flux(occ, individual_phases=True))
+            flat = [np.asarray(x) for g in got for x in (g if isinstance(g, tuple) else (g,))] + [np.asarray(gaps)] + [np.asarray(p) for p in ph]
+            if not ref:
+                ref = flat
+            else:
+                assert len(flat) == len(ref) and all(np.array_equal(a, b) for a, b in zip(flat, ref))
