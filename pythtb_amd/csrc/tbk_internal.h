@@ -70,6 +70,7 @@ struct TbkKnobs {
     int grid_seg = -1;          // TBK_GRID_SEG      chunks per wave tile of k_grid_rows
     int grid_kernel = 0;        // TBK_GRID_KERNEL   1: term-walking mesh kernel instead of the row-polynomial one
     int flux_ti = -1;           // TBK_FLUX_TI       rows per flux tile
+    int pos_tile = 1;           // TBK_POS_TILE      0: position matrices of <= 8 states by the thread-per-entry kernel (A/B)
     int poll_done = 1;          // TBK_POLL_DONE     0: small calls wait with hipStreamSynchronize instead of polling the completion word
     int flux_fused = 0;         // TBK_FLUX_FUSED    1: final flux sum inside the kernel
     int trigv_from = -1;        // TBK_TRIGV_FROM    smallest n of the workgroup-scale direct eigenvector path (default 65; A/B runs down to 17)

@@ -38,6 +38,77 @@ __global__ __launch_bounds__(256) void k_position_matrix(const EvecSrc ev, const
     xmat[idx] = acc;
 }
 
+// The same for up to 8 states on batches (position_hwf_mesh: a 513^2 array of slabs, 8 of 16 bands): the kernel above has every
+// thread walk two 256-byte rows of its own -- 64 threads per point re-read the point's 2 KB sixteen times through the caches, and
+// the launch took 0.59 ms of the call's 0.89 (profiles/r04f).  Here a wavefront stages FOUR points (their nsub rows, coalesced
+// 256-byte runs) in LDS and sixteen lanes per point form X in 2 x 2 blocks (two rows of the bra, two of the ket per lane and
+// component: four LDS reads per sixteen multiply-adds).  The sum over the components runs in the same order, one chain per entry.
+__device__ __forceinline__ void pos_lds_sync_wave() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+template <int NT>   // NT = ceil(nsub / 2) = 1..4
+__global__ __launch_bounds__(256) void k_position_matrix_tile(const EvecSrc ev, const double* __restrict__ pos, const int64_t nk,
+                                                              const int nsub, const int ncomp, cd* __restrict__ xmat) {
+    extern __shared__ __align__(16) unsigned char pos_lds[];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wib) * 4;
+    if (p0 >= nk) return;                              // (no workgroup barrier below: the wavefronts are independent)
+    const int ldp = ncomp + 1, pbuf = nsub * ldp;
+    const int wstride = 4 * pbuf + (ncomp + 1) / 2;   // four points + the coordinates
+    cd* const buf = reinterpret_cast<cd*>(pos_lds) + (size_t)wib * wstride;
+    {   // rows (point, state) of ncomp contiguous components: sixteen lanes per row.  All the loads of a 16-component slice are
+        // issued before the first goes to LDS (a load -> ds_write pair per loop trip serialises eight memory latencies: 0.24 ms
+        // for the 513^2 array where this form takes 0.1)
+        const int j0 = lane & 15, nrow = 4 * nsub;
+        for (int jc = 0; jc < ncomp; jc += 16) {
+            const int j = jc + j0;
+            cd r[8];
+            int dsto[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (lane >> 4) + 4 * i;
+                const int pt = row / nsub, b = row - pt * nsub;
+                const bool ok = row < nrow && j < ncomp && p0 + pt < nk;
+                dsto[i] = ok ? pt * pbuf + b * ldp + j : -1;
+                r[i] = ok ? ev.at(p0 + pt, b)[j] : cd{0.0, 0.0};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (dsto[i] >= 0) buf[dsto[i]] = r[i];
+        }
+    }
+    {
+        double* const pl = reinterpret_cast<double*>(buf + 4 * pbuf);
+        for (int j = lane; j < ncomp; j += 64) pl[j] = pos[j];
+    }
+    pos_lds_sync_wave();
+    const int g = lane >> 4, tl = lane & 15;
+    const int ta = tl / NT, tb = tl - ta * NT;
+    if (tl >= NT * NT || p0 + g >= nk) return;
+    const int m0 = min(2 * ta, nsub - 1), m1 = min(2 * ta + 1, nsub - 1), n0 = min(2 * tb, nsub - 1), n1 = min(2 * tb + 1, nsub - 1);
+    const cd* const pa = buf + g * pbuf;
+    const cd *a0 = pa + m0 * ldp, *a1 = pa + m1 * ldp, *b0 = pa + n0 * ldp, *b1 = pa + n1 * ldp;
+    cd x00{0.0, 0.0}, x01{0.0, 0.0}, x10{0.0, 0.0}, x11{0.0, 0.0};
+    const double* const posl = reinterpret_cast<const double*>(buf + 4 * pbuf);   // (staged behind the points)
+    for (int j = 0; j < ncomp; ++j) {
+        const double r = posl[j];
+        const cd u0 = a0[j], u1 = a1[j], v0 = cscale(b0[j], r), v1 = cscale(b1[j], r);
+        cfmac(x00, u0, v0);
+        cfmac(x01, u0, v1);
+        cfmac(x10, u1, v0);
+        cfmac(x11, u1, v1);
+    }
+    cd* const o = xmat + (p0 + g) * (int64_t)nsub * nsub;
+    o[m0 * nsub + n0] = x00;
+    if (2 * tb + 1 < nsub) o[m0 * nsub + n1] = x01;
+    if (2 * ta + 1 < nsub) {
+        o[m1 * nsub + n0] = x10;
+        if (2 * tb + 1 < nsub) o[m1 * nsub + n1] = x11;
+    }
+}
+
 // band-major eigen-solver outputs -> [k][i] / [k][i][x] in the requested basis
 __global__ __launch_bounds__(256) void k_hwf_out(const double* __restrict__ ev, const cd* __restrict__ vw,
                                                  const EvecSrc src, int64_t nk, int nsub, int ncomp,
@@ -109,8 +180,20 @@ static int position_run(tbk_ctx* ctx, const double* host_evec, EvecSrc src, cons
     {
         ProfScope ps(ctx, "position_matrix");
         const int64_t total = nk * nsub * nsub;
-        hipLaunchKernelGGL(k_position_matrix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                           src, (const double*)d_pos, nk, nsub, ncomp, d_x);
+        const size_t lds_t = (size_t)4 * (4 * nsub * (ncomp + 1) + (ncomp + 1) / 2) * sizeof(cd);   // four wavefronts x (four points + the coordinates)
+        // (TBK_POS_TILE=0: the thread-per-entry kernel at any size)
+        if (nsub <= 8 && nk >= 64 && lds_t <= 64 * 1024 && tbk_knobs().pos_tile != 0) {
+            const dim3 g((unsigned)((nk + 15) / 16)), b(256);
+            switch ((nsub + 1) / 2) {
+                case 1: hipLaunchKernelGGL((k_position_matrix_tile<1>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x); break;
+                case 2: hipLaunchKernelGGL((k_position_matrix_tile<2>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x); break;
+                case 3: hipLaunchKernelGGL((k_position_matrix_tile<3>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x); break;
+                default: hipLaunchKernelGGL((k_position_matrix_tile<4>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x); break;
+            }
+        } else {
+            hipLaunchKernelGGL(k_position_matrix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                               src, (const double*)d_pos, nk, nsub, ncomp, d_x);
+        }
         TBK_HIP(hipGetLastError());
     }
     if (xmat) TBK_HIP(hipMemcpyAsync(xmat, d_x, (size_t)nk * nsub * nsub * sizeof(cd), hipMemcpyDeviceToHost, ctx->stream));

@@ -144,3 +144,45 @@ def test_gpu_hwf_haldane_ribbon_and_spin():
         pos = np.repeat(s._orb[:, 1], 2)
         wf = w.reshape(len(occ), -1)
         assert np.max(np.abs(np.einsum("ij,j,ij->i", wf.conj(), pos, wf).real - c)) < 1e-12   # <hwf|r|hwf> = centre
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsub", [1, 2, 3, 5, 7, 8])
+def test_gpu_position_matrix_tile_kernel_equals_the_entry_kernel(nsub):
+    """Batches of up to 8 states take k_position_matrix_tile (four points per wavefront through LDS, 2 x 2 blocks of X per lane;
+    tbk_position.hip): X, the centres and the functions against the thread-per-entry kernel (TBK_POS_TILE=0) on a ragged batch
+    (99 points: the last wavefront holds three), with an occupied-band list that is not the lowest bands, and on a point list."""
+    import ctypes as C
+    import pythtb_amd as tb
+    from pythtb_amd import _lib
+    g = load_golden("hwf_cubic_slab")
+    m = hp.model_from_tables(tb.tb_model, golden_tables(g))
+    w = tb.wf_array(m, [11, 9])
+    w.solve_on_grid([0.0, 0.0])
+    h = w._ensure_dev()
+    n = m._nsta
+    rng = np.random.default_rng(nsub)
+    occ = np.sort(rng.choice(n, nsub, replace=False)).astype(np.int32)
+    pos = np.ascontiguousarray(np.repeat(m._orb[:, 2], m._nspin), dtype=float)
+    pts = np.ascontiguousarray(rng.choice(99, 70, replace=False).astype(np.int64))
+    got = {}
+    for tile in (0, 1):
+        with _lib.knob("TBK_POS_TILE", tile):
+            out = []
+            for plist in (None, pts):
+                nk = 99 if plist is None else len(plist)
+                x = np.zeros((nk, nsub, nsub), dtype=complex)
+                c = np.zeros((nk, nsub))
+                f = np.zeros((nk, nsub, n), dtype=complex)
+                _lib.check(_lib.lib.tbk_wfs_position_hwf(h, None if plist is None else plist.ctypes.data_as(C.POINTER(C.c_int64)), nk,
+                                                         _lib.iptr(occ), nsub, _lib.dptr(pos), _lib.dptr(x.view(float)), _lib.dptr(c),
+                                                         _lib.dptr(f.view(float)), 1))
+                out.append((x, c, f))
+            got[tile] = out
+    host = w.to_host().reshape(99, n, n)
+    for (x0, c0, f0), (x1, c1, f1), plist in zip(got[0], got[1], (np.arange(99), pts)):
+        assert np.max(np.abs(x1 - x0)) < 1e-15 * max(1.0, np.abs(pos).max())
+        v = host[plist][:, occ, :]
+        ref = np.einsum("kmj,j,knj->kmn", v.conj(), pos, v)
+        assert np.max(np.abs(x1 - ref)) < 1e-13
+        assert np.max(np.abs(c1 - c0)) < 1e-12 and np.max(np.abs(np.abs(f1) - np.abs(f0))) < 1e-9
