@@ -87,10 +87,17 @@ class wf_array(object):
     _SMALL_MIRROR_BYTES = 32 << 20    # wf[i,j] on a resident array at most this big mirrors it whole
 
     def _shape(self, nsta=None):
+        if nsta is None:
+            c = self.__dict__.get("_shape0")
+            if c is not None and c[0] == self._nsta_arr:
+                return c[1]
         shp = [int(x) for x in self._mesh_arr] + [int(self._nsta_arr if nsta is None else nsta), self._norb]
         if self._nspin == 2:
             shp.append(2)
-        return tuple(shp)
+        shp = tuple(shp)
+        if nsta is None:
+            self._shape0 = (self._nsta_arr, shp)      # (the mesh and the orbitals are fixed at construction)
+        return shp
 
     def _host_array(self):
         """Host mirror, brought up to date, without giving up the device copy."""
@@ -672,7 +679,21 @@ class wf_array(object):
     def berry_flux(self, occ="All", dirs=None, individual_phases=False):
         """Berry flux through the (dirs[0],dirs[1]) planes (pythtb.py:3068-3205):
         plaquette phases and their deterministic sum are computed on the device."""
-        occ = self._occ(occ)
+        # (the occupied-band list as a ctypes pointer is kept per distinct list: building it anew is 3 us of a 40 us call)
+        b = self._call_bufs(self._nsta_arr)
+        try:
+            okey = occ if isinstance(occ, str) or occ is None else tuple(occ)
+            o = b["occ"].get(okey)
+        except TypeError:
+            okey, o = None, None
+        if o is None:
+            occ_arr = self._occ(occ)
+            occ32 = np.ascontiguousarray(occ_arr, dtype=np.int32)
+            o = (occ32, _lib.iptr(occ32), len(occ32))
+            if okey is not None and occ_arr.ndim == 1:
+                if len(b["occ"]) > 64:
+                    b["occ"].clear()
+                b["occ"][okey] = o
         if self._model._assume_position_operator_diagonal == False:  # noqa: E712
             raise Exception("\n\nBerry-like objects of Wannier90 models need "
                             "my_model.ignore_position_operator_offdiagonal()")
@@ -692,19 +713,11 @@ class wf_array(object):
             nsl = int(np.prod(rest)) if rest else 1
         n0 = int(self._mesh_arr[dirs[0]]) - 1
         n1 = int(self._mesh_arr[dirs[1]]) - 1
-        b = self._call_bufs(self._nsta_arr)
         t = b["totals"].get(nsl)
         if t is None:
             t = np.zeros(nsl, dtype=float)
             t = b["totals"][nsl] = (t, _lib.dptr(t))
         plaq = np.zeros((nsl, n0, n1), dtype=float) if individual_phases else None
-        okey = (occ.dtype.char, occ.tobytes())
-        o = b["occ"].get(okey)
-        if o is None:
-            if len(b["occ"]) > 64:
-                b["occ"].clear()
-            occ32 = np.ascontiguousarray(occ, dtype=np.int32)
-            o = b["occ"][okey] = (occ32, _lib.iptr(occ32), len(occ32))
         _lib.check(_lib.lib.tbk_berry_flux(h, o[1], o[2], int(dirs[0]), int(dirs[1]), t[1], _lib.dptr(plaq)))
         totals = t[0].copy()
         if self._dim_arr == 2:
