@@ -5,7 +5,7 @@
 //
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -disable-machine-licm -I pythtb_amd/csrc -I include \
 //         profiles/microbench/e16_bench.hip -o profiles/microbench/e16_bench
-//   ./e16_bench [nk = 137312] [n = 16] [kind = 0 random | 1 clustered (two groups of 8) | 2 special structures] [reps = 5]
+//   ./e16_bench [nk = 137312] [n = 16] [kind = 0 random | 1 clustered (two groups of 8) | 2 special structures | 3 H_0 x 1_2 (every level twice)] [reps = 5]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <complex>
@@ -55,6 +55,14 @@ __global__ void k_make(cd* h, const int64_t nk, const int n, const int kind) {
             m[r * n + c] = cd{re, im};
             m[c * n + r] = cd{re, -im};
         }
+    if (kind == 3) {   // H_0 x 1_2: every level twice (a spinful model without spin-orbit coupling), components (orbital, spin)
+        const int h2 = n / 2;
+        cd t[8][8];
+        for (int r = 0; r < h2; ++r)
+            for (int c = 0; c < h2; ++c) t[r][c] = m[r * n + c];
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) m[r * n + c] = (r & 1) == (c & 1) && r / 2 < h2 && c / 2 < h2 ? t[r / 2][c / 2] : cd{0.0, 0.0};
+    }
 }
 
 typedef std::complex<double> cplx;
