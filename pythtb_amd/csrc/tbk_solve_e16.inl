@@ -402,6 +402,7 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     bl = 0;
     bh = n - 1;
     int kb = (int)clo + ((int)j - (int)clo);             // (= j: the whole T is one block)
+    int c_lo = (int)clo, c_hi = (int)chi;                // eigenvalues of the block below lo / at or below hi
     if (splits) {                                        // (wave-uniform: some T of the wavefront splits)
         const int r = j - (int)clo;
         int cum = 0, cl = 0, ch = 0, start = 0;
@@ -417,6 +418,8 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
                 bl = here ? start : bl;
                 bh = here ? i : bh;
                 kb = here ? cl + (r - cum) : kb;
+                c_lo = here ? cl : c_lo;
+                c_hi = here ? ch : c_hi;
                 found = found || here;
                 cum += inc > 0 ? inc : 0;
                 cl = 0;
@@ -459,9 +462,15 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
         const unsigned chg = (unsigned)__builtin_popcount((sgn ^ (sgn >> 1)) & ((1u << len) - 1u) & 0xffffu);
         const bool left = (int)chg <= kb;                // the root is at or above x
         const double nlo = left ? x : lo, nhi = left ? hi : x;
+        const int nclo = left ? (int)chg : c_lo, nchi = left ? c_hi : (int)chg;
+        // Newton for a root of multiplicity m = eigenvalues of the block still inside the bracket: x - m p / p'.  One eigenvalue
+        // (every bracket but those of pairs closer than the 2^-12 |T| the bisection leaves): m = 1 and the same bits as before.
+        // Twins -- Kramers pairs, spin-degenerate bands: both lanes hold the pair in their bracket, plain Newton on the (near-)
+        // double root halves its error per step and twelve steps ended 2.5e-8 |T| away; with m = 2 three steps reach rounding.
+        const double mult = (double)(nchi - nclo > 1 ? nchi - nclo : 1);
         double y = __builtin_amdgcn_rcp(dp1);
         y = fma(fma(-dp1, y, 1.0), y, y);
-        double xn = fma(-p1, y, x);
+        double xn = fma(-(p1 * mult), y, x);
         // A step is taken if it stays inside the bracket -- with a slack of 64 eps |T|: from the far side of a root whose near
         // bound has already closed in to rounding level, the (correct) step lands a few 1e-15 beyond that bound, and the midpoint
         // that a strict test would take instead is half the old error away (12 such steps ended 1e-7 from the root).
@@ -473,6 +482,8 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
         if (!conv) {
             lo = nlo;
             hi = nhi;
+            c_lo = nclo;
+            c_hi = nchi;
             x = p1 == 0.0 ? x : xn;
             conv = done;
             ++dbg_it;
@@ -564,6 +575,105 @@ __device__ __forceinline__ bool e16_twisted(const double (&d0)[16], const double
     // residual |(T - lambda) z| / |z| = |gamma_r| / |z|: a few eps |T| for an eigenvalue that accurate
     const double tn = tnorm + fabs(lam);
     return !(fabs(gam_r) * inz <= 1e-11 * tn);
+}
+
+// The SECOND eigenvector of a pair of eigenvalues of one block closer than gaptol |T| (twins: Kramers pairs, spin-degenerate bands,
+// or merely close levels).  The twisted factorisation gives both lanes of such a pair (nearly) the same vector; xSTEIN's remedy:
+// inverse iteration with reorthogonalisation against the first member.  w = the first member's unit vector (lane j - 1's, fetched
+// by the caller), v = this lane's start vector (its own twisted-factorisation vector) and result; T - lam = L D L^T top-down with
+// d, e streamed from LDS (guarded pivots: the solve only has to amplify the eigenspace, the checks at the end decide).  Two rounds of
+// orthogonalise | solve | orthogonalise | normalise, then the Rayleigh quotient (dlam) and the residual of (lam + dlam, v).
+// Returns false when the result is not an eigenvector to 1e-14 |T| -- the matrix then goes to the list like before.
+__device__ __forceinline__ bool e16_twin(const e16_lcd* xd, const double lam, const int bl, const int bh, const double (&w)[16], double (&v)[16],
+                                         double& dlam, double* dbg = nullptr) {
+    // start: a fixed generic vector on the rows of the block (the lane's own twisted-factorisation vector is the first member's
+    // bit for bit when the two eigenvalues came out equal: nothing would be left of it after the orthogonalisation)
+    {
+        const double c[16] = {0.61, -0.37, 0.93, 0.28, -0.75, 0.49, 0.17, -0.88, 0.55, -0.23, 0.71, 0.39, -0.64, 0.82, -0.12, 0.45};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = i >= bl && i <= bh ? c[i] : 0.0;
+    }
+    double l[15], rdp[16];
+    {
+        e16_d2 t = xd[0];
+        double dp = t.x - lam;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            rdp[i] = e16_rcp(e16_guard(dp));
+            l[i] = t.y * rdp[i];
+            const e16_d2 tn = xd[i + 1];
+            dp = fma(-t.y, l[i], tn.x - lam);
+            t = tn;
+        }
+        rdp[15] = e16_rcp(e16_guard(dp));
+    }
+    auto orth = [&]() {
+        double c = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c = fma(w[i], v[i], c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = fma(-c, w[i], v[i]);
+    };
+    auto normalise = [&]() {
+        double m = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmax(m, fabs(v[i]));
+        int ex = 0;
+        (void)frexp(m, &ex);
+        const double s = m > 0.0 && m < INFINITY ? ldexp(1.0, -ex) : 1.0;      // (the solve grows by up to 1 / pivot)
+        double nz2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v[i] *= s;
+            nz2 = fma(v[i], v[i], nz2);
+        }
+        const double inz = nz2 > 0.0 ? rsqrt_full(nz2) : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] *= inz;
+    };
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+        orth();
+        normalise();
+#pragma unroll
+        for (int i = 0; i < 15; ++i) v[i + 1] = fma(-l[i], v[i], v[i + 1]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] *= rdp[i];
+#pragma unroll
+        for (int i = 14; i >= 0; --i) v[i] = fma(-l[i], v[i + 1], v[i]);
+        normalise();
+        orth();
+        normalise();
+    }
+    // r = (T - lam) v, rq = v.r (Rayleigh correction), residual of (lam + rq, v)
+    double rq = 0.0, r2 = 0.0, cw = 0.0, nv2 = 0.0;
+    {
+        double eprev = 0.0, vprev = 0.0;
+        double r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const e16_d2 t = xd[i];
+            r[i] = fma(t.x - lam, v[i], eprev * vprev);
+            if (i < 15) r[i] = fma(t.y, v[i + 1], r[i]);
+            eprev = t.y;
+            vprev = v[i];
+            rq = fma(v[i], r[i], rq);
+            cw = fma(w[i], v[i], cw);
+            nv2 = fma(v[i], v[i], nv2);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double q = fma(-rq, v[i], r[i]);
+            r2 = fma(q, q, r2);
+        }
+    }
+    dlam = rq;
+    if (dbg) {
+        dbg[0] = r2;
+        dbg[1] = cw;
+        dbg[2] = nv2;
+    }
+    return r2 <= 1e-28 && fabs(cw) <= 1e-12 && fabs(rq) <= 1e-9 && fabs(nv2 - 1.0) <= 1e-12;
 }
 
 // ---------------------------------------------------------------- the kernel
@@ -780,6 +890,39 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = i == j ? 1.0 : d[i] * 1e-3;
     }
+    // ---- twins: the second member of an isolated pair of close eigenvalues of one block gets its vector by inverse iteration
+    // against the first (e16_twin); pairs inside longer clusters stay for the list (close_pair below)
+    bool twin_ok = false;
+    {
+        const double lam_dn = e16_prev(lam), lam_up = e16_next(lam);
+        const int bl_dn = __builtin_amdgcn_update_dpp(0, bl, 0x111, 0xf, 0xf, true);     // lane j - 1
+        const int bl_up = __builtin_amdgcn_update_dpp(0, bl, 0x101, 0xf, 0xf, true);     // lane j + 1
+        const bool cdn = j >= 1 && j < n && bl_dn == bl && !(lam - lam_dn >= gaptol);    // (scaled: |T| < 1, so no narrower than the test below)
+        const bool cup = j + 1 < n && bl_up == bl && !(lam_up - lam >= gaptol);
+        const bool cdn_dn = __builtin_amdgcn_update_dpp(0, cdn ? 1 : 0, 0x111, 0xf, 0xf, true) != 0;
+        const bool second = cdn && !cup && !cdn_dn && !bad && !flag;
+        if (__builtin_amdgcn_ballot_w64(second) != 0) {     // (wave-uniform)
+            double w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = e16_prev(v[i]);     // the first member's vector, before this lane's changes
+            if (second) {
+                double dl2 = 0.0;
+#ifdef E16_DEBUG
+                double tdbg[3] = {0.0, 0.0, 0.0};
+                const bool ok = e16_twin(wxch + mat * 16, lam, bl, bh, w, v, dl2, tdbg);
+                E16_DBG(slot_u, j, 9, tdbg[0]);
+                E16_DBG(slot_u, j, 10, tdbg[1]);
+                E16_DBG(slot_u, j, 11, tdbg[2]);
+                E16_DBG(slot_u, j, 12, ok ? 1.0 : 0.0);
+#else
+                const bool ok = e16_twin(wxch + mat * 16, lam, bl, bh, w, v, dl2);
+#endif
+                dlam = dl2;
+                twin_ok = ok;
+                bad = bad || !ok;
+            }
+        }
+    }
     E16_MARK(4);
     // From here on the matrix this lane works for, whether it exists, and its mesh indices are derived AGAIN from the thread
     // index (through a register the compiler cannot see through): held from the top of the kernel, those eight registers were
@@ -824,13 +967,18 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
             }
         }
     }
+    {   // a repaired twin must not come out below its partner (their Rayleigh corrections differ by ~1e-17 |T|): the bands ascend
+        const double dn = e16_prev(lam_o);
+        if (twin_ok && dn > lam_o) lam_o = dn;
+    }
     const double lam_out = lam_o * e16_rcp(scale);      // (scale is a power of two: exact)
     // two eigenvalues of ONE block closer than gaptol |T| (the Newton-Schulz step below would not reach rounding level)
     bool close_pair = disorder;
     {
         const double up = e16_next(lam_o);              // eigenvalue j + 1 (lane 15: excluded)
         const int bl_up = __builtin_amdgcn_update_dpp(0, bl, 0x101, 0xf, 0xf, true);
-        close_pair = close_pair || (j + 1 < n && ((bl_up == bl && !(up - lam_o >= gaptol * tmax)) || up < lam_o));
+        const bool up_fixed = __builtin_amdgcn_update_dpp(0, twin_ok ? 1 : 0, 0x101, 0xf, 0xf, true) != 0;   // lane j + 1 is the repaired twin of this one
+        close_pair = close_pair || (j + 1 < n && ((bl_up == bl && !(up - lam_o >= gaptol * tmax) && !up_fixed) || up < lam_o));
     }
     const unsigned long long fb = __builtin_amdgcn_ballot_w64((flag || bad || close_pair) && live2 && j < n);
     const bool listed = ((unsigned)(fb >> (lane & 48)) & 0xffffu) != 0;

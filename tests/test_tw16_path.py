@@ -214,3 +214,47 @@ def test_spin_degenerate_bands_on_a_mesh(tb):
     assert np.max(gaps[0::2]) < 1e-13 and np.min(gaps[1::2]) >= 0.0       # gaps inside the pairs vanish
     V = host.reshape(-1, 16, 16)
     assert max(np.max(np.abs(v.conj() @ v.T - np.identity(16))) for v in V) < 1e-13
+
+
+def test_twins_are_repaired_in_the_kernel_not_listed(tb):
+    """Bands degenerate on the whole mesh used to send EVERY matrix of the fused kernel to the QL-replay list (4 x the time): Newton
+    with the multiplicity of the bracket finds the double root, and the second eigenvector of a pair comes from inverse iteration
+    against the first (e16_twin).  The fallback must now be a small part of the launch; pairs split by 1e-7 and by 1e-12 (no
+    degeneracy, merely close) take the same route and come out to rounding level."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(23)
+    m = hp.quiet(tb.tb_model, 2, 2, [[1.0, 0.0], [0.3, 0.9]], rng.random((8, 2)), nspin=2)
+    m.set_onsite(list(rng.standard_normal(8)))
+    for i in range(8):
+        for j in range(i + 1, 8):
+            m.set_hop(0.3 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, [0, 0])
+    for R in ([1, 0], [0, 1]):
+        for i in range(8):
+            for j in range(8):
+                if rng.random() < 0.4:
+                    m.set_hop(0.2 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, R)
+    ctx = _lib.default_context()
+    w = tb.wf_array(m, [257, 257])
+    w.solve_on_grid([0.0, 0.0])
+    ctx.prof_enable(1)
+    ctx.prof_reset()
+    gaps = w.solve_on_grid([0.0, 0.0])
+    rep = ctx.prof_report()
+    ctx.prof_enable(0)
+    assert "e16" in rep and rep.get("tw16_fallback", {"total_ms": 0.0})["total_ms"] < 0.8 * rep["e16"]["total_ms"], rep   # (was 2.6 x; the fallback kernels cost 0.15 ms even for a handful of matrices)
+    assert np.max(gaps[0::2]) < 1e-13
+    V = w.to_host().reshape(-1, 16, 16)[::97]
+    assert max(np.max(np.abs(v.conj() @ v.T - np.identity(16))) for v in V) < 1e-13
+    # supplied matrices with pairs split by a chosen amount
+    n, nk = 16, 4096
+    for split in (0.0, 1e-12, 1e-7):
+        h = np.empty((nk, n, n), dtype=complex)
+        for k in range(nk):
+            u = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0]
+            lev = np.repeat(np.sort(rng.standard_normal(n // 2)), 2) + np.tile([0.0, split], n // 2)
+            a = (u * lev) @ u.conj().T
+            h[k] = 0.5 * (a + a.conj().T)
+        with _forced():
+            ev, vec = _eigh_batch(h)
+        assert max(_quality(h, ev, vec)) < 2e-14, split
+        assert np.all(np.diff(ev, axis=0) >= 0.0)
