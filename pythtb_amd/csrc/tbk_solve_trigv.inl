@@ -115,6 +115,65 @@ __global__ __launch_bounds__(NT) void k_trigv_twisted(const int n, const double2
         const double inz = 1.0 / sqrt(nz2);
         for (int k = 0; k < n; ++k) V[(size_t)k * n + j] *= inz;
     }
+    // ---- twins.  Two eigenvalues of ONE block closer than ~1e-6 |T| (bands degenerate on the whole mesh -- a spinful ribbon
+    // without spin-orbit coupling, Kramers pairs: T splits only to ~1e-13 |T| -- or merely close levels) get (nearly) the same
+    // twisted-factorisation vector; the final Gram matrix then failed and the WHOLE call was repeated on the Jacobi kernels (9 x
+    // the time, profiles/degenerate_regimes_probe.py).  xSTEIN's remedy for the second member of an isolated pair: two rounds of
+    // inverse iteration on T - lambda = L D L^T (pivots recomputed on the fly, multipliers parked in W) with reorthogonalisation
+    // against the first member.  Pairs whose vectors are orthogonal already (different blocks) are left alone; longer clusters
+    // and anything this does not repair are caught by the Gram matrix as before.
+    __syncthreads();
+    const double ctol = 1e-6 * fmax(tnorm, 1e-300);
+    for (int j = tid; j < n; j += NT) {
+        if (j == 0) continue;
+        const double lj = ls[j];
+        const bool cdn = lj - ls[j - 1] <= ctol;
+        const bool cup = j + 1 < n && ls[j + 1] - lj <= ctol;
+        const bool cdd = j >= 2 && ls[j - 1] - ls[j - 2] <= ctol;
+        if (!cdn || cup || cdd) continue;
+        const size_t cw = (size_t)j - 1, cv = (size_t)j;
+        double c0 = 0.0;
+        for (int k = 0; k < n; ++k) c0 = fma(V[(size_t)k * n + cw], V[(size_t)k * n + cv], c0);
+        if (fabs(c0) <= 1e-9) continue;                // (independent already: the Newton-Schulz steps finish the job)
+        for (int k = 0; k < n; ++k) V[(size_t)k * n + cv] = 1.0 + 0.37 * (double)(((k * 7919) % 13) - 6);   // a fixed generic start
+        for (int round = 0; round < 2; ++round) {
+            for (int half = 0; half < 2; ++half) {
+                // orthogonalise against the first member, normalise (the solve grows by up to 1 / pivot: scale by the largest entry first)
+                double c = 0.0, mx = 0.0;
+                for (int k = 0; k < n; ++k) c = fma(V[(size_t)k * n + cw], V[(size_t)k * n + cv], c);
+                for (int k = 0; k < n; ++k) {
+                    const double x = fma(-c, V[(size_t)k * n + cw], V[(size_t)k * n + cv]);
+                    V[(size_t)k * n + cv] = x;
+                    mx = fmax(mx, fabs(x));
+                }
+                const double sc = mx > 0.0 && mx < INFINITY ? 1.0 / mx : 1.0;
+                double nz2 = 0.0;
+                for (int k = 0; k < n; ++k) {
+                    const double x = V[(size_t)k * n + cv] * sc;
+                    nz2 = fma(x, x, nz2);
+                }
+                const double inz = nz2 > 0.0 ? sc / sqrt(nz2) : 0.0;
+                for (int k = 0; k < n; ++k) V[(size_t)k * n + cv] *= inz;
+                if (half == 1) break;
+                // solve (T - lj) x = v: forward with the multipliers l_k = e_k / dp_k (kept in W), then backward
+                double dp = T[0].x - lj, y = 0.0, lprev = 0.0;
+                for (int k = 0; k < n; ++k) {
+                    const double2 t = T[k];
+                    const double p = fabs(dp) < tiny ? -tiny : dp;
+                    y = fma(-lprev, y, V[(size_t)k * n + cv]);
+                    V[(size_t)k * n + cv] = y / p;
+                    lprev = t.y / p;
+                    W[(size_t)k * n + cv] = lprev;
+                    if (k + 1 < n) dp = (T[k + 1].x - lj) - t.y * lprev;
+                }
+                double x = V[(size_t)(n - 1) * n + cv];
+                for (int k = n - 2; k >= 0; --k) {
+                    x = fma(-W[(size_t)k * n + cv], x, V[(size_t)k * n + cv]);
+                    V[(size_t)k * n + cv] = x;
+                }
+            }
+        }
+    }
 }
 
 // ---- 4. Newton-Schulz.  C = A^T B (gram: C = V^T V) or C = A B (apply), batched real n x n, 64 x 64 tiles, 256 threads, 4 x 4

@@ -288,3 +288,42 @@ def test_nan_or_inf_in_a_supplied_matrix(n):
         pass
     ev, vec = _eigh_batch(h)                    # and the next call is clean
     assert np.isfinite(ev).all() and np.isfinite(vec).all()
+
+
+def test_degenerate_bands_above_64_states_stay_on_the_direct_method(tb):
+    """A spinful ribbon-like model without spin-orbit coupling (96 states, every level twice on the whole mesh): the direct method
+    for 65..1024 states used to fail its final Gram matrix on the twins (the twisted factorisation gives both the same vector)
+    and repeat the whole call on the Jacobi kernels -- 9 x the time, residuals 3e-14.  k_trigv_twisted now repairs the second
+    member of a pair by inverse iteration: the call stays on the direct kernels, and the results are at rounding level."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(96)
+    norb = 48
+    m = hp.quiet(tb.tb_model, 2, 2, [[1.0, 0.0], [0.3, 0.9]], rng.random((norb, 2)), nspin=2)
+    m.set_onsite(list(rng.standard_normal(norb)))
+    for i in range(norb):
+        for j in range(i + 1, min(norb, i + 5)):
+            m.set_hop(0.3 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, [0, 0])
+    for R in ([1, 0], [0, 1]):
+        for i in range(norb):
+            for j in range(max(0, i - 2), min(norb, i + 3)):
+                m.set_hop(0.2 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, R)
+    n = 2 * norb
+    ctx = _lib.default_context()
+    w = tb.wf_array(m, [13, 11])
+    w.solve_on_grid([0.05, -0.1])
+    ctx.prof_enable(1)
+    ctx.prof_reset()
+    gaps = w.solve_on_grid([0.05, -0.1])
+    rep = ctx.prof_report()
+    ctx.prof_enable(0)
+    direct = sum(v["total_ms"] for k, v in rep.items() if k.startswith("trigv_"))
+    assert direct > 0.5 * rep["solve_grid"]["total_ms"], rep          # (no second pass on the Jacobi kernels)
+    assert np.max(gaps[0::2]) < 1e-12
+    host = w.to_host()
+    for (i, j) in ((0, 0), (5, 7), (11, 3)):
+        H = m._gen_ham([0.05 + i / 12.0, -0.1 + j / 10.0]).reshape(n, n)
+        V = host[i, j].reshape(n, n)
+        ev = np.einsum("bi,ij,bj->b", V.conj(), H, V).real
+        assert np.abs(V @ H.T - ev[:, None] * V).max() < 2e-14 * np.abs(ev).max()
+        assert np.abs(V.conj() @ V.T - np.identity(n)).max() < 2e-14
+        assert np.max(np.abs(ev - np.linalg.eigvalsh(H))) < 1e-13 * np.abs(ev).max()
