@@ -70,6 +70,7 @@ static void knobs_parse() {
     geti("TBK_FLUX_FUSED", k.flux_fused);
     geti("TBK_POLL_DONE", k.poll_done);
     geti("TBK_POS_TILE", k.pos_tile);
+    geti("TBK_GRID_IMG", k.grid_img);
     geti("TBK_CHAIN_WAVE", k.chain_wave);
     geti("TBK_CHAIN_TILE", k.chain_tile);
     geti("TBK_CHAIN_PROD", k.chain_prod);

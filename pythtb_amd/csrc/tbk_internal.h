@@ -70,6 +70,7 @@ struct TbkKnobs {
     int grid_seg = -1;          // TBK_GRID_SEG      chunks per wave tile of k_grid_rows
     int grid_kernel = 0;        // TBK_GRID_KERNEL   1: term-walking mesh kernel instead of the row-polynomial one
     int flux_ti = -1;           // TBK_FLUX_TI       rows per flux tile
+    int grid_img = 1;           // TBK_GRID_IMG      0: k_grid_rows solves the periodic-image column of a closed mesh row like any other (A/B)
     int pos_tile = 1;           // TBK_POS_TILE      0: position matrices of <= 8 states by the thread-per-entry kernel (A/B)
     int poll_done = 1;          // TBK_POLL_DONE     0: small calls wait with hipStreamSynchronize instead of polling the completion word
     int flux_fused = 0;         // TBK_FLUX_FUSED    1: final flux sum inside the kernel
@@ -114,6 +115,9 @@ __host__ __device__ inline cd cmul(cd a, cd b) {
     return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
 // conj(a) * b
+// the same product with the fused operations spelled out: two places of one kernel that must give the same bits (cmul leaves the
+// choice of which product is fused to the compiler, site by site)
+__host__ __device__ inline cd cmul_x(cd a, cd b) { return cd{fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)}; }
 __host__ __device__ inline cd cmulc(cd a, cd b) {
     return cd{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};
 }

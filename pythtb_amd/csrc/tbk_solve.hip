@@ -745,6 +745,11 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     const bool live = tile < G.ntiles;
     const int last = G.last;
     const int nlast = G.wv.mesh[last];
+    // The last point of a closed mesh row is the periodic image of the first: the same S(k), the same eigenvectors, another
+    // orbital phase (pythtb.py:2729-2747).  When the whole last axis lies in the window the chunks cover nlast - 1 columns and
+    // the lane of column 0 stores the image as well -- a row of 64 q + 1 points (513, 257, 65: N + 1 with N a power of two is what
+    // everybody types) paid a whole wavefront-chunk for that one point: 11 % of configs[3]'s solve, half of a 65-point row.
+    const int ncol = G.img_last ? nlast - 1 : nlast;
     unsigned row = 0;
     int jc0 = 0, jc1 = 0;
     cd frow[N];
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     // together with them -- every wavefront would sit out the full write latency once per chunk.
     cd zl_next{1.0, 0.0}, tf_next[N];
     {
-        const int j0 = min(jc0 * 64 + lane, nlast - 1);
+        const int j0 = min(jc0 * 64 + lane, ncol - 1);
         zl_next = G.tz[last][j0];
 #pragma unroll
         for (int o = 0; o < N; ++o) tf_next[o] = G.tf[last][(int64_t)j0 * N + o];
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
 #pragma unroll
         for (int o = 0; o < N; ++o) tfl[o] = tf_next[o];
         if (jc + 1 < jc1 && TBK_ABLATE(G.ablate) != 5) {   // (ablate 5: diagnostics, no per-chunk table loads)
-            const int jn = min((jc + 1) * 64 + lane, nlast - 1);
+            const int jn = min((jc + 1) * 64 + lane, ncol - 1);
             zl_next = G.tz[last][jn];
 #pragma unroll
             for (int o = 0; o < N; ++o) tf_next[o] = G.tf[last][(int64_t)jn * N + o];
@@ -882,18 +887,18 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
         // eigenvectors of H: D^+ v, periodic-image phases folded into fo
         cd fo[N];
 #pragma unroll
-        for (int o = 0; o < N; ++o) fo[o] = cmul(frow[o], tfl[o]);
+        for (int o = 0; o < N; ++o) fo[o] = cmul_x(frow[o], tfl[o]);     // (cmul_x: the image column below repeats these products)
         // LDS-staged store: per band plane the wave owns one contiguous run of
         // 64*N elements, so lanes trade elements through LDS and every store
         // instruction writes 1 KiB of consecutive bytes.
-        const int nvalid = TBK_ABLATE(G.ablate) == 1 ? 0 : min(64, nlast - jc * 64) * N;   // (ablate 1: no stores, diagnostics)
+        const int nvalid = TBK_ABLATE(G.ablate) == 1 ? 0 : min(64, ncol - jc * 64) * N;   // (ablate 1: no stores, diagnostics)
         const int64_t point0 = (int64_t)row * nlast + (int64_t)jc * 64;
 #pragma unroll
         for (int r = 0; r < N; ++r) {
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int o = 0; o < N; ++o) {
-                const cd val = cmul(M.v[o][r], fo[o]);
+                const cd val = cmul_x(M.v[o][r], fo[o]);
                 stage[wslot[o]] = val;
             }
             asm volatile("" ::: "memory");
@@ -905,10 +910,29 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
                 else if (e < nvalid) dst[e] = stage[rslot[i]];
             }
         }
+        if constexpr (!FULL) {
+            // the periodic image of column 0 (the row's first chunk takes this variant when there is one to store)
+            if (G.img_last && jc == 0 && lane == 0 && TBK_ABLATE(G.ablate) != 1) {
+                cd fi[N];
+#pragma unroll
+                for (int o = 0; o < N; ++o) fi[o] = cmul_x(frow[o], G.tf[last][(int64_t)(nlast - 1) * N + o]);
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    cd* dst = G.wv.data + ((int64_t)r * G.wv.npts + (int64_t)row * nlast + (nlast - 1)) * N;
+#pragma unroll
+                    for (int o = 0; o < N; ++o) dst[o] = cmul_x(M.v[o][r], fi[o]);
+                }
+            }
+        }
     };
-    const int jfull = TBK_ABLATE(G.ablate) == 1 ? jc0 : max(jc0, min(jc1, nlast / 64));   // chunks [jc0, jfull) are complete
-    for (int jc = jc0; jc < jfull; ++jc) chunk(jc, std::true_type{});
-    for (int jc = jfull; jc < jc1; ++jc) chunk(jc, std::false_type{});
+    const int jfull = TBK_ABLATE(G.ablate) == 1 ? jc0 : max(jc0, min(jc1, ncol / 64));   // chunks [jc0, jfull) are complete
+    int jc = jc0;
+    if (G.img_last && jc0 == 0 && jc < jc1) {      // (the chunk that also stores the image: the variant with conditional stores)
+        chunk(jc, std::false_type{});
+        ++jc;
+    }
+    for (; jc < jfull; ++jc) chunk(jc, std::true_type{});
+    for (; jc < jc1; ++jc) chunk(jc, std::false_type{});
     if constexpr (N > 1) {
         // min gaps: one plain store per tile and band pair, reduced when the result is asked for.  (A guarded
         // atomicMin here needs the guard's value: loaded at the end it keeps the wavefront from retiring for
@@ -2360,6 +2384,15 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
                     "tbk_wfs_solve_grid: mesh too large for 32-bit row indices");
         const int64_t nrows = v.npts / v.mesh[D - 1];
         const int64_t want = (int64_t)ctx->cus * 32;     // wave tiles that fill the chip
+        // the last column as the periodic image of the first (k_grid_rows): the whole last axis inside the window
+        // (TBK_GRID_IMG=0: every column solved on its own, the A/B and the reference for the bit-identity test)
+        const size_t lds_rows_need = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
+        const bool rows_kernel = lds_rows_need <= 48 * 1024 && tbk_knobs().grid_kernel != 1;     // (else k_grid_small: every column)
+        G.img_last = rows_kernel && tbk_knobs().grid_img != 0 && v.mesh[D - 1] >= 2 && G.off[D - 1] == 0 && v.mesh[D - 1] == G.gmesh[D - 1] ? 1 : 0;
+        if (G.img_last) {
+            G.cpr = (v.mesh[D - 1] - 1 + 63) / 64;
+            G.nchunks = nrows * G.cpr;
+        }
         G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, G.cpr), G.nchunks / want));
         if (tbk_knobs().grid_seg >= 0) G.seg = std::max(1, std::min(tbk_knobs().grid_seg, G.cpr));
         G.tpr = (G.cpr + G.seg - 1) / G.seg;

@@ -33,6 +33,8 @@ struct GridArgs {
     int wnchunk;             // k_solve_wave: aligned chains per mesh row that touch the window
     int64_t wcfirst;         // ... and the global number of the first of them
     int* flags;              // the context's sticky status words ([0]: an eigen-solver ran into its iteration cap)
+    int img_last;            // k_grid_rows: the window's last column is the periodic image of its first (the whole last axis is
+                             // inside the window): it is not chunked, the lane that solves column 0 stores it too
     int seg;                 // chunks per wave tile (k_grid_rows)
     int tpr;                 // wave tiles per row
     int64_t ntiles;

@@ -327,3 +327,34 @@ def test_degenerate_bands_above_64_states_stay_on_the_direct_method(tb):
         assert np.abs(V @ H.T - ev[:, None] * V).max() < 2e-14 * np.abs(ev).max()
         assert np.abs(V.conj() @ V.T - np.identity(n)).max() < 2e-14
         assert np.max(np.abs(ev - np.linalg.eigvalsh(H))) < 1e-13 * np.abs(ev).max()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_periodic_image_column_is_stored_by_the_lane_of_column_zero(tb, n):
+    """k_grid_rows does not chunk the last column of a closed mesh row: it is the periodic image of the first (pythtb.py:2729-2747)
+    and the lane that solves column 0 stores it with the image's orbital phase.  The same bits as solving it on its own
+    (TBK_GRID_IMG=0), on row lengths around the chunk size, on 1-D / 2-D / 3-D arrays, with a start point off the origin; min
+    gaps equal; windows that do not hold the whole last axis are unaffected (tests/test_tw16_path.py, test_gpu_parity.py)."""
+    from pythtb_amd import _lib
+    if n == 4:
+        m2 = hp.kane_mele(tb.tb_model)
+    elif n == 2:
+        m2 = hp.haldane(tb.tb_model)
+    else:
+        m2 = hp.random_model(tb.tb_model, n, 2, 1, seed=40 + n, nhop=4 * n, rmax=1)
+    m1 = _chain(tb, n, 0.3) if n > 1 else None
+    m3 = hp.random_model(tb.tb_model, n, 3, 1, seed=50 + n, nhop=5 * n, rmax=1)
+    cases = [(m2, [65, 65]), (m2, [130, 9]), (m2, [7, 2]), (m2, [5, 129]), (m2, [3, 64]), (m2, [4, 66]), (m3, [5, 6, 66]), (m3, [3, 4, 65])]
+    if m1 is not None:
+        cases += [(m1, [65]), (m1, [200])]
+    for m, mesh in cases:
+        start = [0.13, -0.21, 0.37][:len(mesh)]
+        out = {}
+        for img in (0, 1):
+            with _lib.knob("TBK_GRID_IMG", img):
+                w = tb.wf_array(m, mesh)
+                gaps = w.solve_on_grid(start)
+                out[img] = (None if gaps is None else np.array(gaps), w.to_host().copy())
+        assert np.array_equal(out[0][1], out[1][1]), mesh
+        if out[0][0] is not None:
+            assert np.array_equal(out[0][0], out[1][0]), mesh
