@@ -2422,22 +2422,30 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
             w->gap_part_n = G.ntiles;       // tbk_wfs_solve_grid_result reduces these instead of the shards
 #define TBK_ROWS(NN, PP) hipLaunchKernelGGL((k_grid_rows<NN, PP>), dim3(blocks), dim3(256), lds, ctx->stream, m->view, G)
             const int pm = m->view.pmax;
-            switch (n * 4 + (pm <= 2 ? pm : 3)) {
-                case 4 + 0: TBK_ROWS(1, 0); break;
-                case 4 + 1: TBK_ROWS(1, 1); break;
-                case 4 + 2: TBK_ROWS(1, 2); break;
-                case 4 + 3: TBK_ROWS(1, -1); break;
-                case 8 + 0: TBK_ROWS(2, 0); break;
-                case 8 + 1: TBK_ROWS(2, 1); break;
-                case 8 + 2: TBK_ROWS(2, 2); break;
-                case 8 + 3: TBK_ROWS(2, -1); break;
-                case 12 + 0: TBK_ROWS(3, 0); break;
-                case 12 + 1: TBK_ROWS(3, 1); break;
-                case 12 + 2: TBK_ROWS(3, 2); break;
-                case 12 + 3: TBK_ROWS(3, -1); break;
-                case 16 + 0: TBK_ROWS(4, 0); break;
-                case 16 + 1: TBK_ROWS(4, 1); break;
-                case 16 + 2: TBK_ROWS(4, 2); break;
+            // (ranges 0..4 along the last axis are compiled in; the generic-range instance costs 1.7 x at 4 states:
+            // profiles/hop_range_probe.py)
+            switch (n * 8 + (pm <= 4 ? pm : 5)) {
+                case 8 + 0: TBK_ROWS(1, 0); break;
+                case 8 + 1: TBK_ROWS(1, 1); break;
+                case 8 + 2: TBK_ROWS(1, 2); break;
+                case 8 + 3: case 8 + 4: case 8 + 5: TBK_ROWS(1, -1); break;
+                case 16 + 0: TBK_ROWS(2, 0); break;
+                case 16 + 1: TBK_ROWS(2, 1); break;
+                case 16 + 2: TBK_ROWS(2, 2); break;
+                case 16 + 3: TBK_ROWS(2, 3); break;
+                case 16 + 4: TBK_ROWS(2, 4); break;
+                case 16 + 5: TBK_ROWS(2, -1); break;
+                case 24 + 0: TBK_ROWS(3, 0); break;
+                case 24 + 1: TBK_ROWS(3, 1); break;
+                case 24 + 2: TBK_ROWS(3, 2); break;
+                case 24 + 3: TBK_ROWS(3, 3); break;
+                case 24 + 4: TBK_ROWS(3, 4); break;
+                case 24 + 5: TBK_ROWS(3, -1); break;
+                case 32 + 0: TBK_ROWS(4, 0); break;
+                case 32 + 1: TBK_ROWS(4, 1); break;
+                case 32 + 2: TBK_ROWS(4, 2); break;
+                case 32 + 3: TBK_ROWS(4, 3); break;
+                case 32 + 4: TBK_ROWS(4, 4); break;
                 default: TBK_ROWS(4, -1); break;
             }
 #undef TBK_ROWS

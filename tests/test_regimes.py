@@ -358,3 +358,23 @@ def test_periodic_image_column_is_stored_by_the_lane_of_column_zero(tb, n):
         assert np.array_equal(out[0][1], out[1][1]), mesh
         if out[0][0] is not None:
             assert np.array_equal(out[0][0], out[1][0]), mesh
+
+
+@pytest.mark.parametrize("n,rmax", [(2, 3), (2, 4), (3, 3), (4, 3), (4, 4), (4, 6), (1, 5)])
+def test_mesh_solve_with_long_hoppings_along_the_last_axis(tb, n, rmax):
+    """k_grid_rows<N, PM> is compiled for hopping ranges 0..4 along the last mesh axis and once for any range: every instance
+    against the k-list path (term walk, another kernel) on the same points, and the orthonormality of what is stored."""
+    m = hp.random_model(tb.tb_model, n, 2, 1, seed=900 + 10 * n + rmax, nhop=6 * n, rmax=rmax)
+    m.set_hop(0.21 - 0.13j, 0, n - 1, [1, rmax], mode="add", allow_conjugate_pair=True)      # (the range is reached for sure)
+    mesh = [9, 70]
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid([0.1, -0.3])
+    host = w.to_host()
+    k = np.array([[0.1 + i / (mesh[0] - 1), -0.3 + j / (mesh[1] - 1)] for i in range(mesh[0] - 1) for j in range(mesh[1] - 1)])
+    ev, vec = m.solve_all(k, eig_vectors=True)
+    V = host[:-1, :-1].reshape(-1, n, n)
+    H = np.array([m._gen_ham(kk).reshape(n, n) for kk in k])
+    e_mesh = np.einsum("kbi,kij,kbj->kb", V.conj(), H, V).real
+    assert np.max(np.abs(e_mesh - ev.T)) < 1e-12
+    assert np.max(np.abs(np.einsum("kij,kbj->kbi", H, V) - e_mesh[:, :, None] * V)) < 1e-12
+    assert np.max(np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.identity(n))) < 1e-13
