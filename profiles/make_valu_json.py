@@ -11,17 +11,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
 # (a key "a+b+c" sums the per-dispatch counts of several kernels that each cover the same points)
 SOURCES = [
-    # round 4, final build: r04h (the two-call step), r04i (--fused-headline), r04hcfg (bench_configs.py B D E under TBK_TW16_STREAMS=1)
-    ("k_grid_rows_flux<2,1,1>", "r04i/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
-    ("k_grid_rows<2,1>", "r04h/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
-    ("k_flux_rows<1,2>", "r04h/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r04hcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r04hcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_e16<1>", "r04hcfg/pmc_per_dispatch.json", "k_e16<1>", 65 ** 3),
-    ("k_mesh_evals<2,1>", "r04hcfg/pmc_per_dispatch.json", "k_mesh_evals<2,1>", 1024 * 1024),
-    ("k_chain_prod_tile<8,2>", "r04hcfg/pmc_per_dispatch.json", "k_chain_prod_tile<8,2>", 65 ** 3),
-    ("k_solve_small_multi<2,false,2>", "r04hcfg/pmc_per_dispatch.json", "k_solve_small_multi<2,false,2>", 1024 * 1024),
-    ("k_solve_small<2,0,true>", "r04hcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
+    # round 4, final build: r04j (the two-call step), r04k (--fused-headline), r04jcfg (bench_configs.py B D E under TBK_TW16_STREAMS=1)
+    ("k_grid_rows_flux<2,1,1>", "r04k/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
+    ("k_grid_rows<2,1>", "r04j/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r04j/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r04jcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r04jcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_e16<1>", "r04jcfg/pmc_per_dispatch.json", "k_e16<1>", 65 ** 3),
+    ("k_mesh_evals<2,1>", "r04jcfg/pmc_per_dispatch.json", "k_mesh_evals<2,1>", 1024 * 1024),
+    ("k_chain_prod_tile<8,2>", "r04jcfg/pmc_per_dispatch.json", "k_chain_prod_tile<8,2>", 65 ** 3),
+    ("k_solve_small_multi<2,false,2>", "r04jcfg/pmc_per_dispatch.json", "k_solve_small_multi<2,false,2>", 1024 * 1024),
+    ("k_solve_small<2,0,true>", "r04jcfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
     # round 3, final build (the three-kernel n = 9..16 path, TBK_E16=0, is still counted from here)
     ("k_tw16<1>", "r03lcfg/pmc_per_dispatch.json", "k_tw16_tridiag<1>+k_tw16_eigvals<1>+k_tw16_vectors<1>", 65 ** 3),
     ("k_grid_rows_flux<2,1,1>", "r03l/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
