@@ -1804,13 +1804,53 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             W.buf1 = buf1;
             W.ywork = ywork;
             W.flags = ctx->flags_dev;
-            {
+            cd *cur = buf0, *nxt = buf1;
+            const int wreg = tbk_knobs().wilson_reg;
+            if (nocc >= 3 && nocc <= 4 && wreg != 0 && ns * L < (int64_t)0x7fffffff * 128) {
+                // 3 or 4 bands in registers (tbk_berry_big.inl): a thread per SEGMENT of a string forms its links, their polar
+                // factors and their ordered product; the segments of a string are multiplied by k_wilson_seg_combine.  (TBK_WILSON_REG=2:
+                // only the polar factors in registers, one thread per link, then the product tree; 0: the workgroup kernels.)
+                if (wreg == 2) {
+                    {
+                        ProfScope ps(ctx, "link_polar_reg");
+                        const dim3 g((unsigned)((ns * L + 255) / 256)), b(256);
+                        if (nocc == 3) hipLaunchKernelGGL((k_link_polar_reg<3>), g, b, 0, ctx->stream, W);
+                        else hipLaunchKernelGGL((k_link_polar_reg<4>), g, b, 0, ctx->stream, W);
+                        TBK_HIP(hipGetLastError());
+                    }
+                } else {
+                    WilsonSegArgs S{};
+                    S.W = W;
+                    // segments: enough threads to fill the chip, none shorter than 4 links
+                    const int64_t want = (int64_t)ctx->cus * 512;
+                    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((L + 3) / 4, (want + ns - 1) / ns));
+                    S.seg_len = (int)((L + nseg - 1) / nseg);
+                    S.nseg = (L + S.seg_len - 1) / S.seg_len;
+                    S.segs = buf1;                 // [ns][nseg][nn]: nseg <= L
+                    S.prod = buf0;                 // string s at buf0 + s L nn, where the tree would have left it
+                    S.pstride = (size_t)L * nn;
+                    {
+                        ProfScope ps(ctx, "wilson_seg_reg");
+                        const dim3 g((unsigned)((ns * S.nseg + 255) / 256)), b(256);
+                        if (nocc == 3) hipLaunchKernelGGL((k_wilson_seg_reg<3>), g, b, 0, ctx->stream, S);
+                        else hipLaunchKernelGGL((k_wilson_seg_reg<4>), g, b, 0, ctx->stream, S);
+                        TBK_HIP(hipGetLastError());
+                    }
+                    {
+                        ProfScope ps(ctx, "wilson_seg_combine");
+                        const dim3 g((unsigned)((ns + 63) / 64)), b(64);
+                        if (nocc == 3) hipLaunchKernelGGL((k_wilson_seg_combine<3>), g, b, 0, ctx->stream, S);
+                        else hipLaunchKernelGGL((k_wilson_seg_combine<4>), g, b, 0, ctx->stream, S);
+                        TBK_HIP(hipGetLastError());
+                    }
+                }
+            } else {
                 ProfScope ps(ctx, "link_polar_big");
                 hipLaunchKernelGGL(k_link_polar_big, dim3((unsigned)std::min<int64_t>(ns * L, nblk)), dim3(256), 0, ctx->stream, W);
                 TBK_HIP(hipGetLastError());
             }
-            cd *cur = buf0, *nxt = buf1;
-            for (int st = 1; st < L; st *= 2) {
+            const bool tree = !(nocc >= 3 && nocc <= 4 && wreg == 1 && ns * L < (int64_t)0x7fffffff * 128);
+            for (int st = 1; tree && st < L; st *= 2) {
                 WilsonTreeArgs T{cur, nxt, nocc, L, st, ns};
                 const int64_t items = ns * ((L + 2 * st - 1) / (2 * st));
                 ProfScope ps(ctx, "wilson_tree");

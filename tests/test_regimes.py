@@ -378,3 +378,27 @@ def test_mesh_solve_with_long_hoppings_along_the_last_axis(tb, n, rmax):
     assert np.max(np.abs(e_mesh - ev.T)) < 1e-12
     assert np.max(np.abs(np.einsum("kij,kbj->kbi", H, V) - e_mesh[:, :, None] * V)) < 1e-12
     assert np.max(np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.identity(n))) < 1e-13
+
+
+@pytest.mark.parametrize("n,nocc,mesh", [(6, 3, [23, 37]), (8, 4, [70, 19]), (8, 3, [5, 6, 41]), (9, 4, [12, 11, 9])])
+def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
+    """Wilson-loop eigenphases (berry_phase(..., berry_evals=True), pythtb.py:3798-3838) of 3 and 4 bands: the string's links,
+    their polar factors and their ordered product in registers (k_wilson_seg_reg, the default), the polar factors alone in
+    registers followed by the product tree (TBK_WILSON_REG=2), and the workgroup-per-link kernels (=0): the same phases along
+    every direction, on string counts and lengths that are no multiples of the wavefront or the segment."""
+    from pythtb_amd import _lib
+    m = hp.random_model(tb.tb_model, n, len(mesh), 1, seed=70 + n + nocc, nhop=4 * n, rmax=1)
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid([0.03, -0.2, 0.1][:len(mesh)])
+    occ = list(range(nocc))
+    for d in range(len(mesh)):
+        got = {}
+        for route in (1, 2, 0):
+            with _lib.knob("TBK_WILSON_REG", route):
+                got[route] = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
+        for route in (2, 0):
+            diff = np.angle(np.exp(1j * (got[1] - got[route])))
+            assert np.max(np.abs(diff)) < 1e-10, (d, route)
+        # the sum of the eigenphases is the determinant form's phase
+        det = np.asarray(w.berry_phase(occ, d, contin=False))
+        assert np.max(np.abs(np.angle(np.exp(1j * (got[1].sum(axis=-1) - det))))) < 1e-9
