@@ -5,7 +5,7 @@ import pythtb_amd as tb
 from pythtb_amd import _lib
 import helpers as hp
 ctx = _lib.default_context()
-for n, occ, side in ((8, [0, 1, 2, 3], 65), (8, [0, 1, 2], 65), (6, [0, 1, 2], 129)):
+for n, occ, side in ((8, [0, 1, 2, 3], 65), (8, [0, 1, 2], 65), (6, [0, 1, 2], 129), (16, list(range(8)), 65), (16, list(range(5)), 65), (16, list(range(8)), 129)):
     m = hp.random_model(tb.tb_model, n, 3, 1, seed=5 + n, nhop=4 * n, rmax=1)
     w = tb.wf_array(m, [side] * 3)
     w.solve_on_grid([0.0, 0.0, 0.0])

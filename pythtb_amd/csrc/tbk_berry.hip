@@ -1789,6 +1789,20 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         std::vector<double> out_h((size_t)nsb * nocc), hmax_h((size_t)nsb), best((size_t)nsb);
         double alphas[4] = {0.7390851332151607, 2.3, 3.9, 5.5};
         if (tbk_knobs().wilson_alpha_set) alphas[0] = tbk_knobs().wilson_alpha;   // test hook: put the pole on an eigenphase
+        // 5..8 wide bands: link matrices, their polar factors and the ordered product of a (string, segment) in ONE wavefront
+        // kernel on the matrix cores (k_chain_prod_tile<.., POLAR>, tbk_berry_prod.inl); the tree then runs over the segments.
+        // (TBK_WILSON_MFMA=0: the workgroup-per-link kernels)
+        bool mfma_route = false;
+        size_t lds_p1 = 0;
+        if (nocc >= 5 && nocc <= 8 && tbk_knobs().wilson_mfma != 0 && chain_wave_applies(v, nocc)) {
+            const size_t lds_pts = (size_t)(TBK_CHAINP_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd), lds_img = (size_t)TBK_CHAINP_G * 256 * sizeof(double);
+            lds_p1 = nocc == 8 ? std::max(lds_pts, lds_img) : lds_pts + lds_img;
+            if (2 * lds_p1 <= 64 * 1024 && fill_occ(w, occ, nocc, A.occ) == TBK_OK) {
+                mfma_route = true;
+                chain_wave_segments(ctx, A);
+                A.flags = ctx->flags_dev;
+            }
+        }
         for (int64_t s0 = 0; s0 < A.nstrings; s0 += nsb) {
             const int64_t ns = std::min<int64_t>(nsb, A.nstrings - s0);
             WilsonBigArgs W{};
@@ -1806,6 +1820,31 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             W.flags = ctx->flags_dev;
             cd *cur = buf0, *nxt = buf1;
             const int wreg = tbk_knobs().wilson_reg;
+            int Lt = L;                            // matrices per string that the tree multiplies
+            if (mfma_route) {
+                const int64_t nw = ns * A.nseg;
+                const int nld = (nocc * v.ncomp + 63) / 64;
+                const dim3 gp((unsigned)((nw + 1) / 2));
+                ProfScope ps(ctx, "wilson_prod_tile");
+#define TBK_WILP(NN, LL) hipLaunchKernelGGL((k_chain_prod_tile<NN, LL, true>), gp, dim3(128), 2 * lds_p1, ctx->stream, A, s0, ns, buf0)
+#define TBK_WILP_N(NN)                                    \
+    switch (nld) {                                        \
+        case 1: TBK_WILP(NN, 1); break;                   \
+        case 2: TBK_WILP(NN, 2); break;                   \
+        case 3: TBK_WILP(NN, 3); break;                   \
+        default: TBK_WILP(NN, 4); break;                  \
+    }
+                switch (nocc) {
+                    case 5: TBK_WILP_N(5) break;
+                    case 6: TBK_WILP_N(6) break;
+                    case 7: TBK_WILP_N(7) break;
+                    default: TBK_WILP_N(8) break;
+                }
+#undef TBK_WILP_N
+#undef TBK_WILP
+                TBK_HIP(hipGetLastError());
+                Lt = A.nseg;
+            } else
             if (nocc >= 3 && nocc <= 4 && wreg != 0 && ns * L < (int64_t)0x7fffffff * 128) {
                 // 3 or 4 bands in registers (tbk_berry_big.inl): a thread per SEGMENT of a string forms its links, their polar
                 // factors and their ordered product; the segments of a string are multiplied by k_wilson_seg_combine.  (TBK_WILSON_REG=2:
@@ -1850,9 +1889,9 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 TBK_HIP(hipGetLastError());
             }
             const bool tree = !(nocc >= 3 && nocc <= 4 && wreg == 1 && ns * L < (int64_t)0x7fffffff * 128);
-            for (int st = 1; tree && st < L; st *= 2) {
-                WilsonTreeArgs T{cur, nxt, nocc, L, st, ns};
-                const int64_t items = ns * ((L + 2 * st - 1) / (2 * st));
+            for (int st = 1; tree && st < Lt; st *= 2) {
+                WilsonTreeArgs T{cur, nxt, nocc, Lt, st, ns};
+                const int64_t items = ns * ((Lt + 2 * st - 1) / (2 * st));
                 ProfScope ps(ctx, "wilson_tree");
                 hipLaunchKernelGGL(k_wilson_tree, dim3((unsigned)std::min<int64_t>(items, (int64_t)ctx->cus * 4)), dim3(256), 0,
                                    ctx->stream, T);
@@ -1862,7 +1901,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             std::fill(best.begin(), best.begin() + ns, 1e300);
             for (int attempt = 0; attempt < 4; ++attempt) {
                 const double alpha = alphas[attempt];
-                CayleyArgs C{cur, (size_t)L * nn, ab, herm, nocc, cos(alpha), sin(alpha)};
+                CayleyArgs C{cur, (size_t)(mfma_route ? Lt : L) * nn, ab, herm, nocc, cos(alpha), sin(alpha)};
                 {
                     ProfScope ps(ctx, "wilson_cayley");
                     hipLaunchKernelGGL(k_wilson_cayley, dim3((unsigned)ns), dim3(256), 0, ctx->stream, C);

@@ -15,7 +15,15 @@
 // k_chain_prod_det takes its determinant.  The matrix cores are otherwise idle on this path; the vector ALU does exactly what
 // k_chain_links_tile did.
 #define TBK_CHAINP_G 4   // links per wavefront step (sixteen lanes per link)
-template <int NOCC, int NLD>
+// POLAR (Wilson-loop eigenphases of 5..8 wide bands, round 4): every link matrix is replaced by its polar factor U = M (M^+ M)^(-1/2)
+// (the reference's U Vh of svd(M), pythtb.py:3820-3826) before it is multiplied on -- by the Newton-Schulz iteration
+// X <- X (3 I - X^T X) / 2 on the real image, ON THE MATRIX CORES: with X and X^T both held in the accumulator layout every operand
+// of the three products of a step is a register as it stands (Y = X^T X is symmetric bit for bit, so its accumulator doubles as
+// its own A operand): 12 v_mfma_f64_16x16x4_f64 per step, no transposition, no LDS.  The loop ends when ||Y - I||_F^2 < 1e-14
+// (wave-uniform: one link at a time), like k_link_polar_big; a link that does not converge in 200 steps raises the singular-link
+// status.  Output: the unitary product of the (string, segment), nocc x nocc compact at pw[(string * nseg + segment) * nocc^2],
+// the layout the product tree / Cayley tail of the Wilson pipeline reads (tbk_berry_big.inl).
+template <int NOCC, int NLD, bool POLAR = false>
 __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ pw) {
     static_assert(NOCC >= 5 && NOCC <= 8, "k_chain_prod_tile: 5..8 bands");
     extern __shared__ __align__(16) unsigned char chainw_lds[];
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, cons
     v4d acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = (gl + 4 * r) == cl ? 1.0 : 0.0;
+    bool singular = false;
     for (int i = 0; i < np; i += G) {
         // points i (kept from the previous step) and i + 1 .. i + G (arriving) go to LDS; the registers take the next group
 #pragma unroll
@@ -165,13 +174,67 @@ __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, cons
         for (int g = 0; g < G; ++g) {
             if (i + g < np) {                        // (wave-uniform)
                 const double* me = Me + g * 256;
-                v4d nw = {0.0, 0.0, 0.0, 0.0};
+                if constexpr (!POLAR) {
+                    v4d nw = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(me[(4 * kb + gl) * 16 + cl], acc[kb], nw, 0, 0, 0);
-                acc = nw;
+                    for (int kb = 0; kb < 4; ++kb) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(me[(4 * kb + gl) * 16 + cl], acc[kb], nw, 0, 0, 0);
+                    acc = nw;
+                } else {
+                    v4d X, Xt;                       // X[4 kb + gl][cl] and X^T[4 kb + gl][cl] = X[cl][4 kb + gl]
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        X[kb] = me[(4 * kb + gl) * 16 + cl];
+                        Xt[kb] = me[cl * 16 + 4 * kb + gl];
+                    }
+                    bool ok = false;
+                    for (int it = 0; it < 200; ++it) {
+                        v4d Y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(X[kb], X[kb], Y, 0, 0, 0);     // X^T X
+                        double r2 = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double dv = Y[r] - ((gl + 4 * r) == cl ? 1.0 : 0.0);
+                            r2 = fma(dv, dv, r2);
+                        }
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
+                        v4d XY = {0.0, 0.0, 0.0, 0.0}, YXt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) XY = __builtin_amdgcn_mfma_f64_16x16x4f64(Xt[kb], Y[kb], XY, 0, 0, 0);    // X Y
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) YXt = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kb], Xt[kb], YXt, 0, 0, 0);  // Y X^T
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            X[r] = fma(1.5, X[r], -0.5 * XY[r]);
+                            Xt[r] = fma(1.5, Xt[r], -0.5 * YXt[r]);
+                        }
+                        if (r2 < 1e-14) {            // residual 1e-7 before this update, its square after it
+                            ok = true;
+                            break;
+                        }
+                    }
+                    singular = singular || !ok;
+                    v4d nw = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(X[kb], acc[kb], nw, 0, 0, 0);
+                    acc = nw;
+                }
             }
         }
         lds_sync_wave();
+    }
+    if constexpr (POLAR) {
+        if (singular && lane == 0) atomicExch(A.flags + 1, 1);
+        if ((gl & 1) == 0) {
+            double* const o = reinterpret_cast<double*>(pw + ((size_t)sl * A.nseg + seg) * (NOCC * NOCC));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = (gl + 4 * r) >> 1, a = cl >> 1;
+                if (a < NOCC && b < NOCC) o[(a * NOCC + b) * 2 + (cl & 1)] = acc[r];
+            }
+        }
+        return;
     }
     // P[a][b] = (P_img[2a][2b], P_img[2a + 1][2b]); register r of lane (gl, cl) holds P^T_img[gl + 4 r][cl] = P_img[cl][gl + 4 r]
     if ((gl & 1) == 0) {

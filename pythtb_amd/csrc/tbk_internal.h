@@ -82,6 +82,7 @@ struct TbkKnobs {
     int chain_wave = 1;         // TBK_CHAIN_WAVE    0: thread-per-string link determinants also for 1..8 bands of wide (>= 8 component) states
     int chain_wave_from = -1;   // TBK_CHAIN_WAVE_FROM  smallest band count of the wave-per-string link kernels (default 1)
     int det_big_from = -1;      // TBK_DET_BIG_FROM  smallest band count of the workgroup-level link determinants
+    int wilson_mfma = 1;        // TBK_WILSON_MFMA   0: Wilson loops of 5..8 wide bands on the workgroup-per-link kernels instead of k_chain_prod_tile<.., POLAR>
     int wilson_reg = 1;         // TBK_WILSON_REG    0: link polar factors of 3-4 bands by the workgroup-per-link kernel (A/B)
     int wilson_big_from = -1;   // TBK_WILSON_BIG_FROM  ... of the workgroup-level Wilson-loop pipeline
     long long wilson_batch_bytes = -1;   // TBK_WILSON_BATCH_BYTES  test hook: workspace bound per batch of strings

@@ -402,3 +402,24 @@ def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
         # the sum of the eigenphases is the determinant form's phase
         det = np.asarray(w.berry_phase(occ, d, contin=False))
         assert np.max(np.abs(np.angle(np.exp(1j * (got[1].sum(axis=-1) - det))))) < 1e-9
+
+
+@pytest.mark.parametrize("n,nocc,mesh", [(16, 8, [9, 7, 40]), (16, 5, [6, 33, 5]), (12, 7, [21, 19]), (10, 6, [5, 4, 70])])
+def test_wilson_loops_of_5_to_8_wide_bands_on_the_matrix_cores(tb, n, nocc, mesh):
+    """Wilson-loop eigenphases of 5..8 bands of states with >= 8 components: k_chain_prod_tile<.., POLAR> forms a string's link
+    matrices, iterates each to its polar factor (Newton-Schulz on v_mfma_f64_16x16x4_f64, X and X^T both in the accumulator
+    layout) and multiplies the factors in order, one wavefront per (string, segment); against the workgroup-per-link kernels
+    (TBK_WILSON_MFMA=0) along every direction, and the sum of the eigenphases against the determinant form."""
+    from pythtb_amd import _lib
+    m = hp.random_model(tb.tb_model, n, len(mesh), 1, seed=300 + n + nocc, nhop=4 * n, rmax=1)
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid([0.02, 0.11, -0.3][:len(mesh)])
+    occ = list(range(nocc))
+    for d in range(len(mesh)):
+        with _lib.knob("TBK_WILSON_MFMA", 1):
+            a = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
+        with _lib.knob("TBK_WILSON_MFMA", 0):
+            b = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
+        assert np.max(np.abs(np.angle(np.exp(1j * (a - b))))) < 1e-9, d
+        det = np.asarray(w.berry_phase(occ, d, contin=False))
+        assert np.max(np.abs(np.angle(np.exp(1j * (a.sum(axis=-1) - det))))) < 1e-9, d
