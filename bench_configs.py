@@ -151,9 +151,20 @@ def single_gpu(which, reps):
             t0 = time.perf_counter()
             _lib.check(lib.tbk_berry_phase(hw, _lib.iptr(occ32), 8, 2, 0, _lib.dptr(phases)))
             t_phase = min(t_phase, time.perf_counter() - t0)
+        # (beside the config: the Wilson-loop eigenphases of the same 8 bands, berry_evals=True -- link polar factors on the matrix cores)
+        wil = np.zeros(65 * 65 * 8)
+        _lib.check(lib.tbk_berry_phase(hw, _lib.iptr(occ32), 8, 2, 1, _lib.dptr(wil)))
+        t_wil = 1e9
+        for _ in range(max(1, reps // 2)):
+            t0 = time.perf_counter()
+            _lib.check(lib.tbk_berry_phase(hw, _lib.iptr(occ32), 8, 2, 1, _lib.dptr(wil)))
+            t_wil = min(t_wil, time.perf_counter() - t0)
+        wil = wil.reshape(-1, 8)
         out.append({"config": "E: cubic16 (888 hops) 64^3 sub-mesh", "nk": nk, "solve_grid_ms": t_solve,
                     "kpts_per_s": nk / t_solve * 1e3, "berry_phase_8band_call_ms": t_phase * 1e3,
-                    "links_per_s": 65 * 65 * 64 / t_phase})
+                    "links_per_s": 65 * 65 * 64 / t_phase, "wilson_loop_8band_call_ms": t_wil * 1e3,
+                    "wilson_links_per_s": 65 * 65 * 64 / t_wil,
+                    "wilson_sum_vs_det_phase": float(np.max(np.abs(np.angle(np.exp(1j * (wil.sum(axis=1) - phases))))))})
         _lib.check(lib.tbk_wfs_free(hw))
     if "W" in which:
         # (not a BASELINE config) SURVEY.md 8f-4: the Wannier90 importer's regime -- silicon, 8 Wannier functions, 2972 hopping terms
