@@ -1751,14 +1751,40 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         // transform + Hermitian eigen-solve.  Strings go in batches whose two ping-pong link arrays fit 1 GiB.
         const size_t nn = (size_t)nocc * nocc;
         const int L = A.nlinks;
+        // 5..8 wide bands: link matrices, their polar factors and the ordered product of a (string, segment) in ONE wavefront
+        // kernel on the matrix cores (k_chain_prod_tile<.., POLAR>, tbk_berry_prod.inl); the tree then runs over the segments.
+        // (TBK_WILSON_MFMA=0: the workgroup-per-link kernels)
+        bool mfma_route = false;
+        size_t lds_p1 = 0;
+        if (nocc >= 5 && nocc <= 8 && tbk_knobs().wilson_mfma != 0 && chain_wave_applies(v, nocc)) {
+            const size_t lds_pts = (size_t)(TBK_CHAINP_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd), lds_img = (size_t)TBK_CHAINP_G * 256 * sizeof(double);
+            lds_p1 = nocc == 8 ? std::max(lds_pts, lds_img) : lds_pts + lds_img;
+            if (2 * lds_p1 <= 64 * 1024 && fill_occ(w, occ, nocc, A.occ) == TBK_OK) {
+                mfma_route = true;
+                chain_wave_segments(ctx, A);
+                A.flags = ctx->flags_dev;
+            }
+        }
+        // 3 or 4 bands: a thread per segment (k_wilson_seg_reg); segments sized on the whole call
+        const int wreg = tbk_knobs().wilson_reg;
+        const bool seg_route = !mfma_route && nocc >= 3 && nocc <= 4 && wreg != 0 && wreg != 2 && A.nstrings * L < (int64_t)0x7fffffff * 128;
+        int seg_len_r = L, nseg_r = 1;
+        if (seg_route) {
+            const int64_t want = (int64_t)ctx->cus * 512;
+            const int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((L + 3) / 4, (want + A.nstrings - 1) / A.nstrings));
+            seg_len_r = (int)((L + nseg - 1) / nseg);
+            nseg_r = (L + seg_len_r - 1) / seg_len_r;
+        }
+        // matrices per string that the buffers hold: every link (the workgroup kernels), or one per segment
+        const int Lb = mfma_route ? A.nseg : (seg_route ? nseg_r : L);
         size_t batch_bytes = (size_t)1 << 30;
         if (tbk_knobs().wilson_batch_bytes >= 0) batch_bytes = (size_t)std::max(1ll, tbk_knobs().wilson_batch_bytes);   // test hook
-        const int64_t cap = std::max<int64_t>(1, (int64_t)(batch_bytes / (2 * (size_t)L * nn * sizeof(cd))));
+        const int64_t cap = std::max<int64_t>(1, (int64_t)(batch_bytes / (2 * (size_t)Lb * nn * sizeof(cd))));
         const int64_t nsb = std::min<int64_t>(A.nstrings, cap);
         const unsigned nblk = (unsigned)std::min<int64_t>(nsb * L, (int64_t)ctx->cus * 4);
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t ob = al((size_t)nocc * sizeof(int));
-        const size_t bb = al((size_t)nsb * L * nn * sizeof(cd));
+        const size_t bb = al((size_t)nsb * Lb * nn * sizeof(cd));
         const size_t yb = al((size_t)nblk * nn * sizeof(cd));
         const size_t abb = al((size_t)nsb * 2 * nn * sizeof(cd));
         const size_t hb = al((size_t)nsb * nn * sizeof(cd));
@@ -1789,20 +1815,6 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         std::vector<double> out_h((size_t)nsb * nocc), hmax_h((size_t)nsb), best((size_t)nsb);
         double alphas[4] = {0.7390851332151607, 2.3, 3.9, 5.5};
         if (tbk_knobs().wilson_alpha_set) alphas[0] = tbk_knobs().wilson_alpha;   // test hook: put the pole on an eigenphase
-        // 5..8 wide bands: link matrices, their polar factors and the ordered product of a (string, segment) in ONE wavefront
-        // kernel on the matrix cores (k_chain_prod_tile<.., POLAR>, tbk_berry_prod.inl); the tree then runs over the segments.
-        // (TBK_WILSON_MFMA=0: the workgroup-per-link kernels)
-        bool mfma_route = false;
-        size_t lds_p1 = 0;
-        if (nocc >= 5 && nocc <= 8 && tbk_knobs().wilson_mfma != 0 && chain_wave_applies(v, nocc)) {
-            const size_t lds_pts = (size_t)(TBK_CHAINP_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd), lds_img = (size_t)TBK_CHAINP_G * 256 * sizeof(double);
-            lds_p1 = nocc == 8 ? std::max(lds_pts, lds_img) : lds_pts + lds_img;
-            if (2 * lds_p1 <= 64 * 1024 && fill_occ(w, occ, nocc, A.occ) == TBK_OK) {
-                mfma_route = true;
-                chain_wave_segments(ctx, A);
-                A.flags = ctx->flags_dev;
-            }
-        }
         for (int64_t s0 = 0; s0 < A.nstrings; s0 += nsb) {
             const int64_t ns = std::min<int64_t>(nsb, A.nstrings - s0);
             WilsonBigArgs W{};
@@ -1819,7 +1831,6 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             W.ywork = ywork;
             W.flags = ctx->flags_dev;
             cd *cur = buf0, *nxt = buf1;
-            const int wreg = tbk_knobs().wilson_reg;
             int Lt = L;                            // matrices per string that the tree multiplies
             if (mfma_route) {
                 const int64_t nw = ns * A.nseg;
@@ -1845,7 +1856,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 TBK_HIP(hipGetLastError());
                 Lt = A.nseg;
             } else
-            if (nocc >= 3 && nocc <= 4 && wreg != 0 && ns * L < (int64_t)0x7fffffff * 128) {
+            if (nocc >= 3 && nocc <= 4 && wreg != 0 && !mfma_route && A.nstrings * L < (int64_t)0x7fffffff * 128) {
                 // 3 or 4 bands in registers (tbk_berry_big.inl): a thread per SEGMENT of a string forms its links, their polar
                 // factors and their ordered product; the segments of a string are multiplied by k_wilson_seg_combine.  (TBK_WILSON_REG=2:
                 // only the polar factors in registers, one thread per link, then the product tree; 0: the workgroup kernels.)
@@ -1860,14 +1871,11 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 } else {
                     WilsonSegArgs S{};
                     S.W = W;
-                    // segments: enough threads to fill the chip, none shorter than 4 links
-                    const int64_t want = (int64_t)ctx->cus * 512;
-                    int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((L + 3) / 4, (want + ns - 1) / ns));
-                    S.seg_len = (int)((L + nseg - 1) / nseg);
-                    S.nseg = (L + S.seg_len - 1) / S.seg_len;
-                    S.segs = buf1;                 // [ns][nseg][nn]: nseg <= L
-                    S.prod = buf0;                 // string s at buf0 + s L nn, where the tree would have left it
-                    S.pstride = (size_t)L * nn;
+                    S.seg_len = seg_len_r;         // (segments: enough threads to fill the chip, none shorter than 4 links)
+                    S.nseg = nseg_r;
+                    S.segs = buf1;                 // [ns][nseg][nn]
+                    S.prod = buf0;                 // string s at buf0 + s nseg nn, where the tree leaves a string's product
+                    S.pstride = (size_t)Lb * nn;
                     {
                         ProfScope ps(ctx, "wilson_seg_reg");
                         const dim3 g((unsigned)((ns * S.nseg + 255) / 256)), b(256);
@@ -1888,7 +1896,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 hipLaunchKernelGGL(k_link_polar_big, dim3((unsigned)std::min<int64_t>(ns * L, nblk)), dim3(256), 0, ctx->stream, W);
                 TBK_HIP(hipGetLastError());
             }
-            const bool tree = !(nocc >= 3 && nocc <= 4 && wreg == 1 && ns * L < (int64_t)0x7fffffff * 128);
+            const bool tree = !seg_route;
             for (int st = 1; tree && st < Lt; st *= 2) {
                 WilsonTreeArgs T{cur, nxt, nocc, Lt, st, ns};
                 const int64_t items = ns * ((Lt + 2 * st - 1) / (2 * st));
@@ -1901,7 +1909,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             std::fill(best.begin(), best.begin() + ns, 1e300);
             for (int attempt = 0; attempt < 4; ++attempt) {
                 const double alpha = alphas[attempt];
-                CayleyArgs C{cur, (size_t)(mfma_route ? Lt : L) * nn, ab, herm, nocc, cos(alpha), sin(alpha)};
+                CayleyArgs C{cur, (size_t)Lb * nn, ab, herm, nocc, cos(alpha), sin(alpha)};
                 {
                     ProfScope ps(ctx, "wilson_cayley");
                     hipLaunchKernelGGL(k_wilson_cayley, dim3((unsigned)ns), dim3(256), 0, ctx->stream, C);
