@@ -25,7 +25,7 @@
 // the layout the product tree / Cayley tail of the Wilson pipeline reads (tbk_berry_big.inl).
 template <int NOCC, int NLD, bool POLAR = false>
 __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ pw) {
-    static_assert(NOCC >= 5 && NOCC <= 8, "k_chain_prod_tile: 5..8 bands");
+    static_assert(NOCC >= 3 && NOCC <= 8 && (POLAR || NOCC >= 5), "k_chain_prod_tile: 5..8 bands (3..8 with polar factors)");
     extern __shared__ __align__(16) unsigned char chainw_lds[];
     constexpr int G = TBK_CHAINP_G, NT = (NOCC + 1) / 2;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;

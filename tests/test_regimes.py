@@ -394,9 +394,10 @@ def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
     for d in range(len(mesh)):
         got = {}
         for route in (1, 2, 0):
-            with _lib.knob("TBK_WILSON_REG", route):
+            with _lib.knob("TBK_WILSON_REG", route), _lib.knob("TBK_WILSON_MFMA", 2):     # (MFMA=2: wide states stay off the tile kernel)
                 got[route] = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
-        for route in (2, 0):
+        got["default"] = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))   # (>= 8 components: the matrix-core kernel)
+        for route in (2, 0, "default"):
             diff = np.angle(np.exp(1j * (got[1] - got[route])))
             assert np.max(np.abs(diff)) < 1e-10, (d, route)
         # the sum of the eigenphases is the determinant form's phase
