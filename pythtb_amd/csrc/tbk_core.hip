@@ -133,7 +133,7 @@ extern "C" int tbk_ctx_create(int device, tbk_ctx** out) {
     TBK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     TBK_HIP(hipEventCreate(&c->timer0));
     TBK_HIP(hipEventCreate(&c->timer1));
-    if (hipHostMalloc(&c->pinned, 64 * 1024, hipHostMallocMapped) != hipSuccess) c->pinned = nullptr;   // (optional: falls back to plain copies)
+    if (hipHostMalloc(&c->pinned, TBK_PINNED_BYTES, hipHostMallocMapped) != hipSuccess) c->pinned = nullptr;   // (optional: falls back to plain copies)
     if (c->pinned && hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0) != hipSuccess) {
         (void)hipGetLastError();
         c->pinned_dev = nullptr;
@@ -211,13 +211,15 @@ extern "C" int tbk_ctx_device_info(tbk_ctx* c, char* name, int cap, int* cus, in
 // ~9).  flags_out (nullable): ctx->flags_dev[0..3] as that kernel saw them.
 __global__ __launch_bounds__(256) void k_copy_small_signal(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
                                                            const unsigned bytes, const DoneArgs done) {
+    // (one workgroup per 32 KB; the last one to arrive stores the completion word: tbk_signal_done)
+    const unsigned lo = blockIdx.x * 32768u, hi = min(bytes, lo + 32768u);
     if ((((size_t)src | (size_t)dst) & 7) == 0) {
-        const unsigned n8 = bytes >> 3;
-        for (unsigned i = threadIdx.x; i < n8; i += 256)
+        const unsigned n8 = hi >> 3;
+        for (unsigned i = (lo >> 3) + threadIdx.x; i < n8; i += 256)
             reinterpret_cast<unsigned long long*>(dst)[i] = reinterpret_cast<const unsigned long long*>(src)[i];
-        for (unsigned i = (n8 << 3) + threadIdx.x; i < bytes; i += 256) dst[i] = src[i];
+        for (unsigned i = max(lo, n8 << 3) + threadIdx.x; i < hi; i += 256) dst[i] = src[i];
     } else {
-        for (unsigned i = threadIdx.x; i < bytes; i += 256) dst[i] = src[i];
+        for (unsigned i = lo + threadIdx.x; i < hi; i += 256) dst[i] = src[i];
     }
     __threadfence_system();
     __syncthreads();
@@ -226,10 +228,10 @@ __global__ __launch_bounds__(256) void k_copy_small_signal(const unsigned char* 
 
 int tbk_small_result(tbk_ctx* c, void* dst, const void* src_dev, size_t bytes, int* flags_out) {
     if (bytes == 0 && !flags_out) return TBK_OK;
-    if (c->pinned && c->pinned_dev && bytes + 64 <= 64 * 1024) {
+    if (c->pinned && c->pinned_dev && bytes + 64 <= TBK_PINNED_BYTES) {
         const DoneArgs d = tbk_done_arm(c, flags_out != nullptr);
         if (d.word) {
-            hipLaunchKernelGGL(k_copy_small_signal, dim3(1), dim3(256), 0, c->stream, (const unsigned char*)src_dev,
+            hipLaunchKernelGGL(k_copy_small_signal, dim3((unsigned)std::max<size_t>(1, (bytes + 32767) / 32768)), dim3(256), 0, c->stream, (const unsigned char*)src_dev,
                                (unsigned char*)c->pinned_dev + 64, (unsigned)bytes, d);
             TBK_HIP(hipGetLastError());
             const int rc = tbk_done_wait(c, d);
@@ -240,7 +242,7 @@ int tbk_small_result(tbk_ctx* c, void* dst, const void* src_dev, size_t bytes, i
             return TBK_OK;
         }
     }
-    if (c->pinned && bytes + 64 <= 64 * 1024) {
+    if (c->pinned && bytes + 64 <= TBK_PINNED_BYTES) {
         unsigned char* pin = (unsigned char*)c->pinned;
         if (bytes) TBK_HIP(hipMemcpyAsync(pin + 64, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
         if (flags_out) TBK_HIP(hipMemcpyAsync(pin, c->flags_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -62,7 +62,8 @@ struct TbkKnobs {
     int wg_nt = 1024;           // TBK_WG_NT         threads of the global-workspace workgroup solver
     int wave_run = -1;          // TBK_WAVE_RUN      chain length of the wavefront solver (1 = always cold)
     int fused_rows = -1;        // TBK_FUSED_ROWS    mesh rows per wave tile of the fused solve + flux kernel (default 6; 10 beyond the LLC)
-    int zero_copy_kb = 64;      // TBK_ZERO_COPY_KB  k list + results of a solve_all / solve_one call up to this size go through mapped host memory (0: always copy)
+    int zero_copy_kb = 1024;    // TBK_ZERO_COPY_KB  k list + results of a solve_all / solve_one call up to this size go through mapped host memory (0: always copy;
+                                //                   64 until round 4: 500 k-points of a 2-band model with eigenvectors 57 -> 21 us, profiles/zero_copy_size_probe.py)
     int small_kpt = -1;         // TBK_SMALL_KPT     k points per lane of the n <= 4 list kernels: 1, 2; default 2 from 2^19 points
     int grid_occ = -1;          // TBK_GRID_OCC      cap on the resident wavefronts per SIMD of k_grid_rows (diagnostic; default none)
     int fused_occ = -1;         // TBK_FUSED_OCC     cap on the resident wavefronts per SIMD of the fused kernel (default: none inside the LLC, 3 beyond)
@@ -211,7 +212,7 @@ struct tbk_ctx {
     void* zc_host = nullptr;
     void* zc_dev = nullptr;
     size_t zc_bytes = 0;
-    void* pinned = nullptr;    // 64 KiB of pinned host memory for small results
+    void* pinned = nullptr;    // TBK_PINNED_BYTES (1 MiB) of pinned host memory for small results
     void* pinned_dev = nullptr;  // ... its device address (k_copy_small_signal writes small results there itself)
     int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
     // completion word of small calls (tbk_done_arm / tbk_done_wait): 64 B of mapped host memory -- [0] the sequence number the last
@@ -246,6 +247,7 @@ int tbk_small_result(tbk_ctx* ctx, void* dst, const void* src_dev, size_t bytes,
 // thread per workgroup after that workgroup's result stores -> `tbk_done_wait(ctx, d)` on the host (polls for at most ~1 ms,
 // then falls back to hipStreamSynchronize, which is also what happens when d.word is null).  Results the host reads after the
 // wait must have been stored by that last kernel (or sit in device memory).
+#define TBK_PINNED_BYTES ((size_t)1 << 20)
 struct DoneArgs {
     unsigned* word;        // device pointer of done_host[0]; null = not armed
     unsigned* cnt;         // arrival counter (device memory), zero between launches
