@@ -579,6 +579,62 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
     }
 }
 
+// ---- planes that do NOT contain the fastest mesh axis (berry_flux of a 3-D array with its default dirs = [0, 1]: one plane per
+// index of axis 2).  Along both plane axes neighbouring points are a whole row of the fastest axis apart, so in the row kernel
+// above every lane fetches a 32..256-byte vector out of a cache line of its own (2.5 x the time per plaquette of a plane that
+// contains the fastest axis, profiles/berry_dirs_probe.py).  Here lane = SLICE: 64 neighbouring planes walk the same plaquette
+// row together, their vectors contiguous in memory; a wavefront owns (64 slices) x (row ia) x (a run of columns) and carries the
+// two vertical link determinants along.  Partial sums per (slice, ia, run); k_flux_reduce adds them up per slice.
+struct FluxSliceArgs {
+    int nfast;         // length of the fastest axis (the last entry of A.other)
+    int ngrp;          // 64-slice groups along it
+    int nrun, run_len; // column runs per row and their length
+    int bps;           // partials per slice = n0 * nrun
+};
+template <int NOCC, int NCOMP>
+__global__ __launch_bounds__(256) void k_flux_slices(const FluxArgs A, const FluxSliceArgs S, const int64_t nwaves) {
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + wib;
+    if (wv >= nwaves) return;
+    const int run = (int)(wv % S.nrun);
+    const int64_t w1 = wv / S.nrun;
+    const int ia = (int)(w1 % A.n0);
+    const int64_t g = w1 / A.n0;
+    const int64_t s_hi = g / S.ngrp;
+    const int j = (int)(g - s_hi * S.ngrp) * 64 + lane;
+    const bool act = j < S.nfast;
+    const int64_t slice = s_hi * S.nfast + (act ? j : S.nfast - 1);
+    const int64_t plane = A.v.npts * NCOMP;
+    const int ib0 = run * S.run_len, ib1 = min(ib0 + S.run_len, A.n1);
+    int64_t p = axis_offset(A.other, slice) + (int64_t)ia * A.s0 + (int64_t)ib0 * A.s1;
+    cd u0[NOCC][NCOMP], u1[NOCC][NCOMP];
+    load_vectors<NOCC, NCOMP>(A.v.data + p * NCOMP, A.occ, plane, u0);
+    load_vectors<NOCC, NCOMP>(A.v.data + (p + A.s0) * NCOMP, A.occ, plane, u1);
+    cd dV = det_overlap<NOCC, NCOMP>(u0, u1);
+    double sum = 0.0;
+    for (int ib = ib0; ib < ib1; ++ib) {
+        p += A.s1;
+        cd v0[NOCC][NCOMP], v1[NOCC][NCOMP];
+        load_vectors<NOCC, NCOMP>(A.v.data + p * NCOMP, A.occ, plane, v0);
+        load_vectors<NOCC, NCOMP>(A.v.data + (p + A.s0) * NCOMP, A.occ, plane, v1);
+        const cd dH0 = det_overlap<NOCC, NCOMP>(u0, v0), dH1 = det_overlap<NOCC, NCOMP>(u1, v1), dVn = det_overlap<NOCC, NCOMP>(v0, v1);
+        // det<00|10> det<10|11> det<11|01> det<01|00>  (pythtb.py:3852-3863)
+        cd d = cmul(dV, dH1);
+        d = cmul(d, cconj(dVn));
+        d = cmul(d, cconj(dH0));
+        sum += -atan2(d.y, d.x);
+        dV = dVn;
+#pragma unroll
+        for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+            for (int o = 0; o < NCOMP; ++o) {
+                u0[a][o] = v0[a][o];
+                u1[a][o] = v1[a][o];
+            }
+    }
+    if (act) A.partial[slice * S.bps + (int64_t)ia * S.nrun + run] = sum;
+}
+
 // F(i,j) = -arg[ det<00|10> det<10|11> det<11|01> det<01|00> ]  (pythtb.py:3852-3863)
 template <int NOCC, int MAXN>
 __global__ __launch_bounds__(256) void k_flux(const FluxArgs A) {
@@ -759,6 +815,22 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     } else {
         A.bps = (int)((per + 255) / 256);
     }
+    // planes without the fastest mesh axis: lanes along the slices (k_flux_slices; TBK_FLUX_SLICES=0: the row kernel)
+    FluxSliceArgs SL{};
+    const int Dm = v.dim_arr;
+    const bool slices_k = rows && !want_plaq && Dm >= 3 && dir0 != Dm - 1 && dir1 != Dm - 1 && v.mesh[Dm - 1] >= 16 &&
+                          tbk_knobs().flux_slices != 0;
+    if (slices_k) {
+        SL.nfast = v.mesh[Dm - 1];
+        SL.ngrp = (SL.nfast + 63) / 64;
+        const int64_t rows_w = (nslices / SL.nfast) * SL.ngrp * A.n0;      // wavefronts with one run per row
+        const int64_t want = (int64_t)ctx->cus * 8;
+        SL.nrun = (int)std::max<int64_t>(1, std::min<int64_t>((A.n1 + 7) / 8, (want + rows_w - 1) / rows_w));
+        SL.run_len = (A.n1 + SL.nrun - 1) / SL.nrun;
+        SL.nrun = (A.n1 + SL.run_len - 1) / SL.run_len;
+        SL.bps = A.n0 * SL.nrun;
+        A.bps = SL.bps;
+    }
     A.nwaves = nslices * A.bps;
     A.bpb = (A.bps + 3) / 4;
     A.fused = tbk_knobs().flux_fused;
@@ -862,7 +934,24 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         TBK_HIP(hipGetLastError());
     } else {
         ProfScope ps(ctx, "berry_flux");
-        if (rows) {
+        if (slices_k) {
+            const int64_t nwv = (nslices / SL.nfast) * SL.ngrp * A.n0 * SL.nrun;
+            const dim3 grid((unsigned)((nwv + 3) / 4)), blk(256);
+#define TBK_SLC(NO, NC) hipLaunchKernelGGL((k_flux_slices<NO, NC>), grid, blk, 0, ctx->stream, A, SL, nwv)
+            switch (v.ncomp * 8 + nocc) {
+                case 1 * 8 + 1: TBK_SLC(1, 1); break;
+                case 2 * 8 + 1: TBK_SLC(1, 2); break;
+                case 2 * 8 + 2: TBK_SLC(2, 2); break;
+                case 3 * 8 + 1: TBK_SLC(1, 3); break;
+                case 3 * 8 + 2: TBK_SLC(2, 3); break;
+                case 3 * 8 + 3: TBK_SLC(3, 3); break;
+                case 4 * 8 + 1: TBK_SLC(1, 4); break;
+                case 4 * 8 + 2: TBK_SLC(2, 4); break;
+                case 4 * 8 + 3: TBK_SLC(3, 4); break;
+                default: TBK_SLC(4, 4); break;
+            }
+#undef TBK_SLC
+        } else if (rows) {
             const dim3 grid((unsigned)(nslices * A.bpb)), blk(256);
 #define TBK_ROWS(NO, NC) hipLaunchKernelGGL((k_flux_rows<NO, NC>), grid, blk, 0, ctx->stream, A)
             switch (v.ncomp * 8 + nocc) {
@@ -893,13 +982,13 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         }
         TBK_HIP(hipGetLastError());
     }
-    if (!rows || !A.fused) {
+    if (!rows || !A.fused || slices_k) {
         ProfScope ps(ctx, "flux_reduce");
         // totals in mapped host memory and no per-plaquette output: this is the call's last kernel, the result call polls its
         // completion word instead of synchronising the stream
         w->flux_done = (w->flux_totals_host && !want_plaq) ? tbk_done_arm(ctx, false) : DoneArgs{nullptr, nullptr, nullptr, 0u};
         hipLaunchKernelGGL(k_flux_reduce, dim3((unsigned)nslices), dim3(1024), 0, ctx->stream,
-                           (const double*)w->flux_partial_dev, rows ? A.bpb : A.bps, w->flux_totals_dev, w->flux_done);
+                           (const double*)w->flux_partial_dev, (rows && !slices_k) ? A.bpb : A.bps, w->flux_totals_dev, w->flux_done);
         TBK_HIP(hipGetLastError());
     } else {
         w->flux_done = DoneArgs{nullptr, nullptr, nullptr, 0u};

@@ -74,6 +74,7 @@ struct TbkKnobs {
     int grid_img = 1;           // TBK_GRID_IMG      0: k_grid_rows solves the periodic-image column of a closed mesh row like any other (A/B)
     int pos_tile = 1;           // TBK_POS_TILE      0: position matrices of <= 8 states by the thread-per-entry kernel (A/B)
     int poll_done = 1;          // TBK_POLL_DONE     0: small calls wait with hipStreamSynchronize instead of polling the completion word
+    int flux_slices = 1;        // TBK_FLUX_SLICES   0: planes without the fastest mesh axis on the row kernel instead of k_flux_slices (lane = slice)
     int flux_fused = 0;         // TBK_FLUX_FUSED    1: final flux sum inside the kernel
     int trigv_from = -1;        // TBK_TRIGV_FROM    smallest n of the workgroup-scale direct eigenvector path (default 65; A/B runs down to 17)
     int chain_ws_mb = 1024;     // TBK_CHAIN_WS_MB   link-matrix workspace per batch of strings, MiB

@@ -424,3 +424,26 @@ def test_wilson_loops_of_5_to_8_wide_bands_on_the_matrix_cores(tb, n, nocc, mesh
         assert np.max(np.abs(np.angle(np.exp(1j * (a - b))))) < 1e-9, d
         det = np.asarray(w.berry_phase(occ, d, contin=False))
         assert np.max(np.abs(np.angle(np.exp(1j * (a.sum(axis=-1) - det))))) < 1e-9, d
+
+
+@pytest.mark.parametrize("n,nspin,occ,mesh", [(2, 1, [0], [9, 8, 70]), (2, 2, [0, 1], [6, 7, 33]), (3, 1, [0, 2], [5, 9, 17]),
+                                              (2, 2, [1, 2, 3], [4, 5, 6, 40]), (1, 1, [0], [7, 6, 130])])
+def test_flux_of_planes_without_the_fastest_axis(tb, n, nspin, occ, mesh):
+    """berry_flux on planes that do not contain the fastest mesh axis takes k_flux_slices (lane = slice, the vectors of 64
+    neighbouring planes contiguous in memory): against the row kernel (TBK_FLUX_SLICES=0) for every such pair of directions in
+    both orders, on slice counts that are no multiple of the wavefront; planes that do contain the fastest axis are untouched."""
+    from pythtb_amd import _lib
+    d = len(mesh)
+    m = hp.random_model(tb.tb_model, n, d, nspin, seed=11 * n + d, nhop=4 * n, rmax=1)
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid([0.01 * (i + 1) for i in range(d)])
+    for d0 in range(d - 1):
+        for d1 in range(d - 1):
+            if d0 == d1:
+                continue
+            a = np.asarray(w.berry_flux(occ, [d0, d1]))
+            with _lib.knob("TBK_FLUX_SLICES", 0):
+                b = np.asarray(w.berry_flux(occ, [d0, d1]))
+            assert a.shape == b.shape and np.max(np.abs(a - b)) < 1e-11 * max(1.0, np.sqrt(mesh[d0] * mesh[d1])), (d0, d1)
+            ind = np.asarray(w.berry_flux(occ, [d0, d1], individual_phases=True))
+            assert np.max(np.abs(ind.sum(axis=(-2, -1)) - a)) < 1e-10
