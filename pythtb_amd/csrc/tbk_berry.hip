@@ -592,18 +592,20 @@ struct FluxSliceArgs {
     int bps;           // partials per slice = n0 * nrun
 };
 template <int NOCC, int NCOMP>
-__global__ __launch_bounds__(256) void k_flux_slices(const FluxArgs A, const FluxSliceArgs S, const int64_t nwaves) {
-    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t wv = (int64_t)blockIdx.x * 4 + wib;
-    if (wv >= nwaves) return;
-    const int run = (int)(wv % S.nrun);
-    const int64_t w1 = wv / S.nrun;
-    const int ia = (int)(w1 % A.n0);
-    const int64_t g = w1 / A.n0;
-    const int64_t s_hi = g / S.ngrp;
-    const int j = (int)(g - s_hi * S.ngrp) * 64 + lane;
-    const bool act = j < S.nfast;
-    const int64_t slice = s_hi * S.nfast + (act ? j : S.nfast - 1);
+__global__ __launch_bounds__(256) void k_flux_slices(const FluxArgs A, const FluxSliceArgs S, const int64_t nitems) {
+    // one lane per (slow slice index, row ia, column run, fast slice index j), j fastest: a wavefront is 64 consecutive items --
+    // neighbouring slices of one run, and at the end of the fastest axis the first slices of the next run (a slice count of
+    // 64 q + 1 no longer costs a wavefront for its last slice)
+    const int64_t item0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool act = item0 < nitems;
+    const int64_t item = act ? item0 : nitems - 1;
+    const int64_t t1 = item / S.nfast;
+    const int j = (int)(item - t1 * S.nfast);
+    const int64_t t2 = t1 / S.nrun;
+    const int run = (int)(t1 - t2 * S.nrun);
+    const int64_t s_hi = t2 / A.n0;
+    const int ia = (int)(t2 - s_hi * A.n0);
+    const int64_t slice = s_hi * S.nfast + j;
     const int64_t plane = A.v.npts * NCOMP;
     const int ib0 = run * S.run_len, ib1 = min(ib0 + S.run_len, A.n1);
     int64_t p = axis_offset(A.other, slice) + (int64_t)ia * A.s0 + (int64_t)ib0 * A.s1;
@@ -612,8 +614,9 @@ __global__ __launch_bounds__(256) void k_flux_slices(const FluxArgs A, const Flu
     load_vectors<NOCC, NCOMP>(A.v.data + (p + A.s0) * NCOMP, A.occ, plane, u1);
     cd dV = det_overlap<NOCC, NCOMP>(u0, u1);
     double sum = 0.0;
-    for (int ib = ib0; ib < ib1; ++ib) {
-        p += A.s1;
+    for (int ib = ib0; __builtin_amdgcn_ballot_w64(ib < ib1) != 0; ++ib) {     // (the last run of a row is shorter)
+        const bool on = ib < ib1;
+        if (on) p += A.s1;
         cd v0[NOCC][NCOMP], v1[NOCC][NCOMP];
         load_vectors<NOCC, NCOMP>(A.v.data + p * NCOMP, A.occ, plane, v0);
         load_vectors<NOCC, NCOMP>(A.v.data + (p + A.s0) * NCOMP, A.occ, plane, v1);
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256) void k_flux_slices(const FluxArgs A, const Flu
         cd d = cmul(dV, dH1);
         d = cmul(d, cconj(dVn));
         d = cmul(d, cconj(dH0));
-        sum += -atan2(d.y, d.x);
+        if (on) sum += -atan2(d.y, d.x);
         dV = dVn;
 #pragma unroll
         for (int a = 0; a < NOCC; ++a)
@@ -935,9 +938,9 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     } else {
         ProfScope ps(ctx, "berry_flux");
         if (slices_k) {
-            const int64_t nwv = (nslices / SL.nfast) * SL.ngrp * A.n0 * SL.nrun;
-            const dim3 grid((unsigned)((nwv + 3) / 4)), blk(256);
-#define TBK_SLC(NO, NC) hipLaunchKernelGGL((k_flux_slices<NO, NC>), grid, blk, 0, ctx->stream, A, SL, nwv)
+            const int64_t nitems = nslices * A.n0 * SL.nrun;          // (slices x rows x runs)
+            const dim3 grid((unsigned)((nitems + 255) / 256)), blk(256);
+#define TBK_SLC(NO, NC) hipLaunchKernelGGL((k_flux_slices<NO, NC>), grid, blk, 0, ctx->stream, A, SL, nitems)
             switch (v.ncomp * 8 + nocc) {
                 case 1 * 8 + 1: TBK_SLC(1, 1); break;
                 case 2 * 8 + 1: TBK_SLC(1, 2); break;
