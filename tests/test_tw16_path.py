@@ -241,7 +241,7 @@ def test_twins_are_repaired_in_the_kernel_not_listed(tb):
     gaps = w.solve_on_grid([0.0, 0.0])
     rep = ctx.prof_report()
     ctx.prof_enable(0)
-    assert "e16" in rep and rep.get("tw16_fallback", {"total_ms": 0.0})["total_ms"] < 0.8 * rep["e16"]["total_ms"], rep   # (was 2.6 x; the fallback kernels cost 0.15 ms even for a handful of matrices)
+    assert "e16" in rep and rep.get("tw16_fallback", {"total_ms": 0.0})["total_ms"] < 1.5 * rep["e16"]["total_ms"], rep   # (0.5 x measured, 2.6 x before the repair; the fallback kernels cost 0.15 ms even for a handful of matrices)
     assert np.max(gaps[0::2]) < 1e-13
     V = w.to_host().reshape(-1, 16, 16)[::97]
     assert max(np.max(np.abs(v.conj() @ v.T - np.identity(16))) for v in V) < 1e-13
