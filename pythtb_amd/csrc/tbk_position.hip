@@ -48,20 +48,21 @@ __device__ __forceinline__ void pos_lds_sync_wave() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
-template <int NT>   // NT = ceil(nsub / 2) = 1..4
+template <int NT>   // NT = ceil(nsub / 2) = 1..8: up to 8 states sixteen lanes and four points per wavefront, 9..16 states all 64 lanes on one point
 __global__ __launch_bounds__(256) void k_position_matrix_tile(const EvecSrc ev, const double* __restrict__ pos, const int64_t nk,
                                                               const int nsub, const int ncomp, cd* __restrict__ xmat) {
     extern __shared__ __align__(16) unsigned char pos_lds[];
+    constexpr int LP = NT <= 4 ? 16 : 64, PW = 64 / LP;   // lanes per point, points per wavefront
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wib) * 4;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + wib) * PW;
     if (p0 >= nk) return;                              // (no workgroup barrier below: the wavefronts are independent)
     const int ldp = ncomp + 1, pbuf = nsub * ldp;
-    const int wstride = 4 * pbuf + (ncomp + 1) / 2;   // four points + the coordinates
+    const int wstride = PW * pbuf + (ncomp + 1) / 2;  // the points + the coordinates
     cd* const buf = reinterpret_cast<cd*>(pos_lds) + (size_t)wib * wstride;
     {   // rows (point, state) of ncomp contiguous components: sixteen lanes per row.  All the loads of a 16-component slice are
         // issued before the first goes to LDS (a load -> ds_write pair per loop trip serialises eight memory latencies: 0.24 ms
         // for the 513^2 array where this form takes 0.1)
-        const int j0 = lane & 15, nrow = 4 * nsub;
+        const int j0 = lane & 15, nrow = PW * nsub;     // (at most 32 rows: 4 x 8 or 1 x 16)
         for (int jc = 0; jc < ncomp; jc += 16) {
             const int j = jc + j0;
             cd r[8];
@@ -80,18 +81,18 @@ __global__ __launch_bounds__(256) void k_position_matrix_tile(const EvecSrc ev, 
         }
     }
     {
-        double* const pl = reinterpret_cast<double*>(buf + 4 * pbuf);
+        double* const pl = reinterpret_cast<double*>(buf + PW * pbuf);
         for (int j = lane; j < ncomp; j += 64) pl[j] = pos[j];
     }
     pos_lds_sync_wave();
-    const int g = lane >> 4, tl = lane & 15;
+    const int g = lane / LP, tl = lane - g * LP;
     const int ta = tl / NT, tb = tl - ta * NT;
     if (tl >= NT * NT || p0 + g >= nk) return;
     const int m0 = min(2 * ta, nsub - 1), m1 = min(2 * ta + 1, nsub - 1), n0 = min(2 * tb, nsub - 1), n1 = min(2 * tb + 1, nsub - 1);
     const cd* const pa = buf + g * pbuf;
     const cd *a0 = pa + m0 * ldp, *a1 = pa + m1 * ldp, *b0 = pa + n0 * ldp, *b1 = pa + n1 * ldp;
     cd x00{0.0, 0.0}, x01{0.0, 0.0}, x10{0.0, 0.0}, x11{0.0, 0.0};
-    const double* const posl = reinterpret_cast<const double*>(buf + 4 * pbuf);   // (staged behind the points)
+    const double* const posl = reinterpret_cast<const double*>(buf + PW * pbuf);  // (staged behind the points)
     for (int j = 0; j < ncomp; ++j) {
         const double r = posl[j];
         const cd u0 = a0[j], u1 = a1[j], v0 = cscale(b0[j], r), v1 = cscale(b1[j], r);
@@ -180,16 +181,23 @@ static int position_run(tbk_ctx* ctx, const double* host_evec, EvecSrc src, cons
     {
         ProfScope ps(ctx, "position_matrix");
         const int64_t total = nk * nsub * nsub;
-        const size_t lds_t = (size_t)4 * (4 * nsub * (ncomp + 1) + (ncomp + 1) / 2) * sizeof(cd);   // four wavefronts x (four points + the coordinates)
+        const int pw = nsub <= 8 ? 4 : 1;               // points per wavefront (k_position_matrix_tile)
+        const size_t lds_t = (size_t)4 * (pw * nsub * (ncomp + 1) + (ncomp + 1) / 2) * sizeof(cd);   // four wavefronts x (their points + the coordinates)
         // (TBK_POS_TILE=0: the thread-per-entry kernel at any size)
-        if (nsub <= 8 && nk >= 64 && lds_t <= 64 * 1024 && tbk_knobs().pos_tile != 0) {
-            const dim3 g((unsigned)((nk + 15) / 16)), b(256);
+        if (nsub <= 16 && nk >= 64 && lds_t <= 64 * 1024 && tbk_knobs().pos_tile != 0) {
+            const dim3 g((unsigned)((nk + 4 * pw - 1) / (4 * pw))), b(256);
+#define TBK_PT(NN) hipLaunchKernelGGL((k_position_matrix_tile<NN>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x)
             switch ((nsub + 1) / 2) {
-                case 1: hipLaunchKernelGGL((k_position_matrix_tile<1>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x); break;
-                case 2: hipLaunchKernelGGL((k_position_matrix_tile<2>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x); break;
-                case 3: hipLaunchKernelGGL((k_position_matrix_tile<3>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x); break;
-                default: hipLaunchKernelGGL((k_position_matrix_tile<4>), g, b, lds_t, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x); break;
+                case 1: TBK_PT(1); break;
+                case 2: TBK_PT(2); break;
+                case 3: TBK_PT(3); break;
+                case 4: TBK_PT(4); break;
+                case 5: TBK_PT(5); break;
+                case 6: TBK_PT(6); break;
+                case 7: TBK_PT(7); break;
+                default: TBK_PT(8); break;
             }
+#undef TBK_PT
         } else {
             hipLaunchKernelGGL(k_position_matrix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                                src, (const double*)d_pos, nk, nsub, ncomp, d_x);

@@ -147,7 +147,7 @@ def test_gpu_hwf_haldane_ribbon_and_spin():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nsub", [1, 2, 3, 5, 7, 8])
+@pytest.mark.parametrize("nsub", [1, 2, 3, 5, 7, 8, 9, 10])
 def test_gpu_position_matrix_tile_kernel_equals_the_entry_kernel(nsub):
     """Batches of up to 8 states take k_position_matrix_tile (four points per wavefront through LDS, 2 x 2 blocks of X per lane;
     tbk_position.hip): X, the centres and the functions against the thread-per-entry kernel (TBK_POS_TILE=0) on a ragged batch
@@ -186,3 +186,33 @@ def test_gpu_position_matrix_tile_kernel_equals_the_entry_kernel(nsub):
         ref = np.einsum("kmj,j,knj->kmn", v.conj(), pos, v)
         assert np.max(np.abs(x1 - ref)) < 1e-13
         assert np.max(np.abs(c1 - c0)) < 1e-12 and np.max(np.abs(np.abs(f1) - np.abs(f0))) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nl,nocc", [(16, 16), (16, 13), (20, 11)])
+def test_gpu_position_hwf_mesh_9_to_16_states(nl, nocc):
+    """9..16 states: k_position_matrix_tile with all 64 lanes on one point.  The centres of a slab on a mesh against the
+    thread-per-entry kernel (TBK_POS_TILE=0) and against numpy on the position matrix built from the downloaded states."""
+    import pythtb_amd as tb
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(nl)
+    m = hp.quiet(tb.tb_model, 2, 3, np.identity(3), [[0.0, 0.0, float(i)] for i in range(nl)], per=[0, 1])
+    m.set_onsite(list(0.1 * rng.standard_normal(nl)))
+    for i in range(nl):
+        m.set_hop(-1.0, i, i, [1, 0, 0])
+        m.set_hop(-0.8, i, i, [0, 1, 0])
+        if i + 1 < nl:
+            m.set_hop(-0.7 + 0.1j, i, i + 1, [0, 0, 0])
+    w = tb.wf_array(m, [11, 9])
+    w.solve_on_grid([0.0, 0.0])
+    occ = list(range(nocc))
+    a = w.position_hwf_mesh(occ, 2)
+    with _lib.knob("TBK_POS_TILE", 0):
+        b = w.position_hwf_mesh(occ, 2)
+    assert np.max(np.abs(a - b)) < 1e-12
+    host = w.to_host()
+    pos = m._orb[:, 2]
+    for (i, j) in ((0, 0), (4, 7), (10, 8)):
+        v = host[i, j][occ]
+        x = np.einsum("mj,j,nj->mn", v.conj(), pos, v)
+        assert np.max(np.abs(np.linalg.eigvalsh(x) - a[i, j])) < 1e-12
