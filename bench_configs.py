@@ -83,14 +83,13 @@ def single_gpu(which, reps):
                 fn()
                 best = min(best, time.perf_counter() - t0)
             return best
-        t_host = wall(lambda: m.solve_all(k))                          # the drop-in call: k is the untouched k_uniform_mesh array, so the list is generated on the device
+        t_host = wall(lambda: m.solve_all(k))                          # the drop-in call: the list is uploaded (16 B per k-point) and solved as a list
         ctx.prof_enable(1)
         ctx.prof_reset()
-        m.solve_all(k)
+        m.solve_all_mesh([1024, 1024])
         prof_mesh = {kk: v["total_ms"] / max(v["launches"], 1) for kk, v in ctx.prof_report().items()}
         ctx.prof_enable(0)
-        kplain = np.array(k)
-        t_list = wall(lambda: m.solve_all(kplain))                     # the same through the list path (k uploaded)
+        t_list = t_host
         t_mesh = wall(lambda: m.solve_all_mesh([1024, 1024]))          # k generated on the device
         t_dos = wall(lambda: m.dos_mesh([1024, 1024], 50, range=(-4.0, 4.0)))   # nothing bulky crosses PCIe
         out.append({"config": "B: Haldane solve_all 1024^2", "nk": nk, "eval_only_ms": t_val, "with_vectors_ms": t_vec,

@@ -15,100 +15,6 @@ from . import _lib
 __all__ = ["tb_model"]
 
 
-class _UniformMeshArray(np.ndarray):
-    """The ndarray `tb_model.k_uniform_mesh` returns (pythtb.py:1792-1861: same shape, dtype, values, writable), which also
-    remembers WHICH mesh it is -- so that `solve_all(k_uniform_mesh(mesh))`, the reference's idiom (examples/haldane.py:96-100),
-    need not upload 8 dim_k bytes per k-point the device can generate itself.  The note is dropped, and solve_all takes the
-    ordinary list path, as soon as the array may have changed: any derived array (view, slice, copy, arithmetic result) is an
-    ordinary array without the note; a write through the array or through one of its views (item assignment, in-place
-    operators, `out=`, fill / sort / put / itemset / partition, np.copyto / np.put / np.place / np.putmask) clears it; and at
-    the moment of use 32 sampled rows must still equal i / N exactly.  (A write that bypasses all of this -- through a base-class
-    alias made with np.asarray, a memoryview or a ctypes pointer -- to rows other than the sampled ones is not seen: documented
-    in DESIGN.md as the one hazard of the shortcut; TBK_MESH_SHORTCUT=0 turns it off.)"""
-
-    def __array_finalize__(self, obj):
-        self._tbk_mesh = None                                   # derived arrays are not THE mesh ...
-        self._tbk_state = getattr(obj, "_tbk_state", None)      # ... but may alias its memory: their writes count
-
-    def __repr__(self):                                         # prints like the plain array it stands for
-        return repr(np.asarray(self))
-
-    def __str__(self):
-        return str(np.asarray(self))
-
-    def __reduce__(self):                                       # pickles / deep-copies as a plain array
-        return np.asarray(self).__reduce__()
-
-    @classmethod
-    def _tag(cls, arr, mesh):
-        out = arr.view(cls)
-        out._tbk_mesh = mesh
-        out._tbk_state = {"clean": True}
-        return out
-
-    def _tbk_touch(self):
-        st = self._tbk_state
-        if st is not None:
-            st["clean"] = False
-
-    def __setitem__(self, key, value):
-        self._tbk_touch()
-        np.ndarray.__setitem__(self, key, value)
-
-    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
-        plain = tuple(np.asarray(x) if isinstance(x, _UniformMeshArray) else x for x in inputs)
-        if out is not None:
-            for o in out:
-                if isinstance(o, _UniformMeshArray):
-                    o._tbk_touch()
-            kwargs["out"] = tuple(np.asarray(o) if isinstance(o, _UniformMeshArray) else o for o in out)
-        return getattr(ufunc, method)(*plain, **kwargs)          # results are ordinary arrays
-
-    def __array_function__(self, func, types, args, kwargs):
-        if func in _MESH_WRITERS:
-            for a in list(args) + list(kwargs.values()):
-                if isinstance(a, _UniformMeshArray):
-                    a._tbk_touch()
-        return super().__array_function__(func, types, args, kwargs)
-
-    @staticmethod
-    def _untouched_mesh(k_list, dim_k):
-        """The mesh sizes if `k_list` is the array k_uniform_mesh returned and still holds what it returned, else None."""
-        if type(k_list) is not _UniformMeshArray or k_list._tbk_mesh is None or not _MESH_SHORTCUT:
-            return None
-        st, mesh = k_list._tbk_state, k_list._tbk_mesh
-        nk = 1
-        for m in mesh:
-            nk *= m
-        if (st is None or not st.get("clean") or len(mesh) != dim_k or k_list.shape != (nk, dim_k)
-                or k_list.dtype != np.float64 or not k_list.flags["C_CONTIGUOUS"]):
-            return None
-        rows = np.unique(np.linspace(0, nk - 1, 32).astype(np.int64))
-        rem, want = rows.copy(), np.empty((len(rows), dim_k))
-        for d in range(dim_k - 1, -1, -1):                          # row r = (i_0, .., i_last), last index fastest
-            want[:, d] = (rem % mesh[d]) / float(mesh[d])
-            rem //= mesh[d]
-        if not np.array_equal(np.ndarray.__getitem__(k_list, rows), want):
-            st["clean"] = False
-            return None
-        return mesh
-
-
-def _mesh_writer(name):
-    def method(self, *a, **kw):
-        self._tbk_touch()
-        return getattr(np.ndarray, name)(self, *a, **kw)
-    method.__name__ = name
-    return method
-
-
-for _nm in ("fill", "sort", "put", "itemset", "partition", "byteswap", "setfield", "resize"):
-    if hasattr(np.ndarray, _nm):
-        setattr(_UniformMeshArray, _nm, _mesh_writer(_nm))
-_MESH_WRITERS = {getattr(np, nm) for nm in ("copyto", "put", "place", "putmask", "put_along_axis", "fill_diagonal") if hasattr(np, nm)}
-_MESH_SHORTCUT = __import__("os").environ.get("TBK_MESH_SHORTCUT", "1") != "0"
-
-
 def _is_int(a):
     return np.issubdtype(type(a), np.integer)        # pythtb.py:3950
 
@@ -449,11 +355,6 @@ class tb_model(object):
                 raise Exception("\n\nHave to provide a k-vector!")
             nk, k = 1, None
         else:
-            mesh = _UniformMeshArray._untouched_mesh(k_list, self._dim_k)
-            if mesh is not None:
-                # solve_all(k_uniform_mesh(mesh)) and nobody has written to the array since: the k list is generated on the
-                # device (tbk_solve_mesh: bit-equal to this array, tests/test_dos.py), 8 dim_k bytes per k-point stay off PCIe
-                return self.solve_all_mesh(mesh, eig_vectors)
             k = self._k_array(k_list) if self._dim_k > 0 else None
             nk = len(k_list)
         ev = np.empty((n, nk), dtype=float)                   # filled completely by the device-to-host copies
@@ -620,10 +521,9 @@ class tb_model(object):
         if self._dim_k not in (1, 2, 3):
             raise Exception("\n\nUnsupported dim_k!")
         idx = np.indices(tuple(use)).reshape(self._dim_k, -1).T
-        k = np.divide(idx, use.astype(float), order='C')         # C-contiguous: solve_all hands it to the device as is
-        # (the same ndarray as the reference's, plus a note of which mesh it is: solve_all on the UNTOUCHED array generates the
-        # list on the device instead of uploading it)
-        return _UniformMeshArray._tag(k, tuple(int(x) for x in use))
+        # a plain ndarray like the reference's; C-contiguous, so solve_all hands it to the device as is.  (solve_all always
+        # solves the k list it is GIVEN; the device-generated mesh is the explicit extension solve_all_mesh.)
+        return np.divide(idx, use.astype(float), order='C')
 
     def k_path(self, kpts, nk, report=True):
         """Piecewise-linear path through `kpts` with `nk` points, spaced by the

@@ -208,6 +208,8 @@ class RcclComm(object):
                     _lib.check(lib.tbk_dev_download(ctx.handle, out.ctypes.data_as(C.c_void_p), recv, out.nbytes))
                 return out
             ends = np.zeros((nrows, 2))
+            if total == 0:                                   # nothing gathered: no first / last entry to fetch
+                return ends
             for row in range(nrows):
                 for j, col in enumerate((0, total - 1)):
                     _lib.check(lib.tbk_dev_download(ctx.handle, ends[row, j:j + 1].ctypes.data_as(C.c_void_p),

@@ -9,7 +9,6 @@ to the caller, after which the device copy is refreshed before its next use).
 """
 import copy
 import ctypes as C
-import sys
 
 import numpy as np
 
@@ -46,6 +45,89 @@ def _array_phases_cont(arr_pha, clos):
     return out
 
 
+class _PointLedger(object):
+    """Points of a device-resident wf_array handed out by wf[i,j] as WRITABLE arrays (pythtb.py:2662-2666 returns a live
+    view of the storage).  Each point has a snapshot of what the device held when it was handed out (or last synchronised);
+    `changed()` is one vectorised bit-compare per chunk of 256 points.  With `own` the ledger also owns the memory the
+    caller's arrays view (chunks that are never reallocated), so a write made through a temporary -- `wf[i,j][0] *= z` --
+    is still there when the next device use looks; otherwise the live rows are rows of the host mirror."""
+    CHUNK = 256
+
+    def __init__(self, pt_shape, own):
+        self.pt_shape, self.own = tuple(pt_shape), own
+        self.slot, self.idx, self.snap, self.live, self.n = {}, [], [], [], 0
+
+    def __len__(self):
+        return self.n
+
+    def __contains__(self, fi):
+        return fi in self.slot
+
+    def add(self, fi, value):
+        c, r = divmod(self.n, self.CHUNK)
+        if r == 0:
+            self.snap.append(np.empty((self.CHUNK,) + self.pt_shape, dtype=complex))
+            if self.own:
+                self.live.append(np.empty((self.CHUNK,) + self.pt_shape, dtype=complex))
+        self.snap[c][r] = value
+        if self.own:
+            self.live[c][r] = value
+        self.slot[fi] = self.n
+        self.idx.append(fi)
+        self.n += 1
+
+    def view(self, fi):
+        c, r = divmod(self.slot[fi], self.CHUNK)
+        return self.live[c][r]
+
+    def set(self, fi, value):
+        """The storage at this point was assigned: snapshot (and the caller's arrays of it) follow."""
+        c, r = divmod(self.slot[fi], self.CHUNK)
+        self.snap[c][r] = value
+        if self.own:
+            self.live[c][r] = value
+
+    def indices(self):
+        return np.array(self.idx, dtype=np.int64)
+
+    def _chunks(self, rows):
+        ids = self.indices()
+        for c in range(len(self.snap)):
+            lo = c * self.CHUNK
+            m = min(self.CHUNK, self.n - lo)
+            cid = ids[lo:lo + m]
+            yield cid, (self.live[c][:m] if self.own else rows[cid]), self.snap[c][:m]
+
+    def changed(self, rows=None):
+        """(flat indices, values) of the points whose live array differs bit for bit from its snapshot; the snapshots
+        are brought up to date.  `rows`: the mirror as [point][...] for a ledger that does not own its live rows."""
+        out_i, out_v = [], []
+        for cid, live, snap in self._chunks(rows):
+            m = len(cid)
+            diff = np.flatnonzero((np.ascontiguousarray(live).view(np.uint64).reshape(m, -1)
+                                   != snap.view(np.uint64).reshape(m, -1)).any(axis=1))
+            if len(diff):
+                out_i.append(cid[diff])
+                out_v.append(np.array(live[diff]))
+                snap[diff] = live[diff]
+        if not out_i:
+            return np.zeros(0, dtype=np.int64), None
+        return np.concatenate(out_i), np.concatenate(out_v)
+
+    def refresh(self, pos, buf, rows=None):
+        """The device copy was rewritten: live rows and snapshots take buf[pos[fi]]."""
+        ids = self.indices()
+        for c in range(len(self.snap)):
+            lo = c * self.CHUNK
+            m = min(self.CHUNK, self.n - lo)
+            src = buf[[pos[int(i)] for i in ids[lo:lo + m]]]
+            self.snap[c][:m] = src
+            if self.own:
+                self.live[c][:m] = src
+            else:
+                rows[ids[lo:lo + m]] = src
+
+
 class wf_array(object):
     """Array of wavefunctions on a (k or parameter) mesh: _wfs[k1..kD, state, orb(,spin)]."""
 
@@ -70,16 +152,17 @@ class wf_array(object):
         self._dev = None           # tbk_wfs handle
         self._dev_shape = None
         self._dev_valid = False
-        self._pt_views = {}        # flat index -> snapshot of a point handed out as a writable view of the mirror
-        self._pt_copies = []       # (flat index, array, snapshot) of points handed out as detached writable arrays
+        self._pt_views = None      # _PointLedger of points handed out as writable views of the mirror
+        self._pt_copies = None     # _PointLedger of points handed out as writable arrays of its own pool (large resident arrays)
 
     # ------------------------------------------------------------------ storage
     # Two copies of the array exist: the device buffer (what every kernel reads and writes) and a lazily
     # created NumPy mirror.  Who is authoritative:
     #   * device, after solve_on_grid / impose_* and as long as the caller only uses wf[i,j], wf[i,j] = v
     #     (single-point upload), berry_*, position_*.  wf[i,j] is WRITABLE like the reference's view
-    #     (pythtb.py:2662-2666): the points handed out are remembered with a snapshot, compared before the
-    #     next device use and the changed ones uploaded (_sync_point_writes) -- one point each, never the array;
+    #     (pythtb.py:2662-2666): the points handed out are remembered with a snapshot (_PointLedger), compared -- one
+    #     vectorised pass, only before the next device use or export, never per wf[i,j] -- and the changed ones uploaded
+    #     (_sync_point_writes): the points, never the array;
     #   * host, once the caller has taken the writable mirror through the private attribute `_wfs` (in the
     #     reference that attribute IS the storage, so a script may keep the array and write to it at any
     #     time): from then on the mirror is re-uploaded before every device use and refreshed after every
@@ -107,6 +190,7 @@ class wf_array(object):
                 self._host_valid = True
         if not self._host_valid:
             if self._dev_valid:
+                self._sync_point_writes()      # (handed-out rows of the stale mirror may hold writes the download would bury)
                 _lib.check(_lib.lib.tbk_wfs_download(self._dev, _lib.dptr(self._host.view(float))))
             self._host_valid = True
         return self._host
@@ -116,7 +200,7 @@ class wf_array(object):
         self._sync_point_writes()
         arr = self._host_array()
         self._host_exported = True         # the caller may keep the array and write through it at any time
-        self._pt_views = {}                # (the whole mirror is live now: no per-point bookkeeping)
+        self._pt_views = None              # (the whole mirror is live now: no per-point bookkeeping)
         return arr
 
     @_wfs.setter
@@ -125,54 +209,52 @@ class wf_array(object):
         self._host_valid = True
         self._host_exported = False
         self._dev_valid = False
-        self._pt_views = {}
-        self._pt_copies = []
+        self._pt_views = None
+        self._pt_copies = None
 
     # ---- writable wf[i,j] on a device-resident array (pythtb.py:2662-2666 returns a live view of the storage)
-    _PT_TRACK_MAX = 1 << 16           # handed-out points remembered before the bookkeeping is compacted / given up
+    _PT_TRACK_MAX = 1 << 16           # handed-out points followed one by one before the whole mirror becomes the live copy
+    _PT_TRACK_BYTES = 256 << 20       # ... or this many bytes of them
+
+    def _pt_cap(self):
+        return max(64, min(self._PT_TRACK_MAX, self._PT_TRACK_BYTES // (16 * int(np.prod(self._shape()[self._dim_arr:])))))
 
     def _point_rows(self):
         """The mirror as [point][state, orb(, spin)] (a view)."""
         return self._host.reshape((-1,) + self._shape()[self._dim_arr:])
 
-    def _upload_point(self, idx, val):
-        if self._dev_valid and self._dev is not None:
-            pt = np.ascontiguousarray(val, dtype=complex)
-            ia = np.array([idx], dtype=np.int64)
-            _lib.check(_lib.lib.tbk_wfs_upload_points(self._dev, ia.ctypes.data_as(C.POINTER(C.c_int64)), 1,
-                                                      _lib.dptr(pt.view(float))))
+    def _upload_points(self, idx, vals):
+        if self._dev_valid and self._dev is not None and len(idx):
+            pts = np.ascontiguousarray(vals, dtype=complex)
+            ia = np.ascontiguousarray(idx, dtype=np.int64)
+            _lib.check(_lib.lib.tbk_wfs_upload_points(self._dev, ia.ctypes.data_as(C.POINTER(C.c_int64)), len(ia),
+                                                      _lib.dptr(pts.view(float))))
 
     def _sync_point_writes(self):
         """Carry writes made through arrays obtained from wf[i,j] into the authoritative copy: every handed-out
-        point is compared with the snapshot taken when it was handed out (or last synchronised)."""
-        if self._pt_views:
+        point is compared with the snapshot taken when it was handed out (or last synchronised).  Called before the
+        device copy is used, exported or overwritten by a download -- not per wf[i,j]."""
+        if self._pt_views is not None:
             # (after a device-side write the mirror as a whole is stale, but its handed-out points were refreshed)
             if self._host is not None and not self._host_exported:
-                rows = self._point_rows()
-                for idx, snap in self._pt_views.items():
-                    cur = rows[idx]
-                    if not np.array_equal(cur, snap):
-                        self._upload_point(idx, cur)
-                        snap[...] = cur
+                idx, vals = self._pt_views.changed(self._point_rows())
+                self._upload_points(idx, vals)
             else:
-                self._pt_views = {}
-        if self._pt_copies:
-            keep = []
-            for idx, arr, snap in self._pt_copies:
-                if not np.array_equal(arr, snap):
-                    self._upload_point(idx, arr)
-                    if self._host is not None and self._host_valid:
-                        self._point_rows()[idx] = arr
-                    snap[...] = arr
-                if sys.getrefcount(arr) > 3:           # still held by the caller (else: this tuple, `arr`, the argument)
-                    keep.append((idx, arr, snap))
-            self._pt_copies = keep
+                self._pt_views = None
+        if self._pt_copies is not None:
+            idx, vals = self._pt_copies.changed()
+            if len(idx):
+                self._upload_points(idx, vals)
+                if self._host is not None and self._host_valid:
+                    self._point_rows()[idx] = vals
 
     def _refresh_handed_points(self):
         """A kernel rewrote the device copy: arrays the caller still holds from wf[i,j] show the new values,
         like the reference's views of its storage."""
-        self._pt_copies = [(i, a, s) for i, a, s in self._pt_copies if sys.getrefcount(a) > 3]
-        idxs = sorted(set(self._pt_views) | {i for i, _, _ in self._pt_copies})
+        ledgers = [l for l in (self._pt_views, self._pt_copies) if l is not None and len(l)]
+        if self._pt_views is not None and self._host is None:
+            ledgers = [l for l in ledgers if l is not self._pt_views]
+        idxs = sorted(set(i for l in ledgers for i in l.idx))
         if not idxs:
             return
         ia = np.ascontiguousarray(idxs, dtype=np.int64)
@@ -180,14 +262,8 @@ class wf_array(object):
         _lib.check(_lib.lib.tbk_wfs_download_points(self._dev, ia.ctypes.data_as(C.POINTER(C.c_int64)), len(idxs),
                                                     _lib.dptr(buf.view(float))))
         pos = {i: n for n, i in enumerate(idxs)}
-        if self._pt_views and self._host is not None:
-            rows = self._point_rows()
-            for i, snap in self._pt_views.items():
-                rows[i] = buf[pos[i]]
-                snap[...] = buf[pos[i]]
-        for i, arr, snap in self._pt_copies:
-            arr[...] = buf[pos[i]]
-            snap[...] = buf[pos[i]]
+        for l in ledgers:
+            l.refresh(pos, buf, None if l.own else self._point_rows())
 
     def mark_dirty(self):
         """Extension: declare that the host mirror was modified in place (only needed after
@@ -211,13 +287,15 @@ class wf_array(object):
         """A kernel has just changed the device copy."""
         self._dev_valid = True
         self._host_valid = False
-        if self._host_exported:            # keep the array the caller holds live, like the reference's storage
-            self._host_array()
-        elif self._pt_views or self._pt_copies:
+        if self._pt_views is not None or self._pt_copies is not None:
             if tuple(self._dev_shape or ()) == self._shape():
+                if self._host_exported:
+                    self._pt_views = None
                 self._refresh_handed_points()
             else:
-                self._pt_views, self._pt_copies = {}, []
+                self._pt_views, self._pt_copies = None, None
+        if self._host_exported:            # keep the array the caller holds live, like the reference's storage
+            self._host_array()
 
     def _free_dev(self):
         if self._dev is not None:
@@ -262,8 +340,8 @@ class wf_array(object):
         st["_dev_shape"] = None
         st["_dev_valid"] = False
         st["_host_exported"] = False
-        st["_pt_views"] = {}
-        st["_pt_copies"] = []
+        st["_pt_views"] = None
+        st["_pt_copies"] = None
         st.pop("_bufs", None)          # (ctypes pointers of the per-call buffers: rebuilt on first use)
         st.pop("_pbc_cache", None)
         return st
@@ -420,8 +498,8 @@ class wf_array(object):
         new._dev = None
         new._dev_shape = None
         new._dev_valid = False
-        new._pt_views = {}
-        new._pt_copies = []
+        new._pt_views = None
+        new._pt_copies = None
         return new
 
     def choose_states(self, subset):
@@ -488,52 +566,68 @@ class wf_array(object):
     def __getitem__(self, key):
         """States at one mesh point, `(nsta_arr, norb[, 2])`, WRITABLE like the reference's view of its storage
         (pythtb.py:2644-2666: `wf[i,j][0] *= phase` changes the array).  A view of the host mirror when there is
-        one, else -- for a large resident array -- just this point fetched from the device; either way the point
-        is remembered with a snapshot and writes made through the returned array reach the device copy before its
-        next use (_sync_point_writes)."""
+        one, else -- for a large resident array -- just this point fetched from the device into a pool the array owns
+        (asking for the same point again returns a view of the same memory, as in the reference); either way the
+        point is remembered with a snapshot and writes made through the returned array reach the device copy before
+        its next use (_sync_point_writes).  Nothing is compared here: a read loop over the mesh is linear."""
         self._check_key(key)
-        self._sync_point_writes()
-        if self._device_only() and int(np.prod(self._shape())) * 16 > self._SMALL_MIRROR_BYTES:
-            out = np.zeros(self._shape()[self._dim_arr:], dtype=complex)
+        pt_shape = self._shape()[self._dim_arr:]
+        if (self._device_only() and not self._host_exported
+                and int(np.prod(self._shape())) * 16 > self._SMALL_MIRROR_BYTES):
             fi = self._flat_index(key)
-            idx = np.array([fi], dtype=np.int64)
-            _lib.check(_lib.lib.tbk_wfs_download_points(self._dev, idx.ctypes.data_as(C.POINTER(C.c_int64)), 1,
-                                                        _lib.dptr(out.view(float))))
-            self._pt_copies.append((fi, out, out.copy()))
-            if len(self._pt_copies) >= self._PT_TRACK_MAX:
-                self._sync_point_writes()                      # (drops the entries nobody holds any more)
-            return out
+            led = self._pt_copies
+            if led is not None and fi in led:
+                return led.view(fi)
+            if led is None or len(led) < self._pt_cap():
+                if self._pt_views is not None and fi in self._pt_views and self._host is not None:
+                    return self._host[key]                     # (handed out as a mirror row earlier: that row is the live one)
+                out = np.zeros(pt_shape, dtype=complex)
+                idx = np.array([fi], dtype=np.int64)
+                _lib.check(_lib.lib.tbk_wfs_download_points(self._dev, idx.ctypes.data_as(C.POINTER(C.c_int64)), 1,
+                                                            _lib.dptr(out.view(float))))
+                if led is None:
+                    led = self._pt_copies = _PointLedger(pt_shape, own=True)
+                led.add(fi, out)
+                return led.view(fi)
+            # too many points to follow one by one: fall through, the whole mirror becomes the live copy (as with `_wfs`)
+            self._sync_point_writes()
+            self._host_array()
+            self._host_exported = True
+            self._pt_views = None
         out = self._host_array()[key]
         if self._dev_valid and self._dev is not None and not self._host_exported:
             fi = self._flat_index(key)
+            if self._pt_copies is not None and fi in self._pt_copies:
+                return self._pt_copies.view(fi)                # (a point lives in one ledger: its pool array is the live one)
+            if self._pt_views is None:
+                self._pt_views = _PointLedger(pt_shape, own=False)
             if fi not in self._pt_views:
-                if len(self._pt_views) >= self._PT_TRACK_MAX:
-                    # too many live points to follow one by one: the whole mirror becomes the live copy, as with `_wfs`
+                if len(self._pt_views) >= self._pt_cap():
+                    self._sync_point_writes()
+                    self._host_array()
                     self._host_exported = True
-                    self._pt_views = {}
+                    self._pt_views = None
                     return out
-                self._pt_views[fi] = np.array(out)
+                self._pt_views.add(fi, out)
         return out
 
     def __setitem__(self, key, value):
         """pythtb.py:2663-2672.  On a resident array only this point crosses PCIe."""
         self._check_key(key)
-        self._sync_point_writes()
         val = np.array(value, dtype=complex)
         if self._dev_valid and self._dev is not None:
             pt = np.ascontiguousarray(np.broadcast_to(val, self._shape()[self._dim_arr:]))
             fi = self._flat_index(key)
-            idx = np.array([fi], dtype=np.int64)
-            _lib.check(_lib.lib.tbk_wfs_upload_points(self._dev, idx.ctypes.data_as(C.POINTER(C.c_int64)), 1,
-                                                      _lib.dptr(pt.view(float))))
-            if self._host is not None and self._host_valid:
-                self._host[key] = val
-            if fi in self._pt_views:
-                self._pt_views[fi][...] = pt
-            for i, arr, snap in self._pt_copies:               # arrays handed out for this point follow the storage
-                if i == fi:
-                    arr[...] = pt
-                    snap[...] = pt
+            self._upload_points([fi], pt[None])
+            tracked = self._pt_views is not None and fi in self._pt_views
+            # the mirror row of a handed-out point is live even while the mirror as a whole is stale (ADVICE r4: skipping it
+            # let the next synchronisation upload the OLD row over this assignment)
+            if self._host is not None and (self._host_valid or tracked):
+                self._host[key] = pt
+            if tracked:
+                self._pt_views.set(fi, pt)
+            if self._pt_copies is not None and fi in self._pt_copies:   # arrays handed out for this point follow the storage
+                self._pt_copies.set(fi, pt)
         else:
             self._host_array()[key] = val
 

@@ -145,42 +145,55 @@ def test_dos_argument_checks(tb):
         m.dos_mesh([4, 4], 0)
 
 
-def test_solve_all_on_the_untouched_uniform_mesh_uploads_nothing(tb):
-    """configs[1]'s drop-in call `m.solve_all(m.k_uniform_mesh([N, N]))` (examples/haldane.py:96-100): the k list is generated
-    on the device -- no 16-bytes-per-k upload, the same eigenvalues as the list path bit for bit -- while
-    a copy of the mesh, or the mesh after any write, takes the list path."""
+def test_solve_all_solves_the_list_it_is_given_and_solve_all_mesh_uploads_nothing(tb):
+    """configs[1]: `m.solve_all(m.k_uniform_mesh([N, N]))` (examples/haldane.py:96-100) is the LIST path on exactly the array
+    passed -- a mesh modified through any alias (np.asarray, a view, .flat) gives the modified list's eigenvalues like the
+    reference (pythtb.py:1047-1060) -- and the explicit extension solve_all_mesh generates the same list on
+    the device: no 16-bytes-per-k upload, the same eigenvalues (bit for bit through the list kernel)."""
+    from oracle import tb_oracle as orc
     from pythtb_amd import _lib
     ctx = _lib.default_context()
-    for m, mesh in ((hp.haldane(tb.tb_model, 0.2), [300, 200]), (hp.kane_mele(tb.tb_model, "odd"), [64, 48]),
-                    (hp.chain3(tb.tb_model, -1.0, 2.0, 0.3), [501]), (hp.cubic16(tb.tb_model), [6, 5, 7])):
+    for m, mo, mesh in ((hp.haldane(tb.tb_model, 0.2), hp.haldane(orc.tb_model, 0.2), [300, 200]),
+                        (hp.kane_mele(tb.tb_model, "odd"), hp.kane_mele(orc.tb_model, "odd"), [64, 48]),
+                        (hp.chain3(tb.tb_model, -1.0, 2.0, 0.3), None, [501]), (hp.cubic16(tb.tb_model), None, [6, 5, 7])):
         k = m.k_uniform_mesh(mesh)
-        plain = np.array(k)                                # an ordinary copy: the list path
+        assert type(k) is np.ndarray
+        plain = np.array(k)
         m.solve_all(plain[:3])                             # (model tables on the device before the counters are read)
-        ctx.transfer_stats(reset=True)
-        ev = m.solve_all(k)
-        st = ctx.transfer_stats(reset=True)
-        assert st["h2d_bytes"] < 1024, st
         ctx.prof_enable(1)
         ctx.prof_reset()
-        ev_list = m.solve_all(plain)
+        ev_list = m.solve_all(k)
         names = set(ctx.prof_report())
         assert not any(nm.startswith("mesh_evals") or nm == "k_mesh" for nm in names), names     # the list path: no mesh kernels
+        ctx.transfer_stats(reset=True)
         ctx.prof_reset()
-        m.solve_all(m.k_uniform_mesh(mesh))
+        ev = m.solve_all_mesh(mesh)
+        st = ctx.transfer_stats(reset=True)
         names = set(ctx.prof_report())
         ctx.prof_enable(0)
+        assert st["h2d_bytes"] < 1024, st
         assert ("mesh_evals" in names) == (m._nsta <= 4) and not any(nm.startswith("solve_list") for nm in names) == (m._nsta <= 4), names
         # (eigenvalues alone of up to 4 states come from the row kernel k_mesh_evals -- the mesh's separable phases, no k list at
         # all: equal to the list kernel's to rounding; everything else is the list kernel on the generated list: the same bits)
         assert ev.shape == ev_list.shape and np.max(np.abs(ev - ev_list)) < 1e-13
         assert m._nsta <= 4 or np.array_equal(ev, ev_list)
         with _lib.knob("TBK_MESH_ROWS", 0):
-            assert np.array_equal(m.solve_all(m.k_uniform_mesh(mesh)), ev_list)
-        ev2, vec2 = m.solve_all(k, eig_vectors=True)
-        evl, vecl = m.solve_all(plain, eig_vectors=True)
+            assert np.array_equal(m.solve_all_mesh(mesh), ev_list)
+        ev2, vec2 = m.solve_all_mesh(mesh, eig_vectors=True)
+        evl, vecl = m.solve_all(k, eig_vectors=True)
         assert np.array_equal(ev2, evl) and vec2.shape == vecl.shape and np.array_equal(vec2, vecl)
-        # a write drops the note: the (shifted) list is uploaded and solved as a list
-        k[1] += 0.25
+        # writes through aliases the array cannot see, at rows no sampling would have looked at: the modified list is what is solved
+        nk = len(k)
+        rows = [1, nk // 3 + 1, nk - 2]
+        np.asarray(k)[rows[0]] += 0.25
+        k.view(np.ndarray).reshape(-1)[rows[1] * k.shape[1]] -= 0.125
+        memoryview(k)[rows[2], 0] = 0.3125
+        plain[rows[0]] += 0.25
+        plain[rows[1], 0] -= 0.125
+        plain[rows[2], 0] = 0.3125
         ev3 = m.solve_all(k)
-        plain[1] += 0.25
-        assert np.array_equal(ev3, m.solve_all(plain)) and not np.array_equal(ev3[:, 1], ev[:, 1])
+        assert np.array_equal(ev3, m.solve_all(plain))
+        for r in rows:
+            assert not np.array_equal(ev3[:, r], ev_list[:, r])
+        if mo is not None:
+            assert np.max(np.abs(ev3[:, rows] - mo.solve_all(plain[rows]))) < 1e-12

@@ -229,44 +229,17 @@ def test_wf_array_host_side():
     assert w[1, 2][0, 1] == 4 and w._wfs[1, 2, 0, 0] == 2 and w[2, 3][1, 0] == 7 and w._wfs[2, 3, 1, 0] == 7
 
 
-def test_uniform_mesh_array_remembers_its_mesh_until_it_may_have_changed():
-    """k_uniform_mesh returns the reference's array (pythtb.py:1792-1861) with a note of which mesh it is, so that
-    solve_all(k_uniform_mesh(mesh)) can generate the list on the device; every way of changing the array drops the note
-    (host-side logic only: no device call here)."""
-    import copy
-    import pickle
-    from pythtb_amd.model import _UniformMeshArray as U
+def test_uniform_mesh_is_a_plain_ndarray():
+    """k_uniform_mesh returns what the reference returns (pythtb.py:1792-1861): an ordinary, writable, C-contiguous ndarray --
+    no subclass, no hidden note of which mesh it is.  (Round 4 tagged it so that solve_all could skip the upload; a write through
+    an untracked alias then returned eigenvalues of a k list the caller no longer held)"""
     m = hp.haldane(tb.tb_model, 0.2)
     ref = np.divide(np.indices((4, 6)).reshape(2, -1).T, np.array([4.0, 6.0]))
     k = m.k_uniform_mesh([4, 6])
-    assert isinstance(k, np.ndarray) and k.flags.writeable and k.flags["C_CONTIGUOUS"] and np.array_equal(k, ref)
-    assert repr(k) == repr(ref) and str(k) == str(ref)
-    assert U._untouched_mesh(k, 2) == (4, 6) and U._untouched_mesh(k, 3) is None
-    # derived arrays are ordinary arrays / carry no note
-    assert type(k + 1.0) is np.ndarray and type(k.sum()) is np.float64 and type(np.mean(k, axis=0)) is np.ndarray
-    for derived in (k.copy(), k[3:], k.T, k.reshape(4, 6, 2), copy.deepcopy(k), pickle.loads(pickle.dumps(k)), np.array(k)):
-        assert U._untouched_mesh(derived, 2) is None
-    assert U._untouched_mesh(k, 2) == (4, 6)                         # ... and looking at them changed nothing
-    # every write drops the note
-    def fresh():
-        return m.k_uniform_mesh([4, 6])
-    cases = []
-    a = fresh(); a[2, 0] = 0.9; cases.append(a)
-    a = fresh(); b = a; b += 0.0; cases.append(a)
-    a = fresh(); v = a[1:3]; v[0, 0] = 5.0; cases.append(a)          # through a view
-    a = fresh(); a.T[0, 5] = 7.0; cases.append(a)
-    a = fresh(); np.copyto(a, 0.0); cases.append(a)
-    a = fresh(); a.fill(0.5); cases.append(a)
-    a = fresh(); np.add(a, 1.0, out=a); cases.append(a)
-    a = fresh(); np.multiply(a[::2], 2.0, out=a[::2]); cases.append(a)
-    a = fresh(); a.sort(axis=0); cases.append(a)
-    a = fresh(); np.put(a, [3], [9.0]); cases.append(a)
-    a = fresh(); np.asarray(a)[0, 1] = 3.0; cases.append(a)         # a base-class alias: caught by the sampled rows
-    for c in cases:
-        assert U._untouched_mesh(c, 2) is None
-    assert U._untouched_mesh(m.k_uniform_mesh([3, 5]), 2) == (3, 5)
+    assert type(k) is np.ndarray and k.flags.writeable and k.flags["C_CONTIGUOUS"] and k.flags.owndata is not None
+    assert k.dtype == np.float64 and np.array_equal(k, ref) and repr(k) == repr(ref)
     m1 = hp.chain3(tb.tb_model, -1.0, 2.0, 0.3)
-    assert U._untouched_mesh(m1.k_uniform_mesh([7]), 1) == (7,)
+    assert type(m1.k_uniform_mesh([7])) is np.ndarray
 
 
 def test_z2_index_from_the_reference_wannier_centres():
@@ -506,3 +479,156 @@ def test_phase_continuity_in_c_equals_the_reference_loops():
             got = wa._array_phases_cont(arr, clos)
             ref = orc.array_phases_cont(arr, np.array(clos, dtype=float))
             assert np.array_equal(got, ref), (n0, nb)
+
+
+class _FakeWfsLib(object):
+    """Stand-in for the seven storage entry points of libtbk that wf_array's host bookkeeping drives (include/tbk.h:145-197):
+    the "device copy" is a NumPy array [point][...].  Test infrastructure for the ledger logic only -- no compute."""
+
+    def __init__(self):
+        self.dev = {}
+        self.calls = {"up_pts": 0, "down_pts": 0, "up": 0, "down": 0}
+        self.next = 1
+
+    def _arr(self, ptr, n):
+        return np.ctypeslib.as_array(ptr, shape=(n,))
+
+    def tbk_wfs_create(self, ctx, dim, mesh, nsta, ncomp, out):
+        m = np.ctypeslib.as_array(mesh, shape=(dim,))
+        h = self.next
+        self.next += 1
+        self.dev[h] = np.zeros((int(np.prod(m)), nsta * ncomp), dtype=complex)
+        out._obj.value = h
+        return 0
+
+    def _h(self, h):
+        return self.dev[h.value if hasattr(h, "value") else h]
+
+    def tbk_wfs_free(self, h):
+        return 0
+
+    def tbk_wfs_upload(self, h, p):
+        d = self._h(h)
+        d[...] = self._arr(p, d.size * 2).view(complex).reshape(d.shape)
+        self.calls["up"] += 1
+        return 0
+
+    def tbk_wfs_download(self, h, p):
+        d = self._h(h)
+        self._arr(p, d.size * 2)[...] = d.reshape(-1).view(float)
+        self.calls["down"] += 1
+        return 0
+
+    def tbk_wfs_upload_points(self, h, idx, n, p):
+        d = self._h(h)
+        ids = np.ctypeslib.as_array(idx, shape=(n,))
+        d[ids] = self._arr(p, n * d.shape[1] * 2).view(complex).reshape(n, -1)
+        self.calls["up_pts"] += 1
+        return 0
+
+    def tbk_wfs_download_points(self, h, idx, n, p):
+        d = self._h(h)
+        ids = np.ctypeslib.as_array(idx, shape=(n,))
+        self._arr(p, n * d.shape[1] * 2)[...] = d[ids].reshape(-1).view(float)
+        self.calls["down_pts"] += 1
+        return 0
+
+    def tbk_wfs_impose(self, h, mesh_dir, phase):
+        return 0
+
+
+def _fake_resident(monkeypatch, mesh, small_mirror_bytes=None):
+    """A wf_array whose device copy is a _FakeWfsLib array filled with recognisable numbers, device authoritative."""
+    import types
+    from pythtb_amd import wfarray as wmod, _lib as real
+    fake = _FakeWfsLib()
+    shim = types.SimpleNamespace(lib=fake, check=real.check, dptr=real.dptr, iptr=real.iptr,
+                                 default_context=lambda: types.SimpleNamespace(handle=None))
+    monkeypatch.setattr(wmod, "_lib", shim)
+    m = hp.haldane(tb.tb_model, 0.3)
+    w = tb.wf_array(m, mesh)
+    if small_mirror_bytes is not None:
+        w._SMALL_MIRROR_BYTES = small_mirror_bytes
+    h = w._dev_handle(w._shape())
+    d = fake._h(h)
+    d[...] = (np.arange(d.size).reshape(d.shape) + 1) * (1.0 + 0.5j)
+    w._dev_valid = True
+
+    def device_write(scale):
+        d[...] = d * scale
+        w._device_wrote()
+    return w, fake, d, device_write
+
+
+@pytest.mark.parametrize("pool", [False, True])
+def test_point_ledger_setitem_after_a_device_write_is_not_reverted(monkeypatch, pool):
+    """wf[i,j] read -> a kernel rewrites the array -> `wf[i,j] = v` -> next device use.  The assignment skipped
+    the (stale) mirror row, so the next synchronisation saw "row differs from snapshot" and uploaded the OLD row over v."""
+    w, fake, d, device_write = _fake_resident(monkeypatch, [5, 4], small_mirror_bytes=0 if pool else None)
+    held = w[2, 1]
+    fi = 2 * 4 + 1
+    assert np.array_equal(held.reshape(-1), d[fi])
+    device_write(2.0)                               # e.g. a second solve_on_grid / impose_pbc
+    assert np.array_equal(held.reshape(-1), d[fi])  # the held array follows the storage
+    v = np.full((2, 2), 7.0 - 1.0j)
+    w[2, 1] = v
+    assert np.array_equal(d[fi], v.reshape(-1)) and np.array_equal(held, v)
+    w._ensure_dev()                                 # what every berry_* / position_* call does first
+    assert np.array_equal(d[fi], v.reshape(-1)) and np.array_equal(w[2, 1], v)
+    held[0, 0] = 3.0                                # and the held array is still live
+    w._ensure_dev()
+    assert d[fi][0] == 3.0 and d[fi][1] == 7.0 - 1.0j
+    assert fake.calls["up"] == 0                    # points only, never the array
+
+
+@pytest.mark.parametrize("pool", [False, True])
+def test_point_ledger_read_loop_is_linear_and_temporaries_are_not_lost(monkeypatch, pool):
+    """a plain `for i, j: wf[i, j]` loop compared every point handed out so far on every access (16 s for
+    61x61).  Nothing is compared per access now; writes -- also through temporaries that die at once -- reach the device copy
+    in ONE batched upload before its next use; asking for a point twice returns the same memory, like the reference's views."""
+    import time
+    n = 61
+    w, fake, d, device_write = _fake_resident(monkeypatch, [n, n], small_mirror_bytes=0 if pool else None)
+    t0 = time.perf_counter()
+    acc = 0.0
+    for i in range(n):
+        for j in range(n):
+            acc += w[i, j][0, 0].real
+    dt = time.perf_counter() - t0
+    assert acc == float(np.sum(d[:, 0].real))
+    assert dt < 2.0, dt                             # (was quadratic: 16 s; linear: ~10-50 ms here)
+    assert fake.calls["up_pts"] == 0
+    w[3, 4][0] *= 2.0                               # temporary array, dies at once
+    a, b = w[10, 11], w[10, 11]
+    a[1, 1] = -5.0
+    assert b[1, 1] == -5.0 and np.shares_memory(a, b)
+    before = d.copy()
+    w._ensure_dev()
+    assert fake.calls["up_pts"] == 1 and fake.calls["up"] == 0
+    before[3 * n + 4, :2] *= 2.0
+    before[10 * n + 11, 3] = -5.0
+    assert np.array_equal(d, before)
+    w._ensure_dev()
+    assert fake.calls["up_pts"] == 1                # nothing changed since: nothing uploaded
+    # a device-side rewrite shows up in arrays still held, and their later writes still count
+    device_write(-1.0)
+    assert np.array_equal(a.reshape(-1), d[10 * n + 11])
+    a[0, 0] = 9.0
+    assert np.array_equal(w.to_host().reshape(n * n, -1), d) and d[10 * n + 11, 0] == 9.0
+
+
+def test_point_ledger_gives_way_to_the_whole_mirror_past_its_cap(monkeypatch):
+    """More live points than the ledger follows one by one: the whole mirror becomes the live copy (as with `_wfs`), and
+    arrays handed out from the pool before that are still honoured."""
+    w, fake, d, device_write = _fake_resident(monkeypatch, [20, 20], small_mirror_bytes=0)
+    w._PT_TRACK_MAX = 64
+    w._PT_TRACK_BYTES = 1 << 40
+    first = w[0, 1]
+    for j in range(70):
+        w[1 + j // 20, j % 20]
+    assert w._host_exported and len(w._pt_copies) == 64
+    first[0, 0] = 11.0
+    late = w[15, 15]                                # a view of the exported mirror
+    late[1, 0] = 12.0
+    w._ensure_dev()
+    assert d[1, 0] == 11.0 and d[15 * 20 + 15, 2] == 12.0
