@@ -160,6 +160,12 @@ int tbk_wfs_upload_points(tbk_wfs* wfs, const int64_t* point_index, int64_t npoi
  * and the per-point forms): lets callers and tests assert that a script causes no re-uploads. */
 int tbk_ctx_transfer_stats(tbk_ctx* ctx, int64_t* h2d_bytes, int64_t* d2h_bytes, int64_t* h2d_calls,
                            int64_t* d2h_calls, int reset);
+/* diagnostics of the eigen-solver since the last reset: `listed_matrices` = matrices of 9..16 states that the direct kernels
+ * (k_e16 / k_tw16_*) could not finish themselves (three or more eigenvalues of a block within gaptol, a failed residual)
+ * and handed to the QL-replay fallback.  Results are the same either way; the count tells a regression of the in-kernel
+ * repairs from a healthy launch without timing anything.  Synchronises the context's stream.  (No reference counterpart:
+ * numpy.linalg.eigh, pythtb.py:939-947, has one path.)                                                              */
+int tbk_ctx_solver_stats(tbk_ctx* ctx, int64_t* listed_matrices, int reset);
 
 /* solve_on_grid (pythtb.py:2421-2532): every mesh point i_d < N_d-1 solved at
  * start_k[d] + i_d/(N_d-1); the points with i_d == N_d-1 are the impose_pbc

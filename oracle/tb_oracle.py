@@ -12,7 +12,7 @@ Parity pin: every function here is checked (tests/test_oracle_golden.py)
   * against vectors generated in the development container by importing the
     reference itself (tests/golden/make_golden.py -> tests/golden/*.npz), and
   * when `/root/reference` is present, live against the imported reference
-    (tests/test_oracle_vs_reference.py, skipped elsewhere).
+    (tests/test_oracle_golden.py::test_oracle_live_against_imported_reference, skipped elsewhere).
 
 Each function cites the reference lines it follows.  The per-k / per-link loop
 structure is kept on purpose (it is what the CPU baseline times); `*_vec`

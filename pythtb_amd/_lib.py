@@ -76,6 +76,7 @@ SIGNATURES = {
     "tbk_wfs_upload_points": (_i, [_p, C.POINTER(C.c_int64), _i64, _dp]),
     "tbk_ctx_transfer_stats": (_i, [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), _i]),
+    "tbk_ctx_solver_stats": (_i, [_p, C.POINTER(C.c_int64), _i]),
     "tbk_wfs_solve_grid": (_i, [_p, _p, _dp, _dp, _i64, _i64, _dp]),
     "tbk_wfs_solve_grid_async": (_i, [_p, _p, _dp, _dp, _i64, _i64]),
     "tbk_wfs_solve_grid_result": (_i, [_p, _dp]),
@@ -192,6 +193,12 @@ class Context(object):
         v = [C.c_int64(0) for _ in range(4)]
         check(lib.tbk_ctx_transfer_stats(self.handle, *[C.byref(x) for x in v], 1 if reset else 0))
         return dict(h2d_bytes=v[0].value, d2h_bytes=v[1].value, h2d_calls=v[2].value, d2h_calls=v[3].value)
+
+    def solver_stats(self, reset=False):
+        """dict(listed_matrices=...): matrices of 9..16 states the direct kernels handed to their fallback since the last reset."""
+        v = C.c_int64(0)
+        check(lib.tbk_ctx_solver_stats(self.handle, C.byref(v), 1 if reset else 0))
+        return dict(listed_matrices=v.value)
 
     # ---- timing helpers (HIP events on this context's stream)
     def timer_begin(self):

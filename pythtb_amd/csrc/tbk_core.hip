@@ -1105,6 +1105,17 @@ extern "C" int tbk_ctx_transfer_stats(tbk_ctx* c, int64_t* h2d_bytes, int64_t* d
     return TBK_OK;
 }
 
+extern "C" int tbk_ctx_solver_stats(tbk_ctx* c, int64_t* listed_matrices, int reset) {
+    TBK_REQUIRE(c, TBK_EINVAL, "tbk_ctx_solver_stats: null context");
+    TBK_HIP(hipSetDevice(c->device));
+    unsigned long long v = 0;
+    TBK_HIP(hipMemcpyAsync(&v, c->flags_dev + TBK_FLAG_LISTED, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    if (reset) TBK_HIP(hipMemsetAsync(c->flags_dev + TBK_FLAG_LISTED, 0, sizeof(v), c->stream));
+    TBK_HIP(hipStreamSynchronize(c->stream));
+    if (listed_matrices) *listed_matrices = (int64_t)v;
+    return TBK_OK;
+}
+
 // wf_array.choose_states (pythtb.py:2568-2608) between two resident arrays of the same mesh: band planes are contiguous on
 // the device, so a subset of the states is nb device-to-device copies -- nothing crosses PCIe.
 extern "C" int tbk_wfs_copy_bands(tbk_wfs* dst, tbk_wfs* src, const int32_t* bands, int nb) {

@@ -215,7 +215,8 @@ struct tbk_ctx {
     size_t zc_bytes = 0;
     void* pinned = nullptr;    // TBK_PINNED_BYTES (1 MiB) of pinned host memory for small results
     void* pinned_dev = nullptr;  // ... its device address (k_copy_small_signal writes small results there itself)
-    int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence)
+    int* flags_dev = nullptr;  // [64] sticky kernel status words (0: eigen no-convergence); [TBK_FLAG_LISTED, +1]: a 64-bit count of
+                               // the matrices the direct n = 9..16 kernels listed for their QL-replay fallback (tbk_ctx_solver_stats)
     // completion word of small calls (tbk_done_arm / tbk_done_wait): 64 B of mapped host memory -- [0] the sequence number the last
     // kernel of the call stores after its results, [4..7] a copy of flags_dev[0..3] taken by that kernel; and its device-side
     // arrival counter.  Null when the mapped allocation failed or TBK_POLL_DONE=0: callers then synchronise the stream.
@@ -249,6 +250,7 @@ int tbk_small_result(tbk_ctx* ctx, void* dst, const void* src_dev, size_t bytes,
 // then falls back to hipStreamSynchronize, which is also what happens when d.word is null).  Results the host reads after the
 // wait must have been stored by that last kernel (or sit in device memory).
 #define TBK_PINNED_BYTES ((size_t)1 << 20)
+#define TBK_FLAG_LISTED 16
 struct DoneArgs {
     unsigned* word;        // device pointer of done_host[0]; null = not armed
     unsigned* cnt;         // arrival counter (device memory), zero between launches

@@ -418,12 +418,15 @@ __device__ __forceinline__ void ql16_replay_body(const int n, const int64_t nk, 
 template <int MODE, bool LIST = false>
 __global__ __launch_bounds__(256) void k_ql16_replay(const int n, const int64_t nk, const int64_t id0, const int64_t nc,
                                                       const Ql16Rec R, cd* __restrict__ evec, const WfsView wv,
-                                                      const int* __restrict__ list = nullptr, const int* __restrict__ count = nullptr) {
+                                                      const int* __restrict__ list = nullptr, const int* __restrict__ count = nullptr,
+                                                      unsigned long long* __restrict__ listed_total = nullptr) {
     if constexpr (!LIST) {
         ql16_replay_body<MODE>(n, nk, id0, nc, R, evec, wv, nullptr, nc, ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4);
         return;
     }
     const int64_t nhave = *count;
+    // tbk_ctx_solver_stats: matrices the direct kernels handed to this fallback since the last reset
+    if (listed_total && nhave > 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(listed_total, (unsigned long long)nhave);
     for (int64_t base = (int64_t)blockIdx.x * 16; base < nhave; base += (int64_t)gridDim.x * 16)
         ql16_replay_body<MODE>(n, nk, id0, nc, R, evec, wv, list, nhave, base + (threadIdx.x >> 4));
 }

@@ -733,7 +733,7 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
                 hipLaunchKernelGGL((k_ql16_lanes<MODE, true>), dim3(f1), dim3(256), 0, sq, mv.nsta, nk, id0, nc, (const double2*)w.de, L.eval, G, w.R,
                                    ctx->flags_dev, (const int*)w.list, (const int*)w.count, fused);
                 hipLaunchKernelGGL((k_ql16_replay<MODE, true>), dim3(f16), dim3(256), 0, sq, mv.nsta, nk, id0, nc, w.R, evec, G.wv, (const int*)w.list,
-                                   (const int*)w.count);
+                                   (const int*)w.count, (unsigned long long*)(ctx->flags_dev + TBK_FLAG_LISTED));
             }
         }
         return TBK_OK;

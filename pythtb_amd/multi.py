@@ -4,6 +4,9 @@
   (reference loop: pythtb.py:1047), ONE gather of the eigenvalues into the band-major (nsta, nkp) array the
   reference returns (pythtb.py:1040,1053-1067) -- `solve_all_sharded`, `solve_all_mesh_sharded`.
 
+* configs[2]: Haldane wf_array([2049, 2049]) solve_on_grid + berry_flux (pythtb.py:2475-2497, :3135-3150): slabs along
+  axis 0, each with its recomputed halo row; ONE gather of [partial flux | min gaps] -- `berry_flux_sharded` through the
+  wf_array API, `GridSlab` the same slab at the C-ABI level (what bench.py times).
 * configs[3]: Kane-Mele wf_array([4097, 513]) -- Wilson-loop eigenphases of the 513 strings along axis 0
   (reference loop: pythtb.py:2987-2996).  Strings shard along axis 1; 513 strings over 8 ranks is an uneven
   split (65 + 7 x 64), so the gather is an all-gather-v.
@@ -31,7 +34,7 @@ from . import shard
 
 __all__ = ["GlooComm", "RcclComm", "plan_strings", "plan_slabs", "plan_list", "wilson_loops_sharded",
            "mesh_phases_sharded", "solve_all_sharded", "solve_all_mesh_sharded", "call_with_timeout", "agree",
-           "rccl_bring_up"]
+           "rccl_bring_up", "GridSlab", "berry_flux_sharded", "combine_flux_blocks"]
 
 
 # ---------------------------------------------------------------------------------------------- plans
@@ -399,6 +402,105 @@ def mesh_phases_sharded(wf_array_cls, model, mesh, start_k, occ, comm, rank, wor
         row += p[2]
         pos += c
     return allv, allg
+
+
+class GridSlab(object):
+    """One rank's slab of configs[2] at the C-ABI level: a device-resident window [row0, row0 + mesh[0]) x mesh[1:] of a
+    global solve_on_grid mesh whose axis 0 has global_n0 points, driven by the asynchronous pair tbk_wfs_solve_grid_async +
+    tbk_berry_flux_async (or the one-pass tbk_wfs_solve_grid_flux_async).  Nothing is read back until gaps() / flux_total():
+    what bench.py times as a step.  berry_flux_sharded below is the same partitioning through the wf_array API."""
+
+    def __init__(self, lib, _lib, ctx, model, mesh, row0=0, global_n0=None):
+        self.lib, self._lib, self.ctx, self.model = lib, _lib, ctx, model
+        self.mesh = [int(x) for x in mesh]
+        n = model._nsta
+        self.n = n
+        self.h = C.c_void_p()
+        m32 = np.ascontiguousarray(self.mesh, dtype=np.int32)
+        _lib.check(lib.tbk_wfs_create(ctx.handle, len(mesh), _lib.iptr(m32), n, n, C.byref(self.h)))
+        self.hm = model._device_model()
+        self.pbc = np.ascontiguousarray(np.array([np.repeat(np.exp(-2j * np.pi * model._orb[:, model._per[d]]), model._nspin)
+                                                  for d in range(len(mesh))]))
+        self.row0 = row0
+        self.g_n0 = self.mesh[0] if global_n0 is None else global_n0
+        self.start = None
+
+    def solve(self, start):
+        self.start = np.ascontiguousarray(start, dtype=float)
+        self._lib.check(self.lib.tbk_wfs_solve_grid_async(self.h, self.hm, self._lib.dptr(self.start),
+                                                          self._lib.dptr(self.pbc.view(float)), self.row0, self.g_n0))
+
+    def flux(self, occ32):
+        self._lib.check(self.lib.tbk_berry_flux_async(self.h, self._lib.iptr(occ32), len(occ32), 0, 1, 0))
+
+    def solve_flux(self, start, occ32):
+        """solve_on_grid + berry_flux(occ) in one pass (tbk_wfs_solve_grid_flux_async): the array is written once and never read back"""
+        self.start = np.ascontiguousarray(start, dtype=float)
+        self._lib.check(self.lib.tbk_wfs_solve_grid_flux_async(self.h, self.hm, self._lib.dptr(self.start), self._lib.dptr(self.pbc.view(float)),
+                                                               self.row0, self.g_n0, self._lib.iptr(occ32), len(occ32)))
+
+    def gaps(self):
+        g = np.zeros(max(self.n - 1, 1))
+        self._lib.check(self.lib.tbk_wfs_solve_grid_result(self.h, self._lib.dptr(g)))
+        return g
+
+    def flux_total(self, nslices=1):
+        t = np.zeros(nslices)
+        self._lib.check(self.lib.tbk_berry_flux_result(self.h, self._lib.dptr(t), None))
+        return t
+
+    def free(self):
+        self._lib.check(self.lib.tbk_wfs_free(self.h))
+
+
+def combine_flux_blocks(blocks, ng):
+    """Rank-ordered combination of the blocks [partial flux | min gaps (ng)] every slab contributes: the flux partial sums are
+    added in rank order (a fixed order: the total does not depend on which rank finished first), the gaps min-reduced."""
+    blocks = np.asarray(blocks, dtype=float)
+    total = 0.0
+    for b in blocks:
+        total += b[0]
+    gaps = blocks[:, 1:1 + ng].min(axis=0) if ng else np.zeros(0)
+    return total, gaps
+
+
+def berry_flux_sharded(wf_array_cls, model, mesh, start_k, occ, comm, rank, world, dirs=None, individual_phases=False):
+    """configs[2]: wf_array(model, mesh).solve_on_grid(start_k) + berry_flux(occ, dirs, individual_phases) of a 2-D array
+    (pythtb.py:2421-2532, :3135-3150) in slabs along mesh axis 0 (SURVEY.md 8e's first partitioning): every rank solves its
+    rows plus ONE halo row -- the next slab's first row, or the periodic image on the last rank, recomputed locally and
+    bit-identical because the kernels are deterministic -- takes the flux of its own plaquette rows, and ONE all-gather-v
+    carries [partial flux (or this slab's plaquette phases) | min gaps].  Returns (flux, global min gaps): flux is the
+    float berry_flux returns, or with individual_phases the (N0-1, N1-1) array (transposed for dirs=[1, 0], like the
+    reference's); partial sums are added in rank order."""
+    mesh = [int(x) for x in mesh]
+    if len(mesh) != 2:
+        raise ValueError("berry_flux_sharded drives 2-D arrays")
+    dirs = [0, 1] if dirs is None else [int(d) for d in dirs]
+    if sorted(dirs) != [0, 1]:
+        raise Exception("\n\nDirections must be different and in range!") if len(set(dirs)) < 2 else ValueError("dirs must be [0,1] or [1,0]")
+    plans = plan_slabs(mesh[0], world)
+    row0, nrows, _ = plans[rank]
+    w = wf_array_cls(model, [nrows, mesh[1]])
+    gaps = w.solve_on_grid_window(start_k, [row0, 0], mesh)
+    gaps = np.zeros(0) if gaps is None else np.asarray(gaps, dtype=float)
+    ng = len(gaps)
+    part = w.berry_flux(occ, dirs=dirs, individual_phases=individual_phases)
+    if not individual_phases:
+        blocks = comm.allgatherv(np.concatenate([[float(part)], gaps]), [1 + ng] * world).reshape(world, 1 + ng)
+        return combine_flux_blocks(blocks, ng)
+    ax = dirs.index(0)                                   # where the slab axis sits in the plaquette array
+    mine = np.ascontiguousarray(np.moveaxis(np.asarray(part, dtype=float), ax, 0))      # (own plaquette rows, N1-1)
+    ncol = mesh[1] - 1
+    counts = [(p[1] - 1) * ncol + ng for p in plans]
+    flat = comm.allgatherv(np.concatenate([mine.reshape(-1), gaps]), counts)
+    out, allg, pos, row = np.empty((mesh[0] - 1, ncol)), np.full(ng, np.inf), 0, 0
+    for p, c in zip(plans, counts):
+        nr = p[1] - 1
+        out[row:row + nr] = flat[pos:pos + nr * ncol].reshape(nr, ncol)
+        allg = np.minimum(allg, flat[pos + nr * ncol:pos + c])
+        row += nr
+        pos += c
+    return np.ascontiguousarray(np.moveaxis(out, 0, ax)), allg
 
 
 def solve_all_sharded(model, k_list, comm, rank, world, solve_chunk=None, root=None):

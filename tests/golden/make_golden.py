@@ -7,7 +7,8 @@ Writes small .npz fixtures next to this file.  Nothing of the reference's source
 travels: only model tables (inputs) and the numbers the reference computes from
 them (expected outputs).  `--full` additionally runs the reference at the
 BASELINE.json config sizes C and D (about 20 minutes of CPU) and stores the
-scalars / small arrays in full_size.npz.
+scalars / small arrays in full_size.npz; `--full-E` does the same for configs[4]
+at 16^3 (full_size_E.npz).
 
 Models are built here through the reference's own public API, following the
 example scripts cited next to each builder.
@@ -371,6 +372,22 @@ def full_size():
     save("full_size", **out)
 
 
+def full_size_E():
+    """BASELINE configs[4]'s recipe at the size the survey measured the reference on (cubic16 at 16^3,
+    gap_78 0.345648, berry_phase(range(8), 2) -> (17, 17)); SURVEY.md 8c(7)."""
+    t0 = time.time()
+    m = cubic16()
+    w = ref.wf_array(m, [17, 17, 17])
+    out = {"E_min_gaps": w.solve_on_grid([0.0, 0.0, 0.0])}
+    out["E_phase"] = w.berry_phase(range(8), 2)                       # (17, 17), contin=True (pythtb.py:3002-3025)
+    out["E_phase_dir0_nocontin"] = w.berry_phase(range(8), 0, contin=False)
+    out["E_flux01"] = w.berry_flux(range(8), dirs=[0, 1])             # (17,) (pythtb.py:3178-3186)
+    ev = m.solve_all(m.k_uniform_mesh([16, 16, 16]))
+    out["E_eval_sum"], out["E_eval_min"], out["E_eval_max"] = ev.sum(axis=1), ev.min(axis=1), ev.max(axis=1)
+    print("E", time.time() - t0, out["E_min_gaps"][7])
+    save("full_size_E", **out)
+
+
 def display_reports():
     """Text printed by tb_model.display() for a few models (expected output only)."""
     import json
@@ -426,6 +443,9 @@ if __name__ == "__main__":
     if "--quad4" in sys.argv:
         grid_case("quad4_4354", quad4(), [4, 3, 5, 4], [0.1, -0.2, 0.3, 0.05], [[0], [0, 1]], [],
                   flux_dirs=[[0, 1], [2, 3], [3, 1]])
+        sys.exit(0)
+    if "--full-E" in sys.argv:
+        full_size_E()
         sys.exit(0)
     if "--full" in sys.argv:
         full_size()

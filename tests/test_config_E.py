@@ -1,11 +1,11 @@
 """BASELINE.json configs[4] (synthetic cubic 16-orbital model, 3-D mesh) on the kernel path the 256^3 run takes.
 
-Below ~2000 mesh points the dispatcher hands n = 16 to the workgroup-per-matrix solver; the production run
-uses the wavefront-per-matrix kernel k_solve_wave<1,true,64> with warm-started chains of 16 points along the
-last mesh axis (tbk_solve.hip, launch_wave).  Every mesh here is larger than that threshold and 3-D, so the
-tests below exercise exactly that kernel: against the oracle (pythtb.py:2499-2511 solve loop, :3002-3025 3-D
-Berry strings, :3178-3202 3-D flux slices) at sizes the oracle finishes in seconds, and through
-size-independent properties at the full 257^3 array."""
+Below ~2000 mesh points the dispatcher hands n = 16 to the workgroup-per-matrix solver; the production run uses the fused
+direct solver k_e16<1> (tbk_solve_e16.inl: Householder on DPP, Sturm / Newton eigenvalues, twisted vectors, one kernel), with
+the listed-matrix fallback of launch_tw16 behind it.  Every mesh here is larger than that threshold and 3-D, so the tests
+below exercise exactly that kernel: against the REFERENCE's own numbers at 17^3 (tests/golden/full_size_E.npz),
+against the oracle (pythtb.py:2499-2511 solve loop, :3002-3025 3-D Berry strings, :3178-3202 3-D flux slices) at sizes the
+oracle finishes in seconds, and through size-independent properties at the full 257^3 array."""
 import ctypes as C
 
 import numpy as np
@@ -51,6 +51,28 @@ def solved(request, tb):
     gaps = w.solve_on_grid(start)
     owfs, ogaps = orc.solve_on_grid(m, mesh, start, vectorised=True)
     return dict(tb=tb, m=m, mesh=mesh, start=start, w=w, gaps=gaps, owfs=owfs, ogaps=ogaps, orc=orc)
+
+
+def test_reference_numbers_at_17_cubed(tb):
+    """The one configs[4] run the reference itself produced (make_golden.py --full-E):
+    cubic16 wf_array([17,17,17]).solve_on_grid([0,0,0]) min gaps (gap_78 0.345648), berry_phase(range(8), 2) -> (17,17),
+    berry_phase(range(8), 0, contin=False), berry_flux(range(8), dirs=[0,1]) -> (17,), and eigenvalue checksums on 16^3."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "full_size_E.npz"))
+    m = hp.cubic16(tb.tb_model)
+    w = tb.wf_array(m, [17, 17, 17])
+    gaps = w.solve_on_grid([0.0, 0.0, 0.0])
+    assert gaps.shape == (15,) and np.max(np.abs(gaps - g["E_min_gaps"])) < 1e-11
+    assert abs(gaps[7] - 0.345648) < 1e-6
+    ph = w.berry_phase(range(8), 2)
+    assert ph.shape == (17, 17) and np.max(np.abs(ph - g["E_phase"])) < TOL_P          # contin=True: no 2 pi freedom left
+    ph0 = w.berry_phase(range(8), 0, contin=False)
+    assert np.max(np.abs(wrap(ph0 - g["E_phase_dir0_nocontin"]))) < TOL_P
+    fl = w.berry_flux(range(8), dirs=[0, 1])
+    assert fl.shape == (17,) and np.max(np.abs(fl - g["E_flux01"])) < 1e-9
+    ev = m.solve_all(m.k_uniform_mesh([16, 16, 16]))
+    assert np.max(np.abs(ev.sum(axis=1) - g["E_eval_sum"])) < 1e-9
+    assert np.max(np.abs(ev.min(axis=1) - g["E_eval_min"])) < 1e-12 and np.max(np.abs(ev.max(axis=1) - g["E_eval_max"])) < 1e-12
 
 
 def test_min_gaps_and_eigenvectors(solved):

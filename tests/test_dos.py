@@ -89,7 +89,9 @@ def test_solve_all_mesh_equals_solve_all_of_host_mesh(tb, builder, mesh):
     assert ev.shape == ev_list.shape and vec.shape == vec_list.shape
     assert np.array_equal(ev, ev_list)          # same kernel, same k bits -> same bits
     assert np.array_equal(vec, vec_list)
-    assert np.array_equal(m.solve_all_mesh(mesh), m.solve_all(k))
+    # eigenvalues alone of up to 4 states: the row kernel k_mesh_evals (separable phases, no list) -- equal to rounding
+    evm = m.solve_all_mesh(mesh)
+    assert np.max(np.abs(evm - ev_list)) < 1e-13 and (m._nsta <= 4 or np.array_equal(evm, ev_list))
     ref = orc.solve_all(orc.Model.from_tables(orc.model_tables(m)), k)
     assert np.max(np.abs(ev - ref)) < 1e-12 * max(1.0, np.abs(ref).max())
 

@@ -479,6 +479,15 @@ def test_config_B_haldane_1024_eigenvalues(tb):
     assert np.max(np.abs(ev[:, sel] - orc.solve_all_vec(m, k[sel]))) < TOL_E
     ev2, vec = m.solve_all(k[:65536], eig_vectors=True)
     assert np.max(np.abs(np.einsum("bko,bko->bk", vec.conj(), vec).real - 1.0)) < 1e-13
+    # the REFERENCE's own numbers for this recipe on the 256^2 sub-mesh (make_golden.py --full: per-band sum / min / max);
+    # every 4th point of the 1024^2 mesh per axis IS that sub-mesh (i/256 = 4i/1024 exactly)
+    g = load_golden("full_size")
+    sub = ev.reshape(2, 1024, 1024)[:, ::4, ::4].reshape(2, -1)
+    assert np.max(np.abs(sub.sum(axis=1) - g["B256_sum"])) < 1e-9
+    assert np.max(np.abs(sub.min(axis=1) - g["B256_min"])) < 1e-12 and np.max(np.abs(sub.max(axis=1) - g["B256_max"])) < 1e-12
+    ev256 = m.solve_all(m.k_uniform_mesh([256, 256]))
+    assert np.max(np.abs(ev256.sum(axis=1) - g["B256_sum"])) < 1e-9
+    assert np.max(np.abs(ev256.min(axis=1) - g["B256_min"])) < 1e-12 and np.max(np.abs(ev256.max(axis=1) - g["B256_max"])) < 1e-12
 
 
 def test_config_C_haldane_2048_chern(tb):

@@ -408,3 +408,53 @@ def test_small_calls_polled_completion_equals_stream_synchronisation(tb):
                 ref = flat
             else:
                 assert len(flat) == len(ref) and all(np.array_equal(a, b) for a, b in zip(flat, ref))
+
+
+def test_berry_flux_sharded_slabs_equal_the_unsharded_flux(tb):
+    """configs[2]'s partitioning (pythtb.py:2475-2497 / :3135-3150) through the library driver
+    multi.berry_flux_sharded: a 1-rank RCCL communicator end to end, and worlds 3 and 8 with the ranks run one after another
+    on this GPU -- every slab recomputes its halo row (the same bits: plaquette phases equal the unsharded array's bit for
+    bit), partial sums add up to the unsharded flux, min gaps min-reduce, one collective per rank."""
+    import ctypes as C
+    from pythtb_amd import _lib, multi
+    lib, ctx = _lib.lib, _lib.default_context()
+    hal = hp.haldane(tb.tb_model, 0.0)
+    mesh, start = [203, 131], [-0.5, -0.5]
+    full = tb.wf_array(hal, mesh)
+    g = full.solve_on_grid(start)
+    ref_plaq = full.berry_flux([0], individual_phases=True)
+    ref_t = full.berry_flux([0], dirs=[1, 0], individual_phases=True)
+    ref_tot = full.berry_flux([0])
+    assert abs(ref_tot / (2 * np.pi) + 1.0) < 1e-10
+    uid = (C.c_ubyte * 128)()
+    _lib.check(lib.tbk_comm_unique_id(uid))
+    rccl = multi.RcclComm(ctx, bytes(uid), 1, 0)
+    try:
+        tot, gaps = multi.berry_flux_sharded(tb.wf_array, hal, mesh, start, [0], rccl, 0, 1)
+        assert tot == ref_tot and np.array_equal(gaps, g)
+        plq, gaps = multi.berry_flux_sharded(tb.wf_array, hal, mesh, start, [0], rccl, 0, 1, individual_phases=True)
+        assert np.array_equal(plq, ref_plaq) and np.array_equal(gaps, g)
+    finally:
+        rccl.close()
+
+    class Recorder(object):
+        def __init__(self):
+            self.parts = []
+        def allgatherv(self, mine, counts):
+            self.parts.append(np.array(mine, dtype=float).reshape(-1))
+            assert self.parts[-1].size == counts[len(self.parts) - 1]
+            return np.zeros(int(sum(counts)))
+    for world in (3, 8):
+        plans = multi.plan_slabs(mesh[0], world)
+        rec = Recorder()
+        for r in range(world):
+            multi.berry_flux_sharded(tb.wf_array, hal, mesh, start, [0], rec, r, world)
+        assert len(rec.parts) == world
+        tot, gaps = multi.combine_flux_blocks(np.array(rec.parts), 1)
+        assert abs(tot - ref_tot) < 1e-11 and np.array_equal(gaps, g)
+        for dirs, ref in (([0, 1], ref_plaq), ([1, 0], ref_t)):
+            rec = Recorder()
+            for r in range(world):
+                multi.berry_flux_sharded(tb.wf_array, hal, mesh, start, [0], rec, r, world, dirs=dirs, individual_phases=True)
+            rows = np.concatenate([rec.parts[r][:-1].reshape(plans[r][1] - 1, mesh[1] - 1) for r in range(world)])
+            assert np.array_equal(rows if dirs == [0, 1] else rows.T, ref)

@@ -177,6 +177,8 @@ class OracleWf(object):
         return np.diff(np.array(ev), axis=1).min(axis=0)
     def berry_phase(self, occ, dir, contin=True, berry_evals=False):
         return orc.berry_phase(self.wfs, len(self.mesh), list(occ), dir, contin=contin, berry_evals=berry_evals)
+    def berry_flux(self, occ, dirs=None, individual_phases=False):
+        return orc.berry_flux(self.wfs, len(self.mesh), list(occ), dirs=dirs, individual_phases=individual_phases, vectorised=True)
 
 
 class Counting(multi.GlooComm):
@@ -246,6 +248,22 @@ assert Counting.calls == 1, Counting.calls                    # phases and min g
 full3, gaps3 = orc.solve_on_grid(m3, mesh3, start3, vectorised=True)
 assert ph.shape == (mesh3[0], 4) and np.array_equal(ph, orc.berry_phase(full3, 3, [0, 1], 2, contin=False))
 assert np.max(np.abs(gaps - gaps3)) < 1e-12
+# configs[2] in small: Haldane, slabs along axis 0 with the halo row recomputed, ONE gather of [partial flux | min gaps]
+hal0 = hp.haldane(tb.tb_model, 0.0)
+mesh2, start2 = [max(12, world + 3), 9], [-0.5, -0.5]        # 11 plaquette rows over 2 / 3 ranks: uneven
+fullw, fgaps = orc.solve_on_grid(hal0, mesh2, start2, vectorised=True)
+for occ2 in ([0], [0, 1]):
+    Counting.calls = 0
+    tot, g2 = multi.berry_flux_sharded(OracleWf, hal0, mesh2, start2, occ2, comm, rank, world)
+    assert Counting.calls == 1, Counting.calls
+    ref_plaq = orc.berry_flux(fullw, 2, occ2, individual_phases=True, vectorised=True)
+    assert abs(tot - ref_plaq.sum()) < 1e-11 and np.max(np.abs(g2 - fgaps)) < 1e-12
+    plq, g2b = multi.berry_flux_sharded(OracleWf, hal0, mesh2, start2, occ2, comm, rank, world, individual_phases=True)
+    assert plq.shape == ref_plaq.shape and np.max(np.abs(plq - ref_plaq)) < 1e-11 and np.array_equal(g2b, g2)
+    plt, _ = multi.berry_flux_sharded(OracleWf, hal0, mesh2, start2, occ2, comm, rank, world, dirs=[1, 0], individual_phases=True)
+    ref_t = orc.berry_flux(fullw, 2, occ2, dirs=[1, 0], individual_phases=True, vectorised=True)
+    assert plt.shape == ref_t.shape == (mesh2[1] - 1, mesh2[0] - 1) and np.max(np.abs(plt - ref_t)) < 1e-11
+assert abs(multi.berry_flux_sharded(OracleWf, hal0, mesh2, start2, [0], comm, rank, world)[0] / (2 * np.pi) + 1.0) < 1e-10   # Chern -1
 if rank == 0:
     print("MULTI_DRIVERS_OK", world, counts)
 dist.barrier()

@@ -238,10 +238,13 @@ def test_twins_are_repaired_in_the_kernel_not_listed(tb):
     w.solve_on_grid([0.0, 0.0])
     ctx.prof_enable(1)
     ctx.prof_reset()
+    ctx.solver_stats(reset=True)
     gaps = w.solve_on_grid([0.0, 0.0])
     rep = ctx.prof_report()
     ctx.prof_enable(0)
-    assert "e16" in rep and rep.get("tw16_fallback", {"total_ms": 0.0})["total_ms"] < 1.5 * rep["e16"]["total_ms"], rep   # (0.5 x measured, 2.6 x before the repair; the fallback kernels cost 0.15 ms even for a handful of matrices)
+    listed = ctx.solver_stats()["listed_matrices"]
+    # a count, not a time (tbk_ctx_solver_stats): before the repair all 256^2 matrices of this mesh were listed
+    assert "e16" in rep and listed <= 256 * 256 // 100, (listed, rep)
     assert np.max(gaps[0::2]) < 1e-13
     V = w.to_host().reshape(-1, 16, 16)[::97]
     assert max(np.max(np.abs(v.conj() @ v.T - np.identity(16))) for v in V) < 1e-13
