@@ -161,46 +161,43 @@ __device__ __forceinline__ bool jacobi_small(SmallMat<N>& M) {
 // about two shifts of at most N - 1 plane rotations per eigenvalue.
 // Every thread runs the same full-range sweep i = N-2 .. 0; a position takes part only inside the thread's
 // active block [l, m) (EXEC-masked), so register indices stay static while l and m are data.
-template <int N, bool VEC>
-__device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
-    static_assert(N == 3 || N == 4, "ql_small: n = 3, 4");
-    cd a[N][N];
-#pragma unroll
-    for (int r = 0; r < N; ++r) {
-        a[r][r] = cd{M.dg[r], 0.0};
-#pragma unroll
-        for (int c = r + 1; c < N; ++c) {
-            a[r][c] = M.up[r][c];
-            a[c][r] = cconj(M.up[r][c]);
-        }
-    }
-    double d[N], e[N];
-    cd delta{1.0, 0.0};                        // D_{K+1} = D_K t_K / |t_K| makes the subdiagonal real
-    // With eigenvectors nothing is accumulated on the way: the reflectors (u_K, beta_K) and the diagonal unitary D are kept, the
-    // QL rotations -- real -- act on a REAL N x N matrix Q (half the arithmetic of rotating complex rows, half the registers of
-    // Z), and the eigenvectors are H_0 .. H_{N-3} D Q at the end, like the larger direct solvers do it.  (Before: Z complex,
-    // updated by every reflection and every rotation -- 210 VGPRs and two wavefronts per SIMD for k_grid_rows<4,1>.)
-    cd us[N > 2 ? N - 2 : 1][N];
-    double betas[N > 2 ? N - 2 : 1];
+// The solver in FACTORED form: eigenvalues d, the REAL eigenvector matrix Q of the tridiagonal T, and what turns a column of Q
+// into an eigenvector of the Hermitian input -- the diagonal unitary D (dph) that made T's couplings real and the N - 2
+// normalised reflectors (us).  Column b of Z = H_0 .. H_{N-3} D Q is formed on demand (small_vector): the mesh kernels sort
+// (d, Q) -- half the selects of sorting complex columns -- and then produce, stage and store ONE band at a time, so the N x N
+// complex eigenvector matrix (64 VGPRs at N = 4) never exists in registers.
+template <int N>
+struct SmallFact {
+    double d[N];
+    double Q[N][N];                             // Q[r][b]: component r of eigenvector b of T
+    cd us[N > 2 ? N - 2 : 1][N];                // reflector K, normalised (H_K = 1 - w w^+): entries r > K (the others are never
+                                                // read); all zero = no reflection
     cd dph[N];
-    dph[0] = cd{1.0, 0.0};
-#pragma unroll
-    for (int K = 0; K + 2 < N; ++K) {
-        betas[K] = 0.0;
-#pragma unroll
-        for (int r = 0; r < N; ++r) us[K][r] = cd{0.0, 0.0};
-    }
+};
+
+// Householder tridiagonalisation on the UPPER triangle (real diagonal dg, up[r][c] for r < c: the rank-2 update touches
+// N (N + 1) / 2 entries instead of N^2 and nothing below the diagonal is kept -- 64 -> 28 registers at N = 4), then implicit
+// QL with Wilkinson shifts on (d, e), the rotations accumulated in the real Q (VEC).
+template <int N, bool VEC>
+__device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], SmallFact<N>& F, double (&e)[N]) {
+    static_assert(N == 3 || N == 4, "ql_small: n = 3, 4");
+    double (&d)[N] = F.d;
+    cd delta{1.0, 0.0};                        // D_{K+1} = D_K t_K / |t_K| makes the subdiagonal real
+    F.dph[0] = cd{1.0, 0.0};
 #pragma unroll
     for (int K = 0; K + 1 < N; ++K) {
-        cd tK = a[K + 1][K];
+        cd tK = cconj(up[K][K + 1]);           // a_{K+1,K}
         if (K + 2 < N) {                       // a reflection annihilates rows K+2.. of column K
             // (the decision is taken on the part to be annihilated ALONE, like LAPACK's zlarfg: compared through the sum
             // with |a_{K+1,K}|^2, entries below ~1e-8 of it would be dropped -- an eigenvalue error of up to their size)
             double rest = 0.0;
 #pragma unroll
-            for (int r = K + 2; r < N; ++r) rest += cabs2(a[r][K]);
+            for (int r = K + 2; r < N; ++r) rest += cabs2(up[K][r]);
             const double absa2 = cabs2(tK);
             const double sigma = rest + absa2;
+            cd u[N];
+#pragma unroll
+            for (int r = 0; r < N; ++r) u[r] = cd{0.0, 0.0};
             if (rest > 0.0) {
                 const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
                 double absa = 0.0;
@@ -210,41 +207,49 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
                     absa = absa2 * inv_a;
                     ph = cd{tK.x * inv_a, tK.y * inv_a};
                 }
-                cd u[N];
 #pragma unroll
-                for (int r = 0; r < N; ++r) u[r] = r > K + 1 ? a[r][K] : cd{0.0, 0.0};
-                u[K + 1] = cd{ph.x * (absa + nrm), ph.y * (absa + nrm)};
-                const double beta = 1.0 / (nrm * (nrm + absa));          // 2 / (u^+ u)
+                for (int r = K + 2; r < N; ++r) u[r] = cconj(up[K][r]);
+                // the reflector is kept NORMALISED, w = u sqrt(beta) with beta = 2 / (u^+ u) = 1 / (nrm (nrm + |a|)), so that
+                // H = 1 - w w^+: no beta to carry (or to divide for), here or in the back-transformation
+                const double sb = rsqrt_full(nrm * (nrm + absa));
+#pragma unroll
+                for (int r = K + 2; r < N; ++r) u[r] = cd{u[r].x * sb, u[r].y * sb};
+                const double u1 = (absa + nrm) * sb;
+                u[K + 1] = cd{ph.x * u1, ph.y * u1};
                 tK = cd{-ph.x * nrm, -ph.y * nrm};
                 cd p[N];
                 double upr = 0.0;
 #pragma unroll
-                for (int r = K + 1; r < N; ++r) {
-                    cd acc{0.0, 0.0};
+                for (int r = K + 1; r < N; ++r) {           // p = A w on the trailing block, A read through the upper triangle
+                    cd acc{dg[r] * u[r].x, dg[r] * u[r].y};
 #pragma unroll
-                    for (int c = K + 1; c < N; ++c) cfma(acc, a[r][c], u[c]);
-                    p[r] = cd{acc.x * beta, acc.y * beta};
+                    for (int c = K + 1; c < N; ++c) {
+                        if (c > r) cfma(acc, up[r][c], u[c]);
+                        else if (c < r) cfmac(acc, up[c][r], u[c]);
+                    }
+                    p[r] = acc;
                     upr += u[r].x * p[r].x + u[r].y * p[r].y;
                 }
-                const double kappa = 0.5 * beta * upr;
+                const double kappa = 0.5 * upr;
                 cd q[N];
 #pragma unroll
                 for (int r = K + 1; r < N; ++r) q[r] = cd{p[r].x - kappa * u[r].x, p[r].y - kappa * u[r].y};
 #pragma unroll
-                for (int r = K + 1; r < N; ++r)
+                for (int r = K + 1; r < N; ++r) {           // A -= u q^+ + q u^+
+                    dg[r] -= 2.0 * (u[r].x * q[r].x + u[r].y * q[r].y);
 #pragma unroll
-                    for (int c = K + 1; c < N; ++c) {   // A -= u q^+ + q u^+
-                        a[r][c].x -= (u[r].x * q[c].x + u[r].y * q[c].y) + (q[r].x * u[c].x + q[r].y * u[c].y);
-                        a[r][c].y -= (u[r].y * q[c].x - u[r].x * q[c].y) + (q[r].y * u[c].x - q[r].x * u[c].y);
+                    for (int c = r + 1; c < N; ++c) {
+                        up[r][c].x -= (u[r].x * q[c].x + u[r].y * q[c].y) + (q[r].x * u[c].x + q[r].y * u[c].y);
+                        up[r][c].y -= (u[r].y * q[c].x - u[r].x * q[c].y) + (q[r].y * u[c].x - q[r].x * u[c].y);
                     }
-                if (VEC) {
-                    betas[K] = beta;
-#pragma unroll
-                    for (int r = 0; r < N; ++r) us[K][r] = u[r];
                 }
             }
+            if (VEC) {
+#pragma unroll
+                for (int r = 0; r < N; ++r) F.us[K][r] = u[r];
+            }
         }
-        d[K] = a[K][K].x;
+        d[K] = dg[K];
         const double t2 = cabs2(tK);
         double mag = 0.0;
         if (t2 > 0.0) {
@@ -253,18 +258,31 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
             delta = cmul(delta, cd{tK.x * inv, tK.y * inv});
         }
         e[K] = mag;
-        dph[K + 1] = delta;
+        F.dph[K + 1] = delta;
     }
-    d[N - 1] = a[N - 1][N - 1].x;
+    d[N - 1] = dg[N - 1];
     e[N - 1] = 0.0;
-    double Q[N][N];
-#pragma unroll
-    for (int r = 0; r < N; ++r)
-#pragma unroll
-        for (int c = 0; c < N; ++c) Q[r][c] = r == c ? 1.0 : 0.0;
+}
 
+// implicit QL on (F.d, e), rotations accumulated in F.Q (VEC).  Returns false when the iteration ran into LAPACK's limit.
+template <int N, bool VEC>
+__device__ __forceinline__ bool ql_iterate_small(SmallFact<N>& F, double (&e)[N]) {
+    double (&d)[N] = F.d;
+    double (&Q)[N][N] = F.Q;
+    if (VEC) {
+#pragma unroll
+        for (int r = 0; r < N; ++r)
+#pragma unroll
+            for (int c = 0; c < N; ++c) Q[r][c] = r == c ? 1.0 : 0.0;
+    }
+
+    // The loop leaves on a WAVE-UNIFORM condition (no lane has an unreduced block left): a lane that is done idles behind its
+    // EXEC bit.  With a per-lane `break` the compiler keeps a second copy of every value that is live after a divergent loop --
+    // d, e and Q once as the running values and once as "the values of the lanes that have left": 48 more registers at N = 4,
+    // the difference between two and four wavefronts per SIMD for the mesh kernels.
     int l = 0;
     int iter = 0;
+    bool work = true;
     for (; iter < 30 * N; ++iter) {
         // first coupling at or after l that is not negligible, then the end m of its block
         bool negl[N];
@@ -274,7 +292,9 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
         int lo = N - 1;
 #pragma unroll
         for (int j = N - 2; j >= 0; --j) lo = (j >= l && !negl[j]) ? j : lo;
-        if (lo == N - 1) break;
+        work = lo != N - 1;
+        if (__builtin_amdgcn_ballot_w64(work) == 0) break;
+        if (work) {
         l = lo;
         int m = N - 1;
 #pragma unroll
@@ -291,15 +311,17 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
         // Wilkinson shift = the eigenvalue of the block's leading 2 x 2 nearer to d_l, to full precision: for a block of
         // two it is exact and the block deflates in ONE sweep (with hardware-estimate reciprocals, 5e-8, it took two:
         // 8.1 instead of 7.1 sweeps per Kane-Mele matrix)
+        // With delta = (d_{l+1} - d_l) / 2 and h = sqrt(delta^2 + e_l^2) the shift is d_l - e_l^2 / (delta + sgn(delta) h): tql2's
+        // g = delta / e_l, e_l / (g + sgn(g) sqrt(g^2 + 1)) multiplied through by e_l -- one reciprocal instead of two.
         auto recip = [](const double x) {
             double y = __builtin_amdgcn_rcp(x);
             y = y * fma(-x, y, 2.0);
             return y * fma(-x, y, 2.0);
         };
-        double g = (dl1 - dl) * (0.5 * recip(el));
-        const double t1 = fma(g, g, 1.0);
-        const double rr = t1 * rsqrt_full(t1);
-        g = dm - dl + el * recip(g + copysign(rr, g));
+        const double dlt = 0.5 * (dl1 - dl), el2 = el * el;
+        const double t1 = fma(dlt, dlt, el2);
+        const double hh = t1 * rsqrt_full(t1);
+        double g = dm - dl + el2 * recip(dlt + copysign(hh, dlt));
         double sn = 1.0, cs = 1.0, pp = 0.0;
         bool alive = true;
 #pragma unroll
@@ -339,34 +361,97 @@ __device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
             }
             if (j == m) e[j] = 0.0;
         }
-    }
-#pragma unroll
-    for (int j = 0; j < N; ++j) M.dg[j] = d[j];
-    if (VEC) {
-#pragma unroll
-        for (int b = 0; b < N; ++b) {          // column b of Z = H_0 .. H_{N-3} D Q
-            cd z[N];
-#pragma unroll
-            for (int r = 0; r < N; ++r) z[r] = cd{dph[r].x * Q[r][b], dph[r].y * Q[r][b]};
-#pragma unroll
-            for (int K = N - 3; K >= 0; --K) {
-                if (betas[K] != 0.0) {
-                    cd w{0.0, 0.0};
-#pragma unroll
-                    for (int r = K + 1; r < N; ++r) cfmac(w, us[K][r], z[r]);      // u^+ z
-                    w = cd{w.x * betas[K], w.y * betas[K]};
-#pragma unroll
-                    for (int r = K + 1; r < N; ++r) {
-                        z[r].x -= us[K][r].x * w.x - us[K][r].y * w.y;
-                        z[r].y -= us[K][r].x * w.y + us[K][r].y * w.x;
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < N; ++r) M.v[r][b] = z[r];
         }
     }
-    return iter < 30 * N;      // (LAPACK's limit: 30 shifts per eigenvalue)
+    return !work;              // (false: LAPACK's limit of 30 shifts per eigenvalue ran out with a block still unreduced)
+}
+
+template <int N, bool VEC>
+__device__ __forceinline__ bool ql_small_core(double (&dg)[N], cd (&up)[N][N], SmallFact<N>& F) {
+    double e[N];
+    tridiag_small<N, VEC>(dg, up, F, e);
+    return ql_iterate_small<N, VEC>(F, e);
+}
+
+// staging slots (16 B) per wavefront of the mesh-row kernels: 64 N for a band's transposition; at N = 4 five more rows of 64
+// hold, per lane, the first reflector (3 complex numbers) and the running minima of the three gaps: 9.7 KB of LDS per
+// wavefront with the coefficient cells, which still lets 16 wavefronts share a compute unit's 160 KB
+__host__ __device__ constexpr int rows_stage_slots(const int n) { return 64 * (n == 4 ? 9 : n); }
+
+// column B of Z = H_0 .. H_{N-3} D Q: the eigenvector of the Hermitian input that belongs to d[B]
+template <int I, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+template <int N, int B>
+__device__ __forceinline__ void small_vector(const SmallFact<N>& F, cd (&z)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) z[r] = cd{F.dph[r].x * F.Q[r][B], F.dph[r].y * F.Q[r][B]};
+#pragma unroll
+    for (int K = N - 3; K >= 0; --K) {
+        // (no test for "no reflection": then w = 0 and the update below is the identity)
+        cd w{0.0, 0.0};
+#pragma unroll
+        for (int r = K + 1; r < N; ++r) cfmac(w, F.us[K][r], z[r]);      // w^+ z
+#pragma unroll
+        for (int r = K + 1; r < N; ++r) {
+            z[r].x -= F.us[K][r].x * w.x - F.us[K][r].y * w.y;
+            z[r].y -= F.us[K][r].x * w.y + F.us[K][r].y * w.x;
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void small_vectors_all(const SmallFact<N>& F, SmallMat<N>& M) {
+    static_for<0, N>([&](auto bt) __attribute__((always_inline)) {
+        constexpr int b = decltype(bt)::value;
+        cd z[N];
+        small_vector<N, b>(F, z);
+#pragma unroll
+        for (int r = 0; r < N; ++r) M.v[r][b] = z[r];
+    });
+}
+
+template <int N, bool VEC>
+__device__ __forceinline__ bool ql_small(SmallMat<N>& M) {
+    SmallFact<N> F;
+    const bool ok = ql_small_core<N, VEC>(M.dg, M.up, F);
+#pragma unroll
+    for (int j = 0; j < N; ++j) M.dg[j] = F.d[j];
+    if (VEC) small_vectors_all<N>(F, M);
+    return ok;
+}
+
+// ascending order of (d, Q columns) by the same networks as sort_small below -- on REAL columns
+template <int N, int I, int J>
+__device__ __forceinline__ void cmpxchg_fact(SmallFact<N>& F) {
+    const bool sw = F.d[I] > F.d[J];
+    const double lo = sw ? F.d[J] : F.d[I], hi = sw ? F.d[I] : F.d[J];
+    F.d[I] = lo;
+    F.d[J] = hi;
+#pragma unroll
+    for (int o = 0; o < N; ++o) {
+        const double a = F.Q[o][I], b = F.Q[o][J];
+        F.Q[o][I] = sw ? b : a;
+        F.Q[o][J] = sw ? a : b;
+    }
+}
+template <int N>
+__device__ __forceinline__ void sort_fact(SmallFact<N>& F) {
+    if constexpr (N == 3) {
+        cmpxchg_fact<N, 0, 1>(F);
+        cmpxchg_fact<N, 1, 2>(F);
+        cmpxchg_fact<N, 0, 1>(F);
+    } else if constexpr (N == 4) {
+        cmpxchg_fact<N, 0, 1>(F);
+        cmpxchg_fact<N, 2, 3>(F);
+        cmpxchg_fact<N, 0, 2>(F);
+        cmpxchg_fact<N, 1, 3>(F);
+        cmpxchg_fact<N, 1, 2>(F);
+    }
 }
 
 // n = 3, 4 on meshes: bring the eigenpairs into ascending order in place with a sorting network (3 / 5 compare-exchanges
@@ -724,6 +809,62 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
     }
 }
 
+// ---- n = 3, 4 on mesh rows: S(k) from the row's coefficient cells, every product spelled out in fused operations --
+// k_grid_rows and k_grid_rows_flux must assemble the same bits (their minimal gaps are compared bit for bit), and the
+// periodic images rely on equal table entries giving equal matrices, hence equal eigenvectors.  (Folding the orbital phases
+// into the matrix -- H(k) = F S F^+ as the reference builds it -- would save the N^2 products on the way out, but the image
+// of a point would then be solved from a DIFFERENT matrix and come out in another gauge: a closed string's Berry phase
+// would pick up the difference.)
+__device__ __forceinline__ void cfma_x(cd& acc, const cd a, const cd b) {          // acc += a b
+    acc.x = fma(-a.y, b.y, fma(a.x, b.x, acc.x));
+    acc.y = fma(a.y, b.x, fma(a.x, b.y, acc.y));
+}
+__device__ __forceinline__ void cfmac_x(cd& acc, const cd a, const cd b) {         // acc += a conj(b)
+    acc.x = fma(a.y, b.y, fma(a.x, b.x, acc.x));
+    acc.y = fma(a.y, b.x, fma(-a.x, b.y, acc.y));
+}
+__device__ __forceinline__ cd cmulc_x(const cd a, const cd b) {                    // a conj(b)
+    return cd{fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y))};
+}
+template <int N, int PM>
+__device__ __forceinline__ void rows_assemble(const cd* __restrict__ C, const int npow, const int pmax, const cd zl,
+                                              double (&dg)[N], cd (&up)[N][N]) {
+    int slot = 0;
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
+#pragma unroll
+        for (int b = a; b < N; ++b, ++slot) {
+            const cd* Cs = C + slot * npow + pmax;
+            cd acc = Cs[0];
+            cd zp = zl;
+            if constexpr (PM >= 0) {
+#pragma unroll
+                for (int p = 1; p <= PM; ++p) {
+                    cfma_x(acc, Cs[p], zp);
+                    cfmac_x(acc, Cs[-p], zp);
+                    if (p < PM) zp = cmul_x(zp, zl);
+                }
+            } else {
+                for (int p = 1; p <= pmax; ++p) {
+                    cfma_x(acc, Cs[p], zp);
+                    cfmac_x(acc, Cs[-p], zp);
+                    zp = cmul_x(zp, zl);
+                }
+            }
+            if (b == a) dg[a] = acc.x;
+            else up[a][b] = acc;
+            // (left alone the scheduler hoists all N (N + 1) / 2 (2 PM + 1) broadcast reads of the cells to the top -- 120 registers
+            // of coefficients in flight at N = 4, the peak of the whole kernel; two slots' worth at a time is plenty of cover)
+            if ((slot & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+// a wave-uniform value the compiler cannot see to be uniform (it depends on threadIdx.x >> 6): into scalar registers
+__device__ __forceinline__ double uniform_d(const double v) {
+    const I2 i = __builtin_bit_cast(I2, v);
+    return __builtin_bit_cast(double, I2{__builtin_amdgcn_readfirstlane(i.lo), __builtin_amdgcn_readfirstlane(i.hi)});
+}
+
 // ---- regular mesh, polynomial form.  On a mesh row the leading-axis phases are
 // fixed, so S_ab(k) = sum_p C_ab,p z_last^p with row coefficients
 //   C_ab,p = sum_{t in cell(ab,p)} amp_t prod_{d<last} z_d^{R_d}
@@ -731,16 +872,21 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
 // the row's coefficient cells once (in parallel, one cell per lane) into LDS and
 // every point then costs (2 pmax + 1) complex FMAs per slot read as LDS broadcasts
 // -- no per-point table walk, no scalar-load latency chain, no sincospi.
+#ifndef TBK_ROWS_OCC
+#define TBK_ROWS_OCC
+#endif
 template <int N, int PM>
-__global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const GridArgs G) {
+__global__ __launch_bounds__(256) TBK_ROWS_OCC void k_grid_rows(const ModelView mv, const GridArgs G) {
     extern __shared__ __align__(16) unsigned char lds_rows[];
     constexpr int NSLOT = N * (N + 1) / 2;
-    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wavefront's number in scalar registers: the tile, its row, chunk range, LDS regions and output base are then scalar too)
+    const int wib = N > 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int pmax = PM >= 0 ? PM : mv.pmax;      // PM: compile-time range of the last lattice component
     const int npow = 2 * pmax + 1;
     const int ncell = NSLOT * npow;
     cd* C = reinterpret_cast<cd*>(lds_rows) + wib * ncell;
-    cd* stage = reinterpret_cast<cd*>(lds_rows) + 4 * ncell + wib * (64 * N);
+    cd* stage = reinterpret_cast<cd*>(lds_rows) + 4 * ncell + wib * rows_stage_slots(N);
     const int64_t tile = (int64_t)blockIdx.x * 4 + wib;
     const bool live = tile < G.ntiles;
     const int last = G.last;
@@ -757,6 +903,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     for (int o = 0; o < N; ++o) frow[o] = cd{1.0, 0.0};
     if (live) {
         row = (unsigned)(tile / G.tpr);
+        if constexpr (N > 2) row = (unsigned)__builtin_amdgcn_readfirstlane((int)row);   // (the division runs on the vector unit)
         const int ts = (int)(tile - (int64_t)row * G.tpr);
         jc0 = ts * G.seg;
         jc1 = min(jc0 + G.seg, G.cpr);
@@ -787,6 +934,20 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     }
     __syncthreads();
     if (!live) return;
+    cd ips[N];
+#pragma unroll
+    for (int o = 0; o < N; ++o) ips[o] = cd{1.0, 0.0};
+    if constexpr (N > 2) {             // (the row's phases are the same on every lane: 4 N scalar registers instead of vector ones)
+#pragma unroll
+        for (int o = 0; o < N; ++o) frow[o] = cd{uniform_d(frow[o].x), uniform_d(frow[o].y)};
+        if (G.img_last && jc0 == 0) {
+#pragma unroll
+            for (int o = 0; o < N; ++o) {
+                const cd t = cmulc_x(G.tf[last][(int64_t)(nlast - 1) * N + o], G.tf[last][(int64_t)o]);
+                ips[o] = cd{uniform_d(t.x), uniform_d(t.y)};
+            }
+        }
+    }
     if (TBK_ABLATE(G.ablate) == 4) {   // diagnostics: tile set-up only
         if (C[0].x == 1.2345e300) G.wv.data[0] = C[1];
         return;
@@ -800,6 +961,11 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
     // for N = 4: 3.5 conflict cycles per LDS instruction measured, profiles/r01g).  XOR-ing bits 0-1 of the slot with
     // bits 3-4 spreads every 8-lane group over all 32 banks and only permutes slots inside aligned groups of four, so
     // the contiguous reads stay conflict-free.
+    if constexpr (N == 4) {
+        const double inf = __longlong_as_double(0x7ff0000000000000ll);
+        stage[7 * 64 + lane] = cd{inf, inf};
+        stage[8 * 64 + lane] = cd{inf, inf};
+    }
     auto slot = [](const int s) { return (N & 1) ? s : (s ^ ((s >> 3) & 3)); };
     int wslot[N], rslot[N];
 #pragma unroll
@@ -815,7 +981,7 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
         const int j0 = min(jc0 * 64 + lane, ncol - 1);
         zl_next = G.tz[last][j0];
 #pragma unroll
-        for (int o = 0; o < N; ++o) tf_next[o] = G.tf[last][(int64_t)j0 * N + o];
+        for (int o = 0; o < N; ++o) tf_next[o] = N > 2 ? cd{0.0, 0.0} : G.tf[last][(int64_t)j0 * N + o];   // (n > 2: fetched after the solve)
         // consume them here: loads still pending at the loop entry would be merged into the loop-head
         // state of the waitcnt pass and cost a vmcnt(0) on every iteration
         asm volatile("" ::"v"(zl_next.x), "v"(zl_next.y));
@@ -925,19 +1091,195 @@ __global__ __launch_bounds__(256) void k_grid_rows(const ModelView mv, const Gri
             }
         }
     };
+    // ---- n = 3, 4: the same chunk around the FACTORED solver (ql_small_core): (d, Q) sorted, then one band at a time formed,
+    // given its orbital phases, staged and stored.  Nothing but the factors is live across the QL iteration: the row's phases sit
+    // in scalar registers and the column's table entries are fetched after the solve (the previous chunk's stores were issued
+    // a whole eigen-solve ago, so waiting for a load behind them costs nothing by then); only z_last(j), which the assembly
+    // needs first thing, keeps the prefetch described above.
+    auto chunk_fact = [&](const int jc, auto) __attribute__((always_inline)) {   // (generic: instantiated for N > 2 only)
+        SmallFact<N> F;
+        {
+            const cd zl = zl_next;
+            double dg[N];
+            cd up[N][N];
+            rows_assemble<N, PM>(C, npow, pmax, zl, dg, up);
+            double e[N];
+            tridiag_small<N, true>(dg, up, F, e);
+            // The first reflector (6 doubles at N = 4) is not needed before the bands are formed, and then only for a moment per
+            // band: it lives in this wavefront's staging space, [quantity][lane] so that every access is a conflict-free 1 KB row
+            if constexpr (N == 4) {
+                stage[4 * 64 + lane] = F.us[0][1];
+                stage[5 * 64 + lane] = F.us[0][2];
+                stage[6 * 64 + lane] = F.us[0][3];
+                asm volatile("" ::: "memory");
+            }
+            if (!ql_iterate_small<N, true>(F, e) && G.flags) G.flags[0] = 1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sort_fact<N>(F);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (N == 4) {                // (the running minima of the three gaps wait in LDS too: 6 registers)
+            const cd g01 = stage[7 * 64 + lane], g2x = stage[8 * 64 + lane];
+            stage[7 * 64 + lane] = cd{fmin(g01.x, F.d[1] - F.d[0]), fmin(g01.y, F.d[2] - F.d[1])};
+            stage[8 * 64 + lane] = cd{fmin(g2x.x, F.d[3] - F.d[2]), 0.0};
+        } else {
+#pragma unroll
+            for (int b = 0; b + 1 < N; ++b) gmin[b] = fmin(gmin[b], F.d[b + 1] - F.d[b]);
+        }
+        {
+            // the orbital phases F = diag(f_o) go INTO the factors: F H_0 H_1 D Q = H_0' H_1' (F D) Q with u' = F u (F is unitary
+            // and diagonal) -- 9 products once instead of 16 per chunk on the way out, and no phase is live while the bands go out
+            const int jj = min(jc * 64 + lane, ncol - 1);
+            cd fo[N];
+#pragma unroll
+            for (int o = 0; o < N; ++o) fo[o] = G.tf[last][(int64_t)jj * N + o];
+            if (jc + 1 < jc1) zl_next = G.tz[last][min((jc + 1) * 64 + lane, ncol - 1)];
+#pragma unroll
+            for (int o = 0; o < N; ++o) fo[o] = cmul_x(frow[o], fo[o]);
+#pragma unroll
+            for (int K = 0; K + 2 < N; ++K)
+#pragma unroll
+                for (int r = K + 1; r < N; ++r) {
+                    if (N == 4 && K == 0) stage[(3 + r) * 64 + lane] = cmul_x(fo[r], stage[(3 + r) * 64 + lane]);
+                    else F.us[K][r] = cmul_x(fo[r], F.us[K][r]);
+                }
+            F.dph[0] = fo[0];
+#pragma unroll
+            for (int r = 1; r < N; ++r) F.dph[r] = cmul_x(fo[r], F.dph[r]);
+        }
+        // ---- ONE form of the store phase for every chunk, each store instruction unconditional (a store under a lane condition
+        // makes the number of outstanding stores unknown to the compiler and costs a vmcnt(0) at the loop head, see above):
+        //  * a partial last chunk: a lane whose element lies beyond the valid points fetches and stores the LAST valid point's
+        //    element instead -- the same bytes to the same address a second time;
+        //  * the periodic image of column 0 (the row's first chunk when the whole last axis is in the window): after a band's
+        //    transposition lanes 0 .. N-1 of the first 1 KB row hold point 0's components; one more store instruction per band in
+        //    which they write them, under the image's column phase, to the image's place while every other lane repeats its
+        //    first store.  The branch around it is wave-uniform.
+        __builtin_amdgcn_sched_barrier(0);
+        const int npv = min(64, ncol - jc * 64);                    // valid points of this chunk
+        const int64_t point0 = (int64_t)row * nlast + (int64_t)jc * 64;
+        int lane_here = lane;                                        // (formed here, not carried through the eigen-solve)
+        asm volatile("" : "+v"(lane_here));
+        cd* const stage_w = stage + lane_here * N;
+        const int swz = (N & 1) ? 0 : (lane_here >> 1) & 3;          // = ((lane N + o) >> 3) & 3 at N = 4 (see `slot` above)
+        cd* const stage_r = stage + ((N & 1) ? lane_here : (lane_here ^ ((lane_here >> 3) & 3)));   // slot(i 64 + lane) - i 64
+        // the element row i of a band's transposition hands this lane (re-formed at every use: a handful of integer operations
+        // against four registers held through the bands)
+        auto eclamp = [&](const int i) {
+            const int e = i * 64 + lane_here;
+            const int pnt = min(e / N, npv - 1);
+            return pnt * N + (e - (e / N) * N);
+        };
+        const bool img_chunk = G.img_last && jc == 0;               // wave-uniform
+        static_for<0, N>([&](auto rt) __attribute__((always_inline)) {
+            constexpr int r = decltype(rt)::value;
+            __builtin_amdgcn_sched_barrier(0);         // (one band at a time: the next band's vector is not formed early)
+            cd z[N];
+            if constexpr (N == 4) {
+                // column r of H_0' H_1' D' Q with the first reflector read from LDS where it is used -- once for w^+ z, once more
+                // for the update: four registers in flight instead of twelve
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < N; ++c) z[c] = cd{F.dph[c].x * F.Q[c][r], F.dph[c].y * F.Q[c][r]};
+                {
+                    cd w{0.0, 0.0};
+                    cfmac(w, F.us[1][2], z[2]);
+                    cfmac(w, F.us[1][3], z[3]);
+#pragma unroll
+                    for (int c = 2; c < N; ++c) {
+                        z[c].x -= F.us[1][c].x * w.x - F.us[1][c].y * w.y;
+                        z[c].y -= F.us[1][c].x * w.y + F.us[1][c].y * w.x;
+                    }
+                }
+                {
+                    cd w{0.0, 0.0};
+#pragma unroll
+                    for (int c = 1; c < N; ++c) cfmac(w, stage[(3 + c) * 64 + lane], z[c]);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int c = 1; c < N; ++c) {
+                        const cd u = stage[(3 + c) * 64 + lane];
+                        z[c].x -= u.x * w.x - u.y * w.y;
+                        z[c].y -= u.x * w.y + u.y * w.x;
+                    }
+                }
+            } else {
+                small_vector<N, r>(F, z);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int o = 0; o < N; ++o) stage_w[o ^ swz] = z[o];
+            asm volatile("" ::: "memory");
+            cd* dst = G.wv.data + ((int64_t)r * G.wv.npts + point0) * N;
+            if (npv == 64) {                           // (wave-uniform; the common case: constant offsets, no index arithmetic)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    dst[i * 64 + lane_here] = stage_r[i * 64];
+                    if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // (two 1 KB rows in flight between LDS and the store)
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const int ec = eclamp(i);
+                    dst[ec] = stage[slot(ec)];
+                    if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (img_chunk) {
+                const cd first = stage[slot(eclamp(0))];
+                // z carries column 0's phase, the image wants its own: tf(image) conj tf(column 0) of component `lane` (< N), the
+                // same for every row -- formed once per tile into scalar registers (ips) and picked by lane here
+                const bool mine = lane_here < N;
+                // (picked with 0 / 1 weights: a chain of selects on lane == o is turned into an indexed read of a scratch copy)
+                cd ip{0.0, 0.0};
+#pragma unroll
+                for (int o = 0; o < N; ++o) {
+                    const double wo = lane_here == o ? 1.0 : 0.0;
+                    ip.x = fma(wo, ips[o].x, ip.x);
+                    ip.y = fma(wo, ips[o].y, ip.y);
+                }
+                const cd vi = cmul_x(first, ip);
+                cd* di = mine ? G.wv.data + ((int64_t)r * G.wv.npts + (int64_t)row * nlast + (nlast - 1)) * N + lane_here : dst + eclamp(0);
+                *di = cd{mine ? vi.x : first.x, mine ? vi.y : first.y};
+            }
+        });
+    };
+    auto run_chunk = [&](const int jc, auto full_tag) __attribute__((always_inline)) {
+        if constexpr (N > 2) {
+            if (TBK_ABLATE(G.ablate) == 0) {
+                chunk_fact(jc, 0);
+                return;
+            }
+        }
+        chunk(jc, full_tag);
+    };
+    if constexpr (N > 2) {
+        if (TBK_ABLATE(G.ablate) == 0) {
+            for (int jc = jc0; jc < jc1; ++jc) chunk_fact(jc, 0);
+            jc0 = jc1;
+        }
+    }
     const int jfull = TBK_ABLATE(G.ablate) == 1 ? jc0 : max(jc0, min(jc1, ncol / 64));   // chunks [jc0, jfull) are complete
     int jc = jc0;
     if (G.img_last && jc0 == 0 && jc < jc1) {      // (the chunk that also stores the image: the variant with conditional stores)
-        chunk(jc, std::false_type{});
+        run_chunk(jc, std::false_type{});
         ++jc;
     }
-    for (; jc < jfull; ++jc) chunk(jc, std::true_type{});
-    for (; jc < jc1; ++jc) chunk(jc, std::false_type{});
+    for (; jc < jfull; ++jc) run_chunk(jc, std::true_type{});
+    for (; jc < jc1; ++jc) run_chunk(jc, std::false_type{});
     if constexpr (N > 1) {
         // min gaps: one plain store per tile and band pair, reduced when the result is asked for.  (A guarded
         // atomicMin here needs the guard's value: loaded at the end it keeps the wavefront from retiring for
         // a memory latency -- 3.8 us of the 2048^2 solve; loaded at set-up it is still +inf for every early
         // wavefront and 10^4 atomics pile up on 64 addresses -- 71 us.)
+        if constexpr (N == 4) {
+            if (TBK_ABLATE(G.ablate) == 0) {
+                const cd g01 = stage[7 * 64 + lane], g2x = stage[8 * 64 + lane];
+                gmin[0] = g01.x;
+                gmin[1] = g01.y;
+                gmin[2] = g2x.x;
+            }
+        }
 #pragma unroll
         for (int b = 0; b + 1 < N; ++b) {
             double g = gmin[b];
@@ -2386,7 +2728,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         const int64_t want = (int64_t)ctx->cus * 32;     // wave tiles that fill the chip
         // the last column as the periodic image of the first (k_grid_rows): the whole last axis inside the window
         // (TBK_GRID_IMG=0: every column solved on its own, the A/B and the reference for the bit-identity test)
-        const size_t lds_rows_need = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
+        const size_t lds_rows_need = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * rows_stage_slots(n)) * sizeof(cd);
         const bool rows_kernel = lds_rows_need <= 48 * 1024 && tbk_knobs().grid_kernel != 1;     // (else k_grid_small: every column)
         G.img_last = rows_kernel && tbk_knobs().grid_img != 0 && v.mesh[D - 1] >= 2 && G.off[D - 1] == 0 && v.mesh[D - 1] == G.gmesh[D - 1] ? 1 : 0;
         if (G.img_last) {
@@ -2398,7 +2740,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         G.tpr = (G.cpr + G.seg - 1) / G.seg;
         G.seg = (G.cpr + G.tpr - 1) / G.tpr;             // balance the tiles of a row (33 chunks -> 7,7,7,7,5)
         G.ntiles = nrows * G.tpr;
-        size_t lds = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * 64 * n) * sizeof(cd);
+        size_t lds = lds_rows_need;
         if (lds <= 48 * 1024 && tbk_knobs().grid_kernel != 1) {
             // (TBK_GRID_OCC: cap on the resident wavefronts per SIMD through the LDS request, as in the fused pass)
             // A dynamic LDS request above 64 KB needs a function attribute this launch does not set: occ = 1 (82 944 B) cannot

@@ -177,88 +177,146 @@ __global__ __launch_bounds__(256) void k_grid_rows_flux(const ModelView mv, cons
             for (int o = 0; o < N; ++o) vprev[a][o] = cd{0.0, 0.0};
         for (int rr = 0; rr < nrows; ++rr) {
             const cd* Crow = C + rr * ncell;
-            SmallMat<N> M;
-            int sl = 0;
-#pragma unroll
-            for (int a = 0; a < N; ++a) {
-#pragma unroll
-                for (int b = a; b < N; ++b, ++sl) {
-                    const cd* Cs = Crow + sl * npow + PM;
-                    cd acc = Cs[0];
-                    cd zp = zl;
-#pragma unroll
-                    for (int p = 1; p <= PM; ++p) {
-                        cfma(acc, Cs[p], zp);
-                        cfma(acc, Cs[-p], cconj(zp));
-                        if (p < PM) zp = cmul(zp, zl);
-                    }
-                    if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
-                }
-            }
-            init_vectors<N, true>(M);
-            if constexpr (N > 2) {
-                if (!jacobi_small<N, true>(M) && G.flags) G.flags[0] = 1;
-                sort_small<N>(M);
-            } else {
-                jacobi_small<N, true>(M);
-            }
             const bool stored = rr < F.R;              // (the halo row belongs to the next row group)
-            if (stored) {
-#pragma unroll
-                for (int b = 0; b + 1 < N; ++b) gmin[b] = fmin(gmin[b], M.dg[b + 1] - M.dg[b]);
-            }
-            cd fo[N];
-#pragma unroll
-            for (int o = 0; o < N; ++o) fo[o] = cmul(frowL[rr * N + o], tfl[o]);
-            // the stored components of the occupied states: what berry_flux would read back
             cd psi[NOCC][N];
-#pragma unroll
-            for (int o = 0; o < N; ++o) {
-                // (the band is picked with 0 / 1 weights: written as "M.v[o][occ]", or as a chain of selects on occ == b, the
-                // compiler parks the candidates in SCRATCH memory and indexes them -- and a scratch load is a vector-memory
-                // operation, so every row of every chunk then waited for all of its own stores to land: 2.4 x slower)
-                cd c0{0.0, 0.0}, c1{0.0, 0.0};
-#pragma unroll
-                for (int b = 0; b < N; ++b) {
-                    c0.x = fma(wsel0[b], M.v[o][b].x, c0.x);
-                    c0.y = fma(wsel0[b], M.v[o][b].y, c0.y);
-                    if constexpr (NOCC > 1) {
-                        c1.x = fma(wsel1[b], M.v[o][b].x, c1.x);
-                        c1.y = fma(wsel1[b], M.v[o][b].y, c1.y);
-                    }
+            if constexpr (N > 2) {
+                // n = 3, 4: the factored solver of k_grid_rows' chunk_fact (the same assembly, hence the same eigenvalues bit for
+                // bit): (d, Q) sorted, then one band at a time formed, phased, picked for the links and staged / stored
+                SmallFact<N> Fc;
+                {
+                    double dg[N];
+                    cd up[N][N];
+                    rows_assemble<N, PM>(Crow, npow, PM, zl, dg, up);
+                    if (!ql_small_core<N, true>(dg, up, Fc) && G.flags) G.flags[0] = 1;
                 }
-                psi[0][o] = cmul(c0, fo[o]);
-                if constexpr (NOCC > 1) psi[1][o] = cmul(c1, fo[o]);
-            }
-            bool do_store = stored;
+                sort_fact<N>(Fc);
+                if (stored) {
+#pragma unroll
+                    for (int b = 0; b + 1 < N; ++b) gmin[b] = fmin(gmin[b], Fc.d[b + 1] - Fc.d[b]);
+                }
+                cd fo[N];
+#pragma unroll
+                for (int o = 0; o < N; ++o) fo[o] = cmul_x(frowL[rr * N + o], tfl[o]);
+#pragma unroll
+                for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+                    for (int o = 0; o < N; ++o) psi[a][o] = cd{0.0, 0.0};
+                bool do_store = stored;
 #ifdef TBK_DIAG
-            // diagnostic build (TBK_ABLATE_GRID): 1 = no global stores, 3 = no links / phases, 4 = neither
-            if (G.ablate == 1 || G.ablate == 4) do_store = do_store && M.dg[0] == 1.2345e300;
+                if (G.ablate == 1 || G.ablate == 4) do_store = do_store && Fc.d[0] == 1.2345e300;
 #endif
-            if (do_store) {
                 const int nvalid = nvalid_pts * N;
                 const int64_t point0 = (int64_t)(r0 + rr) * nlast + (int64_t)jc * 64;
-                // NB bands go through the staging tile at once
+                static_for<0, N>([&](auto rt) __attribute__((always_inline)) {
+                    constexpr int r = decltype(rt)::value;
+                    cd val[N];
+                    small_vector<N, r>(Fc, val);
 #pragma unroll
-                for (int rb = 0; rb < N; rb += NB) {
-                    asm volatile("" ::: "memory");
+                    for (int o = 0; o < N; ++o) {
+                        val[o] = cmul_x(val[o], fo[o]);
+                        // (0 / 1 weights pick the occupied bands: see the note in the n <= 2 branch)
+                        psi[0][o].x = fma(wsel0[r], val[o].x, psi[0][o].x);
+                        psi[0][o].y = fma(wsel0[r], val[o].y, psi[0][o].y);
+                        if constexpr (NOCC > 1) {
+                            psi[1][o].x = fma(wsel1[r], val[o].x, psi[1][o].x);
+                            psi[1][o].y = fma(wsel1[r], val[o].y, psi[1][o].y);
+                        }
+                    }
+                    if (do_store) {
+                        asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int r = rb; r < rb + NB; ++r)
-#pragma unroll
-                        for (int o = 0; o < N; ++o) stage[(r - rb) * 64 * N + wslot[o]] = cmul(M.v[o][r], fo[o]);
-                    asm volatile("" ::: "memory");
-                    cd out[NB][N];
-#pragma unroll
-                    for (int r = 0; r < NB; ++r)
-#pragma unroll
-                        for (int i = 0; i < N; ++i) out[r][i] = stage[r * 64 * N + rslot[i]];
-#pragma unroll
-                    for (int r = 0; r < NB; ++r) {
-                        cd* dst = G.wv.data + ((int64_t)(rb + r) * G.wv.npts + point0) * N;
+                        for (int o = 0; o < N; ++o) stage[wslot[o]] = val[o];
+                        asm volatile("" ::: "memory");
+                        cd* dst = G.wv.data + ((int64_t)r * G.wv.npts + point0) * N;
 #pragma unroll
                         for (int i = 0; i < N; ++i) {
                             const int e = i * 64 + lane;
-                            if (full || e < nvalid) dst[e] = out[r][i];
+                            if (full || e < nvalid) dst[e] = stage[rslot[i]];
+                        }
+                    }
+                });
+            } else {
+                SmallMat<N> M;
+                int sl = 0;
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+#pragma unroll
+                    for (int b = a; b < N; ++b, ++sl) {
+                        const cd* Cs = Crow + sl * npow + PM;
+                        cd acc = Cs[0];
+                        cd zp = zl;
+#pragma unroll
+                        for (int p = 1; p <= PM; ++p) {
+                            cfma(acc, Cs[p], zp);
+                            cfma(acc, Cs[-p], cconj(zp));
+                            if (p < PM) zp = cmul(zp, zl);
+                        }
+                        if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
+                    }
+                }
+                init_vectors<N, true>(M);
+                if constexpr (N > 2) {
+                    if (!jacobi_small<N, true>(M) && G.flags) G.flags[0] = 1;
+                    sort_small<N>(M);
+                } else {
+                    jacobi_small<N, true>(M);
+                }
+                if (stored) {
+#pragma unroll
+                    for (int b = 0; b + 1 < N; ++b) gmin[b] = fmin(gmin[b], M.dg[b + 1] - M.dg[b]);
+                }
+                cd fo[N];
+#pragma unroll
+                for (int o = 0; o < N; ++o) fo[o] = cmul(frowL[rr * N + o], tfl[o]);
+                // the stored components of the occupied states: what berry_flux would read back
+#pragma unroll
+                for (int o = 0; o < N; ++o) {
+                    // (the band is picked with 0 / 1 weights: written as "M.v[o][occ]", or as a chain of selects on occ == b, the
+                    // compiler parks the candidates in SCRATCH memory and indexes them -- and a scratch load is a vector-memory
+                    // operation, so every row of every chunk then waited for all of its own stores to land: 2.4 x slower)
+                    cd c0{0.0, 0.0}, c1{0.0, 0.0};
+#pragma unroll
+                    for (int b = 0; b < N; ++b) {
+                        c0.x = fma(wsel0[b], M.v[o][b].x, c0.x);
+                        c0.y = fma(wsel0[b], M.v[o][b].y, c0.y);
+                        if constexpr (NOCC > 1) {
+                            c1.x = fma(wsel1[b], M.v[o][b].x, c1.x);
+                            c1.y = fma(wsel1[b], M.v[o][b].y, c1.y);
+                        }
+                    }
+                    psi[0][o] = cmul(c0, fo[o]);
+                    if constexpr (NOCC > 1) psi[1][o] = cmul(c1, fo[o]);
+                }
+                bool do_store = stored;
+#ifdef TBK_DIAG
+                // diagnostic build (TBK_ABLATE_GRID): 1 = no global stores, 3 = no links / phases, 4 = neither
+                if (G.ablate == 1 || G.ablate == 4) do_store = do_store && M.dg[0] == 1.2345e300;
+#endif
+                if (do_store) {
+                    const int nvalid = nvalid_pts * N;
+                    const int64_t point0 = (int64_t)(r0 + rr) * nlast + (int64_t)jc * 64;
+                    // NB bands go through the staging tile at once
+#pragma unroll
+                    for (int rb = 0; rb < N; rb += NB) {
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int r = rb; r < rb + NB; ++r)
+#pragma unroll
+                            for (int o = 0; o < N; ++o) stage[(r - rb) * 64 * N + wslot[o]] = cmul(M.v[o][r], fo[o]);
+                        asm volatile("" ::: "memory");
+                        cd out[NB][N];
+#pragma unroll
+                        for (int r = 0; r < NB; ++r)
+#pragma unroll
+                            for (int i = 0; i < N; ++i) out[r][i] = stage[r * 64 * N + rslot[i]];
+#pragma unroll
+                        for (int r = 0; r < NB; ++r) {
+                            cd* dst = G.wv.data + ((int64_t)(rb + r) * G.wv.npts + point0) * N;
+#pragma unroll
+                            for (int i = 0; i < N; ++i) {
+                                const int e = i * 64 + lane;
+                                if (full || e < nvalid) dst[e] = out[r][i];
+                            }
                         }
                     }
                 }

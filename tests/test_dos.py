@@ -90,8 +90,8 @@ def test_solve_all_mesh_equals_solve_all_of_host_mesh(tb, builder, mesh):
     assert np.array_equal(ev, ev_list)          # same kernel, same k bits -> same bits
     assert np.array_equal(vec, vec_list)
     # eigenvalues alone of up to 4 states: the row kernel k_mesh_evals (separable phases, no list) -- equal to rounding
-    evm = m.solve_all_mesh(mesh)
-    assert np.max(np.abs(evm - ev_list)) < 1e-13 and (m._nsta <= 4 or np.array_equal(evm, ev_list))
+    evm, evl = m.solve_all_mesh(mesh), m.solve_all(k)
+    assert np.max(np.abs(evm - evl)) < 1e-13 and (m._nsta <= 4 or np.array_equal(evm, evl))
     ref = orc.solve_all(orc.Model.from_tables(orc.model_tables(m)), k)
     assert np.max(np.abs(ev - ref)) < 1e-12 * max(1.0, np.abs(ref).max())
 
@@ -155,8 +155,8 @@ def test_solve_all_solves_the_list_it_is_given_and_solve_all_mesh_uploads_nothin
     from oracle import tb_oracle as orc
     from pythtb_amd import _lib
     ctx = _lib.default_context()
-    for m, mo, mesh in ((hp.haldane(tb.tb_model, 0.2), hp.haldane(orc.tb_model, 0.2), [300, 200]),
-                        (hp.kane_mele(tb.tb_model, "odd"), hp.kane_mele(orc.tb_model, "odd"), [64, 48]),
+    for m, mo, mesh in ((hp.haldane(tb.tb_model, 0.2), True, [300, 200]),
+                        (hp.kane_mele(tb.tb_model, "odd"), True, [64, 48]),
                         (hp.chain3(tb.tb_model, -1.0, 2.0, 0.3), None, [501]), (hp.cubic16(tb.tb_model), None, [6, 5, 7])):
         k = m.k_uniform_mesh(mesh)
         assert type(k) is np.ndarray
@@ -198,4 +198,4 @@ def test_solve_all_solves_the_list_it_is_given_and_solve_all_mesh_uploads_nothin
         for r in rows:
             assert not np.array_equal(ev3[:, r], ev_list[:, r])
         if mo is not None:
-            assert np.max(np.abs(ev3[:, rows] - mo.solve_all(plain[rows]))) < 1e-12
+            assert np.max(np.abs(ev3[:, rows] - orc.solve_all(orc.Model.from_tables(orc.model_tables(m)), plain[rows]))) < 1e-12

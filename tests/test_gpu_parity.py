@@ -968,8 +968,13 @@ def test_sharded_windows_equal_unsharded(tb):
             w.solve_on_grid_window(start, [0, b], mesh)
             wl.append(w.berry_phase([0, 1], 0, contin=False, berry_evals=True)[:e - b])
             bp.append(w.berry_phase([2, 3], 0, contin=False)[:e - b])
-        assert np.array_equal(np.concatenate(wl), ref_wl)
-        assert np.array_equal(np.concatenate(bp), ref_bp)
+        # Bit for bit -- except the string at the periodic-image column.  In the full array that column is column 0's vectors
+        # times (image phase / column-0 phase), written by the lanes that hold column 0 (k_grid_rows, n = 3, 4: the phases are
+        # folded into the solver's factors, round 5); a window that holds the image column without column 0 solves it as a column
+        # of its own.  The same numbers to rounding, not the same bits.
+        wl, bp = np.concatenate(wl), np.concatenate(bp)
+        assert np.array_equal(wl[:-1], ref_wl[:-1]) and np.array_equal(bp[:-1], ref_bp[:-1])
+        assert np.max(np.abs(wl[-1] - ref_wl[-1])) < 1e-13 and abs(bp[-1] - ref_bp[-1]) < 1e-13
 
 
 @pytest.mark.parametrize("half,mesh", [(3, [23, 53]), (6, [41, 53]), (7, [41, 53]), (8, [41, 53]), (12, [41, 53])])

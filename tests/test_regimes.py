@@ -333,7 +333,7 @@ def test_degenerate_bands_above_64_states_stay_on_the_direct_method(tb):
 def test_periodic_image_column_is_stored_by_the_lane_of_column_zero(tb, n):
     """k_grid_rows does not chunk the last column of a closed mesh row: it is the periodic image of the first (pythtb.py:2729-2747)
     and the lane that solves column 0 stores it with the image's orbital phase.  The same bits as solving it on its own
-    (TBK_GRID_IMG=0), on row lengths around the chunk size, on 1-D / 2-D / 3-D arrays, with a start point off the origin; min
+    (TBK_GRID_IMG=0) for n <= 2, the same numbers to rounding for n = 3, 4, on row lengths around the chunk size, on 1-D / 2-D / 3-D arrays, with a start point off the origin; min
     gaps equal; windows that do not hold the whole last axis are unaffected (tests/test_tw16_path.py, test_gpu_parity.py)."""
     from pythtb_amd import _lib
     if n == 4:
@@ -355,7 +355,17 @@ def test_periodic_image_column_is_stored_by_the_lane_of_column_zero(tb, n):
                 w = tb.wf_array(m, mesh)
                 gaps = w.solve_on_grid(start)
                 out[img] = (None if gaps is None else np.array(gaps), w.to_host().copy())
-        assert np.array_equal(out[0][1], out[1][1]), mesh
+        if n <= 2:
+            assert np.array_equal(out[0][1], out[1][1]), mesh
+        else:
+            # n = 3, 4 (round 5): the orbital phases are folded into the solver's factors, and the image is column 0's stored vector
+            # times (image phase / column-0 phase) -- the same numbers as the column solved on its own to rounding, every other
+            # column bit for bit
+            D = len(mesh)
+            a0 = np.moveaxis(out[0][1], D - 1, 0)
+            a1 = np.moveaxis(out[1][1], D - 1, 0)
+            assert np.array_equal(a0[:-1], a1[:-1]), mesh
+            assert np.max(np.abs(a0[-1] - a1[-1])) < 4e-15, mesh
         if out[0][0] is not None:
             assert np.array_equal(out[0][0], out[1][0]), mesh
 
