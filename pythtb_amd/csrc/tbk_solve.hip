@@ -161,6 +161,13 @@ __device__ __forceinline__ bool jacobi_small(SmallMat<N>& M) {
 // about two shifts of at most N - 1 plane rotations per eigenvalue.
 // Every thread runs the same full-range sweep i = N-2 .. 0; a position takes part only inside the thread's
 // active block [l, m) (EXEC-masked), so register indices stay static while l and m are data.
+template <int I, int E, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
 // The solver in FACTORED form: eigenvalues d, the REAL eigenvector matrix Q of the tridiagonal T, and what turns a column of Q
 // into an eigenvector of the Hermitian input -- the diagonal unitary D (dph) that made T's couplings real and the N - 2
 // normalised reflectors (us).  Column b of Z = H_0 .. H_{N-3} D Q is formed on demand (small_vector): the mesh kernels sort
@@ -264,106 +271,99 @@ __device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], S
     e[N - 1] = 0.0;
 }
 
-// implicit QL on (F.d, e), rotations accumulated in F.Q (VEC).  Returns false when the iteration ran into LAPACK's limit.
-template <int N, bool VEC>
-__device__ __forceinline__ bool ql_iterate_small(SmallFact<N>& F, double (&e)[N]) {
+// implicit QL on (F.d, e), rotations accumulated in F.Q (VEC).  Returns false when the iteration ran into LAPACK's limit
+// (30 shifts per eigenvalue).
+// tql2's own structure: for l = 0 .. N-2 sweep the block [l, m) -- m the first negligible coupling after l -- until e_l is
+// negligible.  One loop PER l, so that d_l, d_{l+1}, e_l and the positions of a sweep are static registers: finding "the
+// first coupling at or after l that is not negligible" and picking its d's and e by selects cost 80 of the ~200 instructions
+// of a sweep when l was data.
+// Every loop leaves on a WAVE-UNIFORM condition (no lane has work left): a lane that is done idles behind its EXEC bit.  With a
+// per-lane `break` the compiler keeps a second copy of every value that is live after a divergent loop -- d, e and Q once as
+// the running values and once as "the values of the lanes that have left": 48 more registers at N = 4, the difference between
+// two and four wavefronts per SIMD for the mesh kernels.
+template <int N, bool VEC, int L>
+__device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N]) {
     double (&d)[N] = F.d;
     double (&Q)[N][N] = F.Q;
+    auto negligible = [&](const int j) { return fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1])); };
+    bool work = true;
+    for (int iter = 0; iter < 30; ++iter) {
+        work = !negligible(L);
+        if (__builtin_amdgcn_ballot_w64(work) == 0) break;
+        if (work) {
+            int m = N - 1;                     // end of the block: the first negligible coupling after L
+#pragma unroll
+            for (int j = N - 2; j > L; --j) m = negligible(j) ? j : m;
+            double dm = d[N - 1];
+#pragma unroll
+            for (int j = L + 1; j + 1 < N; ++j) dm = m == j ? d[j] : dm;
+            // Wilkinson shift = the eigenvalue of the block's leading 2 x 2 nearer to d_L, to full precision: for a block of two it
+            // is exact and the block deflates in ONE sweep.  With delta = (d_{L+1} - d_L) / 2 and h = sqrt(delta^2 + e_L^2) it is
+            // d_L - e_L^2 / (delta + sgn(delta) h): tql2's g = delta / e_L, e_L / (g + sgn(g) sqrt(g^2 + 1)) multiplied through
+            // by e_L -- one reciprocal instead of two.
+            auto recip = [](const double x) {
+                double y = __builtin_amdgcn_rcp(x);
+                y = y * fma(-x, y, 2.0);
+                return y * fma(-x, y, 2.0);
+            };
+            const double dlt = 0.5 * (d[L + 1] - d[L]), el2 = e[L] * e[L];
+            const double t1 = fma(dlt, dlt, el2);
+            const double hh = t1 * rsqrt_full(t1);
+            double g = dm - d[L] + el2 * recip(dlt + copysign(hh, dlt));
+            double sn = 1.0, cs = 1.0, pp = 0.0;
+            bool alive = true;
+#pragma unroll
+            for (int i = N - 2; i >= L; --i) {
+                if (alive && i < m) {
+                    const double f = sn * e[i], b = cs * e[i];
+                    const double t = f * f + g * g;
+                    if (t > 0.0) {
+                        const double inv = rsqrt_full(t), r = t * inv;
+                        e[i + 1] = r;
+                        sn = f * inv;
+                        cs = g * inv;
+                        g = d[i + 1] - pp;
+                        const double r2 = (d[i] - g) * sn + 2.0 * cs * b;
+                        pp = sn * r2;
+                        d[i + 1] = g + pp;
+                        g = cs * r2 - b;
+                        if (VEC) {
+#pragma unroll
+                            for (int r_ = 0; r_ < N; ++r_) {
+                                const double zi = Q[r_][i], zj = Q[r_][i + 1];
+                                Q[r_][i + 1] = sn * zi + cs * zj;
+                                Q[r_][i] = cs * zi - sn * zj;
+                            }
+                        }
+                    } else {                   // r == 0 (underflow): tql2's recovery
+                        d[i + 1] -= pp;
+                        alive = false;
+                    }
+                }
+            }
+            if (alive) {
+                d[L] -= pp;
+                e[L] = g;
+            }
+#pragma unroll
+            for (int j = L + 1; j < N; ++j)
+                if (j == m) e[j] = 0.0;
+        }
+    }
+    return !work;
+}
+
+template <int N, bool VEC>
+__device__ __forceinline__ bool ql_iterate_small(SmallFact<N>& F, double (&e)[N]) {
     if (VEC) {
 #pragma unroll
         for (int r = 0; r < N; ++r)
 #pragma unroll
-            for (int c = 0; c < N; ++c) Q[r][c] = r == c ? 1.0 : 0.0;
+            for (int c = 0; c < N; ++c) F.Q[r][c] = r == c ? 1.0 : 0.0;
     }
-
-    // The loop leaves on a WAVE-UNIFORM condition (no lane has an unreduced block left): a lane that is done idles behind its
-    // EXEC bit.  With a per-lane `break` the compiler keeps a second copy of every value that is live after a divergent loop --
-    // d, e and Q once as the running values and once as "the values of the lanes that have left": 48 more registers at N = 4,
-    // the difference between two and four wavefronts per SIMD for the mesh kernels.
-    int l = 0;
-    int iter = 0;
-    bool work = true;
-    for (; iter < 30 * N; ++iter) {
-        // first coupling at or after l that is not negligible, then the end m of its block
-        bool negl[N];
-#pragma unroll
-        for (int j = 0; j + 1 < N; ++j) negl[j] = fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1]));
-        negl[N - 1] = true;
-        int lo = N - 1;
-#pragma unroll
-        for (int j = N - 2; j >= 0; --j) lo = (j >= l && !negl[j]) ? j : lo;
-        work = lo != N - 1;
-        if (__builtin_amdgcn_ballot_w64(work) == 0) break;
-        if (work) {
-        l = lo;
-        int m = N - 1;
-#pragma unroll
-        for (int j = N - 2; j >= 0; --j) m = (j > l && negl[j]) ? j : m;
-        double dl = d[0], dl1 = d[1], el = e[0], dm = d[N - 1];
-#pragma unroll
-        for (int j = 1; j + 1 < N; ++j) {
-            dl = l == j ? d[j] : dl;
-            dl1 = l == j ? d[j + 1] : dl1;
-            el = l == j ? e[j] : el;
-        }
-#pragma unroll
-        for (int j = 1; j + 1 < N; ++j) dm = m == j ? d[j] : dm;
-        // Wilkinson shift = the eigenvalue of the block's leading 2 x 2 nearer to d_l, to full precision: for a block of
-        // two it is exact and the block deflates in ONE sweep (with hardware-estimate reciprocals, 5e-8, it took two:
-        // 8.1 instead of 7.1 sweeps per Kane-Mele matrix)
-        // With delta = (d_{l+1} - d_l) / 2 and h = sqrt(delta^2 + e_l^2) the shift is d_l - e_l^2 / (delta + sgn(delta) h): tql2's
-        // g = delta / e_l, e_l / (g + sgn(g) sqrt(g^2 + 1)) multiplied through by e_l -- one reciprocal instead of two.
-        auto recip = [](const double x) {
-            double y = __builtin_amdgcn_rcp(x);
-            y = y * fma(-x, y, 2.0);
-            return y * fma(-x, y, 2.0);
-        };
-        const double dlt = 0.5 * (dl1 - dl), el2 = el * el;
-        const double t1 = fma(dlt, dlt, el2);
-        const double hh = t1 * rsqrt_full(t1);
-        double g = dm - dl + el2 * recip(dlt + copysign(hh, dlt));
-        double sn = 1.0, cs = 1.0, pp = 0.0;
-        bool alive = true;
-#pragma unroll
-        for (int i = N - 2; i >= 0; --i) {
-            if (alive && i >= l && i < m) {
-                const double f = sn * e[i], b = cs * e[i];
-                const double t = f * f + g * g;
-                if (t > 0.0) {
-                    const double inv = rsqrt_full(t), r = t * inv;
-                    e[i + 1] = r;
-                    sn = f * inv;
-                    cs = g * inv;
-                    g = d[i + 1] - pp;
-                    const double r2 = (d[i] - g) * sn + 2.0 * cs * b;
-                    pp = sn * r2;
-                    d[i + 1] = g + pp;
-                    g = cs * r2 - b;
-                    if (VEC) {
-#pragma unroll
-                        for (int r_ = 0; r_ < N; ++r_) {
-                            const double zi = Q[r_][i], zj = Q[r_][i + 1];
-                            Q[r_][i + 1] = sn * zi + cs * zj;
-                            Q[r_][i] = cs * zi - sn * zj;
-                        }
-                    }
-                } else {                       // r == 0 (underflow): tql2's recovery
-                    d[i + 1] -= pp;
-                    alive = false;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (alive && j == l) {
-                d[j] -= pp;
-                e[j] = g;
-            }
-            if (j == m) e[j] = 0.0;
-        }
-        }
-    }
-    return !work;              // (false: LAPACK's limit of 30 shifts per eigenvalue ran out with a block still unreduced)
+    bool ok = true;
+    static_for<0, N - 1>([&](auto lt) __attribute__((always_inline)) { ok = ql_deflate_small<N, VEC, decltype(lt)::value>(F, e) && ok; });
+    return ok;
 }
 
 template <int N, bool VEC>
@@ -379,13 +379,6 @@ __device__ __forceinline__ bool ql_small_core(double (&dg)[N], cd (&up)[N][N], S
 __host__ __device__ constexpr int rows_stage_slots(const int n) { return 64 * (n == 4 ? 9 : n); }
 
 // column B of Z = H_0 .. H_{N-3} D Q: the eigenvector of the Hermitian input that belongs to d[B]
-template <int I, int E, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f) {
-    if constexpr (I < E) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, E>(f);
-    }
-}
 template <int N, int B>
 __device__ __forceinline__ void small_vector(const SmallFact<N>& F, cd (&z)[N]) {
 #pragma unroll
@@ -1342,42 +1335,69 @@ __global__ __launch_bounds__(256) void k_mesh_evals(const ModelView mv, const Gr
     for (int jc = jc0; jc < jc1; ++jc) {
         const int j = jc * 64 + lane;
         const cd zl = G.tz[last][min(j, nlast - 1)];
-        SmallMat<N> M;
-        int slot = 0;
-#pragma unroll
-        for (int a = 0; a < N; ++a) {
-#pragma unroll
-            for (int b = a; b < N; ++b, ++slot) {
-                const cd* Cs = C + slot * npow + pmax;
-                cd acc = Cs[0];
-                cd zp = zl;
-                if constexpr (PM >= 0) {
-#pragma unroll
-                    for (int p = 1; p <= PM; ++p) {
-                        cfma(acc, Cs[p], zp);
-                        cfma(acc, Cs[-p], cconj(zp));
-                        if (p < PM) zp = cmul(zp, zl);
-                    }
-                } else {
-                    for (int p = 1; p <= pmax; ++p) {
-                        cfma(acc, Cs[p], zp);
-                        cfma(acc, Cs[-p], cconj(zp));
-                        zp = cmul(zp, zl);
-                    }
-                }
-                if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
-            }
-        }
+        double evs[N];
         if constexpr (N > 2) {
-            if (!jacobi_small<N, false>(M) && G.flags) G.flags[0] = 1;
-            sort_small<N>(M);
+            // n = 3, 4: the factored solver without its vectors -- (d, e) only -- on the cells assembled two slots at a time
+            // (rows_assemble; the old form held all the cells' broadcast reads in flight and sorted an eigenvector matrix it never
+            // computed: 192 registers, two wavefronts per SIMD, for a kernel that stores 8 bytes per band)
+            double dg[N];
+            cd up[N][N];
+            rows_assemble<N, PM>(C, npow, pmax, zl, dg, up);
+            SmallFact<N> F;
+            if (!ql_small_core<N, false>(dg, up, F) && G.flags) G.flags[0] = 1;
+#pragma unroll
+            for (int b = 0; b < N; ++b) evs[b] = F.d[b];
+            auto cx = [&](const int i, const int k) {
+                const double lo = fmin(evs[i], evs[k]), hi = fmax(evs[i], evs[k]);
+                evs[i] = lo;
+                evs[k] = hi;
+            };
+            if constexpr (N == 3) {
+                cx(0, 1);
+                cx(1, 2);
+                cx(0, 1);
+            } else {
+                cx(0, 1);
+                cx(2, 3);
+                cx(0, 2);
+                cx(1, 3);
+                cx(1, 2);
+            }
         } else {
+            SmallMat<N> M;
+            int slot = 0;
+#pragma unroll
+            for (int a = 0; a < N; ++a) {
+#pragma unroll
+                for (int b = a; b < N; ++b, ++slot) {
+                    const cd* Cs = C + slot * npow + pmax;
+                    cd acc = Cs[0];
+                    cd zp = zl;
+                    if constexpr (PM >= 0) {
+#pragma unroll
+                        for (int p = 1; p <= PM; ++p) {
+                            cfma(acc, Cs[p], zp);
+                            cfma(acc, Cs[-p], cconj(zp));
+                            if (p < PM) zp = cmul(zp, zl);
+                        }
+                    } else {
+                        for (int p = 1; p <= pmax; ++p) {
+                            cfma(acc, Cs[p], zp);
+                            cfma(acc, Cs[-p], cconj(zp));
+                            zp = cmul(zp, zl);
+                        }
+                    }
+                    if (b == a) M.dg[a] = acc.x; else M.up[a][b] = acc;
+                }
+            }
             jacobi_small<N, false>(M);
+#pragma unroll
+            for (int b = 0; b < N; ++b) evs[b] = M.dg[b];
         }
         if (j < nlast) {
             const int64_t point = (int64_t)row * nlast + j;
 #pragma unroll
-            for (int b = 0; b < N; ++b) eval[(int64_t)b * G.wv.npts + point] = M.dg[b];
+            for (int b = 0; b < N; ++b) eval[(int64_t)b * G.wv.npts + point] = evs[b];
         }
     }
 }
@@ -2725,7 +2745,9 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         TBK_REQUIRE(v.npts / v.mesh[D - 1] < (int64_t)0xffffffffu && G.nchunks < (int64_t)0x7fffffff * 4, TBK_EUNSUPPORTED,
                     "tbk_wfs_solve_grid: mesh too large for 32-bit row indices");
         const int64_t nrows = v.npts / v.mesh[D - 1];
-        const int64_t want = (int64_t)ctx->cus * 32;     // wave tiles that fill the chip
+        // wave tiles that fill the chip (n = 3, 4: 16 wavefronts per compute unit are resident since round 5, and a tile is a long
+        // chain of eigen-solves -- four rounds of shorter tiles measured 5 % faster than two rounds of tiles twice as long)
+        const int64_t want = (int64_t)ctx->cus * (n > 2 ? 64 : 32);
         // the last column as the periodic image of the first (k_grid_rows): the whole last axis inside the window
         // (TBK_GRID_IMG=0: every column solved on its own, the A/B and the reference for the bit-identity test)
         const size_t lds_rows_need = ((size_t)4 * (n * (n + 1) / 2) * (2 * m->view.pmax + 1) + (size_t)4 * rows_stage_slots(n)) * sizeof(cd);

@@ -164,7 +164,12 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
 #pragma unroll
             for (int b = 0; b < N; ++b) M.v[i][b] = cd{sub + L * i == b ? 1.0 : 0.0, 0.0};
     }
+    // The loop leaves on a WAVE-UNIFORM condition (no lane has off-diagonal weight left); a lane that is done idles behind its
+    // EXEC bit.  After a per-lane `break` the compiler keeps every live-out value of the divergent loop twice -- the running one
+    // and "the value of the lanes that have left": here the whole of A and V (tbk_solve.hip, ql_deflate_small, measured it:
+    // 48 registers at n = 4).
     int sweep = 0;
+    bool work = true;
     for (; sweep < TBK_JACOBI_MAX_SWEEPS; ++sweep) {
         double off = 0.0, dia = 0.0;
 #pragma unroll
@@ -173,11 +178,12 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
 #pragma unroll
             for (int q = p + 1; q < N; ++q) off += cabs2(M.up[p][q]);
         }
-        if (off <= 1.0e-32 * (dia + off)) break;
-        SweepReg<N, NR, 0, 1, VEC>::run(M);
+        work = !(off <= 1.0e-32 * (dia + off));
+        if (__builtin_amdgcn_ballot_w64(work) == 0) break;
+        if (work) SweepReg<N, NR, 0, 1, VEC>::run(M);
     }
     // (ran into the sweep cap: NaN input, or no convergence -- the reference's eigh raises there, pythtb.py:939,944)
-    if (sweep >= TBK_JACOBI_MAX_SWEEPS) {
+    if (work) {
         int* fl = MODE == 1 ? G.flags : Lst.flags;
         if (fl) fl[0] = 1;
     }
