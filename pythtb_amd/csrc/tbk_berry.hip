@@ -462,6 +462,15 @@ __device__ __forceinline__ cd det_overlap(const cd (&p)[NOCC][NCOMP], const cd (
     return det_small<NOCC>(M);
 }
 
+// value of lane + 1; lane 63 keeps its own (DPP wave_shl:1 leaves the destination of a lane without a source untouched)
+__device__ __forceinline__ double flux_shl1(const double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi2 << 32) | (unsigned)lo2);
+}
+
 template <int NOCC, int NCOMP>
 __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -480,26 +489,32 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
     const bool has_plaq = live && lane < 63 && jb < A.nb;
     const int64_t plane = A.v.npts * A.v.ncomp;
     const int64_t rstep = A.sa * A.v.ncomp;
-    // right neighbour; the last mesh column pairs with itself (det<u|u> = 1, value unused)
-    const int64_t cstep = jbc < A.nb ? A.sb * A.v.ncomp : 0;
     const cd* col = A.v.data + (axis_offset(A.other, slice) + (int64_t)jbc * A.sb) * A.v.ncomp + (int64_t)ia0 * rstep;
     const int64_t per = (int64_t)A.na * A.nb;
-    cd cur[NOCC][NCOMP], nxt[NOCC][NCOMP], rgt[NOCC][NCOMP], pn[NOCC][NCOMP], pr[NOCC][NCOMP];
+    // Each mesh point is fetched ONCE per tile, by the lane of its column; the right neighbour's vectors come from lane + 1 by a
+    // one-lane wavefront shift (DPP wave_shl:1 -- lane 63 keeps its own, it owns no plaquette).  Round 4 loaded them: an L1 hit,
+    // but twice the load instructions of a kernel that waits on its loads, and 1.137 x the algorithmic bytes at the L2.
+    auto from_right = [](const cd (&u)[NOCC][NCOMP], cd (&r)[NOCC][NCOMP]) {
+#pragma unroll
+        for (int a = 0; a < NOCC; ++a)
+#pragma unroll
+            for (int o = 0; o < NCOMP; ++o) r[a][o] = cd{flux_shl1(u[a][o].x), flux_shl1(u[a][o].y)};
+    };
+    cd cur[NOCC][NCOMP], nxt[NOCC][NCOMP], rgt[NOCC][NCOMP], pn[NOCC][NCOMP];
     load_vectors<NOCC, NCOMP>(col, A.occ, plane, cur);
-    load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, rgt);
+    from_right(cur, rgt);
     cd dHc = det_overlap<NOCC, NCOMP>(cur, rgt);
     col += rstep;
     load_vectors<NOCC, NCOMP>(col, A.occ, plane, nxt);
-    load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, rgt);
     double sum = 0.0;
     for (int ia = ia0; ia < ia1; ++ia) {
         // prefetch mesh row ia+2 while row ia+1 is consumed (the tile's last row re-reads itself)
         if (ia + 1 < ia1 && TBK_ABLATE(A.ablate) != 2) col += rstep;
         load_vectors<NOCC, NCOMP>(col, A.occ, plane, pn);
-        load_vectors<NOCC, NCOMP>(col + cstep, A.occ, plane, pr);
+        from_right(nxt, rgt);
         const cd dV = det_overlap<NOCC, NCOMP>(cur, nxt);
         const cd dHn = det_overlap<NOCC, NCOMP>(nxt, rgt);
-        const cd dVr{__shfl_down(dV.x, 1), __shfl_down(dV.y, 1)};
+        const cd dVr{flux_shl1(dV.x), flux_shl1(dV.y)};
         const cd z = cmul(cmul(dV, dHn), cconj(cmul(dVr, dHc)));
         double pha = 0.0;
         if (has_plaq) {
@@ -515,7 +530,6 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
             for (int o = 0; o < NCOMP; ++o) {
                 cur[a][o] = nxt[a][o];
                 nxt[a][o] = pn[a][o];
-                rgt[a][o] = pr[a][o];
             }
         dHc = dHn;
     }

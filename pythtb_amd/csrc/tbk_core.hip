@@ -653,7 +653,8 @@ static int model_flatten(int dim_k, int norb, int nspin, const double* orb, cons
             nz.push_back(0);
         }
     const int nnz = (int)(nz.size() / 4);
-    if (n >= 5 && n <= 64 && nterm > 0) {
+    // (n <= 4, round 5: the k-list kernels stage this table in LDS instead of walking the term table with scalar loads)
+    if (n <= 64 && nterm > 0) {
         std::map<std::array<int, 4>, int> rid;
         for (int64_t t = 0; t < nterm; ++t) {
             std::array<int, 4> key{R4[t * 4], R4[t * 4 + 1], R4[t * 4 + 2], R4[t * 4 + 3]};
@@ -661,7 +662,7 @@ static int model_flatten(int dim_k, int norb, int nspin, const double* orb, cons
                 for (int d = 0; d < 4; ++d) rvec.push_back(key[d]);
         }
         // n <= 16: always (the register kernels assemble from this table only), else when dense enough
-        if (rid.size() <= 256 && ((n <= 16 && rid.size() <= 64) || (int64_t)rid.size() * nslot <= 4 * nterm + 64)) {
+        if (rid.size() <= 256 && ((n <= 16 && rid.size() <= 64) || (n >= 5 && (int64_t)rid.size() * nslot <= 4 * nterm + 64))) {
             nR = (int)rid.size();
             rblock.assign((size_t)nR * nslot, cd{0.0, 0.0});
             for (int s = 0; s < nslot; ++s)

@@ -122,6 +122,15 @@ __host__ __device__ inline cd cmul(cd a, cd b) {
 // the same product with the fused operations spelled out: two places of one kernel that must give the same bits (cmul leaves the
 // choice of which product is fused to the compiler, site by site)
 __host__ __device__ inline cd cmul_x(cd a, cd b) { return cd{fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)}; }
+// acc += a b and acc += a conj(b), every operation a spelled-out fused multiply-add (see cmul_x)
+__host__ __device__ inline void cfma_x(cd& acc, const cd a, const cd b) {
+    acc.x = fma(-a.y, b.y, fma(a.x, b.x, acc.x));
+    acc.y = fma(a.y, b.x, fma(a.x, b.y, acc.y));
+}
+__host__ __device__ inline void cfmac_x(cd& acc, const cd a, const cd b) {
+    acc.x = fma(a.y, b.y, fma(a.x, b.x, acc.x));
+    acc.y = fma(a.y, b.x, fma(-a.x, b.y, acc.y));
+}
 __host__ __device__ inline cd cmulc(cd a, cd b) {
     return cd{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};
 }

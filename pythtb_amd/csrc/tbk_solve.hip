@@ -542,9 +542,83 @@ __global__ void k_signal_only(const DoneArgs done) {
     if (threadIdx.x == 0) tbk_signal_done(done);
 }
 
+// ---- k lists, n <= 4: S(k) = sum_R e^{2 pi i k.R} U_R from an LDS image of the model's R-grouped table (tbk_model_upload: the
+// distinct lattice vectors and, per vector, the dense block of slot coefficients) -- BASELINE north_star's "coalesced HBM reads of
+// the hopping table and an LDS-staged orbital tile" for the list kernels.  Rounds 1-4 walked the term table per slot with scalar
+// loads: a chain of 43 dependent loads per wavefront (Haldane), 5.6 k of a wavefront's 15 k cycles.  Here the workgroup copies the
+// table once (16-byte coalesced loads), every lane then reads it as LDS broadcasts, and a lattice vector's phase is formed once
+// per point instead of once per term.  The same operations in the same order for one or two points per lane (fused
+// multiply-adds spelled out): the two kernels stay bit-identical (tests/test_regimes.py::test_two_points_per_lane_...).
+template <int N>
+__device__ __forceinline__ void rtable_stage(const ModelView& mv, unsigned char* lds) {
+    constexpr int NSLOT = N * (N + 1) / 2;
+    int4* rv = reinterpret_cast<int4*>(lds);
+    cd* blk = reinterpret_cast<cd*>(rv + mv.nR);
+    for (int i = threadIdx.x; i < mv.nR; i += 256) rv[i] = mv.rvec[i];
+    for (int i = threadIdx.x; i < mv.nR * NSLOT; i += 256) blk[i] = mv.rblock[i];
+    __syncthreads();
+}
+template <int N, int KPT>
+__device__ __forceinline__ void assemble_small_rlds(const unsigned char* lds, const int nR, const cd (&z)[KPT][4], SmallMat<N> (&M)[KPT]) {
+    constexpr int NSLOT = N * (N + 1) / 2;
+    const int4* rv = reinterpret_cast<const int4*>(lds);
+    const cd* blk = reinterpret_cast<const cd*>(rv + nR);
+    cd acc[KPT][NSLOT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) acc[j][s] = cd{0.0, 0.0};
+    auto one_vector = [&](const int r) __attribute__((always_inline)) {
+        const int4 Rv = rv[r];
+        // (the same on every lane: into scalar registers, so that the loops over |R_d| below are scalar-controlled)
+        const int Rr[4] = {__builtin_amdgcn_readfirstlane(Rv.x), __builtin_amdgcn_readfirstlane(Rv.y),
+                           __builtin_amdgcn_readfirstlane(Rv.z), __builtin_amdgcn_readfirstlane(Rv.w)};
+        cd e[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) e[j] = cd{1.0, 0.0};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int m = Rr[d] < 0 ? -Rr[d] : Rr[d];
+            const double sg = Rr[d] < 0 ? -1.0 : 1.0;
+            for (int q = 0; q < m; ++q)
+#pragma unroll
+                for (int j = 0; j < KPT; ++j) e[j] = cmul_x(e[j], cd{z[j][d].x, sg * z[j][d].y});
+        }
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const cd c = blk[r * NSLOT + s];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) cfma_x(acc[j][s], c, e[j]);
+        }
+    };
+    // up to 8 lattice vectors (nearest and second neighbours of a 2-D lattice: 7): unrolled under wave-uniform guards, so that
+    // the LDS reads of all of them are in flight before the first phase is formed; longer tables run the plain loop
+    if (nR <= 8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < nR) one_vector(r);
+    } else {
+        for (int r = 0; r < nR; ++r) one_vector(r);
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        int s = 0;
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+#pragma unroll
+            for (int b = a; b < N; ++b, ++s) {
+                if (b == a) M[j].dg[a] = acc[j][s].x; else M[j].up[a][b] = acc[j][s];
+            }
+    }
+}
+
 // ---- k list (MODE 0) or supplied matrices (MODE 2) -> eval[b][k], evec[b][k][o]
 template <int N, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const int64_t nk, const ListArgs L) {
+    extern __shared__ __align__(16) unsigned char lds_rtab[];
+    if constexpr (MODE == 0) {
+        if (mv.nR > 0) rtable_stage<N>(mv, lds_rtab);
+    }
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     // (the point's work stays INLINE under this test: moved into a function of its own the compiler fused other products and
     // the eigenvectors differed from k_solve_small_multi's by an ulp -- tests/test_regimes.py::test_two_points_per_lane_...)
@@ -566,7 +640,25 @@ __global__ __launch_bounds__(256) void k_solve_small(const ModelView mv, const i
             if (d < mv.dim_k) kk[d] = L.k[idx * mv.dim_k + d];
             z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
         }
-        assemble_small<N>(mv, z, M);
+        if constexpr (MODE == 0) {
+            if (mv.nR > 0) {
+                cd z1[1][4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) z1[0][d] = z[d];
+                SmallMat<N> M1[1];
+                assemble_small_rlds<N, 1>(lds_rtab, mv.nR, z1, M1);
+#pragma unroll
+                for (int a = 0; a < N; ++a) {
+                    M.dg[a] = M1[0].dg[a];
+#pragma unroll
+                    for (int b = a + 1; b < N; ++b) M.up[a][b] = M1[0].up[a][b];
+                }
+            } else {
+                assemble_small<N>(mv, z, M);
+            }
+        } else {
+            assemble_small<N>(mv, z, M);
+        }
     }
     init_vectors<N, VEC>(M);
     if constexpr (N > 2) {
@@ -648,6 +740,8 @@ __device__ __forceinline__ void assemble_small_multi(const ModelView& mv, const 
 
 template <int N, bool VEC, int KPT>
 __global__ __launch_bounds__(256) void k_solve_small_multi(const ModelView mv, const int64_t nk, const ListArgs L) {
+    extern __shared__ __align__(16) unsigned char lds_rtab[];
+    if (mv.nR > 0) rtable_stage<N>(mv, lds_rtab);
     const int64_t idx0 = (int64_t)blockIdx.x * (256 * KPT) + threadIdx.x;
     if (idx0 >= nk) return;
     double kk[KPT][4];
@@ -664,7 +758,8 @@ __global__ __launch_bounds__(256) void k_solve_small_multi(const ModelView mv, c
         }
     }
     SmallMat<N> M[KPT];
-    assemble_small_multi<N, KPT>(mv, z, M);
+    if (mv.nR > 0) assemble_small_rlds<N, KPT>(lds_rtab, mv.nR, z, M);
+    else assemble_small_multi<N, KPT>(mv, z, M);
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         init_vectors<N, VEC>(M[j]);
@@ -808,14 +903,7 @@ __global__ __launch_bounds__(256) void k_grid_small(const ModelView mv, const Gr
 // into the matrix -- H(k) = F S F^+ as the reference builds it -- would save the N^2 products on the way out, but the image
 // of a point would then be solved from a DIFFERENT matrix and come out in another gauge: a closed string's Berry phase
 // would pick up the difference.)
-__device__ __forceinline__ void cfma_x(cd& acc, const cd a, const cd b) {          // acc += a b
-    acc.x = fma(-a.y, b.y, fma(a.x, b.x, acc.x));
-    acc.y = fma(a.y, b.x, fma(a.x, b.y, acc.y));
-}
-__device__ __forceinline__ void cfmac_x(cd& acc, const cd a, const cd b) {         // acc += a conj(b)
-    acc.x = fma(a.y, b.y, fma(a.x, b.x, acc.x));
-    acc.y = fma(a.y, b.x, fma(-a.x, b.y, acc.y));
-}
+// (cfma_x / cfmac_x: tbk_internal.h)
 __device__ __forceinline__ cd cmulc_x(const cd a, const cd b) {                    // a conj(b)
     return cd{fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y))};
 }
@@ -1951,6 +2039,8 @@ __global__ void k_arm_gaps(unsigned long long* p, const int n) {
 template <int MODE, bool VEC>
 static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L) {
     const unsigned blocks = (unsigned)((nk + 255) / 256);
+    // LDS image of the R-grouped table (k lists of n <= 4 states: rtable_stage)
+    const size_t rlds = MODE == 0 && mv.nR > 0 ? (size_t)mv.nR * (sizeof(int4) + (size_t)(n * (n + 1) / 2) * sizeof(cd)) : 0;
     // eigenvalue-only k lists that fill the chip more than once: two points per lane (k_solve_small_multi; 2^20 Haldane points
     // 21.8 -> 19.9 us; with eigenvectors the second point's registers cost more than the shared scalar stream saves: 30.1 ->
     // 31.2 us, so those keep one point per lane).  TBK_SMALL_KPT=1 / 2 forces either form where both exist.
@@ -1959,19 +2049,19 @@ static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
         const bool many = kpt == 2 || (kpt < 0 && !VEC && nk >= ((int64_t)1 << 19));
         if (many && (n == 2 || (!VEC && (n == 3 || n == 4)))) {
             const unsigned b2 = (unsigned)((nk + 511) / 512);
-            if (n == 2) hipLaunchKernelGGL((k_solve_small_multi<2, VEC, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
-            else if (n == 3) hipLaunchKernelGGL((k_solve_small_multi<3, false, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
-            else hipLaunchKernelGGL((k_solve_small_multi<4, false, 2>), dim3(b2), dim3(256), 0, ctx->stream, mv, nk, L);
+            if (n == 2) hipLaunchKernelGGL((k_solve_small_multi<2, VEC, 2>), dim3(b2), dim3(256), rlds, ctx->stream, mv, nk, L);
+            else if (n == 3) hipLaunchKernelGGL((k_solve_small_multi<3, false, 2>), dim3(b2), dim3(256), rlds, ctx->stream, mv, nk, L);
+            else hipLaunchKernelGGL((k_solve_small_multi<4, false, 2>), dim3(b2), dim3(256), rlds, ctx->stream, mv, nk, L);
             if (L.done.word) hipLaunchKernelGGL(k_signal_only, dim3(1), dim3(64), 0, ctx->stream, L.done);   // (TBK_SMALL_KPT=2 on a small call)
             TBK_HIP(hipGetLastError());
             return TBK_OK;
         }
     }
     switch (n) {
-        case 1: hipLaunchKernelGGL((k_solve_small<1, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
-        case 2: hipLaunchKernelGGL((k_solve_small<2, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
-        case 3: hipLaunchKernelGGL((k_solve_small<3, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
-        case 4: hipLaunchKernelGGL((k_solve_small<4, MODE, VEC>), dim3(blocks), dim3(256), 0, ctx->stream, mv, nk, L); break;
+        case 1: hipLaunchKernelGGL((k_solve_small<1, MODE, VEC>), dim3(blocks), dim3(256), rlds, ctx->stream, mv, nk, L); break;
+        case 2: hipLaunchKernelGGL((k_solve_small<2, MODE, VEC>), dim3(blocks), dim3(256), rlds, ctx->stream, mv, nk, L); break;
+        case 3: hipLaunchKernelGGL((k_solve_small<3, MODE, VEC>), dim3(blocks), dim3(256), rlds, ctx->stream, mv, nk, L); break;
+        case 4: hipLaunchKernelGGL((k_solve_small<4, MODE, VEC>), dim3(blocks), dim3(256), rlds, ctx->stream, mv, nk, L); break;
         default: tbk_set_error("launch_small: n=%d", n); return TBK_EINVAL;
     }
     TBK_HIP(hipGetLastError());
