@@ -227,27 +227,32 @@ __device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], S
                 cd p[N];
                 double upr = 0.0;
 #pragma unroll
+                // (every accumulation below is a chain of fused multiply-adds spelled out: "acc += a b + c d" as written costs a
+                // multiply, a fused multiply-add and an add; the chain costs two)
                 for (int r = K + 1; r < N; ++r) {           // p = A w on the trailing block, A read through the upper triangle
                     cd acc{dg[r] * u[r].x, dg[r] * u[r].y};
 #pragma unroll
                     for (int c = K + 1; c < N; ++c) {
-                        if (c > r) cfma(acc, up[r][c], u[c]);
-                        else if (c < r) cfmac(acc, up[c][r], u[c]);
+                        if (c > r) cfma_x(acc, up[r][c], u[c]);
+                        else if (c < r) {                   // conj(up[c][r]) u_c
+                            acc.x = fma(up[c][r].y, u[c].y, fma(up[c][r].x, u[c].x, acc.x));
+                            acc.y = fma(-up[c][r].y, u[c].x, fma(up[c][r].x, u[c].y, acc.y));
+                        }
                     }
                     p[r] = acc;
-                    upr += u[r].x * p[r].x + u[r].y * p[r].y;
+                    upr = fma(u[r].y, p[r].y, fma(u[r].x, p[r].x, upr));
                 }
                 const double kappa = 0.5 * upr;
                 cd q[N];
 #pragma unroll
-                for (int r = K + 1; r < N; ++r) q[r] = cd{p[r].x - kappa * u[r].x, p[r].y - kappa * u[r].y};
+                for (int r = K + 1; r < N; ++r) q[r] = cd{fma(-kappa, u[r].x, p[r].x), fma(-kappa, u[r].y, p[r].y)};
 #pragma unroll
                 for (int r = K + 1; r < N; ++r) {           // A -= u q^+ + q u^+
-                    dg[r] -= 2.0 * (u[r].x * q[r].x + u[r].y * q[r].y);
+                    dg[r] = fma(-2.0 * u[r].y, q[r].y, fma(-2.0 * u[r].x, q[r].x, dg[r]));
 #pragma unroll
                     for (int c = r + 1; c < N; ++c) {
-                        up[r][c].x -= (u[r].x * q[c].x + u[r].y * q[c].y) + (q[r].x * u[c].x + q[r].y * u[c].y);
-                        up[r][c].y -= (u[r].y * q[c].x - u[r].x * q[c].y) + (q[r].y * u[c].x - q[r].x * u[c].y);
+                        up[r][c].x = fma(-q[r].y, u[c].y, fma(-q[r].x, u[c].x, fma(-u[r].y, q[c].y, fma(-u[r].x, q[c].x, up[r][c].x))));
+                        up[r][c].y = fma(q[r].x, u[c].y, fma(-q[r].y, u[c].x, fma(u[r].x, q[c].y, fma(-u[r].y, q[c].x, up[r][c].y))));
                     }
                 }
             }
@@ -388,11 +393,14 @@ __device__ __forceinline__ void small_vector(const SmallFact<N>& F, cd (&z)[N]) 
         // (no test for "no reflection": then w = 0 and the update below is the identity)
         cd w{0.0, 0.0};
 #pragma unroll
-        for (int r = K + 1; r < N; ++r) cfmac(w, F.us[K][r], z[r]);      // w^+ z
+        for (int r = K + 1; r < N; ++r) {                                  // w^+ z
+            w.x = fma(F.us[K][r].y, z[r].y, fma(F.us[K][r].x, z[r].x, w.x));
+            w.y = fma(-F.us[K][r].y, z[r].x, fma(F.us[K][r].x, z[r].y, w.y));
+        }
 #pragma unroll
         for (int r = K + 1; r < N; ++r) {
-            z[r].x -= F.us[K][r].x * w.x - F.us[K][r].y * w.y;
-            z[r].y -= F.us[K][r].x * w.y + F.us[K][r].y * w.x;
+            z[r].x = fma(F.us[K][r].y, w.y, fma(-F.us[K][r].x, w.x, z[r].x));
+            z[r].y = fma(-F.us[K][r].y, w.x, fma(-F.us[K][r].x, w.y, z[r].y));
         }
     }
 }
@@ -1264,24 +1272,31 @@ __global__ __launch_bounds__(256) TBK_ROWS_OCC void k_grid_rows(const ModelView 
                 for (int c = 0; c < N; ++c) z[c] = cd{F.dph[c].x * F.Q[c][r], F.dph[c].y * F.Q[c][r]};
                 {
                     cd w{0.0, 0.0};
-                    cfmac(w, F.us[1][2], z[2]);
-                    cfmac(w, F.us[1][3], z[3]);
 #pragma unroll
                     for (int c = 2; c < N; ++c) {
-                        z[c].x -= F.us[1][c].x * w.x - F.us[1][c].y * w.y;
-                        z[c].y -= F.us[1][c].x * w.y + F.us[1][c].y * w.x;
+                        w.x = fma(F.us[1][c].y, z[c].y, fma(F.us[1][c].x, z[c].x, w.x));
+                        w.y = fma(-F.us[1][c].y, z[c].x, fma(F.us[1][c].x, z[c].y, w.y));
+                    }
+#pragma unroll
+                    for (int c = 2; c < N; ++c) {
+                        z[c].x = fma(F.us[1][c].y, w.y, fma(-F.us[1][c].x, w.x, z[c].x));
+                        z[c].y = fma(-F.us[1][c].y, w.x, fma(-F.us[1][c].x, w.y, z[c].y));
                     }
                 }
                 {
                     cd w{0.0, 0.0};
 #pragma unroll
-                    for (int c = 1; c < N; ++c) cfmac(w, stage[(3 + c) * 64 + lane], z[c]);
+                    for (int c = 1; c < N; ++c) {
+                        const cd u = stage[(3 + c) * 64 + lane];
+                        w.x = fma(u.y, z[c].y, fma(u.x, z[c].x, w.x));
+                        w.y = fma(-u.y, z[c].x, fma(u.x, z[c].y, w.y));
+                    }
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int c = 1; c < N; ++c) {
                         const cd u = stage[(3 + c) * 64 + lane];
-                        z[c].x -= u.x * w.x - u.y * w.y;
-                        z[c].y -= u.x * w.y + u.y * w.x;
+                        z[c].x = fma(u.y, w.y, fma(-u.x, w.x, z[c].x));
+                        z[c].y = fma(-u.y, w.x, fma(-u.x, w.y, z[c].y));
                     }
                 }
             } else {
