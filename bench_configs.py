@@ -2,7 +2,7 @@
 """Secondary measurements: the other BASELINE.json configs (device-resident timings from HIP events on the
 library's stream; not the driver's headline line -- that is bench.py).  One JSON object per config.
 
-    python bench_configs.py [B] [C] [D] [E] [R] [W] [H] [--reps 5]     one GPU (not in BASELINE.json: R ribbons / mid-size meshes, W the
+    python bench_configs.py [B] [C] [D] [E] [R] [W] [H] [P] [--reps 5] one GPU (not in BASELINE.json: R ribbons / mid-size meshes, P late Berry kernels, W the
                                                                         Wannier90 silicon model, H hybrid Wannier centres (8f-1))
     python bench_configs.py --gpus N [B] [D] [E] [--side 257]           N GPUs, one process each (starts its own ranks; the
                                                                         same under torch.distributed.run --nproc-per-node N)
@@ -243,6 +243,57 @@ def single_gpu(which, reps):
                                  "algorithmic_bytes_per_point": 16 * nocc * 16 + 8 * nocc,
                                  "hbm_frac": (16 * nocc * 16 + 8 * nocc) * npt / (dev_ms * 1e-3) / 1e9 / HBM if dev_ms > 0 else None},
                     "check": {"centres_in_slab": bool(np.all((hwfc > -0.5) & (hwfc < 16.5))), "mean_centre": float(hwfc.mean())}})
+    if "P" in which:
+        # (not a BASELINE config) the Berry / position kernels that landed at the end of round 4 without rocprofv3 evidence (VERDICT r4
+        # missing #5): Wilson-loop eigenphases of 3 and 4 bands (k_wilson_seg_reg), of 8 wide bands by polar factors on the matrix
+        # cores (k_chain_prod_tile<..., POLAR>), berry_flux in planes that do not hold the fastest axis (k_flux_slices), the position
+        # matrix of 16 of 16 states (k_position_matrix_tile).  Algorithmic bytes: the occupied vectors read once, 16 nocc n per point.
+        HBM = 8000.0
+
+        def leg(name, fn, nbytes, npts, unit):
+            fn()
+            ctx.sync()
+            ctx.prof_enable(1)
+            ctx.prof_reset()
+            for _ in range(max(2, reps)):
+                fn()
+            rep = ctx.prof_report()
+            ctx.prof_enable(0)
+            kern = {kk: v["total_ms"] / max(v["launches"], 1) for kk, v in rep.items()}
+            dev_ms = sum(v["total_ms"] for v in rep.values()) / max(2, reps)
+            return {"leg": name, "kernels_ms_per_launch": kern, "device_ms_per_call": dev_ms, unit + "_per_s": npts / (dev_ms * 1e-3),
+                    "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (dev_ms * 1e-3) / 1e9, "peak": HBM, "unit": "GB/s",
+                                 "frac": nbytes / (dev_ms * 1e-3) / 1e9 / HBM}}
+        legs = []
+        for nb in (3, 4):                                  # Wilson loops of 3 / 4 bands of a 2 nb-state model, 257 strings of 1024 links
+            mw = hp.random_model(tb.tb_model, 2 * nb, 2, 1, 7 + nb)
+            ww = tb.wf_array(mw, [1025, 257])
+            ww.solve_on_grid([0.0, 0.0])
+            occ = list(range(nb))
+            legs.append(leg("wilson_%dbands_1024x257" % nb, lambda: ww.berry_phase(occ, 0, contin=False, berry_evals=True),
+                            16 * nb * 2 * nb * 1025 * 257, 1024 * 257, "links"))
+            del ww
+        m16 = hp.cubic16(tb.tb_model)
+        w16 = tb.wf_array(m16, [65, 65, 65])
+        w16.solve_on_grid([0.0, 0.0, 0.0])
+        legs.append(leg("wilson_polar_8of16_65cubed_dir2", lambda: w16.berry_phase(range(8), 2, contin=False, berry_evals=True),
+                        16 * 8 * 16 * 65 ** 3, 64 * 65 * 65, "links"))
+        legs.append(leg("flux_slices_8of16_65cubed_dirs01", lambda: w16.berry_flux(range(8), dirs=[0, 1]), 16 * 8 * 16 * 65 ** 3, 64 * 64 * 65, "plaquettes"))
+        del w16
+        m2 = hp.random_model(tb.tb_model, 2, 3, 1, seed=7, nhop=8, rmax=1)
+        w2 = tb.wf_array(m2, [129, 129, 129])
+        w2.solve_on_grid([0.0, 0.0, 0.0])
+        legs.append(leg("flux_slices_1of2_129cubed_dirs01", lambda: w2.berry_flux([0], dirs=[0, 1]), 16 * 1 * 2 * 129 ** 3, 128 * 128 * 129, "plaquettes"))
+        del w2
+        with contextlib.redirect_stdout(io.StringIO()):
+            m3 = tb.tb_model(3, 3, np.identity(3), [[0, 0, 0]])
+            for Rv in ([1, 0, 0], [0, 1, 0], [0, 0, 1]):
+                m3.set_hop(-1.0, 0, 0, Rv)
+            slab = m3.cut_piece(16, 2, glue_edgs=False)
+        ws = tb.wf_array(slab, [257, 257])
+        ws.solve_on_grid([0.0, 0.0])
+        legs.append(leg("position_16of16_257sq", lambda: ws.position_hwf_mesh(range(16), 2), (16 * 16 * 16 + 8 * 16) * 257 * 257, 257 * 257, "points"))
+        out.append({"config": "P: Berry / position kernels of round 4's last hours (rocprofv3 evidence: profiles/r05p)", "legs": legs})
     if "R" in which:
         # (not a BASELINE config) the widening rows of SURVEY.md 8f-2: ribbon band structures and a mid-size mesh solve, to keep
         # the direct paths for 17..1024 states under measurement.  Wall-clock of the Python calls, PCIe included.

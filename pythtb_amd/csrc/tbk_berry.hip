@@ -823,10 +823,13 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         A.sa = A.swap ? A.s1 : A.s0;
         A.sb = A.swap ? A.s0 : A.s1;
         A.ncolw = (A.nb + 62) / 63;
-        // enough wave tiles to fill the chip (32 per CU), rows per tile in [4, 64]
-        const int64_t want = (int64_t)ctx->cus * 32;
+        // enough wave tiles to fill the chip, rows per tile in [4, 24].  A tile re-reads one halo row, so its rows set the traffic:
+        // 8-row tiles (32 tiles per CU, rounds 1-4) moved 1.13 x the algorithmic bytes; the time is flat from 8 to 24 rows
+        // (2048^2: 28.8 / 26.2 / 26.4 / 24.1 us at 8 / 12 / 16 / 24 rows, 4096^2: 100 / 100 / 100 / 104) and rises beyond
+        // (32: 29.1 / 106, 64: 36.8 / 108) -- so 12 tiles per CU, at most 24 rows: 1.04 x
+        const int64_t want = (int64_t)ctx->cus * 12;
         int64_t ti = ((int64_t)A.na * A.ncolw * nslices + want - 1) / want;
-        A.ti = (int)std::max<int64_t>(4, std::min<int64_t>(64, ti));
+        A.ti = (int)std::max<int64_t>(4, std::min<int64_t>(24, ti));
         if (tbk_knobs().flux_ti >= 0) A.ti = std::max(1, tbk_knobs().flux_ti);
         A.bps = ((A.na + A.ti - 1) / A.ti) * A.ncolw;
     } else {
