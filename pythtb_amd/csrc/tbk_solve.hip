@@ -286,12 +286,18 @@ __device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], S
 // per-lane `break` the compiler keeps a second copy of every value that is live after a divergent loop -- d, e and Q once as
 // the running values and once as "the values of the lanes that have left": 48 more registers at N = 4, the difference between
 // two and four wavefronts per SIMD for the mesh kernels.
+// `first_shift` (with `guided`): the shift of this index's FIRST sweep when the block still reaches the end of T -- an eigenvalue
+// of T known to ~1e-6 beforehand (ql_lower_roots4) instead of Wilkinson's guess from the leading 2 x 2.  A shift that good leaves
+// e_L ~ 1e-6 |T| after one sweep and the cubically convergent second sweep (Wilkinson's shift again) finishes: two sweeps for
+// EVERY lane, where the plain iteration takes 2-4 and a wavefront waits for its slowest lane (Kane-Mele rows: 3.98 + 2.45 + 1.02
+// sweeps per wavefront for the three indices, 2 + 2 + 1 with the guesses).  A poor guess costs sweeps, never accuracy.
 template <int N, bool VEC, int L>
-__device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N]) {
+__device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N], const bool guided = false, const double first_shift = 0.0) {
     double (&d)[N] = F.d;
     double (&Q)[N][N] = F.Q;
     auto negligible = [&](const int j) { return fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1])); };
     bool work = true;
+    bool first = guided;                       // (a per-lane flag, not "iter == 0": the compiler peels a loop on the latter and keeps two copies of everything)
     for (int iter = 0; iter < 30; ++iter) {
         work = !negligible(L);
         if (__builtin_amdgcn_ballot_w64(work) == 0) break;
@@ -315,6 +321,8 @@ __device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N]
             const double t1 = fma(dlt, dlt, el2);
             const double hh = t1 * rsqrt_full(t1);
             double g = dm - d[L] + el2 * recip(dlt + copysign(hh, dlt));
+            if (first && m == N - 1) g = dm - first_shift;
+            first = false;
             double sn = 1.0, cs = 1.0, pp = 0.0;
             bool alive = true;
 #pragma unroll
@@ -358,8 +366,59 @@ __device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N]
     return !work;
 }
 
+// The two LOWEST eigenvalues of the 4 x 4 symmetric tridiagonal (d, e) in closed form, to ~1e-6 |T|: first-sweep shifts for
+// ql_deflate_small<.., 0> and <.., 1>.  det(x - T') = x^4 + p x^2 + q x + r for T' = (T - tr T / 4) / |T| (sums of principal
+// minors; the cubic and quartic power sums by Newton's identities since tr T' = 0), factored as (x^2 + a x + b)(x^2 - a x + c) with
+// a^2 the LARGEST root of the resolvent z^3 + 2 p z^2 + (p^2 - 4 r) z - q^2 -- three real roots, so the trigonometric form, its
+// arccos and cos in single precision (a polynomial and v_cos_f32: the roots are shifts, not results).  The largest a pairs the two
+// lowest roots in the first factor: x = (-a -+ sqrt(a^2 - 4 b)) / 2, ascending.  Returns false when T is (numerically) a multiple
+// of the identity or the resolvent degenerates: the caller then sweeps with Wilkinson's shift as before.
+__device__ __forceinline__ bool ql_lower_roots4(const double (&d)[4], const double (&e)[4], double& x1, double& x2) {
+    const double nrm = fmax(fmax(fmax(fabs(d[0]), fabs(d[1])), fmax(fabs(d[2]), fabs(d[3]))), fmax(fmax(fabs(e[0]), fabs(e[1])), fabs(e[2])));
+    const double s = __builtin_amdgcn_rcp(nrm);                  // (a scale, not a result: the hardware estimate is plenty)
+    const double mu = 0.25 * ((d[0] + d[1]) + (d[2] + d[3]));
+    const double a0 = (d[0] - mu) * s, a1 = (d[1] - mu) * s, a2 = (d[2] - mu) * s, a3 = (d[3] - mu) * s;
+    const double f0 = e[0] * s, f1 = e[1] * s, f2 = e[2] * s;
+    const double b0 = f0 * f0, b1 = f1 * f1, b2 = f2 * f2;
+    const double p = fma(-0.5, fma(a0, a0, fma(a1, a1, fma(a2, a2, a3 * a3))), -(b0 + b1 + b2));
+    const double cub = fma(a0 * a0, a0, fma(a1 * a1, a1, fma(a2 * a2, a2, a3 * a3 * a3)));
+    const double q = fma(b0, a2 + a3, fma(b1, a0 + a3, b2 * (a0 + a1))) - cub * (1.0 / 3.0);
+    const double r = fma(a0 * a1, a2 * a3, fma(-b0 * a2, a3, fma(-b1 * a0, a3, fma(-b2 * a0, a1, b0 * b2))));
+    const double P = fma(p * p, -1.0 / 3.0, -4.0 * r);
+    const double Q = fma(p * p * p, -2.0 / 27.0, fma(p * r, 8.0 / 3.0, -q * q));
+    const double m2 = P * (-1.0 / 3.0);
+    if (!(m2 > 1e-30) || !(nrm > 0.0)) return false;
+    const double im = __builtin_amdgcn_rsq(m2), m = m2 * im;
+    const float arg = fminf(1.0f, fmaxf(-1.0f, (float)(-0.5 * Q * (im * im * im))));
+    // arccos on [-1, 1]: sqrt(1 - |x|) * (a degree-7 polynomial in |x|), mirrored for x < 0 (Abramowitz & Stegun 4.4.46, 2e-8)
+    const float ax = fabsf(arg);
+    float pl = -0.0012624911f;
+    pl = fmaf(pl, ax, 0.0066700901f);
+    pl = fmaf(pl, ax, -0.0170881256f);
+    pl = fmaf(pl, ax, 0.0308918810f);
+    pl = fmaf(pl, ax, -0.0501743046f);
+    pl = fmaf(pl, ax, 0.0889789874f);
+    pl = fmaf(pl, ax, -0.2145988016f);
+    pl = fmaf(pl, ax, 1.5707963050f);
+    float th = __builtin_sqrtf(1.0f - ax) * pl;
+    th = arg < 0.0f ? 3.14159265f - th : th;
+    const float c3 = __builtin_amdgcn_cosf(th * (1.0f / (3.0f * 6.28318531f)));      // v_cos_f32 takes revolutions
+    const double z1 = fma(2.0 * m, (double)c3, p * (-2.0 / 3.0));
+    if (!(z1 > 1e-30)) return false;
+    const double ia = __builtin_amdgcn_rsq(z1), al = z1 * ia;
+    const double beta = 0.5 * (p + z1 - q * ia);
+    const double disc = fmax(fma(-4.0, beta, z1), 0.0);
+    const double sd = disc > 0.0 ? disc * __builtin_amdgcn_rsq(disc) : 0.0;
+    x1 = fma(0.5 * (-al - sd), nrm, mu);
+    x2 = fma(0.5 * (-al + sd), nrm, mu);
+    return true;
+}
+
 template <int N, bool VEC>
 __device__ __forceinline__ bool ql_iterate_small(SmallFact<N>& F, double (&e)[N]) {
+    bool guided = false;
+    double g0 = 0.0, g1 = 0.0;
+    if constexpr (N == 4) guided = ql_lower_roots4(F.d, e, g0, g1);
     if (VEC) {
 #pragma unroll
         for (int r = 0; r < N; ++r)
@@ -367,7 +426,11 @@ __device__ __forceinline__ bool ql_iterate_small(SmallFact<N>& F, double (&e)[N]
             for (int c = 0; c < N; ++c) F.Q[r][c] = r == c ? 1.0 : 0.0;
     }
     bool ok = true;
-    static_for<0, N - 1>([&](auto lt) __attribute__((always_inline)) { ok = ql_deflate_small<N, VEC, decltype(lt)::value>(F, e) && ok; });
+    static_for<0, N - 1>([&](auto lt) __attribute__((always_inline)) {
+        constexpr int L = decltype(lt)::value;
+        if constexpr (N == 4 && L < 2) ok = ql_deflate_small<N, VEC, L>(F, e, guided, L == 0 ? g0 : g1) && ok;
+        else ok = ql_deflate_small<N, VEC, L>(F, e) && ok;
+    });
     return ok;
 }
 
