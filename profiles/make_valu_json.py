@@ -11,6 +11,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
 # (a key "a+b+c" sums the per-dispatch counts of several kernels that each cover the same points)
 SOURCES = [
+    # round 5, final build: r05c (the two-call headline step), r05ccfg (bench_configs.py B D E), r05p (leg P)
+    ("k_grid_rows<2,1>", "r05c/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r05c/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r05ccfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r05ccfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_e16<1>", "r05ccfg/pmc_per_dispatch.json", "k_e16<1>", 65 ** 3),
+    ("k_mesh_evals<2,1>", "r05ccfg/pmc_per_dispatch.json", "k_mesh_evals<2,1>", 1024 * 1024),
+    ("k_chain_prod_tile<8,2>", "r05ccfg/pmc_per_dispatch.json", "k_chain_prod_tile<8,2,false>", 65 ** 3),
+    ("k_solve_small_multi<2,false,2>", "r05ccfg/pmc_per_dispatch.json", "k_solve_small_multi<2,false,2>", 1024 * 1024),
+    ("k_solve_small<2,0,true>", "r05ccfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
     # round 4, final build: r04j (the two-call step), r04k (--fused-headline), r04jcfg (bench_configs.py B D E under TBK_TW16_STREAMS=1)
     ("k_grid_rows_flux<2,1,1>", "r04k/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
     ("k_grid_rows<2,1>", "r04j/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
@@ -55,7 +65,7 @@ FLOPS = {
     "k_flux_rows<1,2>": (2 * 2 * 8 + 18 + 30, "plaquette nocc=1 n=2: two links x 2 cmadd + product of four link variables 18 + atan2 30"),
     "k_grid_rows_flux<2,1,1>": (15 * 8 + 60 + 24 + 2 * 2 * 8 + 18 + 30, "the two rows above in one pass"),
     # Kane-Mele: 10 slots, 9 hops of 2x2 blocks + onsite -> ~60 merged scalar terms
-    "k_grid_rows<4,1>": (60 * 8 + (16.0 / 3.0) * 64 + 12 * 64 + 6 * 16, "mesh solve n=4: 60 terms x 8 + Householder 341 + QL with vectors 768 + phases 96"),
+    "k_grid_rows<4,1>": (60 * 8 + (16.0 / 3.0) * 64 + 12 * 64 + 6 * 16, "mesh solve n=4: 60 terms x 8 + Householder 341 + QL with vectors 768 + phases 96 (the model of rounds 2-4, kept so that the fraction stays comparable; round 5's guided sweeps do ~25 % less QL work than it assumes)"),
     "k_flux_rows<2,4>": (2 * 4 * 4 * 8 + 2 * 14 + 18 + 30, "plaquette nocc=2 n=4: two links x 4 entries x 4 cmadd + two 2x2 dets + product + atan2"),
     # cubic16: 136 slots x 4 lattice vectors (R-grouped) = 544 complex multiply-adds
     "k_tw16<1>": (544 * 8 + _eig16(16) + 6 * 256, "mesh solve n=16: 544 cmadd assembly + tridiagonalise 21.8k + QL 7.7k + twisted 2.6k + Newton-Schulz 16.4k + back-transform 16.4k + phases 1.5k"),
