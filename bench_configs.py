@@ -200,7 +200,7 @@ def single_gpu(which, reps):
                     "term_evals_per_s_list": nk / t_list * 1e3 * nterm,
                     "grid": G, "solve_on_grid_ms": t_grid, "kpts_per_s_grid": G ** 3 / t_grid * 1e3,
                     "term_evals_per_s_grid": G ** 3 / t_grid * 1e3 * nterm, "kernels_ms": kern,
-                    "roofline": {"solve_list": {"bound": "fp64 VALU issue (the assembly's multiply-adds and the 8 x 8 Jacobi); the table streams from L2 by scalar loads",
+                    "roofline": {"solve_list": {"bound": "fp64 VALU issue: the assembly's multiply-adds (~12 k instructions per k-point; the table streams from L2 by scalar loads), then Householder + QL on (d, e) (~3.5 k; cyclic Jacobi, ~20 k, until round 5)",
                                                 "hbm_frac": 8 * (3 + 8) * nk / (t_list * 1e-3) / 1e9 / HBM, "algorithmic_bytes_per_k": 8 * (3 + 8),
                                                 "assembly_useful_tflops": 8.0 * nterm * nk / (t_list * 1e-3) / 1e12},
                                  "solve_grid": {"bound": "fp64 VALU issue", "hbm_frac": 16 * 64 * G ** 3 / (t_grid * 1e-3) / 1e9 / HBM,
@@ -239,7 +239,7 @@ def single_gpu(which, reps):
         out.append({"config": "H: hybrid Wannier centres, 16-layer cubic slab, wf_array([513,513]), position_hwf_mesh(range(8), dir=2)",
                     "points": npt, "nocc": nocc, "n": 16, "call_ms_incl_download": best * 1e3, "points_per_s_call": npt / best,
                     "kernels_ms": kern, "device_ms": dev_ms, "points_per_s_device": npt / (dev_ms * 1e-3) if dev_ms > 0 else None,
-                    "roofline": {"bound": "fp64 VALU issue / latency of the batched 8 x 8 eigen-solve (k_solve_reg)",
+                    "roofline": {"bound": "position matrices: HBM; then the batched 8 x 8 eigen-solve (k_solve_reg: the direct solver since round 5 when no vectors are asked for)",
                                  "algorithmic_bytes_per_point": 16 * nocc * 16 + 8 * nocc,
                                  "hbm_frac": (16 * nocc * 16 + 8 * nocc) * npt / (dev_ms * 1e-3) / 1e9 / HBM if dev_ms > 0 else None},
                     "check": {"centres_in_slab": bool(np.all((hwfc > -0.5) & (hwfc < 16.5))), "mean_centre": float(hwfc.mean())}})

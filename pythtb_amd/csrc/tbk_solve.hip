@@ -187,7 +187,7 @@ struct SmallFact {
 // QL with Wilkinson shifts on (d, e), the rotations accumulated in the real Q (VEC).
 template <int N, bool VEC>
 __device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], SmallFact<N>& F, double (&e)[N]) {
-    static_assert(N == 3 || N == 4, "ql_small: n = 3, 4");
+    static_assert(N >= 3 && N <= 8 && (N <= 4 || !VEC), "ql_small: n = 3, 4 with eigenvectors, 3..8 without");
     double (&d)[N] = F.d;
     cd delta{1.0, 0.0};                        // D_{K+1} = D_K t_K / |t_K| makes the subdiagonal real
     F.dph[0] = cd{1.0, 0.0};

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
                 const cd ph = phase_of_R(z, mv.rvec[r]);
                 const cd* u = mv.rblock + (size_t)r * NS;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) cfma(acc[s], u[s], ph);
+                for (int s = 0; s < NS; ++s) cfma_x(acc[s], u[s], ph);      // (two fused operations per component; `cfma` as written is three)
             }
             int slot = 0;
 #pragma unroll
@@ -164,6 +164,21 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
 #pragma unroll
             for (int b = 0; b < N; ++b) M.v[i][b] = cd{sub + L * i == b ? 1.0 : 0.0, 0.0};
     }
+    if constexpr (!VEC && L == 1) {
+        // Eigenvalues only (band structures, DOS: what a Wannier-interpolated model is mostly asked for): the DIRECT solver of the
+        // n <= 4 kernels -- Householder on the upper triangle, then implicit QL on (d, e), one loop per deflation index
+        // (tridiag_small / ql_deflate_small, tbk_solve.hip) -- instead of cyclic Jacobi on the complex matrix: ~3.5 k instead of
+        // ~20 k instructions per 8 x 8 matrix (6 sweeps x 28 rotations x ~120).  Eigenvectors keep the Jacobi sweeps below: the real
+        // Q of the direct solver would need N^2 more registers than a lane has.
+        SmallFact<N> F;
+        const bool ok = ql_small_core<N, false>(M.dg, M.up, F);
+#pragma unroll
+        for (int b = 0; b < N; ++b) M.dg[b] = F.d[b];
+        if (!ok) {
+            int* fl = MODE == 1 ? G.flags : Lst.flags;
+            if (fl) fl[0] = 1;
+        }
+    } else {
     // The loop leaves on a WAVE-UNIFORM condition (no lane has off-diagonal weight left); a lane that is done idles behind its
     // EXEC bit.  After a per-lane `break` the compiler keeps every live-out value of the divergent loop twice -- the running one
     // and "the value of the lanes that have left": here the whole of A and V (tbk_solve.hip, ql_deflate_small, measured it:
@@ -186,6 +201,7 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
     if (work) {
         int* fl = MODE == 1 ? G.flags : Lst.flags;
         if (fl) fl[0] = 1;
+    }
     }
     int rk[N];
     double sorted[N];
