@@ -414,11 +414,45 @@ __device__ __forceinline__ bool ql_lower_roots4(const double (&d)[4], const doub
     return true;
 }
 
+// The same for 3 x 3: the LOWEST root of x^3 + p x + q (T centred and scaled), x = 2 m cos((theta + 2 pi) / 3) with m = sqrt(-p / 3),
+// cos theta = -q / (2 m^3) -- the first-sweep shift of index 0 (index 1 is a block of two: Wilkinson's shift is exact there).
+__device__ __forceinline__ bool ql_lowest_root3(const double (&d)[3], const double (&e)[3], double& x1) {
+    const double nrm = fmax(fmax(fmax(fabs(d[0]), fabs(d[1])), fabs(d[2])), fmax(fabs(e[0]), fabs(e[1])));
+    const double s = __builtin_amdgcn_rcp(nrm);
+    const double mu = (d[0] + d[1] + d[2]) * (1.0 / 3.0);
+    const double a0 = (d[0] - mu) * s, a1 = (d[1] - mu) * s, a2 = (d[2] - mu) * s;
+    const double f0 = e[0] * s, f1 = e[1] * s;
+    const double b0 = f0 * f0, b1 = f1 * f1;
+    // det(x - T') = x^3 + p x + q: p = sum of the principal 2 x 2 minors, q = -det T'
+    const double p = fma(a0, a1, fma(a0, a2, a1 * a2)) - (b0 + b1);
+    const double q = -(fma(a0 * a1, a2, fma(-b0, a2, -b1 * a0)));
+    const double m2 = p * (-1.0 / 3.0);
+    if (!(m2 > 1e-30) || !(nrm > 0.0)) return false;
+    const double im = __builtin_amdgcn_rsq(m2), m = m2 * im;
+    const float arg = fminf(1.0f, fmaxf(-1.0f, (float)(-0.5 * q * (im * im * im))));
+    const float ax = fabsf(arg);
+    float pl = -0.0012624911f;
+    pl = fmaf(pl, ax, 0.0066700901f);
+    pl = fmaf(pl, ax, -0.0170881256f);
+    pl = fmaf(pl, ax, 0.0308918810f);
+    pl = fmaf(pl, ax, -0.0501743046f);
+    pl = fmaf(pl, ax, 0.0889789874f);
+    pl = fmaf(pl, ax, -0.2145988016f);
+    pl = fmaf(pl, ax, 1.5707963050f);
+    float th = __builtin_sqrtf(1.0f - ax) * pl;
+    th = arg < 0.0f ? 3.14159265f - th : th;
+    // the three roots are 2 m cos((theta - 2 pi k) / 3); the lowest is k = 1 ... in revolutions for v_cos_f32
+    const float c = __builtin_amdgcn_cosf((th + 6.28318531f) * (1.0f / (3.0f * 6.28318531f)));
+    x1 = fma(2.0 * m * (double)c, nrm, mu);
+    return true;
+}
+
 template <int N, bool VEC>
 __device__ __forceinline__ bool ql_iterate_small(SmallFact<N>& F, double (&e)[N]) {
     bool guided = false;
     double g0 = 0.0, g1 = 0.0;
     if constexpr (N == 4) guided = ql_lower_roots4(F.d, e, g0, g1);
+    if constexpr (N == 3) guided = ql_lowest_root3(F.d, e, g0);
     if (VEC) {
 #pragma unroll
         for (int r = 0; r < N; ++r)
@@ -428,7 +462,7 @@ __device__ __forceinline__ bool ql_iterate_small(SmallFact<N>& F, double (&e)[N]
     bool ok = true;
     static_for<0, N - 1>([&](auto lt) __attribute__((always_inline)) {
         constexpr int L = decltype(lt)::value;
-        if constexpr (N == 4 && L < 2) ok = ql_deflate_small<N, VEC, L>(F, e, guided, L == 0 ? g0 : g1) && ok;
+        if constexpr ((N == 4 && L < 2) || (N == 3 && L == 0)) ok = ql_deflate_small<N, VEC, L>(F, e, guided, L == 0 ? g0 : g1) && ok;
         else ok = ql_deflate_small<N, VEC, L>(F, e) && ok;
     });
     return ok;
