@@ -185,9 +185,11 @@ struct SmallFact {
 // Householder tridiagonalisation on the UPPER triangle (real diagonal dg, up[r][c] for r < c: the rank-2 update touches
 // N (N + 1) / 2 entries instead of N^2 and nothing below the diagonal is kept -- 64 -> 28 registers at N = 4), then implicit
 // QL with Wilkinson shifts on (d, e), the rotations accumulated in the real Q (VEC).
-template <int N, bool VEC>
-__device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], SmallFact<N>& F, double (&e)[N]) {
-    static_assert(N >= 3 && N <= 8 && (N <= 4 || !VEC), "ql_small: n = 3, 4 with eigenvectors, 3..8 without");
+// `put_u(K, r, w_r)`: where the normalised reflector K goes, entry r > K (all zero when there was nothing to reflect).  The n <= 4
+// kernels keep it in F.us (registers); k_solve_regd (n = 5..8 with eigenvectors) sends it to LDS.
+template <int N, bool VEC, class PutU>
+__device__ __forceinline__ void tridiag_small_to(double (&dg)[N], cd (&up)[N][N], SmallFact<N>& F, double (&e)[N], PutU&& put_u) {
+    static_assert(N >= 3 && N <= 8, "ql_small: n = 3..8");
     double (&d)[N] = F.d;
     cd delta{1.0, 0.0};                        // D_{K+1} = D_K t_K / |t_K| makes the subdiagonal real
     F.dph[0] = cd{1.0, 0.0};
@@ -258,7 +260,7 @@ __device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], S
             }
             if (VEC) {
 #pragma unroll
-                for (int r = 0; r < N; ++r) F.us[K][r] = u[r];
+                for (int r = K + 1; r < N; ++r) put_u(K, r, u[r]);
             }
         }
         d[K] = dg[K];
@@ -274,6 +276,12 @@ __device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], S
     }
     d[N - 1] = dg[N - 1];
     e[N - 1] = 0.0;
+}
+
+template <int N, bool VEC>
+__device__ __forceinline__ void tridiag_small(double (&dg)[N], cd (&up)[N][N], SmallFact<N>& F, double (&e)[N]) {
+    static_assert(N <= 4 || !VEC, "tridiag_small keeps the reflectors in registers: n = 3, 4 with eigenvectors, 3..8 without");
+    tridiag_small_to<N, VEC>(dg, up, F, e, [&](const int K, const int r, const cd w) __attribute__((always_inline)) { F.us[K][r] = w; });
 }
 
 // implicit QL on (F.d, e), rotations accumulated in F.Q (VEC).  Returns false when the iteration ran into LAPACK's limit

@@ -238,6 +238,158 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
     }
 }
 
+// ---- n = 5..8 WITH eigenvectors by the direct method (round 5): Householder on the upper triangle, implicit QL with the rotations
+// accumulated in the REAL Q, then one band at a time Z[:, b] = H_0 .. H_{N-3} D Q[:, b] (the factored solver of the n <= 4 mesh kernels,
+// tbk_solve.hip).  Cyclic Jacobi on the complex matrix with V -- the kernel above -- spends ~6 sweeps x 28 rotations x ~250
+// instructions on an 8 x 8 matrix (41 k) and needs 256 VGPRs + AGPRs for A and V; this is ~8 k.  Q takes N^2 registers, so the
+// normalised reflectors -- N (N - 1) / 2 - 1 complex numbers per matrix -- wait in LDS, [quantity][lane]: 27 KB per wavefront at
+// n = 8, hence 64-thread workgroups (five of them share a compute unit).  One lane per matrix; bands go out to the plane of
+// their rank like in the kernel above.
+template <int N>
+__host__ __device__ constexpr int regd_nu() { return N * (N - 1) / 2 - 1; }
+
+template <int N, int MODE>
+__global__ __launch_bounds__(64) void k_solve_regd(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G) {
+    extern __shared__ __align__(16) unsigned char lds_regd[];
+    cd* const Rf = reinterpret_cast<cd*>(lds_regd);           // [regd_nu<N>()][64]
+    constexpr int NS = N * (N + 1) / 2;
+    const int lane = threadIdx.x;
+    const int64_t id_raw = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = id_raw < nk;
+    const int64_t id = live ? id_raw : nk - 1;                // idle tail lanes shadow the last point
+    double kk[4] = {0.0, 0.0, 0.0, 0.0};
+    bool wrap[4] = {false, false, false, false};
+    double dg[N];
+    cd up[N][N];
+    if constexpr (MODE == 2) {
+        const cd* h = Lst.ham + id * (int64_t)(N * N);
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            dg[a] = h[a * N + a].x;
+#pragma unroll
+            for (int b = a + 1; b < N; ++b) up[a][b] = h[a * N + b];
+        }
+    } else {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (d < mv.dim_k) kk[d] = Lst.k[id * mv.dim_k + d];
+        } else {
+            grid_point(G, id, kk, wrap);
+        }
+        cd z[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
+        if (mv.nR > 0) {                                      // R-grouped table: one phase per lattice vector (see k_solve_reg)
+            cd acc[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = cd{0.0, 0.0};
+            for (int r = 0; r < mv.nR; ++r) {
+                const cd ph = phase_of_R(z, mv.rvec[r]);
+                const cd* u = mv.rblock + (size_t)r * NS;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) cfma_x(acc[s], u[s], ph);
+            }
+            int slot = 0;
+#pragma unroll
+            for (int a = 0; a < N; ++a)
+#pragma unroll
+                for (int b = a; b < N; ++b, ++slot) {
+                    if (b == a) dg[a] = acc[slot].x; else up[a][b] = acc[slot];
+                }
+        } else {
+            int slot = 0;
+#pragma unroll
+            for (int a = 0; a < N; ++a)
+#pragma unroll
+                for (int b = a; b < N; ++b, ++slot) {
+                    const cd s = slot_sum(mv, slot, z);
+                    if (b == a) dg[a] = s.x; else up[a][b] = s;
+                }
+        }
+    }
+    SmallFact<N> F;
+    double e[N];
+    // reflector K, entry r > K  ->  row K (N - 1) - K (K - 1) / 2 + (r - K - 1) of this wavefront's LDS table
+    tridiag_small_to<N, true>(dg, up, F, e, [&](const int K, const int r, const cd w) __attribute__((always_inline)) {
+        Rf[(K * (N - 1) - K * (K - 1) / 2 + (r - K - 1)) * 64 + lane] = w;
+    });
+    asm volatile("" ::: "memory");
+    const bool ok = ql_iterate_small<N, true>(F, e);
+    if (!ok) {
+        int* fl = MODE == 1 ? G.flags : Lst.flags;
+        if (fl) fl[0] = 1;
+    }
+    int rk[N];
+    double sorted[N];
+    ranks_small<N>(F.d, rk, sorted);
+    if constexpr (MODE == 1) {
+        unsigned long long* shard = G.gaps + (size_t)(blockIdx.x & (TBK_GAP_SHARDS - 1)) * N;
+#pragma unroll
+        for (int b = 0; b + 1 < N; ++b) gap_min_wave(shard, b, live ? sorted[b + 1] - sorted[b] : INFINITY);
+    } else {
+        if (live) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) Lst.eval[(int64_t)b * nk + id] = sorted[b];
+        }
+    }
+    // the orbital phases go into D once: Z = F H_0 .. H_{N-3} D Q needs them on every component of every band, and
+    // F H = (F H F^+) F with F H F^+ = 1 - (F w)(F w)^+ ... but the reflectors sit in LDS; cheaper here: N products per band
+    cd fo[N];
+#pragma unroll
+    for (int o = 0; o < N; ++o) {
+        cd f{1.0, 0.0};
+        if constexpr (MODE != 2) {
+            if (mv.nspin == 2 && (o & 1)) f = fo[o - (o > 0)];           // both spin components of an orbital share its phase
+            else f = cconj(expi2pi(kdot(kk, mv.orb[o])));
+        }
+        fo[o] = f;
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int o = 0; o < N; ++o)
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (wrap[d]) fo[o] = cmul(fo[o], G.pbc[d * N + o]);
+    }
+    asm volatile("" ::: "memory");
+    if (live) {
+        static_for<0, N>([&](auto bt) __attribute__((always_inline)) {
+            constexpr int b = decltype(bt)::value;
+            // (every band reads the reflectors from LDS again: left to itself the compiler reads them once and keeps all
+            // N (N - 1) / 2 - 1 of them -- 108 registers at n = 8, through AGPR copies -- for the sake of 27 LDS reads per band)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            cd z[N];
+#pragma unroll
+            for (int r = 0; r < N; ++r) z[r] = cd{F.dph[r].x * F.Q[r][b], F.dph[r].y * F.Q[r][b]};
+#pragma unroll
+            for (int K = N - 3; K >= 0; --K) {
+                const cd* uK = Rf + (K * (N - 1) - K * (K - 1) / 2 - (K + 1)) * 64 + lane;      // entry r at uK[r * 64]
+                cd w{0.0, 0.0};
+#pragma unroll
+                for (int r = K + 1; r < N; ++r) {
+                    const cd u = uK[r * 64];
+                    w.x = fma(u.y, z[r].y, fma(u.x, z[r].x, w.x));
+                    w.y = fma(-u.y, z[r].x, fma(u.x, z[r].y, w.y));
+                }
+#pragma unroll
+                for (int r = K + 1; r < N; ++r) {
+                    const cd u = uK[r * 64];
+                    z[r].x = fma(u.y, w.y, fma(-u.x, w.x, z[r].x));
+                    z[r].y = fma(-u.y, w.x, fma(-u.x, w.y, z[r].y));
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < N; ++o) {
+                const cd val = cmul_x(z[o], fo[o]);
+                if constexpr (MODE == 1) wf_at(G.wv, rk[b], id)[o] = val;
+                else Lst.evec[((int64_t)rk[b] * nk + id) * N + o] = val;
+            }
+        });
+    }
+}
+
 // lanes per matrix when eigenvectors are wanted
 static int reg_lanes(int) {
 #ifdef TBK_REG_MULTILANE
@@ -251,6 +403,14 @@ template <int N, int MODE, bool VEC>
 static int launch_reg_n(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G) {
     const int lanes = VEC ? reg_lanes(N) : 1;
     const unsigned blocks = (unsigned)((nk * lanes + 255) / 256);
+    if constexpr (VEC) {
+        if (lanes == 1 && tbk_knobs().reg_direct != 0) {     // the direct method (TBK_REG_DIRECT=0: the Jacobi kernel, for A/B runs)
+            const size_t lds = (size_t)regd_nu<N>() * 64 * sizeof(cd);
+            hipLaunchKernelGGL((k_solve_regd<N, MODE>), dim3((unsigned)((nk + 63) / 64)), dim3(64), lds, ctx->stream, mv, nk, L, G);
+            TBK_HIP(hipGetLastError());
+            return TBK_OK;
+        }
+    }
     if constexpr (VEC) {
         switch (lanes) {
 #ifdef TBK_REG_MULTILANE
