@@ -552,11 +552,19 @@ __device__ __forceinline__ void sort_fact(SmallFact<N>& F) {
         cmpxchg_fact<N, 1, 2>(F);
         cmpxchg_fact<N, 0, 1>(F);
     } else if constexpr (N == 4) {
-        cmpxchg_fact<N, 0, 1>(F);
-        cmpxchg_fact<N, 2, 3>(F);
-        cmpxchg_fact<N, 0, 2>(F);
-        cmpxchg_fact<N, 1, 3>(F);
-        cmpxchg_fact<N, 1, 2>(F);
+        // With the guided first sweeps (ql_lower_roots4) index 0 deflates to the lowest eigenvalue and index 1 to the second, so
+        // only the last pair can be out of order -- unless a guess missed or T split.  One wave-uniform test decides between
+        // one compare-exchange and the full network (5): most wavefronts take the short way.
+        const bool nearly = F.d[0] <= F.d[1] && F.d[1] <= fmin(F.d[2], F.d[3]);
+        if (__builtin_amdgcn_ballot_w64(!nearly) == 0) {
+            cmpxchg_fact<N, 2, 3>(F);
+        } else {
+            cmpxchg_fact<N, 0, 1>(F);
+            cmpxchg_fact<N, 2, 3>(F);
+            cmpxchg_fact<N, 0, 2>(F);
+            cmpxchg_fact<N, 1, 3>(F);
+            cmpxchg_fact<N, 1, 2>(F);
+        }
     }
 }
 
