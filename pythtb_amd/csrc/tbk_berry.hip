@@ -408,6 +408,7 @@ struct FluxArgs {
     int64_t nwaves;    // nslices * bps
     int bpb;           // blocks per slice of the row kernel (4 wave tiles each)
     int fused;         // row kernel: last-arriving block finishes the sum (else k_flux_reduce does)
+    int ascending;     // row kernel: tiles dealt oldest rows first (else newest first)
     unsigned* counters;  // [nslices][16] arrival tickets (8 shards + top), zero between launches
     double* totals;    // [nslices]
 #ifdef TBK_DIAG
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(256) void k_flux_rows(const FluxArgs A) {
     // Tiles are dealt in DESCENDING row order: the array was usually written a moment ago by solve_on_grid, rows
     // ascending, so the rows still sitting in the last-level cache (and not yet written back) are the last ones --
     // reading newest-first takes them from the cache while the older rows' write-back drains.
-    const int t = live ? A.bps - 1 - (blk * 4 + wib) : A.bps - 1;
+    const int t = live ? (A.ascending ? blk * 4 + wib : A.bps - 1 - (blk * 4 + wib)) : A.bps - 1;
     const int trow = t / A.ncolw, colw = t - trow * A.ncolw;
     const int ia0 = trow * A.ti;
     const int ia1 = min(ia0 + A.ti, A.na);
@@ -854,6 +855,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
     A.nwaves = nslices * A.bps;
     A.bpb = (A.bps + 3) / 4;
     A.fused = tbk_knobs().flux_fused;
+    A.ascending = tbk_knobs().flux_order == 1 ? 1 : 0;
 #ifdef TBK_DIAG
     A.ablate = tbk_knobs().ablate_flux;
 #endif

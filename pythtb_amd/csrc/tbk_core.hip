@@ -68,6 +68,7 @@ static void knobs_parse() {
     geti("TBK_GRID_KERNEL", k.grid_kernel);
     geti("TBK_FLUX_TI", k.flux_ti);
     geti("TBK_FLUX_FUSED", k.flux_fused);
+    geti("TBK_FLUX_ORDER", k.flux_order);
     geti("TBK_REG_DIRECT", k.reg_direct);
     geti("TBK_FLUX_SLICES", k.flux_slices);
     geti("TBK_POLL_DONE", k.poll_done);

@@ -76,6 +76,7 @@ struct TbkKnobs {
     int poll_done = 1;          // TBK_POLL_DONE     0: small calls wait with hipStreamSynchronize instead of polling the completion word
     int flux_slices = 1;        // TBK_FLUX_SLICES   0: planes without the fastest mesh axis on the row kernel instead of k_flux_slices (lane = slice)
     int flux_fused = 0;         // TBK_FLUX_FUSED    1: final flux sum inside the kernel
+    int flux_order = -1;        // TBK_FLUX_ORDER    0: row tiles newest rows first, 1: oldest first (default: by the array's size)
     int trigv_from = -1;        // TBK_TRIGV_FROM    smallest n of the workgroup-scale direct eigenvector path (default 65; A/B runs down to 17)
     int chain_ws_mb = 1024;     // TBK_CHAIN_WS_MB   link-matrix workspace per batch of strings, MiB
     int mesh_rows = 1;          // TBK_MESH_ROWS     0: eigenvalues on a generated uniform mesh by the list kernel on the generated list instead of the row kernel k_mesh_evals
