@@ -457,3 +457,77 @@ def test_flux_of_planes_without_the_fastest_axis(tb, n, nspin, occ, mesh):
             assert a.shape == b.shape and np.max(np.abs(a - b)) < 1e-11 * max(1.0, np.sqrt(mesh[d0] * mesh[d1])), (d0, d1)
             ind = np.asarray(w.berry_flux(occ, [d0, d1], individual_phases=True))
             assert np.max(np.abs(ind.sum(axis=(-2, -1)) - a)) < 1e-10
+
+
+# ------------------------------------------ round 5: the direct solvers of 3..8 states on matrices with special structure
+def _special_hermitian(n, rng):
+    """Supplied matrices that stress the direct small solvers (tridiag_small / ql_deflate_small, the closed-form first-sweep shifts of
+    n = 3, 4, k_solve_regd): generic, multiples of the identity, diagonal, block-diagonal (T splits), every level double (Kramers-like),
+    nearly double (split by 1e-12 and 1e-7), clustered, graded over 12 orders of magnitude, one huge scale, tiny scale, zero matrix."""
+    def conj_by_random_unitary(lev):
+        u = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))[0]
+        a = (u * lev) @ u.conj().T
+        return 0.5 * (a + a.conj().T)
+    out = []
+    for _ in range(40):
+        a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        out.append(0.5 * (a + a.conj().T))
+    out.append(np.identity(n) * 1.75)
+    out.append(np.zeros((n, n)))
+    out.append(np.diag(rng.standard_normal(n)).astype(complex))
+    blk = np.zeros((n, n), dtype=complex)
+    h = n // 2
+    for lo, hi in ((0, h), (h, n)):
+        a = rng.standard_normal((hi - lo, hi - lo)) + 1j * rng.standard_normal((hi - lo, hi - lo))
+        blk[lo:hi, lo:hi] = 0.5 * (a + a.conj().T)
+    out.append(blk)
+    for split in (0.0, 1e-12, 1e-7):
+        lev = np.repeat(np.sort(rng.standard_normal((n + 1) // 2)), 2)[:n] + np.tile([0.0, split], (n + 1) // 2)[:n]
+        for _ in range(6):
+            out.append(conj_by_random_unitary(lev))
+    out.append(conj_by_random_unitary(1.0 + 1e-9 * rng.standard_normal(n)))            # one tight cluster
+    out.append(conj_by_random_unitary(10.0 ** np.linspace(-6, 6, n)))                   # graded
+    out.append(conj_by_random_unitary(rng.standard_normal(n)) * 1e150)
+    out.append(conj_by_random_unitary(rng.standard_normal(n)) * 1e-150)
+    t = np.diag(rng.standard_normal(n)).astype(complex)                                 # already tridiagonal, real couplings
+    for i in range(n - 1):
+        t[i, i + 1] = t[i + 1, i] = rng.standard_normal()
+    out.append(t)
+    return np.array(out)
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 8])
+def test_direct_small_solvers_on_special_matrices(tb, n):
+    """_sol_ham-type calls (pythtb.py:927-953) through tbk_eigh_batch, eigenvalues alone and with eigenvectors; for 5..8 states also the
+    register-Jacobi kernel the direct method replaced (TBK_REG_DIRECT=0) as a second opinion."""
+    from pythtb_amd import _lib
+    ctx = _lib.default_context()
+    h = _special_hermitian(n, np.random.default_rng(700 + n))
+    nk = len(h)
+    ref = np.linalg.eigvalsh(h)
+    scale = np.maximum(np.abs(ref).max(axis=1), 1e-300)
+
+    def run(with_vec):
+        ev = np.zeros((n, nk))
+        vec = np.zeros((n, nk, n), dtype=complex) if with_vec else None
+        hc = np.ascontiguousarray(h)
+        _lib.check(_lib.lib.tbk_eigh_batch(ctx.handle, n, _lib.dptr(hc.view(float)), nk, _lib.dptr(ev),
+                                           _lib.dptr(vec.view(float)) if with_vec else None))
+        return ev, vec
+    ev0, _ = run(False)
+    assert np.all(np.diff(ev0, axis=0) >= 0.0)
+    assert np.max(np.abs(ev0.T - ref) / scale[:, None]) < 4e-15
+    variants = [("direct", None)] + ([("jacobi", 0)] if n >= 5 else [])
+    for name, knob in variants:
+        if knob is None:
+            ev, vec = run(True)
+        else:
+            with _lib.knob("TBK_REG_DIRECT", knob):
+                ev, vec = run(True)
+        V = vec.transpose(1, 0, 2)                      # [k][band][comp]
+        assert np.max(np.abs(ev.T - ref) / scale[:, None]) < 4e-15, name
+        res = np.abs(np.einsum("kij,kbj->kbi", h, V) - V * ev.T[:, :, None]).reshape(nk, -1).max(axis=1) / scale
+        orth = np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.eye(n)).reshape(nk, -1).max(axis=1)
+        # (the Jacobi kernel's convergence test squares the entries: on the 1e-150 matrix it stops at a residual of 5e-13 |H| -- the
+        # direct method, which works on norms with rsqrt, does not have that cliff)
+        assert res.max() < (1e-14 if name == "direct" else 2e-12) and orth.max() < 1e-14, (name, res.max(), orth.max())
