@@ -14,8 +14,8 @@ SOURCES = [
     # round 5, final build: r05c (the two-call headline step), r05ccfg (bench_configs.py B D E), r05p (leg P)
     ("k_grid_rows<2,1>", "r05c/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
     ("k_flux_rows<1,2>", "r05c/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
-    ("k_grid_rows<4,1>", "r05ccfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
-    ("k_flux_rows<2,4>", "r05ccfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_grid_rows<4,1>", "r05dcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),      # (after the sort's short way)
+    ("k_flux_rows<2,4>", "r05dcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
     ("k_e16<1>", "r05ccfg/pmc_per_dispatch.json", "k_e16<1>", 65 ** 3),
     ("k_mesh_evals<2,1>", "r05ccfg/pmc_per_dispatch.json", "k_mesh_evals<2,1>", 1024 * 1024),
     ("k_chain_prod_tile<8,2>", "r05ccfg/pmc_per_dispatch.json", "k_chain_prod_tile<8,2,false>", 65 ** 3),
