@@ -75,6 +75,69 @@ struct SweepReg {
     }
 };
 
+// ---- S(k) from the R-grouped table, the table STREAMED THROUGH LDS by the wavefront in tiles of REG_TR lattice vectors (round 5).
+// The table (silicon: 93 lattice vectors x 36 slots = 53 KB) used to arrive by scalar loads, a block of slots at a time because
+// 36 complex numbers do not fit the scalar registers: ~10 dependent load -> wait -> use rounds per lattice vector, and at the one
+// or two wavefronts per SIMD these kernels run at nothing hides them -- a wavefront spent ~80 % of its life waiting (0.9 ms per
+// 65^3 for ~100 k cycles of arithmetic per wavefront).  Here tiles go from L2 straight into LDS (global_load_lds_dwordx4: no vector
+// registers in between -- staged through registers the allocator parked them in scratch next to the 36 accumulators), two tiles
+// ahead of the one being consumed as broadcast reads; the lattice vector itself comes the same way and goes into scalar registers
+// (readfirstlane) so that the loops over |R_d| stay scalar-controlled.  vmcnt counts the transfers in order, so "tile t has landed"
+// is "at most one tile's worth of transfers outstanding".  Same terms, same order, same operations as the scalar-load form: the
+// same bits.  One wavefront per workgroup (no workgroup barrier; the LDS operations of a wavefront execute in order).
+#define REG_TR 8
+template <int N>
+__host__ __device__ constexpr int reg_tile_nld() { return (REG_TR * (N * (N + 1) / 2) + 63) / 64; }        // transfers of 64 x 16 B per tile
+template <int N>
+__host__ __device__ constexpr int reg_tile_slots() { return (reg_tile_nld<N>() + 1) * 64; }               // + one row for the R's
+
+template <int N>
+__device__ __forceinline__ void reg_assemble_tiled(const ModelView& mv, const cd (&z)[4], cd* const tiles /* [2][reg_tile_slots] */,
+                                                   const int lane, cd (&acc)[N * (N + 1) / 2]) {
+    constexpr int NS = N * (N + 1) / 2;
+    constexpr int NLD = reg_tile_nld<N>();
+    constexpr int TS = reg_tile_slots<N>();
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int nR = mv.nR;
+    const int ntile = (nR + REG_TR - 1) / REG_TR;
+    const int64_t total = (int64_t)nR * NS;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = cd{0.0, 0.0};
+#define REG_ISSUE(T, BUF)                                                                                         \
+    {                                                                                                             \
+        const int64_t e0_ = (int64_t)(T) * REG_TR * NS;                                                           \
+        _Pragma("unroll") for (int j = 0; j < NLD; ++j) {                                                         \
+            const int64_t e_ = e0_ + j * 64 + lane;                                                               \
+            __builtin_amdgcn_global_load_lds((const void*)(mv.rblock + (e_ < total ? e_ : total - 1)), (lds_ptr)((BUF) + j * 64), 16, 0, 0); \
+        }                                                                                                         \
+        const int r_ = (T) * REG_TR + (lane < REG_TR ? lane : REG_TR - 1);                                       \
+        __builtin_amdgcn_global_load_lds((const void*)(mv.rvec + (r_ < nR ? r_ : nR - 1)), (lds_ptr)((BUF) + NLD * 64), 16, 0, 0);          \
+    }
+    REG_ISSUE(0, tiles)
+    if (ntile > 1) REG_ISSUE(1, tiles + TS)
+    for (int t = 0; t < ntile; ++t) {
+        cd* const buf = tiles + (t & 1) * TS;
+        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int nhere = min(REG_TR, nR - t * REG_TR);
+        for (int rr = 0; rr < nhere; ++rr) {
+            const int4 Rv = *reinterpret_cast<const int4*>(buf + NLD * 64 + rr);
+            const int4 Rs{__builtin_amdgcn_readfirstlane(Rv.x), __builtin_amdgcn_readfirstlane(Rv.y),
+                          __builtin_amdgcn_readfirstlane(Rv.z), __builtin_amdgcn_readfirstlane(Rv.w)};
+            const cd ph = phase_of_R(z, Rs);
+            const cd* u = buf + rr * NS;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) cfma_x(acc[s], u[s], ph);
+        }
+        // (every read of this buffer has been consumed by the multiply-adds above: it can take the tile after next)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (t + 2 < ntile) REG_ISSUE(t + 2, buf)
+    }
+#undef REG_ISSUE
+}
+
 // MODE 0: k list, 1: regular mesh into a wf_array (+ min gaps), 2: supplied matrices
 template <int N, int L, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G) {
@@ -113,6 +176,8 @@ __global__ __launch_bounds__(256) void k_solve_reg(const ModelView mv, const int
             cd acc[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) acc[s] = cd{0.0, 0.0};
+            // (the eigenvalue-only kernel runs three wavefronts per SIMD, which hide the scalar loads: the LDS tiles of
+            // reg_assemble_tiled measured 0.154 against 0.144 ms per 48^3 of silicon here and are used by k_solve_regd only)
             for (int r = sub; r < mv.nR; r += L) {
                 const cd ph = phase_of_R(z, mv.rvec[r]);
                 const cd* u = mv.rblock + (size_t)r * NS;
@@ -251,7 +316,8 @@ __host__ __device__ constexpr int regd_nu() { return N * (N - 1) / 2 - 1; }
 template <int N, int MODE>
 __global__ __launch_bounds__(64) void k_solve_regd(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G) {
     extern __shared__ __align__(16) unsigned char lds_regd[];
-    cd* const Rf = reinterpret_cast<cd*>(lds_regd);           // [regd_nu<N>()][64]
+    cd* const Rf = reinterpret_cast<cd*>(lds_regd);           // [regd_nu<N>()][64], then two table tiles (reg_assemble_tiled)
+    cd* const tiles = Rf + regd_nu<N>() * 64;
     constexpr int NS = N * (N + 1) / 2;
     const int lane = threadIdx.x;
     const int64_t id_raw = (int64_t)blockIdx.x * 64 + lane;
@@ -280,16 +346,9 @@ __global__ __launch_bounds__(64) void k_solve_regd(const ModelView mv, const int
         cd z[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
-        if (mv.nR > 0) {                                      // R-grouped table: one phase per lattice vector (see k_solve_reg)
+        if (mv.nR > 0) {                                      // R-grouped table: one phase per lattice vector, the table through LDS
             cd acc[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[s] = cd{0.0, 0.0};
-            for (int r = 0; r < mv.nR; ++r) {
-                const cd ph = phase_of_R(z, mv.rvec[r]);
-                const cd* u = mv.rblock + (size_t)r * NS;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) cfma_x(acc[s], u[s], ph);
-            }
+            reg_assemble_tiled<N>(mv, z, tiles, lane, acc);
             int slot = 0;
 #pragma unroll
             for (int a = 0; a < N; ++a)
@@ -405,7 +464,7 @@ static int launch_reg_n(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const Lis
     const unsigned blocks = (unsigned)((nk * lanes + 255) / 256);
     if constexpr (VEC) {
         if (lanes == 1 && tbk_knobs().reg_direct != 0) {     // the direct method (TBK_REG_DIRECT=0: the Jacobi kernel, for A/B runs)
-            const size_t lds = (size_t)regd_nu<N>() * 64 * sizeof(cd);
+            const size_t lds = ((size_t)regd_nu<N>() * 64 + 2 * (size_t)reg_tile_slots<N>()) * sizeof(cd);
             hipLaunchKernelGGL((k_solve_regd<N, MODE>), dim3((unsigned)((nk + 63) / 64)), dim3(64), lds, ctx->stream, mv, nk, L, G);
             TBK_HIP(hipGetLastError());
             return TBK_OK;
