@@ -1074,6 +1074,8 @@ __device__ __forceinline__ double uniform_d(const double v) {
 // the row's coefficient cells once (in parallel, one cell per lane) into LDS and
 // every point then costs (2 pmax + 1) complex FMAs per slot read as LDS broadcasts
 // -- no per-point table walk, no scalar-load latency chain, no sincospi.
+// (TBK_ROWS_OCC: empty in every build; profiles/dev_tu_rows4.sh defines it as __attribute__((amdgpu_waves_per_eu(N, 8))) to measure, by
+// the spill bytes it forces, how far the kernel is from the next occupancy step)
 #ifndef TBK_ROWS_OCC
 #define TBK_ROWS_OCC
 #endif
