@@ -26,8 +26,8 @@
 // a list and solved again by the QL-replay kernels of tbk_solve_ql16.inl (LIST mode), exactly as round 3's path did; the
 // decision depends on the matrix alone, so periodic images, halo rows and shard windows stay bit-identical.
 
-#define E16_REC 143                       // 16-byte entries of a matrix's reflector record: 119 elements of u_K packed by column,
-                                          // 16 phases of the diagonal unitary, 14 beta_K (7 entries), 1 spare; the stride keeps
+#define E16_REC 143                       // 16-byte entries of a matrix's reflector record: 119 elements of w_K packed by column,
+                                          // 16 phases of the diagonal unitary, 8 spare (round 4 kept beta_K there); the stride keeps
                                           // the four broadcasts of a read on different banks
 #define E16_XCH 144                       // 16-byte entries of the wavefront's exchange region (2304 B): q of a reflection,
                                           // (d, e) of T, Sturm counts, one matrix's V for the matrix cores
@@ -135,18 +135,18 @@ __device__ __forceinline__ void e16_pass2(cd (&a)[16], const cd u, const cd q) {
 #undef E16_BC
 // Step K on the rows of A (lane x = row x).  mag = |T[K+1][K]|, unit = T[K+1][K] / |T[K+1][K]| (1 when it vanishes): with a
 // reflection they are |x| and -alpha / |alpha|, both at hand -- no second square root for the phase fix.  rec: this matrix's
-// record, which keeps u_K UNSCALED with beta_K = 2 / (u^+ u) beside it for the back-transformation.
+// record, which keeps the NORMALISED reflector w_K = u_K sqrt(beta_K) (H_K = 1 - w w^+: no beta in the products here or in the
+// back-transformation).
+// Rows <= K are finished (row x is last read at step x - 1, its diagonal entry is never a column > K): nothing below masks them
+// out of the products -- what the passes leave in their columns > K is never read -- only out of the two sums over the rows.
 template <int K>
 __device__ __forceinline__ void e16_house(cd (&a)[16], const int x, e16_lcd* rec, double& mag, cd& unit) {
-    const bool below = x > K;
-    const cd xk = below ? a[K] : cd{0.0, 0.0};
+    const cd ak = a[K];
     // (decided on the entries below the subdiagonal alone, like LAPACK's zlarfg: see ql16_house)
-    const double rest = row_allsum(x > K + 1 ? cabs2(xk) : 0.0);
-    const cd alpha = cd{e16_bcast<K + 1>(a[K].x), e16_bcast<K + 1>(a[K].y)};   // A[K+1][K]
+    const double rest = row_allsum(x > K + 1 ? cabs2(ak) : 0.0);
+    const cd alpha = cd{e16_bcast<K + 1>(ak.x), e16_bcast<K + 1>(ak.y)};   // A[K+1][K]
     const double absa2 = cabs2(alpha);
-    const double sigma = rest + absa2;
     e16_lcd* const ru = rec + (e16_off(K) - (K + 1));
-    e16_ld* const betas = reinterpret_cast<e16_ld*>(rec + 135);
     double absa = 0.0;
     cd ph{1.0, 0.0};
     if (absa2 > 0.0) {
@@ -157,24 +157,27 @@ __device__ __forceinline__ void e16_house(cd (&a)[16], const int x, e16_lcd* rec
     mag = absa;
     unit = ph;
     if (rest > 0.0) {                                    // row-uniform
+        const double sigma = rest + absa2;
         const double inv_n = rsqrt_full(sigma), nrm = sigma * inv_n;
-        cd u = x == K + 1 ? cd{ph.x * (absa + nrm), ph.y * (absa + nrm)} : xk;
-        const double sb = rsqrt_full(nrm * (nrm + absa)), beta = sb * sb;   // beta = 2 / (u^+ u)
+        const double sb = rsqrt_full(nrm * (nrm + absa));                   // sqrt(beta), beta = 2 / (u^+ u)
+        cd w{ak.x * sb, ak.y * sb};
+        if (x == K + 1) {
+            const double t = (absa + nrm) * sb;
+            w = cd{ph.x * t, ph.y * t};
+        }
         mag = nrm;                                       // T[K+1][K] = -ph |x|
         unit = cd{-ph.x, -ph.y};
-        if (below) e16_put(ru + x, u);
-        if (x == 0) betas[K] = beta;
-        e16_dpp_ready(u);
+        if (x > K) e16_put(ru + x, w);
+        e16_dpp_ready(w);
         cd p{0.0, 0.0};
-        e16_pass1<K, K + 1>(a, u, p);
-        p = cd{p.x * beta, p.y * beta};
-        const double kappa = 0.5 * beta * row_allsum(u.x * p.x + u.y * p.y);
-        cd q = below ? cd{fma(-kappa, u.x, p.x), fma(-kappa, u.y, p.y)} : cd{0.0, 0.0};
+        e16_pass1<K, K + 1>(a, w, p);
+        const double ws = fma(w.x, p.x, w.y * p.y);
+        const double kappa = 0.5 * row_allsum(x > K ? ws : 0.0);
+        cd q{fma(-kappa, w.x, p.x), fma(-kappa, w.y, p.y)};
         e16_dpp_ready(q);
-        e16_pass2<K, K + 1>(a, u, q);
+        e16_pass2<K, K + 1>(a, w, q);
     } else {                                             // nothing to reflect: H_K = I
-        if (below) e16_put(ru + x, cd{0.0, 0.0});
-        if (x == 0) betas[K] = 0.0;
+        if (x > K) e16_put(ru + x, cd{0.0, 0.0});
     }
 }
 
@@ -280,7 +283,9 @@ __device__ double e16_dbg[64 * 16];
 #ifndef E16_NBISECT
 #define E16_NBISECT 8
 #endif
+#ifndef E16_NEWTON_MAX
 #define E16_NEWTON_MAX 12
+#endif
 #ifndef E16_NEWTON_TOL
 #define E16_NEWTON_TOL 5.820766091346741e-11   // 2^-34
 #endif
@@ -838,20 +843,16 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     }
 
     E16_MARK(1);
-    // ---- 1. tridiagonalisation; lane x ends up with d_x and e_x = |T[x+1][x]|, and with the phase of column x of D
-    double ee = 0.0;
-    cd delta{1.0, 0.0}, dx{1.0, 0.0};
-    auto step_phase = [&](const cd t, const int col) {
-        const double t2 = cabs2(t);
-        double mag = 0.0;
-        if (t2 > 0.0) {
-            const double inv = rsqrt_full(t2);
-            mag = t2 * inv;
-            delta = cmul(delta, cd{t.x * inv, t.y * inv});
-        }
-        if (x == col - 1) ee = mag;
-        if (x == col) dx = delta;
-    };
+    // ---- 1. tridiagonalisation.  d_x, e_x = |T[x+1][x]| and the phase of column x of D are final after step x - 1: the lane that
+    // owns them then (x == K + 1: one exec mask) parks them in LDS -- (d, e) in the matrix's slots of the exchange region, idle
+    // during the reflections, the phase in the record -- and every lane picks its own up afterwards.  (Kept in registers, the
+    // three were six conditional moves per step, and d_x a 15-deep select chain at the end.)
+    cd delta{1.0, 0.0};
+    e16_ld* const xde = reinterpret_cast<e16_ld*>(wxch + mat * 16);                     // [16] x (d, e)
+    if (x == 0) {
+        e16_put(rec + 119, cd{1.0, 0.0});
+        xde[0] = a[0].x;
+    }
     {
 #define TBK_E16_HOUSE(KK)                                     \
     {                                                         \
@@ -859,8 +860,11 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         cd unit;                                              \
         e16_house<KK>(a, x, rec, mag, unit);                  \
         delta = cmul(delta, unit);                            \
-        if (x == KK) ee = mag;                                \
-        if (x == KK + 1) dx = delta;                          \
+        if (x == KK + 1) {                                    \
+            e16_put(rec + 119 + (KK + 1), delta);             \
+            xde[2 * KK + 1] = mag;                            \
+            xde[2 * KK + 2] = a[KK + 1].x;                    \
+        }                                                     \
     }
         if constexpr (!(E16_SKIP & 1)) {
         TBK_E16_HOUSE(0) TBK_E16_HOUSE(1) TBK_E16_HOUSE(2) TBK_E16_HOUSE(3) TBK_E16_HOUSE(4) TBK_E16_HOUSE(5) TBK_E16_HOUSE(6)
@@ -868,11 +872,26 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         }
 #undef TBK_E16_HOUSE
     }
+    {
+        const cd t14 = rowbcast_c<15>(a[14]);            // T[15][14]: never reflected
+        const double t2 = cabs2(t14);
+        double mag = 0.0;
+        if (t2 > 0.0) {
+            const double inv = rsqrt_full(t2);
+            mag = t2 * inv;
+            delta = cmul(delta, cd{t14.x * inv, t14.y * inv});
+        }
+        if (x == 15) {
+            e16_put(rec + 119 + 15, delta);
+            xde[29] = mag;
+            xde[30] = a[15].x;
+            xde[31] = 0.0;
+        }
+    }
     E16_ORDER();
-    const cd t14 = rowbcast_c<15>(a[14]);                // T[15][14]: never reflected
-    step_phase(t14, 15);
-    const double dd = sel16<0>(a, x, cd{0.0, 0.0}).x;    // d_x = A[x][x]
-    e16_put(rec + 119 + x, dx);
+    const e16_d2 de_x = wxch[mat * 16 + x];
+    const double dd = de_x.x, ee = de_x.y;               // d_x = A[x][x], e_x (0 in lane 15)
+    E16_ORDER();
     E16_MARK(2);
     double d[16], e[16];
     E16_ORDER();
@@ -881,7 +900,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     int bl = 0, bh = 15;
     unsigned split = 0;
     bool flag = false;
-    e16_eigenvalue(dd, x < 15 ? ee : 0.0, d, e, n, j, wxch + mat * 16, scale, lam, bl, bh, split, flag, slot_u);
+    e16_eigenvalue(dd, ee, d, e, n, j, wxch + mat * 16, scale, lam, bl, bh, split, flag, slot_u);
     E16_MARK(3);
     double v[16], dlam = 0.0;
     bool bad = false;
@@ -1047,7 +1066,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     }
 
     E16_MARK(6);
-    // ---- 5. z = H_0 ( H_1 ( ... H_13 (D v))), H_K = I - beta_K u_K u_K^+; the reflectors are read from LDS by broadcast
+    // ---- 5. z = H_0 ( H_1 ( ... H_13 (D v))), H_K = I - w_K w_K^+; the reflectors are read from LDS by broadcast
     cd y[16];
 #pragma unroll
     for (int xx = 0; xx < 16; ++xx) {
@@ -1055,7 +1074,6 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         y[xx] = cd{ph.x * v[xx], ph.y * v[xx]};
     }
     if constexpr (!(E16_SKIP & 16)) {
-        const e16_ld* const betas = reinterpret_cast<const e16_ld*>(rec + 135);
         auto reflect = [&](auto KC) {
             constexpr int K = decltype(KC)::value;
             const e16_lcd* const ru = rec + (e16_off(K) - (K + 1));
@@ -1070,8 +1088,6 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
                 w.y = fma(u[xx].x, y[xx].y, w.y);
                 w.y = fma(-u[xx].y, y[xx].x, w.y);
             }
-            const double beta = betas[K];
-            w = cd{w.x * beta, w.y * beta};
 #pragma unroll
             for (int xx = K + 1; xx < 16; ++xx) {
                 // y_x -= u_x w
