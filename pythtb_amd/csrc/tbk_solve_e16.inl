@@ -29,9 +29,10 @@
 #define E16_REC 143                       // 16-byte entries of a matrix's reflector record: 119 elements of w_K packed by column,
                                           // 16 phases of the diagonal unitary, 8 spare (round 4 kept beta_K there); the stride keeps
                                           // the four broadcasts of a read on different banks
-#define E16_XCH 144                       // 16-byte entries of the wavefront's exchange region (2304 B): q of a reflection,
-                                          // (d, e) of T, Sturm counts, one matrix's V for the matrix cores
-#define E16_WAVE_LDS ((4 * E16_REC + E16_XCH) * 16)   // 11 456 B per wavefront: 3 wavefronts per SIMD fit 160 KB
+#define E16_XCH 160                       // 16-byte entries of the wavefront's exchange region (2560 B): the staged U_R, (d, e) of T
+                                          // (64), Sturm counts (32), (g, d g) of the scaled recurrence (64), one matrix's V for the
+                                          // matrix cores (144)
+#define E16_WAVE_LDS ((4 * E16_REC + E16_XCH) * 16)   // 11 712 B per wavefront: 3 wavefronts per SIMD fit 160 KB
 __host__ __device__ constexpr int e16_off(const int K) { return 15 * K - K * (K - 1) / 2; }   // first element of u_K
 
 // LDS through pointers that carry their address space (the loads and stores are ds_read / ds_write whatever the compiler can
@@ -204,26 +205,49 @@ __device__ __forceinline__ unsigned e16_signs(const double (&d)[16], const doubl
     return acc & 0xffffu;
 }
 
-// The same bits from the three-term recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} (bit: p_i and p_{i-1} differ in sign) for a
-// T that does not split: four full-rate instructions per position where the pivots take a quarter-rate reciprocal, and exact.
-// (With every e^2 > 0 a vanishing p_i has neighbours of opposite signs and counts once, as it should; |T| <= 1 here, so
-// |p_i| <= 3^16: no scaling needed.  A split T takes the pivots above: after a zero p_i of one block the rest would vanish.)
+// The same bits from the three-term recurrence p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2} for a T that does not split, in the
+// SCALED form s_i = p_i / m_i with m_i = e_{i-1}^2 m_{i-2} > 0 (m_{-1} = m_0 = 1): the coefficient of s_{i-2} becomes exactly one,
+//     s_i = (d_i - x) g_i s_{i-1} - s_{i-2},   g_i = m_{i-1} / m_i,
+// two multiply-adds per position on the tables g_i and d_i g_i (e16_eigenvalue forms them once per matrix, lane i its own entry)
+// where the plain recurrence takes three full-rate instructions and the pivots a quarter-rate reciprocal; the signs of s_i are those
+// of p_i (bit: p_i and p_{i-1} differ in sign; collected raw, the differences taken once at the end).  With every e^2 > 0 a
+// vanishing p_i has neighbours of opposite signs and counts once, as it should; |T| <= 1 and m_i >= 1e-250 here (a smaller m_i
+// sends the wavefront to the pivots, like a split T: after a zero p_i of one block the rest would vanish), so |s_i| <= 3^16 1e250.
+// Rows n.. (the padding of a matrix smaller than 16) are left out: the branch is scalar.
 template <int I>
-__device__ __forceinline__ void e16_count_poly_step(const double (&d)[16], const double (&e2)[16], const int n, const double x, double& p1,
-                                                    double& p2, unsigned& acc) {
-    {
-        const double p = I == 0 ? d[0] - x : fma(d[I] - x, p1, -e2[I > 0 ? I - 1 : 0] * p2);
-        acc = __builtin_amdgcn_alignbit(acc, (unsigned)(__double2hiint(p) ^ __double2hiint(p1)), 31);
-        p2 = p1;
-        p1 = p;
+__device__ __forceinline__ void e16_count_scaled_step(const double (&g)[16], const double (&dg)[16], const int n, const double x, double& s1,
+                                                      double& s2, unsigned& acc) {
+    const double s = fma(fma(-x, g[I], dg[I]), s1, -s2);
+    acc = __builtin_amdgcn_alignbit(acc, (unsigned)__double2hiint(s), 31);
+    s2 = s1;
+    s1 = s;
+    if constexpr (I + 1 < 16) {
+        if (I + 1 < 2 || I + 1 < n) e16_count_scaled_step<I + 1>(g, dg, n, x, s1, s2, acc);   // (nested: one way out, no copies per position)
     }
-    if constexpr (I + 1 < 16) e16_count_poly_step<I + 1>(d, e2, n, x, p1, p2, acc);
 }
-__device__ __forceinline__ unsigned e16_signs_poly(const double (&d)[16], const double (&e2)[16], const int n, const double x) {
-    double p1 = 1.0, p2 = 0.0;
+__device__ __forceinline__ unsigned e16_signs_scaled(const double (&g)[16], const double (&dg)[16], const int n, const double x) {
+    double s1 = 1.0, s2 = 0.0;
     unsigned acc = 0;
-    e16_count_poly_step<0>(d, e2, n, x, p1, p2, acc);
-    return acc & 0xffffu;
+    e16_count_scaled_step<0>(g, dg, n, x, s1, s2, acc);
+    const unsigned raw = acc & ((1u << n) - 1u);         // sign of p_0 in bit n - 1 .. of p_{n-1} in bit 0; p_{-1} = 1 is positive
+    return ((raw ^ (raw >> 1)) << (16 - n)) & 0xffffu;
+}
+// ... and with the derivative, for the Newton steps on an unsplit T: s'_i = (d_i - x) g_i s'_{i-1} - g_i s_{i-1} - s'_{i-2}
+// (p / p' = s / s': the scale cancels).  sgn collects the signs of s_0 .. s_{n-1}, newest in bit 0.
+template <int I>
+__device__ __forceinline__ void e16_newton_scaled_step(const double (&g)[16], const double (&dg)[16], const int n, const double x, double& s1,
+                                                       double& s2, double& ds1, double& ds2, unsigned& sgn) {
+    const double tg = fma(-x, g[I], dg[I]);
+    const double s = fma(tg, s1, -s2);
+    const double ds = fma(-g[I], s1, fma(tg, ds1, -ds2));
+    sgn = __builtin_amdgcn_alignbit(sgn, (unsigned)__double2hiint(s), 31);
+    s2 = s1;
+    ds2 = ds1;
+    s1 = s;
+    ds1 = ds;
+    if constexpr (I + 1 < 16) {
+        if (I + 1 < 2 || I + 1 < n) e16_newton_scaled_step<I + 1>(g, dg, n, x, s1, s2, ds1, ds2, sgn);
+    }
 }
 
 // One evaluation of the characteristic polynomial of the block [bl, bh] of T at x with its derivative and the number of sign
@@ -258,6 +282,20 @@ __device__ __forceinline__ double e16_next(const double v) {
 __device__ __forceinline__ double e16_prev(const double v) {
     const I2 i = __builtin_bit_cast(I2, v);
     const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x111, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, i.hi, 0x111, 0xf, 0xf, true)};
+    return __builtin_bit_cast(double, o);
+}
+
+__device__ __forceinline__ double e16_rcp(const double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    y = fma(fma(-p, y, 1.0), y, y);
+    y = fma(fma(-p, y, 1.0), y, y);
+    return y;
+}
+// value of lane x - N of the 16-lane row (row_shr:N); the lanes 0 .. N-1, which have no such neighbour, read 1.0
+template <int N>
+__device__ __forceinline__ double e16_shr_one(const double v) {
+    const I2 i = __builtin_bit_cast(I2, v);
+    const I2 o{__builtin_amdgcn_update_dpp(0, i.lo, 0x110 + N, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0x3ff00000, i.hi, 0x110 + N, 0xf, 0xf, false)};
     return __builtin_bit_cast(double, o);
 }
 
@@ -330,16 +368,37 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     gl -= 1e-13;
     gu += 1e-13;
     double e2[16];
+    // tables of the scaled recurrence (e16_signs_scaled): m_j = product of the e_{k-1}^2 over k = j, j - 2, .. >= 1 by a stride-2
+    // scan along the row, g_j = m_{j-1} / m_j; lane j forms entry j
+    const double ep = e16_prev(es);                      // scaled e_{j-1} (0 in lane 0)
+    double mj = j >= 1 && j < n ? ep * ep : 1.0;
+    mj *= e16_shr_one<2>(mj);
+    mj *= e16_shr_one<4>(mj);
+    mj *= e16_shr_one<8>(mj);
+    const double gj = e16_shr_one<1>(mj) * e16_rcp(mj);
+    // (wave-uniform) does any T of the wavefront split, or scale out of range?  No: the scaled recurrence; yes: the pivots
+    const bool splits = __builtin_amdgcn_ballot_w64((split & 0x7fffu & ((1u << (n - 1)) - 1u)) != 0 || (!(mj >= 1e-250) && j < n)) != 0;
+    e16_lcd* const xg = xd + 96;                         // (g, d g): past the four (d, e) blocks and the counts
     E16_ORDER();
     xd[j] = e16_d2{ds, es};
+    xg[j] = e16_d2{gj, ds * gj};
     E16_ORDER();
     // (the scaled e_i themselves stay in LDS until the eigenvalue is known: 32 registers the isolation and the Newton steps do not
-    // need -- they work on d and e^2 -- and that were being spilled to scratch here)
+    // need -- they work on (d, e^2), or on (g, d g) held in the same registers -- and that were being spilled to scratch here)
+    if (splits) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const e16_d2 t = xd[i];
-        d[i] = t.x;
-        e2[i] = fmax(t.y * t.y, 1e-300);                 // (1e-300 at the splits: 0 x inf never appears among the pivots)
+        for (int i = 0; i < 16; ++i) {
+            const e16_d2 t = xd[i];
+            d[i] = t.x;
+            e2[i] = fmax(t.y * t.y, 1e-300);             // (1e-300 at the splits: 0 x inf never appears among the pivots)
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const e16_d2 t = xg[i];
+            d[i] = t.x;                                  // g_i
+            e2[i] = t.y;                                 // d_i g_i
+        }
     }
     E16_ORDER();
     e16_lu2* const xch = reinterpret_cast<e16_lu2*>(xd - 16 * ((threadIdx.x & 63) >> 4) + 64) + 16 * ((threadIdx.x & 63) >> 4);   // counts: past the four (d, e) blocks
@@ -348,9 +407,7 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     // ---- one multisection shared by the 16 lanes: lane j looks at point j of 16 inside (gl, gu)
     const double w = (gu - gl) * (1.0 / 17.0);
     const double tj = fma(w, (double)(j + 1), gl);
-    // (wave-uniform) does any T of the wavefront split?  No: the exact four-instruction recurrence; yes: the pivots
-    const bool splits = __builtin_amdgcn_ballot_w64((split & 0x7fffu & ((1u << (n - 1)) - 1u)) != 0) != 0;
-    const unsigned sj = splits ? e16_signs(d, e2, n, tj) : e16_signs_poly(d, e2, n, tj);
+    const unsigned sj = splits ? e16_signs(d, e2, n, tj) : e16_signs_scaled(d, e2, n, tj);
     xch[j] = e16_u2{(unsigned)__builtin_popcount(sj), sj};
     E16_ORDER();
     double lo = gl, hi = gu;
@@ -390,7 +447,7 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
 #pragma unroll 1
     for (int it = 0; it < E16_NBISECT; ++it) {
         const double mid = 0.5 * (lo + hi);
-        const unsigned s = splits ? e16_signs(d, e2, n, mid) : e16_signs_poly(d, e2, n, mid);
+        const unsigned s = splits ? e16_signs(d, e2, n, mid) : e16_signs_scaled(d, e2, n, mid);
         const unsigned c = (unsigned)__builtin_popcount(s);
         const bool left = c <= (unsigned)j;              // eigenvalue j is at or above mid
         lo = left ? mid : lo;
@@ -456,12 +513,13 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     for (int it = 0; it < E16_NEWTON_MAX; ++it) {
         if (__builtin_amdgcn_ballot_w64(!conv) == 0) break;
         double p1 = 1.0, p2 = 0.0, dp1 = 0.0, dp2 = 0.0;
-        unsigned sgn = 0, len = 16u;                      // (unsplit: all 16 positions, the padding ones never change sign)
+        unsigned sgn = 0, len = 16u;
         if (splits) {
             len = 0;
             e16_poly_step<0, true>(d, e2, n, bl, bh, x, p1, p2, dp1, dp2, sgn, len);
         } else {
-            e16_poly_step<0, false>(d, e2, n, bl, bh, x, p1, p2, dp1, dp2, sgn, len);
+            len = (unsigned)n;
+            e16_newton_scaled_step<0>(d, e2, n, x, p1, p2, dp1, dp2, sgn);
         }
         // sign changes of 1, p_bl, .., p_bh: bit k of sgn = sign of the (len - k)-th value; the leading 1 is positive
         const unsigned chg = (unsigned)__builtin_popcount((sgn ^ (sgn >> 1)) & ((1u << len) - 1u) & 0xffffu);
@@ -502,7 +560,11 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     lam = x;
     E16_ORDER();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) e[i] = xd[i].y;         // (the couplings, for the twisted factorisation)
+    for (int i = 0; i < 16; ++i) {                       // (d and the couplings, for the twisted factorisation)
+        const e16_d2 t = xd[i];
+        d[i] = t.x;
+        e[i] = t.y;
+    }
     E16_ORDER();
     if (j >= n) {                                        // a padding row: decoupled, its eigenvector is e_j (V stays orthogonal)
         bl = j;
@@ -515,12 +577,6 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
 }
 
 // ---------------------------------------------------------------- 3. eigenvector of T for lam by the twisted factorisation
-__device__ __forceinline__ double e16_rcp(const double p) {
-    double y = __builtin_amdgcn_rcp(p);
-    y = fma(fma(-p, y, 1.0), y, y);
-    y = fma(fma(-p, y, 1.0), y, y);
-    return y;
-}
 #define E16_TINY 1e-290
 __device__ __forceinline__ double e16_guard(const double p) { return fabs(p) < E16_TINY ? -E16_TINY : p; }
 
@@ -687,7 +743,10 @@ __device__ __forceinline__ bool e16_twin(const e16_lcd* xd, const double lam, co
 template <int MODE>
 __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G, const int64_t id0,
                                                 const int64_t nc, int* __restrict__ list, int* __restrict__ count, const double gaptol) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * E16_WAVE_LDS];
+#ifndef E16_LDS_PAD   // (profiles/microbench/e16_bench.hip only: extra LDS per block, to run the kernel at a lower occupancy)
+#define E16_LDS_PAD 0
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * E16_WAVE_LDS + E16_LDS_PAD];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = lane & 15, mat = lane >> 4, g = lane >> 4;
     const int j = x;
