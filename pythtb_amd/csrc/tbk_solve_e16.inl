@@ -1210,14 +1210,27 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
             if (dd2 < G.wv.dim_arr) f = cmul(f, G.tf[dd2][(int64_t)mj[dd2] * n + c]);
     }
     // (lane b of the matrix computed eigenvalue b: the bands are in ascending order by construction)
+    // One 64-bit address per lane, stepped by the (wave-uniform) band stride: formed band by band from (band, point, component) it
+    // was three 64-bit multiplies per store, 250 instructions of this stage.
+    cd* outp;
+    int64_t bstride;
+    if constexpr (MODE == 1) {
+        outp = wf_at(G.wv, 0, id2) + c;
+        bstride = G.wv.npts * G.wv.ncomp;
+    } else {
+        outp = Lst.evec + (id2 * n + c);
+        bstride = nk * n;
+    }
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
         if (b < n) {
             const cd val = cmul(zt[b], f);
             if constexpr (E16_SKIP & 32) {
                 if (val.x == 1.2345e-300) Lst.evec[0] = val;     // (keeps the value alive)
-            } else if constexpr (MODE == 1) wf_at(G.wv, b, id2)[c] = val;
-            else Lst.evec[((int64_t)b * nk + id2) * n + c] = val;
+            } else {
+                *outp = val;
+                outp += bstride;
+            }
         }
     }
 }
