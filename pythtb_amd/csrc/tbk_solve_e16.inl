@@ -327,6 +327,10 @@ __device__ double e16_dbg[64 * 16];
 #ifndef E16_NEWTON_TOL
 #define E16_NEWTON_TOL 5.820766091346741e-11   // 2^-34
 #endif
+#ifndef E16_NS_TRIPLE
+#define E16_NS_TRIPLE 1e-2                     // three eigenvalues within this much of |T|, or two within E16_NS_PAIR |T|: the full
+#define E16_NS_PAIR 1e-3                       // Newton-Schulz step (stage 4)
+#endif
 
 // d, e: T of this lane's matrix (replicated over its 16 lanes); on return scaled by `scale` (a power of two: exact) with the
 // negligible couplings zeroed, lam = eigenvalue j of the scaled T, [bl, bh] its unreduced block.  flag: this lane could not do
@@ -1078,14 +1082,49 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     }
 
     E16_MARK(5);
-    // ---- 4. one Newton-Schulz step V <- V (1.5 I - 0.5 V^T V), per matrix two 16 x 16 x 16 real products on the matrix cores
-    // v_mfma_f64_16x16x4_f64: lane l supplies A[l & 15][4 kb + (l >> 4)] and B[4 kb + (l >> 4)][l & 15], and holds
-    // D[(l >> 4) + 4 r][l & 15] in register r (profiles/microbench/mfma_f64_layout.hip).  One matrix at a time through the
-    // exchange region (16 x 18 doubles).
+    // ---- 4. one Newton-Schulz step V <- V (1.5 I - 0.5 V^T V) = V (I - E / 2), E = V^T V - I.
+    // The vectors of the twisted factorisation are orthogonal to ~eps |T| / (distance of their eigenvalues): what is not at rounding
+    // level already sits beside the diagonal of E.  A matrix whose T does not split and that has NO three eigenvalues inside
+    // E16_NS_TRIPLE |T| and no two inside E16_NS_PAIR |T| takes the step
+    // with E cut to its tridiagonal part -- the neighbours' vectors by DPP, 150 instructions, no LDS.  The others take the full
+    // step, per matrix two 16 x 16 x 16 real products on the matrix cores (v_mfma_f64_16x16x4_f64: lane l supplies
+    // A[l & 15][4 kb + (l >> 4)] and B[4 kb + (l >> 4)][l & 15], and holds D[(l >> 4) + 4 r][l & 15] in register r,
+    // profiles/microbench/mfma_f64_layout.hip), one matrix at a time through the exchange region (16 x 18 doubles): on gfx950 a
+    // v_mfma_f64_16x16x4 holds the SIMD's double-precision pipe for 64 cycles (profiles/microbench/valu_rates.hip) -- the 32 of a
+    // wavefront were 9 % of the kernel, for every matrix (E16_SKIP=8).  The choice depends on the matrix alone.
+    unsigned long long ns_full = 0;
+    if constexpr (!(E16_SKIP & 8)) {
+        const double lam_up2 = e16_next(e16_next(lam_o));                 // eigenvalue j + 2
+        // (a T that splits interleaves the eigenvalues of its blocks: neighbours in the spectrum are then exactly orthogonal and
+        // the overlaps that matter lie further from the diagonal -- the full step)
+        const bool splits_here = (split & 0x7fffu & ((1u << (n - 1)) - 1u)) != 0;
+        // (... and a close pair leaves its vectors -- the second one of a twin comes from inverse iteration -- less accurate towards the
+        // rest of the spectrum, not only towards each other)
+        const double lam_up1 = e16_next(lam_o);
+        const bool near = (j + 2 < n && !(lam_up2 - lam_o >= E16_NS_TRIPLE * tmax)) || (j + 1 < n && !(lam_up1 - lam_o >= E16_NS_PAIR * tmax));
+        ns_full = __builtin_amdgcn_ballot_w64(live2 && (splits_here || near));
+        if ((((unsigned)(ns_full >> (lane & 48))) & 0xffffu) == 0) {      // (row-uniform) this lane's matrix: the tridiagonal part
+            double vn[16];
+            double s_up = 0.0, s_self = 0.0;                              // v_j . v_{j+1} (0 in lane 15), v_j . v_j
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                vn[i] = e16_next(v[i]);
+                s_up = fma(v[i], vn[i], s_up);
+                s_self = fma(v[i], v[i], s_self);
+            }
+            const double h_dn = -0.5 * e16_prev(s_up), h_up = -0.5 * s_up, cs = fma(-0.5, s_self, 1.5);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double vp = e16_prev(v[i]);                         // (lane j - 1 has not touched its v[i] yet: same instruction)
+                v[i] = fma(h_dn, vp, fma(h_up, vn[i], cs * v[i]));
+            }
+        }
+    }
     if constexpr (!(E16_SKIP & 8)) {
         e16_ld* const Vm = reinterpret_cast<e16_ld*>(wxch);
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) {
+            if (((unsigned)(ns_full >> (16 * m4)) & 0xffffu) == 0) continue;   // (wave-uniform)
             E16_ORDER();
             if (mat == m4) {
 #pragma unroll
