@@ -11,7 +11,7 @@ import re,sys
 lines=open(sys.argv[1]).read().split('\n')
 kern=sys.argv[2]
 start=[i for i,l in enumerate(lines) if l.startswith(kern)][0]
-end=[i for i,l in enumerate(lines) if i>start and l.strip().startswith('s_endpgm')][0]
+end=[i for i,l in enumerate(lines) if i>start and l.strip().startswith('.Lfunc_end')][0]-1   # (a kernel may hold several s_endpgm)
 ins=[]  # (lineno, text, label)
 labels={}
 for i in range(start+1,end+1):

@@ -275,6 +275,19 @@ static void mesh_leg(int side, int reps) {
     int c0;
     CK(hipMemcpy(&c0, cnt, 4, hipMemcpyDeviceToHost));
     printf("listed by k_e16<1>: %d\n", c0);
+#ifdef E16_ITER_HIST
+    {
+        unsigned h[32];
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(e16_iter_hist), sizeof h));
+        double tl = 0, tw = 0, nl = 0, nw = 0;
+        for (int i = 0; i < 16; ++i) { tl += (double)i * h[i]; nl += h[i]; tw += (double)i * h[16 + i]; nw += h[16 + i]; }
+        printf("Newton steps (all launches of this run): per lane mean %.2f, per wavefront (the slowest lane) mean %.2f\n  lanes     :", tl / nl, tw / nw);
+        for (int i = 0; i < 16; ++i) printf(" %.3f", h[i] / nl);
+        printf("\n  wavefronts:");
+        for (int i = 0; i < 16; ++i) printf(" %.3f", h[16 + i] / nw);
+        printf("\n");
+    }
+#endif
 }
 
 int main(int argc, char** argv) {

@@ -321,6 +321,9 @@ __device__ double e16_dbg[64 * 16];
 #ifndef E16_NBISECT
 #define E16_NBISECT 8
 #endif
+#ifdef E16_ITER_HIST
+__device__ unsigned e16_iter_hist[32];
+#endif
 #ifndef E16_NEWTON_MAX
 #define E16_NEWTON_MAX 12
 #endif
@@ -560,6 +563,15 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
             E16_DBG(dbg_slot, j, 12, (double)chg);
         }
     }
+#ifdef E16_ITER_HIST   // (profiles/microbench/e16_bench.hip only: Newton steps per lane [0..15] and per wavefront [16..31])
+    atomicAdd(&e16_iter_hist[dbg_it < 15 ? dbg_it : 15], 1u);
+    {
+        int wmax = dbg_it;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
+        if ((threadIdx.x & 63) == 0) atomicAdd(&e16_iter_hist[16 + (wmax < 15 ? wmax : 15)], 1u);
+    }
+#endif
     flag = flag || !conv;
     lam = x;
     E16_ORDER();
