@@ -73,6 +73,19 @@ def special_matrices(n, rng):
     out.append(w.astype(complex))
     out.append((a * 1e-150))                                                          # tiny scale
     out.append((a * 1e+120))                                                          # huge scale
+    # round 5 (k_e16's scaled Sturm recurrence and its choice of Newton-Schulz step):
+    g = np.diag(10.0 ** (-20.0 * np.arange(n))).astype(complex)                       # graded tridiagonal: the products of the e^2 leave
+    for i in range(n - 1):                                                            # the range of the scaled recurrence (pivots instead)
+        g[i, i + 1] = g[i + 1, i] = 10.0 ** (-20.0 * i - 10.0)
+    out.append(g)
+    lev = np.arange(n, dtype=float)
+    lev[1], lev[2] = lev[0] + 1e-3 * n, lev[0] + 2e-3 * n                              # three levels inside 1e-2 |T|: the full step
+    tri = u @ np.diag(lev) @ u.conj().T
+    out.append(0.5 * (tri + tri.conj().T))
+    lev = np.arange(n, dtype=float)
+    lev[n // 2] = lev[n // 2 - 1] + 3e-4 * n                                          # a pair inside 1e-3 |T| but far above gaptol
+    par = u @ np.diag(lev) @ u.conj().T
+    out.append(0.5 * (par + par.conj().T))
     return out
 
 
