@@ -16,9 +16,9 @@ SOURCES = [
     ("k_flux_rows<1,2>", "r05c/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
     ("k_grid_rows<4,1>", "r05dcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),      # (after the sort's short way)
     ("k_flux_rows<2,4>", "r05dcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
-    ("k_e16<1>", "r05ccfg/pmc_per_dispatch.json", "k_e16<1>", 65 ** 3),
+    ("k_e16<1>", "r05ecfg/pmc_per_dispatch.json", "k_e16<1>", 65 ** 3),                        # (after the round-5 work on k_e16)
     ("k_mesh_evals<2,1>", "r05ccfg/pmc_per_dispatch.json", "k_mesh_evals<2,1>", 1024 * 1024),
-    ("k_chain_prod_tile<8,2>", "r05ccfg/pmc_per_dispatch.json", "k_chain_prod_tile<8,2,false>", 65 ** 3),
+    ("k_chain_prod_tile<8,2>", "r05ecfg/pmc_per_dispatch.json", "k_chain_prod_tile<8,2,false>", 65 ** 3),
     ("k_solve_small_multi<2,false,2>", "r05ccfg/pmc_per_dispatch.json", "k_solve_small_multi<2,false,2>", 1024 * 1024),
     ("k_solve_small<2,0,true>", "r05ccfg/pmc_per_dispatch.json", "k_solve_small<2,0,true>", 1024 * 1024),
     # round 4, final build: r04j (the two-call step), r04k (--fused-headline), r04jcfg (bench_configs.py B D E under TBK_TW16_STREAMS=1)
