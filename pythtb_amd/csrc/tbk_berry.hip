@@ -1870,7 +1870,8 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         // (3 and 4 bands of WIDE states too: a thread per segment walks 256-byte rows of its own -- TBK_WILSON_MFMA=2 keeps them on k_wilson_seg_reg)
         const int mfma_from = tbk_knobs().wilson_mfma == 2 ? 5 : 3;
         if (nocc >= mfma_from && nocc <= 8 && tbk_knobs().wilson_mfma != 0 && chain_wave_applies(v, nocc)) {
-            const size_t lds_pts = (size_t)(TBK_CHAINP_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd), lds_img = (size_t)TBK_CHAINP_G * 256 * sizeof(double);
+            const size_t lds_pts = (size_t)(TBK_CHAINP_G + 1) * (nocc * (v.ncomp + 1) + 1) * sizeof(cd);
+            const size_t lds_img = (size_t)TBK_CHAINP_G * 16 * TBK_CHAINP_LD(true) * sizeof(double);
             lds_p1 = nocc == 8 ? std::max(lds_pts, lds_img) : lds_pts + lds_img;
             if (2 * lds_p1 <= 64 * 1024 && fill_occ(w, occ, nocc, A.occ) == TBK_OK) {
                 mfma_route = true;

@@ -15,6 +15,10 @@
 // k_chain_prod_det takes its determinant.  The matrix cores are otherwise idle on this path; the vector ALU does exactly what
 // k_chain_links_tile did.
 #define TBK_CHAINP_G 4   // links per wavefront step (sixteen lanes per link)
+// row stride (doubles) of a link's 16 x 16 real image in LDS: 16 for the plain product (its one read pattern, rows of 16 lanes, is
+// conflict-free); 18 with polar factors, whose iteration also reads the image and its own iterate TRANSPOSED (stride-16 columns put
+// the 16 lanes of a row on two banks: 43 % of that kernel's LDS cycles were conflicts, profiles/r05ecfg)
+#define TBK_CHAINP_LD(POLAR) ((POLAR) ? 18 : 16)
 // POLAR (Wilson-loop eigenphases of 5..8 wide bands, round 4): every link matrix is replaced by its polar factor U = M (M^+ M)^(-1/2)
 // (the reference's U Vh of svd(M), pythtb.py:3820-3826) before it is multiplied on -- by the Newton-Schulz iteration
 // X <- X (3 I - X^T X) / 2 on the real image, ON THE MATRIX CORES: with X and X^T both held in the accumulator layout every operand
@@ -27,7 +31,7 @@ template <int NOCC, int NLD, bool POLAR = false>
 __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, const int64_t s0, const int64_t ns, cd* __restrict__ pw) {
     static_assert(NOCC >= 3 && NOCC <= 8 && (POLAR || NOCC >= 5), "k_chain_prod_tile: 5..8 bands (3..8 with polar factors)");
     extern __shared__ __align__(16) unsigned char chainw_lds[];
-    constexpr int G = TBK_CHAINP_G, NT = (NOCC + 1) / 2;
+    constexpr int G = TBK_CHAINP_G, NT = (NOCC + 1) / 2, LD = TBK_CHAINP_LD(POLAR), IMG = 16 * LD;
     const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     if (t >= ns * A.nseg) return;                    // (no workgroup barrier below: waves are independent)
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, cons
     // once the overlaps are in registers): 10.7 instead of 18.7 KB per wavefront, 14 instead of 8 wavefronts per CU -- the kernel
     // waits on HBM latency, not on the vector ALU (43 % busy at two wavefronts per SIMD)
     constexpr bool ALIAS = NOCC == 8;
-    const size_t pts_bytes = (size_t)(G + 1) * pbuf * sizeof(cd), img_bytes = (size_t)G * 256 * sizeof(double);
+    const size_t pts_bytes = (size_t)(G + 1) * pbuf * sizeof(cd), img_bytes = (size_t)G * IMG * sizeof(double);
     const size_t wave_bytes = ALIAS ? (pts_bytes > img_bytes ? pts_bytes : img_bytes) : pts_bytes + img_bytes;
     cd* const buf = reinterpret_cast<cd*>(chainw_lds + (size_t)wib * wave_bytes);        // slots 0 .. G: points i .. i + G
     double* const Me = ALIAS ? reinterpret_cast<double*>(buf)                            // [G][16][16]: the links' real images
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, cons
 #pragma unroll
         for (int q = 0; q < G * 256 / 64; ++q) {
             const int e = q * 64 + lane, rc = e & 255;
-            Me[e] = (rc >> 4) == (rc & 15) ? 1.0 : 0.0;
+            Me[(e >> 8) * IMG + (rc >> 4) * LD + (rc & 15)] = (rc >> 4) == (rc & 15) ? 1.0 : 0.0;
         }
     }
     // this lane's block of M (as in k_chain_links_tile)
@@ -147,23 +151,23 @@ __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, cons
         if constexpr (ALIAS) lds_sync_wave();        // every lane has read its points before the images overwrite them
         if (mine) {
             // entry (a, b) = re + i im  ->  rows 2a, 2a + 1 x columns 2b, 2b + 1 of the link's real image: [[re, -im], [im, re]]
-            double* const me = Me + g4 * 256;
+            double* const me = Me + g4 * IMG;
             {
-                double* r0 = me + (2 * a0) * 16 + 2 * b0;
+                double* r0 = me + (2 * a0) * LD + 2 * b0;
                 *reinterpret_cast<v2d*>(r0) = v2d{m00.x, -m00.y};
-                *reinterpret_cast<v2d*>(r0 + 16) = v2d{m00.y, m00.x};
+                *reinterpret_cast<v2d*>(r0 + LD) = v2d{m00.y, m00.x};
                 if (vb1) {
                     *reinterpret_cast<v2d*>(r0 + 2) = v2d{m01.x, -m01.y};
-                    *reinterpret_cast<v2d*>(r0 + 18) = v2d{m01.y, m01.x};
+                    *reinterpret_cast<v2d*>(r0 + LD + 2) = v2d{m01.y, m01.x};
                 }
             }
             if (va1) {
-                double* r1 = me + (2 * a1) * 16 + 2 * b0;
+                double* r1 = me + (2 * a1) * LD + 2 * b0;
                 *reinterpret_cast<v2d*>(r1) = v2d{m10.x, -m10.y};
-                *reinterpret_cast<v2d*>(r1 + 16) = v2d{m10.y, m10.x};
+                *reinterpret_cast<v2d*>(r1 + LD) = v2d{m10.y, m10.x};
                 if (vb1) {
                     *reinterpret_cast<v2d*>(r1 + 2) = v2d{m11.x, -m11.y};
-                    *reinterpret_cast<v2d*>(r1 + 18) = v2d{m11.y, m11.x};
+                    *reinterpret_cast<v2d*>(r1 + LD + 2) = v2d{m11.y, m11.x};
                 }
             }
         }
@@ -173,18 +177,18 @@ __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, cons
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (i + g < np) {                        // (wave-uniform)
-                const double* me = Me + g * 256;
+                double* me = Me + g * IMG;
                 if constexpr (!POLAR) {
                     v4d nw = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(me[(4 * kb + gl) * 16 + cl], acc[kb], nw, 0, 0, 0);
+                    for (int kb = 0; kb < 4; ++kb) nw = __builtin_amdgcn_mfma_f64_16x16x4f64(me[(4 * kb + gl) * LD + cl], acc[kb], nw, 0, 0, 0);
                     acc = nw;
                 } else {
                     v4d X, Xt;                       // X[4 kb + gl][cl] and X^T[4 kb + gl][cl] = X[cl][4 kb + gl]
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) {
-                        X[kb] = me[(4 * kb + gl) * 16 + cl];
-                        Xt[kb] = me[cl * 16 + 4 * kb + gl];
+                        X[kb] = me[(4 * kb + gl) * LD + cl];
+                        Xt[kb] = me[cl * LD + 4 * kb + gl];
                     }
                     bool ok = false;
                     for (int it = 0; it < 200; ++it) {
@@ -199,20 +203,24 @@ __global__ __launch_bounds__(128) void k_chain_prod_tile(const ChainArgs A, cons
                         }
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
-                        v4d XY = {0.0, 0.0, 0.0, 0.0}, YXt = {0.0, 0.0, 0.0, 0.0};
+                        v4d XY = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                         for (int kb = 0; kb < 4; ++kb) XY = __builtin_amdgcn_mfma_f64_16x16x4f64(Xt[kb], Y[kb], XY, 0, 0, 0);    // X Y
 #pragma unroll
-                        for (int kb = 0; kb < 4; ++kb) YXt = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kb], Xt[kb], YXt, 0, 0, 0);  // Y X^T
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            X[r] = fma(1.5, X[r], -0.5 * XY[r]);
-                            Xt[r] = fma(1.5, Xt[r], -0.5 * YXt[r]);
-                        }
+                        for (int r = 0; r < 4; ++r) X[r] = fma(1.5, X[r], -0.5 * XY[r]);
+                        // X^T of the new iterate through the link's own image slot (X came from there; nobody reads it again): a third
+                        // product Y X^T kept it current in round 4 -- on gfx950 four more v_mfma_f64 are 256 cycles of the fp64 pipe, the
+                        // eight LDS accesses of a transposition none
                         if (r2 < 1e-14) {            // residual 1e-7 before this update, its square after it
                             ok = true;
                             break;
                         }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) me[(4 * r + gl) * LD + cl] = X[r];
+                        lds_sync_wave();
+#pragma unroll
+                        for (int kb = 0; kb < 4; ++kb) Xt[kb] = me[cl * LD + 4 * kb + gl];
+                        lds_sync_wave();
                     }
                     singular = singular || !ok;
                     v4d nw = {0.0, 0.0, 0.0, 0.0};
