@@ -12,8 +12,10 @@
 // B operand is the accumulator of the previous product as it stands (lane l holds D[(l >> 4) + 4 r][l & 15] in register r,
 // which is B[4 kb + (l >> 4)][l & 15] for kb = r: profiles/microbench/mfma_f64_layout.hip).  The link matrices leave the
 // vector ALU through 2 KB of LDS each.  One nocc x nocc matrix per (string, segment) goes out (1 KB for 256 links) and
-// k_chain_prod_det takes its determinant.  The matrix cores are otherwise idle on this path; the vector ALU does exactly what
-// k_chain_links_tile did.
+// k_chain_prod_det takes its determinant.  The vector ALU does exactly what k_chain_links_tile did.  (Round 4 counted the matrix
+// cores as idle capacity; round 5 measured a v_mfma_f64_16x16x4 at 64 cycles of the SIMD's own fp64 pipe -- the vector rate,
+// profiles/microbench/valu_rates.hip.  The four per link are 18 % of this kernel's pipe time, affordable for a product that needs
+// no data movement between lanes; the polar form below, 40 per link, was cut to 28.)
 #define TBK_CHAINP_G 4   // links per wavefront step (sixteen lanes per link)
 // row stride (doubles) of a link's 16 x 16 real image in LDS: 16 for the plain product (its one read pattern, rows of 16 lanes, is
 // conflict-free); 18 with polar factors, whose iteration also reads the image and its own iterate TRANSPOSED (stride-16 columns put
@@ -22,8 +24,9 @@
 // POLAR (Wilson-loop eigenphases of 5..8 wide bands, round 4): every link matrix is replaced by its polar factor U = M (M^+ M)^(-1/2)
 // (the reference's U Vh of svd(M), pythtb.py:3820-3826) before it is multiplied on -- by the Newton-Schulz iteration
 // X <- X (3 I - X^T X) / 2 on the real image, ON THE MATRIX CORES: with X and X^T both held in the accumulator layout every operand
-// of the three products of a step is a register as it stands (Y = X^T X is symmetric bit for bit, so its accumulator doubles as
-// its own A operand): 12 v_mfma_f64_16x16x4_f64 per step, no transposition, no LDS.  The loop ends when ||Y - I||_F^2 < 1e-14
+// of the two products of a step, Y = X^T X and X Y, is a register as it stands (Y is symmetric bit for bit, so its accumulator
+// doubles as its own A operand): 8 v_mfma_f64_16x16x4_f64 per step; X^T of the new iterate comes back through the link's own LDS
+// image (round 4 kept it current with a third product, Y X^T: 12 per step, no LDS).  The loop ends when ||Y - I||_F^2 < 1e-14
 // (wave-uniform: one link at a time), like k_link_polar_big; a link that does not converge in 200 steps raises the singular-link
 // status.  Output: the unitary product of the (string, segment), nocc x nocc compact at pw[(string * nseg + segment) * nocc^2],
 // the layout the product tree / Cayley tail of the Wilson pipeline reads (tbk_berry_big.inl).
