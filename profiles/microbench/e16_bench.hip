@@ -270,7 +270,7 @@ static void mesh_leg(int side, int reps) {
     }, "three kernels <1> back to back");
     time_it([&]() {
         CK(hipMemsetAsync(cnt, 0, 4, 0));
-        hipLaunchKernelGGL((k_e16<1>), dim3(b16), dim3(256), 0, 0, mv, nc, L, G, (int64_t)0, nc, list, cnt, 1e-5);
+        hipLaunchKernelGGL((k_e16<1>), dim3(b16), dim3(256), 0, 0, mv, nc, L, G, (int64_t)0, nc, list, cnt, 1e-5, getenv("E16_NS_FULL") ? 1 : 0);
     }, "k_e16<1>");
     int c0;
     CK(hipMemcpy(&c0, cnt, 4, hipMemcpyDeviceToHost));
@@ -392,7 +392,7 @@ int main(int argc, char** argv) {
     };
     auto e16 = [&]() {
         CK(hipMemsetAsync(cnt + 16, 0, 4, 0));
-        hipLaunchKernelGGL((k_e16<2>), dim3(b16), dim3(256), 0, 0, mv, nk, Lb, G, (int64_t)0, nk, list_b, cnt + 16, gaptol);
+        hipLaunchKernelGGL((k_e16<2>), dim3(b16), dim3(256), 0, 0, mv, nk, Lb, G, (int64_t)0, nk, list_b, cnt + 16, gaptol, getenv("E16_NS_FULL") ? 1 : 0);
     };
     printf("nk = %lld, n = %d, kind = %d\n", (long long)nk, n, kind);
     const float t1 = time_it(tw_tri, "k_tw16_tridiag<2>");

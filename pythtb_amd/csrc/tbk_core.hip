@@ -48,6 +48,7 @@ static void knobs_parse() {
     geti("TBK_QL16_EVONLY", k.ql16_evonly);
     geti("TBK_TW16", k.tw16);
     geti("TBK_E16", k.e16);
+    geti("TBK_E16_NS_FULL", k.e16_ns_full);
     geti("TBK_TW16_STREAMS", k.tw16_streams);
     if (const char* e = getenv("TBK_TW16_GAPTOL")) k.tw16_gaptol = atof(e);
     geti("TBK_QL16_SPLIT", k.ql16_split);

@@ -758,7 +758,8 @@ __device__ __forceinline__ bool e16_twin(const e16_lcd* xd, const double lam, co
 // list / count: the matrices (relative to id0) left to the QL-replay kernels.
 template <int MODE>
 __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G, const int64_t id0,
-                                                const int64_t nc, int* __restrict__ list, int* __restrict__ count, const double gaptol) {
+                                                const int64_t nc, int* __restrict__ list, int* __restrict__ count, const double gaptol,
+                                                const int ns_all) {
 #ifndef E16_LDS_PAD   // (profiles/microbench/e16_bench.hip only: extra LDS per block, to run the kernel at a lower occupancy)
 #define E16_LDS_PAD 0
 #endif
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         // rest of the spectrum, not only towards each other)
         const double lam_up1 = e16_next(lam_o);
         const bool near = (j + 2 < n && !(lam_up2 - lam_o >= E16_NS_TRIPLE * tmax)) || (j + 1 < n && !(lam_up1 - lam_o >= E16_NS_PAIR * tmax));
-        ns_full = __builtin_amdgcn_ballot_w64(live2 && (splits_here || near));
+        ns_full = __builtin_amdgcn_ballot_w64(live2 && (splits_here || near || ns_all != 0));   // (ns_all: TBK_E16_NS_FULL=1, round 4's form)
         if ((((unsigned)(ns_full >> (lane & 48))) & 0xffffu) == 0) {      // (row-uniform) this lane's matrix: the tridiagonal part
             double vn[16];
             double s_up = 0.0, s_self = 0.0;                              // v_j . v_{j+1} (0 in lane 15), v_j . v_j

@@ -111,6 +111,32 @@ def test_supplied_matrices_against_lapack(tb, n):
         assert max(q) < 2e-14, (i, q)
 
 
+def test_tridiagonal_newton_schulz_step_against_the_full_one(tb):
+    """round 5: k_e16 takes the Newton-Schulz step with V^T V - I cut to its tridiagonal part unless T splits or eigenvalues crowd;
+    TBK_E16_NS_FULL=1 is round 4's form (the full step on the matrix cores for every matrix).  Same eigenvalues bit for bit (the
+    step only touches the vectors), both orthonormal to rounding, the vectors equal up to that rounding; crowded and split matrices
+    (the special ones) take the full step either way: identical bits."""
+    from pythtb_amd import _lib
+    rng = np.random.default_rng(55)
+    n, nk = 16, 4000
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    sp = special_matrices(n, rng)
+    h[:len(sp)] = np.array(sp)
+    with _forced():
+        ev_t, v_t = _eigh_batch(h)
+        with _lib.knob("TBK_E16_NS_FULL", 1):
+            ev_f, v_f = _eigh_batch(h)
+    assert np.array_equal(ev_t, ev_f)
+    q_t, q_f = _quality(h, ev_t, v_t), _quality(h, ev_f, v_f)
+    assert max(q_t) < 2e-14 and max(q_f) < 2e-14, (q_t, q_f)
+    assert q_t[2] < 2.0 * q_f[2] + 1e-15, (q_t, q_f)                                   # orthonormality: no worse than the full step's
+    assert not np.array_equal(v_t[:, len(sp):], v_f[:, len(sp):])                      # (the generic matrices do take the short form)
+    assert np.max(np.abs(v_t - v_f)) < 1e-12
+    for i in (0, 1, 2, 3, 5):                                                          # zero, diagonal, repeated levels, blocks, exact pairs
+        assert np.array_equal(v_t[:, i], v_f[:, i]), i
+
+
 def test_every_matrix_listed_equals_the_ql_replay_form_bit_for_bit(tb):
     """TBK_TW16_GAPTOL = 1e300 lists every matrix: the result is the QL-replay kernels' own (TBK_TW16=0), bit for bit; and a
     threshold of 0 lists none but the residual failures -- exact pairs still come out orthonormal (their T splits)."""
