@@ -293,7 +293,7 @@ def single_gpu(which, reps):
         ws = tb.wf_array(slab, [257, 257])
         ws.solve_on_grid([0.0, 0.0])
         legs.append(leg("position_16of16_257sq", lambda: ws.position_hwf_mesh(range(16), 2), (16 * 16 * 16 + 8 * 16) * 257 * 257, 257 * 257, "points"))
-        out.append({"config": "P: Berry / position kernels of round 4's last hours (rocprofv3 evidence: profiles/r05p)", "legs": legs})
+        out.append({"config": "P: Berry / position kernels of round 4's last hours (rocprofv3 evidence: profiles/r05fcfg)", "legs": legs})
     if "R" in which:
         # (not a BASELINE config) the widening rows of SURVEY.md 8f-2: ribbon band structures and a mid-size mesh solve, to keep
         # the direct paths for 17..1024 states under measurement.  Wall-clock of the Python calls, PCIe included.
