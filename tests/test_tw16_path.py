@@ -123,8 +123,9 @@ def test_tridiagonal_newton_schulz_step_against_the_full_one(tb):
     h = h + h.conj().transpose(0, 2, 1)
     sp = special_matrices(n, rng)
     h[:len(sp)] = np.array(sp)
-    with _forced():
-        ev_t, v_t = _eigh_batch(h)
+    with _forced(), _lib.knob("TBK_E16", 1):              # (whatever the environment says: this test is about the fused kernel's two forms)
+        with _lib.knob("TBK_E16_NS_FULL", 0):
+            ev_t, v_t = _eigh_batch(h)
         with _lib.knob("TBK_E16_NS_FULL", 1):
             ev_f, v_f = _eigh_batch(h)
     assert np.array_equal(ev_t, ev_f)
@@ -274,13 +275,14 @@ def test_twins_are_repaired_in_the_kernel_not_listed(tb):
                     m.set_hop(0.2 * (rng.standard_normal() + 1j * rng.standard_normal()), i, j, R)
     ctx = _lib.default_context()
     w = tb.wf_array(m, [257, 257])
-    w.solve_on_grid([0.0, 0.0])
-    ctx.prof_enable(1)
-    ctx.prof_reset()
-    ctx.solver_stats(reset=True)
-    gaps = w.solve_on_grid([0.0, 0.0])
-    rep = ctx.prof_report()
-    ctx.prof_enable(0)
+    with _lib.knob("TBK_E16", 1):                        # (the fused kernel, whatever the environment says)
+        w.solve_on_grid([0.0, 0.0])
+        ctx.prof_enable(1)
+        ctx.prof_reset()
+        ctx.solver_stats(reset=True)
+        gaps = w.solve_on_grid([0.0, 0.0])
+        rep = ctx.prof_report()
+        ctx.prof_enable(0)
     listed = ctx.solver_stats()["listed_matrices"]
     # a count, not a time (tbk_ctx_solver_stats): before the repair all 256^2 matrices of this mesh were listed
     assert "e16" in rep and listed <= 256 * 256 // 100, (listed, rep)
