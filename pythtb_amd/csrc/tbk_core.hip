@@ -71,6 +71,7 @@ static void knobs_parse() {
     geti("TBK_FLUX_FUSED", k.flux_fused);
     geti("TBK_FLUX_ORDER", k.flux_order);
     geti("TBK_REG_DIRECT", k.reg_direct);
+    geti("TBK_REG_CELLS", k.reg_cells);
     geti("TBK_FLUX_SLICES", k.flux_slices);
     geti("TBK_POLL_DONE", k.poll_done);
     geti("TBK_POS_TILE", k.pos_tile);

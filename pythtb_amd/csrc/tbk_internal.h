@@ -94,6 +94,7 @@ struct TbkKnobs {
     bool wilson_alpha_set = false;
     long long big_batch = -1;   // TBK_BIG_BATCH     test hook: matrices per workspace batch
     int reg_lanes = 0;          // TBK_REG_LANES     (multilane build only)
+    int reg_cells = 1;          // TBK_REG_CELLS     0: n = 5..8 meshes sum every lattice vector per point instead of the row's coefficient cells
     int reg_direct = 1;         // TBK_REG_DIRECT    0: n = 5..8 with eigenvectors by the register Jacobi kernel instead of the direct method
     int ablate_grid = 0;        // TBK_ABLATE_GRID   -DTBK_DIAG builds only
     int ablate_flux = 0;        // TBK_ABLATE_FLUX   -DTBK_DIAG builds only

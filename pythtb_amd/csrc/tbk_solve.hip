@@ -2844,6 +2844,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
     G.last = D - 1;
     G.cpr = (v.mesh[D - 1] + 63) / 64;
     G.nchunks = (v.npts / v.mesh[D - 1]) * G.cpr;
+    G.reg_cells = tbk_knobs().reg_cells != 0 && G.gmesh[D - 1] >= 32 ? 1 : 0;   // (decided on the GLOBAL mesh: a window of it must take the same form)
 #ifdef TBK_DIAG
     G.ablate = tbk_knobs().ablate_grid;
 #endif

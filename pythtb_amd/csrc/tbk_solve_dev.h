@@ -38,6 +38,7 @@ struct GridArgs {
     int seg;                 // chunks per wave tile (k_grid_rows)
     int tpr;                 // wave tiles per row
     int64_t ntiles;
+    int reg_cells;           // k_solve_regd on a mesh: S(k) from the row's coefficient cells (reg_assemble_cells; TBK_REG_CELLS=0: the tiled sum)
 #ifdef TBK_DIAG
     int ablate;              // diagnostic build only (TBK_ABLATE_GRID): 1 = no stores, 2 = no eigen-solve, ...
 #endif

@@ -135,8 +135,146 @@ __device__ __forceinline__ void reg_assemble_tiled(const ModelView& mv, const cd
         __builtin_amdgcn_wave_barrier();
         if (t + 2 < ntile) REG_ISSUE(t + 2, buf)
     }
-#undef REG_ISSUE
 }
+
+// ---- the same sum on a MESH ROW (round 5): along the last mesh axis only z_last = exp(2 pi i k_last) changes, so
+//     S_slot(k) = sum_p C_p[slot] z_last^p,     C_p[slot] = sum over the R with R_last = p of U_R[slot] exp(2 pi i k_lead . R_lead),
+// the row's coefficient cells (what k_grid_rows does for n <= 4 from the per-slot term lists).  A wavefront's 64 consecutive points
+// lie in at most three rows when the last axis holds >= 32 of them: the wavefront forms their cells TOGETHER -- lane = slot, the
+// table streamed through LDS exactly as above, the (row, R) phases computed once by the lanes in parallel (lane = R) and parked in
+// LDS -- 3 complex multiply-adds per lattice vector and lane instead of NS, and then every lane sums its point's 2 pmax + 1 cells per
+// slot.  Silicon's 93 lattice vectors x 36 slots: ~2 k instead of 14.5 k vector instructions per wavefront (the kernel runs at one
+// wavefront per SIMD -- the reflectors' LDS -- so its time follows its instruction count).  work: the reflector region of the
+// wavefront, idle until the tridiagonalisation: [3][nR] phases, then [3][np][NS] cells.  Returns false (nothing touched but LDS)
+// when the geometry does not fit; the caller then takes the tiled sum.  The terms of a point are added in an order that depends on
+// the model and the point alone, and the choice between this form and the tiled one on the GLOBAL mesh, so windows cut anywhere and
+// shards stay bit-identical (a narrow window takes more rounds of three rows); against the tiled sum and the k-list path the sums
+// differ by rounding.
+#define REG_CELLS_NPMAX 9
+#define REG_CELLS_ROWS 3
+__device__ __forceinline__ double rowv_d(const double v, const int src) {   // the value of lane src (wave-uniform), in every lane
+    const I2 i = __builtin_bit_cast(I2, v);
+    const I2 o{__builtin_amdgcn_readlane(i.lo, src), __builtin_amdgcn_readlane(i.hi, src)};
+    return __builtin_bit_cast(double, o);
+}
+template <int N>
+__device__ __forceinline__ bool reg_assemble_cells(const ModelView& mv, const GridArgs& G, const cd (&z)[4], const int64_t id, cd* const tiles,
+                                                   cd* const work, const int work_entries, const int lane, cd (&acc)[N * (N + 1) / 2]) {
+    constexpr int NS = N * (N + 1) / 2;
+    constexpr int NLD = reg_tile_nld<N>();
+    constexpr int TS = reg_tile_slots<N>();
+    constexpr int NPM = REG_CELLS_NPMAX, NRW = REG_CELLS_ROWS;
+    static_assert(NS <= 64, "reg_assemble_cells: one lane per slot");
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int nR = mv.nR, last = G.last;
+    const int np = 2 * mv.pmax + 1;
+    const int mlast = G.wv.mesh[last];
+    if (last != mv.dim_k - 1 || last > 2 || np > NPM || NRW * (nR + np * NS) > work_entries || G.wv.npts >= (int64_t)0x7fffffff)
+        return false;                                    // (kernel-uniform)
+    const int row = (int)((unsigned)id / (unsigned)mlast);
+    const int row0 = __builtin_amdgcn_readfirstlane(row);
+    const int rw = row - row0;                           // 0 .. : 64 consecutive points (ascending with the lane)
+    const int nrows_all = __builtin_amdgcn_readlane(rw, 63) + 1;
+    // z_last by 0 / 1 weights (a select on `last` turns z[] into an indexed array in scratch memory)
+    const double w0 = last == 0 ? 1.0 : 0.0, w1 = last == 1 ? 1.0 : 0.0, w2 = last == 2 ? 1.0 : 0.0;
+    const cd zl{fma(w2, z[2].x, fma(w1, z[1].x, w0 * z[0].x)), fma(w2, z[2].y, fma(w1, z[1].y, w0 * z[0].y))};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = cd{0.0, 0.0};
+    const int ntile = (nR + REG_TR - 1) / REG_TR;
+    const int64_t total = (int64_t)nR * NS;
+    const int sl = lane < NS ? lane : NS - 1;
+    cd* const cells = work + NRW * nR;                   // [NRW][np][NS]
+    // three rows at a time (rows of >= 32 points: one round; a narrow WINDOW of such an array takes more rounds and the same sums,
+    // so it stays bit-identical to the whole array)
+    for (int g0 = 0; g0 < nrows_all; g0 += NRW) {
+        const int nrows = min(NRW, nrows_all - g0);
+        // exp(2 pi i k_d) of the leading axes, per row (the same bits in every lane of a row: its first lane speaks for it)
+        cd zr[NRW][4];
+#pragma unroll
+        for (int w = 0; w < NRW; ++w) {
+            const unsigned long long mw = __builtin_amdgcn_ballot_w64(rw == g0 + w);
+            const int lf = mw != 0 ? (int)__builtin_ctzll(mw) : 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const cd zd = d < last ? z[d] : cd{1.0, 0.0};
+                zr[w][d] = cd{rowv_d(zd.x, lf), rowv_d(zd.y, lf)};
+            }
+        }
+        // phases of (row, R), lane = R
+        for (int r = lane; r < nR; r += 64) {
+            int4 R = mv.rvec[r];
+            if (last == 0) R.x = 0; else if (last == 1) R.y = 0; else R.z = 0;
+            R.w = 0;
+#pragma unroll
+            for (int w = 0; w < NRW; ++w)
+                if (w < nrows) work[w * nR + r] = phase_of_R(zr[w], R);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // cells, lane = slot: the table through the same two LDS tiles
+        cd c[NRW][NPM];
+#pragma unroll
+        for (int w = 0; w < NRW; ++w)
+#pragma unroll
+            for (int p = 0; p < NPM; ++p) c[w][p] = cd{0.0, 0.0};
+        REG_ISSUE(0, tiles)
+        if (ntile > 1) REG_ISSUE(1, tiles + TS)
+        for (int t = 0; t < ntile; ++t) {
+            cd* const buf = tiles + (t & 1) * TS;
+            if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int nhere = min(REG_TR, nR - t * REG_TR);
+            for (int rr = 0; rr < nhere; ++rr) {
+                const int4 Rv = *reinterpret_cast<const int4*>(buf + NLD * 64 + rr);
+                const int pl = __builtin_amdgcn_readfirstlane(last == 0 ? Rv.x : last == 1 ? Rv.y : Rv.z) + mv.pmax;   // 0 .. np - 1
+                const int r = t * REG_TR + rr;
+                const cd u = buf[rr * NS + sl];
+                cd ph[NRW];
+#pragma unroll
+                for (int w = 0; w < NRW; ++w) ph[w] = work[(w < nrows ? w : 0) * nR + r];
+#pragma unroll
+                for (int p = 0; p < NPM; ++p) {
+                    if (p == pl) {                       // (scalar branch: the registers stay statically indexed)
+#pragma unroll
+                        for (int w = 0; w < NRW; ++w)
+                            if (w < nrows) cfma_x(c[w][p], u, ph[w]);   // (scalar branch)
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (t + 2 < ntile) REG_ISSUE(t + 2, buf)
+        }
+        if (lane < NS) {
+#pragma unroll
+            for (int w = 0; w < NRW; ++w)
+#pragma unroll
+                for (int p = 0; p < NPM; ++p)
+                    if (p < np) cells[(w * np + p) * NS + lane] = c[w][p];
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // the point's sum: z_last^p for p = -pmax .. pmax
+        if (rw >= g0 && rw < g0 + NRW) {
+            cd zc{1.0, 0.0};
+            for (int q = 0; q < mv.pmax; ++q) zc = cmul(zc, cd{zl.x, -zl.y});
+            const cd* mine = cells + (rw - g0) * np * NS;
+            for (int p = 0; p < np; ++p) {
+                const cd* cp = mine + p * NS;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) cfma_x(acc[s], cp[s], zc);
+                zc = cmul(zc, zl);
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();                 // (the next round overwrites phases and cells)
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                     // (the region goes back to the reflectors)
+    return true;
+}
+#undef REG_ISSUE
 
 // MODE 0: k list, 1: regular mesh into a wf_array (+ min gaps), 2: supplied matrices
 template <int N, int L, int MODE, bool VEC>
@@ -348,7 +486,11 @@ __global__ __launch_bounds__(64) void k_solve_regd(const ModelView mv, const int
         for (int d = 0; d < 4; ++d) z[d] = d < mv.dim_k ? expi2pi(kk[d]) : cd{1.0, 0.0};
         if (mv.nR > 0) {                                      // R-grouped table: one phase per lattice vector, the table through LDS
             cd acc[NS];
-            reg_assemble_tiled<N>(mv, z, tiles, lane, acc);
+            bool done = false;
+            if constexpr (MODE == 1) {
+                if (G.reg_cells) done = reg_assemble_cells<N>(mv, G, z, id, tiles, Rf, regd_nu<N>() * 64, lane, acc);
+            }
+            if (!done) reg_assemble_tiled<N>(mv, z, tiles, lane, acc);
             int slot = 0;
 #pragma unroll
             for (int a = 0; a < N; ++a)

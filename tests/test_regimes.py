@@ -390,6 +390,51 @@ def test_mesh_solve_with_long_hoppings_along_the_last_axis(tb, n, rmax):
     assert np.max(np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.identity(n))) < 1e-13
 
 
+@pytest.mark.parametrize("n,rmax,mesh", [(5, 1, [5, 70]), (6, 2, [3, 4, 65]), (8, 3, [7, 129]), (8, 4, [66]), (7, 2, [4, 64])])
+def test_mesh_rows_of_5_to_8_states_from_coefficient_cells(tb, n, rmax, mesh):
+    """round 5: k_solve_regd on a mesh whose last axis holds >= 64 points sums the row's coefficient cells (reg_assemble_cells: two rows
+    per wavefront, lane = slot) instead of every lattice vector per point (TBK_REG_CELLS=0).  Against the reference Hamiltonian of
+    every point, against the other form, and window against whole array bit for bit (the order of the terms depends on the model and
+    the mesh alone)."""
+    from pythtb_amd import _lib
+    D = len(mesh)
+    m = hp.random_model(tb.tb_model, n, D, 1, seed=1300 + 10 * n + rmax, nhop=7 * n, rmax=rmax)
+    R = [0] * (D - 1) + [rmax]
+    if D > 1:
+        R[0] = 1
+    m.set_hop(0.17 + 0.11j, 0, n - 1, R, mode="add", allow_conjugate_pair=True)               # (the range is reached for sure)
+    start = [0.1, -0.3, 0.2][:D]
+    w = tb.wf_array(m, mesh)
+    gaps = w.solve_on_grid(start)
+    host = w.to_host().copy()
+    with _lib.knob("TBK_REG_CELLS", 0):
+        w0 = tb.wf_array(m, mesh)
+        gaps0 = w0.solve_on_grid(start)
+        host0 = w0.to_host().copy()
+    assert np.max(np.abs(gaps - gaps0)) < 1e-13
+    idx = np.stack(np.meshgrid(*[np.arange(s - 1) for s in mesh], indexing="ij"), axis=-1).reshape(-1, D)
+    k = np.array(start) + idx / (np.array(mesh) - 1.0)
+    sel = np.arange(0, len(k), max(1, len(k) // 400))
+    V = host[tuple(idx[sel].T)]                                                                # [point][band][component]
+    V0 = host0[tuple(idx[sel].T)]
+    H = np.array([m._gen_ham(kk).reshape(n, n) for kk in k[sel]])
+    ev = np.linalg.eigvalsh(H)
+    e_mesh = np.einsum("kbi,kij,kbj->kb", V.conj(), H, V).real
+    assert np.max(np.abs(e_mesh - ev)) < 1e-12
+    assert np.max(np.abs(np.einsum("kij,kbj->kbi", H, V) - e_mesh[:, :, None] * V)) < 1e-12
+    assert np.max(np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.identity(n))) < 1e-13
+    ov = np.abs(np.einsum("kbi,kbi->kb", V.conj(), V0))
+    gapmin = np.minimum(np.diff(ev, axis=1, prepend=-np.inf), np.diff(ev, axis=1, append=np.inf))
+    assert np.all(ov[gapmin > 1e-6] > 1.0 - 1e-9)
+    assert not np.array_equal(host, host0)                                                     # (the cells were used: another order of the terms)
+    # a window that starts inside a row block of 64 points and ends before the last row: the same bits as the whole array
+    lo = [1] * (D - 1) + [3]
+    sub = [max(2, s - 2) for s in mesh[:-1]] + [mesh[-1] - 3]
+    ww = tb.wf_array(m, sub)
+    ww.solve_on_grid_window(start, lo, mesh)
+    assert np.array_equal(ww.to_host(), host[tuple(slice(a, a + b) for a, b in zip(lo, sub))])
+
+
 @pytest.mark.parametrize("n,nocc,mesh", [(6, 3, [23, 37]), (8, 4, [70, 19]), (8, 3, [5, 6, 41]), (9, 4, [12, 11, 9])])
 def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
     """Wilson-loop eigenphases (berry_phase(..., berry_evals=True), pythtb.py:3798-3838) of 3 and 4 bands: the string's links,
