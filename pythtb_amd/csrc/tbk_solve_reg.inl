@@ -178,8 +178,6 @@ __device__ __forceinline__ bool reg_assemble_cells(const ModelView& mv, const Gr
     // z_last by 0 / 1 weights (a select on `last` turns z[] into an indexed array in scratch memory)
     const double w0 = last == 0 ? 1.0 : 0.0, w1 = last == 1 ? 1.0 : 0.0, w2 = last == 2 ? 1.0 : 0.0;
     const cd zl{fma(w2, z[2].x, fma(w1, z[1].x, w0 * z[0].x)), fma(w2, z[2].y, fma(w1, z[1].y, w0 * z[0].y))};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) acc[s] = cd{0.0, 0.0};
     const int ntile = (nR + REG_TR - 1) / REG_TR;
     const int64_t total = (int64_t)nR * NS;
     const int sl = lane < NS ? lane : NS - 1;
@@ -225,20 +223,27 @@ __device__ __forceinline__ bool reg_assemble_cells(const ModelView& mv, const Gr
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             const int nhere = min(REG_TR, nR - t * REG_TR);
-            for (int rr = 0; rr < nhere; ++rr) {
-                const int4 Rv = *reinterpret_cast<const int4*>(buf + NLD * 64 + rr);
-                const int pl = __builtin_amdgcn_readfirstlane(last == 0 ? Rv.x : last == 1 ? Rv.y : Rv.z) + mv.pmax;   // 0 .. np - 1
-                const int r = t * REG_TR + rr;
-                const cd u = buf[rr * NS + sl];
-                cd ph[NRW];
+            // (the tile's LDS reads all at once: one exposed latency per tile instead of one per lattice vector -- this kernel runs at
+            // one wavefront per SIMD)
+            cd u[REG_TR], ph[REG_TR][NRW];
+            int pl[REG_TR];
 #pragma unroll
-                for (int w = 0; w < NRW; ++w) ph[w] = work[(w < nrows ? w : 0) * nR + r];
+            for (int rr = 0; rr < REG_TR; ++rr) {
+                const int rc = rr < nhere ? rr : 0;
+                const int4 Rv = *reinterpret_cast<const int4*>(buf + NLD * 64 + rc);
+                pl[rr] = rr < nhere ? __builtin_amdgcn_readfirstlane(last == 0 ? Rv.x : last == 1 ? Rv.y : Rv.z) + mv.pmax : -1;   // 0 .. np - 1
+                u[rr] = buf[rc * NS + sl];
+#pragma unroll
+                for (int w = 0; w < NRW; ++w) ph[rr][w] = work[(w < nrows ? w : 0) * nR + t * REG_TR + rc];
+            }
+#pragma unroll
+            for (int rr = 0; rr < REG_TR; ++rr) {
 #pragma unroll
                 for (int p = 0; p < NPM; ++p) {
-                    if (p == pl) {                       // (scalar branch: the registers stay statically indexed)
+                    if (p == pl[rr]) {                   // (scalar branch: the registers stay statically indexed)
 #pragma unroll
                         for (int w = 0; w < NRW; ++w)
-                            if (w < nrows) cfma_x(c[w][p], u, ph[w]);   // (scalar branch)
+                            if (w < nrows) cfma_x(c[w][p], u[rr], ph[rr][w]);   // (scalar branch)
                     }
                 }
             }
@@ -256,7 +261,9 @@ __device__ __forceinline__ bool reg_assemble_cells(const ModelView& mv, const Gr
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // the point's sum: z_last^p for p = -pmax .. pmax
-        if (rw >= g0 && rw < g0 + NRW) {
+        if (rw >= g0 && rw < g0 + NRW) {                 // (every lane passes here in exactly one round)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = cd{0.0, 0.0};
             cd zc{1.0, 0.0};
             for (int q = 0; q < mv.pmax; ++q) zc = cmul(zc, cd{zl.x, -zl.y});
             const cd* mine = cells + (rw - g0) * np * NS;
