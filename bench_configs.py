@@ -203,7 +203,8 @@ def single_gpu(which, reps):
                     "roofline": {"solve_list": {"bound": "fp64 VALU issue: the assembly's multiply-adds (~12 k instructions per k-point; the table streams from L2 by scalar loads), then Householder + QL on (d, e) (~3.5 k; cyclic Jacobi, ~20 k, until round 5)",
                                                 "hbm_frac": 8 * (3 + 8) * nk / (t_list * 1e-3) / 1e9 / HBM, "algorithmic_bytes_per_k": 8 * (3 + 8),
                                                 "assembly_useful_tflops": 8.0 * nterm * nk / (t_list * 1e-3) / 1e12},
-                                 "solve_grid": {"bound": "fp64 VALU issue", "hbm_frac": 16 * 64 * G ** 3 / (t_grid * 1e-3) / 1e9 / HBM,
+                                 "solve_grid": {"bound": "fp64 VALU issue at one wavefront per SIMD (the reflectors' LDS): H(k) from the rows' coefficient cells (reg_assemble_cells, round 5: ~3.5 k instead of 14.5 k instructions per wavefront), then Householder + QL with Q and the bands' back-transformation (~5 k); assembly_useful_tflops counts the merged terms as if each were still evaluated per point",
+                                                "hbm_frac": 16 * 64 * G ** 3 / (t_grid * 1e-3) / 1e9 / HBM,
                                                 "algorithmic_bytes_per_k": 16 * 64,
                                                 "assembly_useful_tflops": 8.0 * nterm * G ** 3 / (t_grid * 1e-3) / 1e12}}})
         _lib.check(lib.tbk_wfs_free(hw))
