@@ -49,6 +49,7 @@ static void knobs_parse() {
     geti("TBK_TW16", k.tw16);
     geti("TBK_E16", k.e16);
     geti("TBK_E16_NS_FULL", k.e16_ns_full);
+    geti("TBK_E16_CELLS", k.e16_cells);
     geti("TBK_TW16_STREAMS", k.tw16_streams);
     if (const char* e = getenv("TBK_TW16_GAPTOL")) k.tw16_gaptol = atof(e);
     geti("TBK_QL16_SPLIT", k.ql16_split);
@@ -665,8 +666,10 @@ static int model_flatten(int dim_k, int norb, int nspin, const double* orb, cons
             if (rid.emplace(key, (int)rid.size()).second)
                 for (int d = 0; d < 4; ++d) rvec.push_back(key[d]);
         }
-        // n <= 16: always (the register kernels assemble from this table only), else when dense enough
-        if (rid.size() <= 256 && ((n <= 16 && rid.size() <= 64) || (n >= 5 && (int64_t)rid.size() * nslot <= 4 * nterm + 64))) {
+        // n <= 4: up to 64 lattice vectors (the k-list kernels stage the whole table in LDS); 5 <= n <= 16: always (the register kernels
+        // and k_e16 assemble from this table only -- round 5: up to 256 vectors whatever the density, a sparse model of 16 functions
+        // with 125 of them used to fall back to the wavefront Jacobi kernel, 10 x the time per point); above: when dense enough
+        if (rid.size() <= 256 && ((n <= 4 && rid.size() <= 64) || (n >= 5 && n <= 16) || (n >= 5 && (int64_t)rid.size() * nslot <= 4 * nterm + 64))) {
             nR = (int)rid.size();
             rblock.assign((size_t)nR * nslot, cd{0.0, 0.0});
             for (int s = 0; s < nslot; ++s)

@@ -101,6 +101,15 @@ __device__ __forceinline__ double e16_bcast(const double v) {
     return v;
 #endif
 }
+// the value of lane `src` (wave-uniform index) in every lane
+__device__ __forceinline__ double e16_lane_d(const double v, const int src) {
+    const I2 i = __builtin_bit_cast(I2, v);
+    const I2 o{__builtin_amdgcn_readlane(i.lo, src), __builtin_amdgcn_readlane(i.hi, src)};
+    return __builtin_bit_cast(double, o);
+}
+#ifndef E16_CELLS_MIN_NR
+#define E16_CELLS_MIN_NR 16               // models with more lattice vectors than this take the row's coefficient cells on a mesh
+#endif
 // (a VGPR written by the vector ALU may be read through DPP two wait states later at the earliest; the compiler does not see
 // into the assembly above, so the values it broadcasts pass through here once)
 __device__ __forceinline__ void e16_dpp_ready(cd& v) { asm volatile("s_nop 1" : "+v"(v.x), "+v"(v.y)); }
@@ -863,13 +872,100 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
             return lastax >= 0 && (lastax == 0 ? R.x : lastax == 1 ? R.y : lastax == 2 ? R.z : R.w) == 0;
         };
         bool shared = false;
+        bool same = true;                                  // this lane's point lies in the mesh row of lane 0's
         if constexpr (MODE == 1) {
-            bool same = true;
 #pragma unroll
             for (int d = 0; d < 3; ++d)
                 if (d < lastax) same = same && mi[d] == __builtin_amdgcn_readfirstlane(mi[d]);
             shared = lastax >= 1 && __builtin_amdgcn_ballot_w64(!same && live) == 0;
         }
+        // ---- models with MANY lattice vectors (a Wannier-interpolated model of 9..16 functions: ~100, most of them with a component
+        // along the last axis): the per-vector staging below -- a scalar load of R ahead of every branch, three vector loads waited
+        // for, an LDS round trip and 64 multiply-adds per lane, each vector on its own -- made a dense 16-function model 10 x slower per
+        // point than cubic16 (profiles/e16_many_R_probe.py: 83 against 7.8 ns).  Such models take the ROW's coefficient cells,
+        //     S = sum_p C_p z_last^p,   C_p = sum over the R with R_last = p of U_R exp(2 pi i k_lead . R_lead),
+        // C_p formed by the lanes together like the row part below (slot t, t + 64, t + 128 each: three multiply-adds per lattice
+        // vector), the lattice vectors held in the LANES (one coalesced load per 64; which of them belong to p is one ballot, the
+        // walk a bit scan, their lead phases computed by the lanes in parallel and fetched by v_readlane: no memory in the control
+        // flow), one LDS hand-over and 64 multiply-adds per lane PER p.  A wavefront that straddles two rows does all of it once per
+        // row, the lanes of the other row idling through the last step: the same bits for a point whatever shares its wavefront.
+        // The choice depends on the model alone (nR), so windows and shards stay bit-identical; cubic16 (7 vectors) keeps the form below.
+        bool cells_done = false;
+        if constexpr (MODE == 1) {
+            if (nRr > E16_CELLS_MIN_NR && lastax >= 0 && (ns_all & 2) == 0) {       // ((ns_all & 2): TBK_E16_CELLS=0)
+                cells_done = true;
+                const int pmax = mv.pmax;
+                // z_last by 0 / 1 weights (a select on `lastax` would turn zk[] into an indexed array in scratch memory)
+                const double w0 = lastax == 0 ? 1.0 : 0.0, w1 = lastax == 1 ? 1.0 : 0.0, w2 = lastax == 2 ? 1.0 : 0.0, w3 = lastax == 3 ? 1.0 : 0.0;
+                const cd zl{fma(w3, zk[3].x, fma(w2, zk[2].x, fma(w1, zk[1].x, w0 * zk[0].x))),
+                            fma(w3, zk[3].y, fma(w2, zk[2].y, fma(w1, zk[1].y, w0 * zk[0].y)))};
+                const unsigned long long other = __builtin_amdgcn_ballot_w64(!same);
+                const int nrow = other != 0 ? 2 : 1;
+                for (int rowi = 0; rowi < nrow; ++rowi) {
+                    const bool mine = rowi == 0 ? same : !same;
+                    const int lsrc = rowi == 0 ? 0 : (int)__builtin_ctzll(other);
+                    cd zrow[4];                            // exp(2 pi i k_d) of the row's leading axes (wave-uniform)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const cd zd = d < lastax ? zk[d] : cd{1.0, 0.0};
+                        zrow[d] = cd{e16_lane_d(zd.x, lsrc), e16_lane_d(zd.y, lsrc)};
+                    }
+                    cd zc{1.0, 0.0};                       // z_last^p, from p = -pmax upwards
+                    for (int q = 0; q < pmax; ++q) zc = cd{fma(zc.x, zl.x, zc.y * zl.y), fma(zc.y, zl.x, -(zc.x * zl.y))};
+                    for (int p = -pmax; p <= pmax; ++p) {
+                        cd cs[3] = {cd{0.0, 0.0}, cd{0.0, 0.0}, cd{0.0, 0.0}};
+                        bool any = false;
+                        for (int base = 0; base < nRr; base += 64) {
+                            const bool have = base + lane < nRr;
+                            int4 Rl = have ? mv.rvec[base + lane] : int4{0, 0, 0, 0};
+                            const int rl = lastax == 0 ? Rl.x : lastax == 1 ? Rl.y : lastax == 2 ? Rl.z : Rl.w;
+                            unsigned long long bits = __builtin_amdgcn_ballot_w64(have && rl == p);
+                            if (bits == 0) continue;
+                            any = true;
+                            if (lastax == 0) Rl.x = 0; else if (lastax == 1) Rl.y = 0; else if (lastax == 2) Rl.z = 0; else Rl.w = 0;
+                            const cd phl = e16_phase_of_R(zrow, Rl);       // lane l: the lead phase of R_{base + l}
+                            while (bits != 0) {
+                                int rr[2];
+                                cd u[2][3];
+#pragma unroll
+                                for (int q = 0; q < 2; ++q) {
+                                    rr[q] = bits != 0 ? (int)__builtin_ctzll(bits) : -1;
+                                    bits &= bits - 1;      // (0 stays 0)
+                                    if (rr[q] >= 0) {
+                                        const cd* un = mv.rblock + (size_t)(base + rr[q]) * nsl;
+#pragma unroll
+                                        for (int t = 0; t < 3; ++t) u[q][t] = t * 64 + lane < nsl ? un[t * 64 + lane] : cd{0.0, 0.0};
+                                    }
+                                }
+#pragma unroll
+                                for (int q = 0; q < 2; ++q) {
+                                    if (rr[q] >= 0) {
+                                        const cd ph{e16_lane_d(phl.x, rr[q]), e16_lane_d(phl.y, rr[q])};
+#pragma unroll
+                                        for (int t = 0; t < 3; ++t)
+                                            if (t * 64 + lane < nsl) e16_cfma(cs[t], u[q][t], ph);
+                                    }
+                                }
+                            }
+                        }
+                        if (any) {                         // (wave-uniform)
+                            E16_ORDER();
+#pragma unroll
+                            for (int t = 0; t < 3; ++t)
+                                if (t * 64 + lane < nsl) e16_put(wxch + t * 64 + lane, cs[t]);
+                            E16_ORDER();
+                            if (mine) {
+#pragma unroll
+                                for (int c = 0; c < 16; ++c)
+                                    if (sidx[c] >= 0) e16_cfma(a[c], e16_get(wxch + sidx[c]), zc);
+                            }
+                        }
+                        zc = cd{fma(zc.x, zl.x, -(zc.y * zl.y)), fma(zc.x, zl.y, zc.y * zl.x)};
+                    }
+                }
+            }
+        }
+        if (!cells_done) {
         auto stage_and_add = [&](const int r) {            // a[c] += U_r[slot(x, c)] e^{2 pi i k.R_r}, U_r through the exchange region
             const cd ph = e16_phase_of_R(zk, mv.rvec[r]);
             const cd* un = mv.rblock + (size_t)r * nsl;
@@ -910,6 +1006,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         }
         for (int r = 0; r < nRr; ++r)
             if (!in_row_part(mv.rvec[r])) stage_and_add(r);
+        }
         E16_ORDER();
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -1115,7 +1212,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         // rest of the spectrum, not only towards each other)
         const double lam_up1 = e16_next(lam_o);
         const bool near = (j + 2 < n && !(lam_up2 - lam_o >= E16_NS_TRIPLE * tmax)) || (j + 1 < n && !(lam_up1 - lam_o >= E16_NS_PAIR * tmax));
-        ns_full = __builtin_amdgcn_ballot_w64(live2 && (splits_here || near || ns_all != 0));   // (ns_all: TBK_E16_NS_FULL=1, round 4's form)
+        ns_full = __builtin_amdgcn_ballot_w64(live2 && (splits_here || near || (ns_all & 1) != 0));   // (ns_all & 1: TBK_E16_NS_FULL=1, round 4's form)
         if ((((unsigned)(ns_full >> (lane & 48))) & 0xffffu) == 0) {      // (row-uniform) this lane's matrix: the tridiagonal part
             double vn[16];
             double s_up = 0.0, s_self = 0.0;                              // v_j . v_{j+1} (0 in lane 15), v_j . v_j

@@ -390,6 +390,47 @@ def test_mesh_solve_with_long_hoppings_along_the_last_axis(tb, n, rmax):
     assert np.max(np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.identity(n))) < 1e-13
 
 
+@pytest.mark.parametrize("n,rmax,mesh", [(9, 2, [6, 41]), (12, 2, [3, 4, 23]), (16, 2, [5, 4, 19]), (16, 9, [37]), (13, 1, [4, 3, 5, 6])])
+def test_mesh_solve_of_9_to_16_states_with_many_lattice_vectors(tb, n, rmax, mesh):
+    """round 5: k_e16 on a mesh takes the row's coefficient cells when the model has more than 16 lattice vectors (a dense model of 16
+    functions was 10 x slower per point than cubic16, profiles/e16_many_R_probe.py).  Against the reference Hamiltonian of sampled
+    points, against the per-vector form (TBK_E16_CELLS=0) to rounding, and a window cut anywhere against the whole array bit for bit
+    (wavefronts of four points straddle rows of 19..41 all the time)."""
+    from pythtb_amd import _lib
+    D = len(mesh)
+    m = hp.random_model(tb.tb_model, n, D, 1, seed=1700 + 10 * n + rmax, nhop=40 * n, rmax=rmax)
+    start = [0.1, -0.3, 0.2, 0.05][:D]
+    with _lib.knob("TBK_E16", 1), _lib.knob("TBK_QL16_MIN", 0), _lib.knob("TBK_QL16_SPLIT_MIN", 0):
+        w = tb.wf_array(m, mesh)
+        gaps = w.solve_on_grid(start)
+        host = w.to_host().copy()
+        with _lib.knob("TBK_E16_CELLS", 0):
+            w0 = tb.wf_array(m, mesh)
+            gaps0 = w0.solve_on_grid(start)
+            host0 = w0.to_host().copy()
+        sub = [max(2, s - 2) for s in mesh[:-1]] + [max(2, mesh[-1] - 5)]
+        lo = [1] * (D - 1) + [min(2, mesh[-1] - sub[-1])]
+        ww = tb.wf_array(m, sub)
+        ww.solve_on_grid_window(start, lo, mesh)
+        assert np.array_equal(ww.to_host(), host[tuple(slice(a, a + b) for a, b in zip(lo, sub))])
+    assert np.max(np.abs(gaps - gaps0)) < 1e-13
+    assert not np.array_equal(host, host0)                                                     # (another order of the terms: the cells were used)
+    idx = np.stack(np.meshgrid(*[np.arange(s - 1) for s in mesh], indexing="ij"), axis=-1).reshape(-1, D)
+    k = np.array(start) + idx / (np.array(mesh) - 1.0)
+    sel = np.arange(0, len(k), max(1, len(k) // 300))
+    V = host[tuple(idx[sel].T)]                                                                # [point][band][component]
+    V0 = host0[tuple(idx[sel].T)]
+    H = np.array([m._gen_ham(kk).reshape(n, n) for kk in k[sel]])
+    ev = np.linalg.eigvalsh(H)
+    e_mesh = np.einsum("kbi,kij,kbj->kb", V.conj(), H, V).real
+    assert np.max(np.abs(e_mesh - ev)) < 1e-12
+    assert np.max(np.abs(np.einsum("kij,kbj->kbi", H, V) - e_mesh[:, :, None] * V)) < 1e-12
+    assert np.max(np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.identity(n))) < 1e-13
+    ov = np.abs(np.einsum("kbi,kbi->kb", V.conj(), V0))
+    gapmin = np.minimum(np.diff(ev, axis=1, prepend=-np.inf), np.diff(ev, axis=1, append=np.inf))
+    assert np.all(ov[gapmin > 1e-6] > 1.0 - 1e-9)
+
+
 @pytest.mark.parametrize("n,rmax,mesh", [(5, 1, [5, 70]), (6, 2, [3, 4, 65]), (8, 3, [7, 129]), (8, 4, [66]), (7, 2, [4, 64])])
 def test_mesh_rows_of_5_to_8_states_from_coefficient_cells(tb, n, rmax, mesh):
     """round 5: k_solve_regd on a mesh whose last axis holds >= 64 points sums the row's coefficient cells (reg_assemble_cells: two rows
