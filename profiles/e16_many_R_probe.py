@@ -25,3 +25,14 @@ for name, model in (("cubic16-like nearest neighbours", hp.random_model(tb.tb_mo
     nR = len({tuple(int(x) for x in R) for R in np.asarray(model._hoppings, dtype=object)[:, 3]}) if hasattr(model, "_hoppings") and len(model._hoppings) else -1
     out[name] = {"ms": best, "ns_per_point": best * 1e6 / side ** 3, "lattice_vectors_one_sign": nR}
 print(json.dumps({"n": n, "side": side, **out}, indent=1))
+
+# the same two models on a k LIST (the mesh's points as a list): eigenvalues only and with eigenvectors
+for name, model in (("nearest neighbours", hp.random_model(tb.tb_model, n, 3, 1, seed=5, nhop=6 * n, rmax=1)),
+                    ("dense", hp.random_model(tb.tb_model, n, 3, 1, seed=6, nhop=60 * n, rmax=rmax))):
+    k = model.k_uniform_mesh([side] * 3)
+    for vec in (False, True):
+        model.solve_all(k, eig_vectors=vec)
+        t0 = time.perf_counter(); model.solve_all(k, eig_vectors=vec); t = time.perf_counter() - t0
+        ctx.prof_enable(1); ctx.prof_reset(); model.solve_all(k, eig_vectors=vec); rep = ctx.prof_report(); ctx.prof_enable(0)
+        kern = sum(v["total_ms"] for v in rep.values())
+        print("list %-20s vectors=%d: kernels %.3f ms = %.1f ns per point (call %.1f ms)" % (name, vec, kern, kern * 1e6 / len(k), t * 1e3))
