@@ -873,9 +873,23 @@ __global__ __launch_bounds__(256) void k_solve_small_multi(const ModelView mv, c
         idx[j] = idx0 + 256 * j;
         const int64_t src = idx[j] < nk ? idx[j] : nk - 1;      // (a point past the end shadows the last one and is not stored)
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            kk[j][d] = d < mv.dim_k ? L.k[src * mv.dim_k + d] : 0.0;
-            z[j][d] = d < mv.dim_k ? expi2pi(kk[j][d]) : cd{1.0, 0.0};
+        for (int d = 0; d < 4; ++d) kk[j][d] = d < mv.dim_k ? L.k[src * mv.dim_k + d] : 0.0;
+    }
+    // exp(2 pi i k_d): a list from k_uniform_mesh runs along its last axis, so the points of a lane (256 apart) mostly share their
+    // leading coordinates bit for bit -- the same function of the same argument is then taken once (wave-uniform test; the bits of
+    // every result are what they were)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d < mv.dim_k) {
+            z[0][d] = expi2pi(kk[0][d]);
+#pragma unroll
+            for (int j = 1; j < KPT; ++j) {
+                if (__builtin_amdgcn_ballot_w64(kk[j][d] != kk[j - 1][d]) == 0) z[j][d] = z[j - 1][d];
+                else z[j][d] = expi2pi(kk[j][d]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) z[j][d] = cd{1.0, 0.0};
         }
     }
     SmallMat<N> M[KPT];
