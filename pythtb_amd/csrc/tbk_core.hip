@@ -666,10 +666,14 @@ static int model_flatten(int dim_k, int norb, int nspin, const double* orb, cons
             if (rid.emplace(key, (int)rid.size()).second)
                 for (int d = 0; d < 4; ++d) rvec.push_back(key[d]);
         }
-        // n <= 4: up to 64 lattice vectors (the k-list kernels stage the whole table in LDS); 5 <= n <= 16: always (the register kernels
-        // and k_e16 assemble from this table only -- round 5: up to 256 vectors whatever the density, a sparse model of 16 functions
-        // with 125 of them used to fall back to the wavefront Jacobi kernel, 10 x the time per point); above: when dense enough
-        if (rid.size() <= 256 && ((n <= 4 && rid.size() <= 64) || (n >= 5 && n <= 16) || (n >= 5 && (int64_t)rid.size() * nslot <= 4 * nterm + 64))) {
+        // n <= 16: up to 64 lattice vectors always (the k-list kernels of n <= 4 stage the whole table in LDS; the register kernels
+        // of 5..8 and k_e16 assemble from it); 9 <= n <= 16: up to 256 whatever the density (round 5: k_e16 assembles from this table
+        // ONLY -- a sparse model of 16 functions with 125 vectors used to fall back to the wavefront Jacobi kernel, 10 x the time per
+        // point); else when dense enough -- for 5..8 states, whose kernels have the term walk as well, from an eighth of the table
+        // filled (profiles/list_5_8_dense_probe.py / list_5_8_sparse_probe.py: 60 n hoppings over 125 vectors 10-20 % faster on
+        // lists and up to 1.65 x on meshes WITH the table, 100 hoppings over ~150 vectors 1.5-2 x faster on lists WITHOUT it)
+        const int64_t fill = n <= 8 ? 8 : 4;
+        if (rid.size() <= 256 && ((n <= 16 && rid.size() <= 64) || (n >= 9 && n <= 16) || (n >= 5 && (int64_t)rid.size() * nslot <= fill * nterm + 64))) {
             nR = (int)rid.size();
             rblock.assign((size_t)nR * nslot, cd{0.0, 0.0});
             for (int s = 0; s < nslot; ++s)
