@@ -151,19 +151,20 @@ __device__ __forceinline__ void reg_assemble_tiled(const ModelView& mv, const cd
 // shards stay bit-identical (a narrow window takes more rounds of three rows); against the tiled sum and the k-list path the sums
 // differ by rounding.
 #define REG_CELLS_NPMAX 9
-#define REG_CELLS_ROWS 3
 __device__ __forceinline__ double rowv_d(const double v, const int src) {   // the value of lane src (wave-uniform), in every lane
     const I2 i = __builtin_bit_cast(I2, v);
     const I2 o{__builtin_amdgcn_readlane(i.lo, src), __builtin_amdgcn_readlane(i.hi, src)};
     return __builtin_bit_cast(double, o);
 }
-template <int N>
+// NRW: rows per round -- a tuning parameter only (a wavefront with more rows takes more rounds; the sums of a point are the same
+// whatever NRW): 2 when the rows hold >= 64 points (never more than two rows per wavefront then), else 3.
+template <int N, int NRW>
 __device__ __forceinline__ bool reg_assemble_cells(const ModelView& mv, const GridArgs& G, const cd (&z)[4], const int64_t id, cd* const tiles,
                                                    cd* const work, const int work_entries, const int lane, cd (&acc)[N * (N + 1) / 2]) {
     constexpr int NS = N * (N + 1) / 2;
     constexpr int NLD = reg_tile_nld<N>();
     constexpr int TS = reg_tile_slots<N>();
-    constexpr int NPM = REG_CELLS_NPMAX, NRW = REG_CELLS_ROWS;
+    constexpr int NPM = REG_CELLS_NPMAX;
     static_assert(NS <= 64, "reg_assemble_cells: one lane per slot");
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int nR = mv.nR, last = G.last;
@@ -495,7 +496,10 @@ __global__ __launch_bounds__(64) void k_solve_regd(const ModelView mv, const int
             cd acc[NS];
             bool done = false;
             if constexpr (MODE == 1) {
-                if (G.reg_cells) done = reg_assemble_cells<N>(mv, G, z, id, tiles, Rf, regd_nu<N>() * 64, lane, acc);
+                if (G.reg_cells) {
+                    if (G.wv.mesh[G.last] >= 64) done = reg_assemble_cells<N, 2>(mv, G, z, id, tiles, Rf, regd_nu<N>() * 64, lane, acc);
+                    else done = reg_assemble_cells<N, 3>(mv, G, z, id, tiles, Rf, regd_nu<N>() * 64, lane, acc);
+                }
             }
             if (!done) reg_assemble_tiled<N>(mv, z, tiles, lane, acc);
             int slot = 0;
