@@ -212,6 +212,7 @@ static void mesh_leg(int side, int reps) {
     mv.nslot = nslot;
     mv.orb = d_orb;
     mv.nR = nR;
+    mv.pmax = 1;            // (largest |R_last|: the row-cell assembly walks p = -pmax .. pmax)
     mv.rvec = d_rvec;
     mv.rblock = d_rblock;
     GridArgs G{};

@@ -108,7 +108,7 @@ __device__ __forceinline__ double e16_lane_d(const double v, const int src) {
     return __builtin_bit_cast(double, o);
 }
 #ifndef E16_CELLS_MIN_NR
-#define E16_CELLS_MIN_NR 16               // models with more lattice vectors than this take the row's coefficient cells on a mesh
+#define E16_CELLS_MIN_NR 16               // models with more lattice vectors than this take the row's coefficient cells on a mesh (cubic16, 7 vectors: 1-2 % slower with them; 27: even; 125: 2 x faster)
 #endif
 // (a VGPR written by the vector ALU may be read through DPP two wait states later at the earliest; the compiler does not see
 // into the assembly above, so the values it broadcasts pass through here once)
