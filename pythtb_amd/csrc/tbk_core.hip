@@ -50,6 +50,7 @@ static void knobs_parse() {
     geti("TBK_E16", k.e16);
     geti("TBK_E16_NS_FULL", k.e16_ns_full);
     geti("TBK_E16_CELLS", k.e16_cells);
+    geti("TBK_E16_EVALS", k.e16_evals);
     geti("TBK_TW16_STREAMS", k.tw16_streams);
     if (const char* e = getenv("TBK_TW16_GAPTOL")) k.tw16_gaptol = atof(e);
     geti("TBK_QL16_SPLIT", k.ql16_split);

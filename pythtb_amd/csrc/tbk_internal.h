@@ -54,6 +54,7 @@ struct TbkKnobs {
     int tw16_streams = -1;      // TBK_TW16_STREAMS  chunks of the twisted-factorisation path in flight at once, 1..3 (default 3; 1 = the context's own stream alone, with per-kernel brackets)
     int e16 = 1;                // TBK_E16           0: n = 9..16 with eigenvectors through round 3's three kernels (tridiagonalise | QL eigenvalues | twisted vectors) instead of the ONE fused kernel k_e16
     int tw16 = 1;               // TBK_TW16          0: n = 9..16 with eigenvectors through the QL-replay three-kernel form instead of twisted-factorisation vectors
+    int e16_evals = 1;          // TBK_E16_EVALS     0: eigenvalue-only lists of 9..16 states take round 3's pair of kernels instead of k_e16<.., false>
     int e16_cells = 1;          // TBK_E16_CELLS     0: k_e16 on a mesh stages every lattice vector per point even for models with many of them
     int e16_ns_full = 0;        // TBK_E16_NS_FULL   1: k_e16 takes the full Newton-Schulz step (matrix cores) for EVERY matrix, as round 4 did
     double tw16_gaptol = 1e-5;  // TBK_TW16_GAPTOL   relative eigenvalue gap (of one unreduced block) below which a matrix is solved again by QL replay

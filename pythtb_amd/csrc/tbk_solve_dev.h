@@ -314,5 +314,6 @@ __device__ __forceinline__ double qle_pick(const double (&a)[16], const int idx,
 // tbk_solve_e16.hip: the fused n = 9..16 solver with eigenvectors (one kernel, reflectors in LDS)
 int tbk_e16_launch(int mode, hipStream_t stream, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G, int64_t id0,
                    int64_t nc, int* list, int* count, double gaptol, int ns_full);
+int tbk_e16_launch_evals(int mode, hipStream_t stream, const ModelView& mv, int64_t nk, const ListArgs& L, int64_t id0, int64_t nc);
 
 #endif  // TBK_SOLVE_DEV_H

@@ -18,3 +18,15 @@ int tbk_e16_launch(int mode, hipStream_t stream, const ModelView& mv, int64_t nk
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }
+
+// Eigenvalues only (k list: mode 0, supplied matrices: mode 2) -> L.eval[b][id0 .. id0 + nc); nothing is listed, nothing else written.
+int tbk_e16_launch_evals(int mode, hipStream_t stream, const ModelView& mv, int64_t nk, const ListArgs& L, int64_t id0, int64_t nc) {
+    TBK_REQUIRE((mode == 0 || mode == 2) && nc >= 1 && nc < (int64_t)0x7fffffff / 16 && mv.nsta >= 2 && mv.nsta <= 16 && L.eval, TBK_EINVAL,
+                "tbk_e16_launch_evals: mode %d, %lld matrices of %d states", mode, (long long)nc, mv.nsta);
+    const unsigned blocks = (unsigned)((nc * 16 + 255) / 256);
+    const GridArgs G{};
+    if (mode == 0) hipLaunchKernelGGL((k_e16<0, false>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, (int*)nullptr, (int*)nullptr, 0.0, 0);
+    else hipLaunchKernelGGL((k_e16<2, false>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, (int*)nullptr, (int*)nullptr, 0.0, 0);
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}

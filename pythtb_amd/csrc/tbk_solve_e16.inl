@@ -149,7 +149,7 @@ __device__ __forceinline__ void e16_pass2(cd (&a)[16], const cd u, const cd q) {
 // back-transformation).
 // Rows <= K are finished (row x is last read at step x - 1, its diagonal entry is never a column > K): nothing below masks them
 // out of the products -- what the passes leave in their columns > K is never read -- only out of the two sums over the rows.
-template <int K>
+template <int K, bool VEC = true>
 __device__ __forceinline__ void e16_house(cd (&a)[16], const int x, e16_lcd* rec, double& mag, cd& unit) {
     const cd ak = a[K];
     // (decided on the entries below the subdiagonal alone, like LAPACK's zlarfg: see ql16_house)
@@ -157,7 +157,7 @@ __device__ __forceinline__ void e16_house(cd (&a)[16], const int x, e16_lcd* rec
     const cd alpha = cd{e16_bcast<K + 1>(ak.x), e16_bcast<K + 1>(ak.y)};   // A[K+1][K]
     const double absa2 = cabs2(alpha);
     e16_lcd* const ru = rec + (e16_off(K) - (K + 1));
-    double absa = 0.0;
+    double absa = absa2;                                 // (0 -- or a NaN, which must reach the coupling and not turn into a split of T)
     cd ph{1.0, 0.0};
     if (absa2 > 0.0) {
         const double inv_a = rsqrt_full(absa2);
@@ -177,7 +177,9 @@ __device__ __forceinline__ void e16_house(cd (&a)[16], const int x, e16_lcd* rec
         }
         mag = nrm;                                       // T[K+1][K] = -ph |x|
         unit = cd{-ph.x, -ph.y};
-        if (x > K) e16_put(ru + x, w);
+        if constexpr (VEC) {
+            if (x > K) e16_put(ru + x, w);
+        }
         e16_dpp_ready(w);
         cd p{0.0, 0.0};
         e16_pass1<K, K + 1>(a, w, p);
@@ -187,7 +189,9 @@ __device__ __forceinline__ void e16_house(cd (&a)[16], const int x, e16_lcd* rec
         e16_dpp_ready(q);
         e16_pass2<K, K + 1>(a, w, q);
     } else {                                             // nothing to reflect: H_K = I
-        if (x > K) e16_put(ru + x, cd{0.0, 0.0});
+        if constexpr (VEC) {
+            if (x > K) e16_put(ru + x, cd{0.0, 0.0});
+        }
     }
 }
 
@@ -205,6 +209,20 @@ __device__ __forceinline__ void e16_count_step(const double (&d)[16], const doub
         acc = __builtin_amdgcn_alignbit(acc, __double2hiint(q), 31);   // (acc << 1) | sign(q)
     }
     if constexpr (I + 1 < 16) e16_count_step<I + 1>(d, e2, n, x, q, acc);
+}
+// The same count with the reciprocal refined to full precision (dstebz's recurrence: backward stable) -- the eigenvalue-only form's
+// last resort, a plain bisection to rounding level for a lane whose Newton iteration did not settle (e16_eigenvalue, RESCUE).
+template <int I>
+__device__ __forceinline__ void e16_count_step_exact(const double (&d)[16], const double (&e2)[16], const double x, double& q, unsigned& acc) {
+    {
+        const double r0 = __builtin_amdgcn_rcp(q);       // (a vanishing pivot: infinite, and it stays that way -- the refinement of an
+        double r = fma(fma(-q, r0, 1.0), r0, r0);        // infinity is a NaN, and so is that of the zero after it; unrefined both behave)
+        r = fma(fma(-q, r, 1.0), r, r);
+        r = fabs(r0) < INFINITY && fabs(q) < INFINITY ? r : r0;
+        q = I == 0 ? d[0] - x : fma(-e2[I > 0 ? I - 1 : 0], r, d[I] - x);
+        acc += (unsigned)__double2hiint(q) >> 31;
+    }
+    if constexpr (I + 1 < 16) e16_count_step_exact<I + 1>(d, e2, x, q, acc);
 }
 // -> bit (15 - i) of the result: pivot i negative
 __device__ __forceinline__ unsigned e16_signs(const double (&d)[16], const double (&e2)[16], const int n, const double x) {
@@ -347,6 +365,7 @@ __device__ unsigned e16_iter_hist[32];
 // d, e: T of this lane's matrix (replicated over its 16 lanes); on return scaled by `scale` (a power of two: exact) with the
 // negligible couplings zeroed, lam = eigenvalue j of the scaled T, [bl, bh] its unreduced block.  flag: this lane could not do
 // its part (no convergence).  n: real states (rows n.. of T are decoupled padding and take no part).
+template <bool RESCUE = false>
 __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_in, double (&d)[16], double (&e)[16], const int n, const int j,
                                                e16_lcd* xd /* [16] of this matrix */, double& scale, double& lam, int& bl, int& bh, unsigned& split,
                                                bool& flag, const int64_t dbg_slot = -1) {
@@ -392,8 +411,11 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     mj *= e16_shr_one<4>(mj);
     mj *= e16_shr_one<8>(mj);
     const double gj = e16_shr_one<1>(mj) * e16_rcp(mj);
-    // (wave-uniform) does any T of the wavefront split, or scale out of range?  No: the scaled recurrence; yes: the pivots
-    const bool splits = __builtin_amdgcn_ballot_w64((split & 0x7fffu & ((1u << (n - 1)) - 1u)) != 0 || (!(mj >= 1e-250) && j < n)) != 0;
+    // does THIS T split, or scale out of range?  No: the scaled recurrence; yes: the pivots.  (Row-uniform, not wave-uniform as in
+    // round 4: a matrix's arithmetic must not depend on what shares its wavefront -- the same k-point in another list, window or
+    // chunk has to come out with the same bits.  A wavefront with both kinds runs both forms behind EXEC masks; that is rare.)
+    const unsigned long long sp_b = __builtin_amdgcn_ballot_w64((split & 0x7fffu & ((1u << (n - 1)) - 1u)) != 0 || (!(mj >= 1e-250) && j < n));
+    const bool splits = ((unsigned)(sp_b >> (lane & 48)) & 0xffffu) != 0;
     e16_lcd* const xg = xd + 96;                         // (g, d g): past the four (d, e) blocks and the counts
     E16_ORDER();
     xd[j] = e16_d2{ds, es};
@@ -423,7 +445,9 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     // ---- one multisection shared by the 16 lanes: lane j looks at point j of 16 inside (gl, gu)
     const double w = (gu - gl) * (1.0 / 17.0);
     const double tj = fma(w, (double)(j + 1), gl);
-    const unsigned sj = splits ? e16_signs(d, e2, n, tj) : e16_signs_scaled(d, e2, n, tj);
+    unsigned sj;
+    if (splits) sj = e16_signs(d, e2, n, tj);
+    else sj = e16_signs_scaled(d, e2, n, tj);
     xch[j] = e16_u2{(unsigned)__builtin_popcount(sj), sj};
     E16_ORDER();
     double lo = gl, hi = gu;
@@ -463,7 +487,9 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
 #pragma unroll 1
     for (int it = 0; it < E16_NBISECT; ++it) {
         const double mid = 0.5 * (lo + hi);
-        const unsigned s = splits ? e16_signs(d, e2, n, mid) : e16_signs_scaled(d, e2, n, mid);
+        unsigned s;
+        if (splits) s = e16_signs(d, e2, n, mid);
+        else s = e16_signs_scaled(d, e2, n, mid);
         const unsigned c = (unsigned)__builtin_popcount(s);
         const bool left = c <= (unsigned)j;              // eigenvalue j is at or above mid
         lo = left ? mid : lo;
@@ -481,7 +507,7 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     bh = n - 1;
     int kb = (int)clo + ((int)j - (int)clo);             // (= j: the whole T is one block)
     int c_lo = (int)clo, c_hi = (int)chi;                // eigenvalues of the block below lo / at or below hi
-    if (splits) {                                        // (wave-uniform: some T of the wavefront splits)
+    if (splits) {                                        // (row-uniform: this T splits)
         const int r = j - (int)clo;
         int cum = 0, cl = 0, ch = 0, start = 0;
         bool found = false;
@@ -581,6 +607,43 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
         if ((threadIdx.x & 63) == 0) atomicAdd(&e16_iter_hist[16 + (wmax < 15 ? wmax : 15)], 1u);
     }
 #endif
+    if constexpr (RESCUE) {
+        // eigenvalues only: nothing is listed -- a lane that is not done (no convergence in E16_NEWTON_MAX steps, inconsistent counts
+        // of a split T) bisects on the exact count from the Gershgorin interval down to rounding level.  Rare; the whole wavefront
+        // walks along (padding rows sit at 2: they add nothing below it).
+        // (... and so does a lane whose eigenvalue has a neighbour within 1e-5 |T|: Newton's last step leaves step^2 / gap behind, which
+        // the eigenvector form repairs by listing the matrix and by the Rayleigh quotient -- neither exists here)
+        const double xup = e16_next(x), xdn = e16_prev(x);
+        const bool crowded = (j + 1 < n && !(xup - x >= 1e-5)) || (j >= 1 && j < n && !(x - xdn >= 1e-5));
+        const bool need = (flag || !conv || crowded) && j < n;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            E16_ORDER();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const e16_d2 t = xd[i];
+                d[i] = t.x;
+                e2[i] = fmax(t.y * t.y, 1e-300);
+            }
+            double blo = gl, bhi = gu;
+#pragma unroll 1
+            for (int it = 0; it < 64; ++it) {
+                const double mid = 0.5 * (blo + bhi);
+                double q = 1.0;
+                unsigned cnt = 0;
+                e16_count_step_exact<0>(d, e2, mid, q, cnt);
+                const bool left = cnt <= (unsigned)j;
+                blo = left ? mid : blo;
+                bhi = left ? bhi : mid;
+            }
+            if (need) x = 0.5 * (blo + bhi);
+            conv = true;
+            flag = false;
+        }
+        // (a matrix with a NaN or an infinity in it has no eigenvalues to bisect for: the caller raises like the reference's eigh.
+        // fmax drops NaNs, so the norm above does not show them: ask d and e themselves, any position of the row)
+        const unsigned long long nb = __builtin_amdgcn_ballot_w64(!(fabs(dd) < INFINITY) || !(fabs(ee_in) < INFINITY));
+        flag = flag || !(tn < INFINITY) || ((unsigned)(nb >> (lane & 48)) & 0xffffu) != 0;
+    }
     flag = flag || !conv;
     lam = x;
     E16_ORDER();
@@ -765,7 +828,10 @@ __device__ __forceinline__ bool e16_twin(const e16_lcd* xd, const double lam, co
 // ---------------------------------------------------------------- the kernel
 // MODE 0: k list, 1: regular mesh into a wf_array, 2: supplied matrices.  The launch covers the matrices [id0, id0 + nc);
 // list / count: the matrices (relative to id0) left to the QL-replay kernels.
-template <int MODE>
+// VEC = false (round 5): eigenvalues only -- the reflector record, the phases, the eigenvector stages and the stores are left out
+// and nothing is listed (e16_eigenvalue<RESCUE>); eigenvalue-only k lists of 9..16 states used to take an older pair of kernels
+// that was SLOWER than this kernel with its eigenvectors (cubic16: 5.1 against 3.7 ns per point).
+template <int MODE, bool VEC = true>
 __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G, const int64_t id0,
                                                 const int64_t nc, int* __restrict__ list, int* __restrict__ count, const double gaptol,
                                                 const int ns_all) {
@@ -1023,7 +1089,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     cd delta{1.0, 0.0};
     e16_ld* const xde = reinterpret_cast<e16_ld*>(wxch + mat * 16);                     // [16] x (d, e)
     if (x == 0) {
-        e16_put(rec + 119, cd{1.0, 0.0});
+        if constexpr (VEC) e16_put(rec + 119, cd{1.0, 0.0});
         xde[0] = a[0].x;
     }
     {
@@ -1031,10 +1097,10 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     {                                                         \
         double mag;                                           \
         cd unit;                                              \
-        e16_house<KK>(a, x, rec, mag, unit);                  \
-        delta = cmul(delta, unit);                            \
+        e16_house<KK, VEC>(a, x, rec, mag, unit);             \
+        if constexpr (VEC) delta = cmul(delta, unit);         \
         if (x == KK + 1) {                                    \
-            e16_put(rec + 119 + (KK + 1), delta);             \
+            if constexpr (VEC) e16_put(rec + 119 + (KK + 1), delta); \
             xde[2 * KK + 1] = mag;                            \
             xde[2 * KK + 2] = a[KK + 1].x;                    \
         }                                                     \
@@ -1048,14 +1114,14 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     {
         const cd t14 = rowbcast_c<15>(a[14]);            // T[15][14]: never reflected
         const double t2 = cabs2(t14);
-        double mag = 0.0;
+        double mag = t2;                                 // (0, or a NaN that must stay one)
         if (t2 > 0.0) {
             const double inv = rsqrt_full(t2);
             mag = t2 * inv;
-            delta = cmul(delta, cd{t14.x * inv, t14.y * inv});
+            if constexpr (VEC) delta = cmul(delta, cd{t14.x * inv, t14.y * inv});
         }
         if (x == 15) {
-            e16_put(rec + 119 + 15, delta);
+            if constexpr (VEC) e16_put(rec + 119 + 15, delta);
             xde[29] = mag;
             xde[30] = a[15].x;
             xde[31] = 0.0;
@@ -1073,8 +1139,33 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
     int bl = 0, bh = 15;
     unsigned split = 0;
     bool flag = false;
-    e16_eigenvalue(dd, ee, d, e, n, j, wxch + mat * 16, scale, lam, bl, bh, split, flag, slot_u);
+    e16_eigenvalue<!VEC>(dd, ee, d, e, n, j, wxch + mat * 16, scale, lam, bl, bh, split, flag, slot_u);
     E16_MARK(3);
+    if constexpr (!VEC) {
+        // ---- eigenvalues only: ascending by construction up to ties between the blocks of a split T (neighbours exchange), out
+        int tid3 = threadIdx.x;
+        asm volatile("" : "+v"(tid3));
+        const int64_t slot_u3 = ((int64_t)blockIdx.x * 4 + (tid3 >> 6)) * 4 + ((tid3 & 63) >> 4);
+        const bool live3 = slot_u3 < nc;
+        const int64_t id3 = id0 + (live3 ? slot_u3 : nc - 1);
+        double lam_o = lam;
+        if (__builtin_amdgcn_ballot_w64((split & 0x7fffu & ((1u << (n - 1)) - 1u)) != 0) != 0) {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const double up = e16_next(lam_o), dn = e16_prev(lam_o);
+                if ((j & 1) == pass) {
+                    if (j + 1 < n && up < lam_o) lam_o = up;
+                } else {
+                    if (j >= 1 && j < n && dn > lam_o) lam_o = dn;
+                }
+            }
+        }
+        if constexpr (MODE != 1) {
+            if (live3 && j < n) Lst.eval[(int64_t)j * nk + id3] = lam_o * e16_rcp(scale);   // (scale is a power of two: exact)
+            if (flag && j < n && live3 && Lst.flags) Lst.flags[0] = 1;                              // (NaN / infinite input: TBK_ENOCONV)
+        }
+        return;
+    }
     double v[16], dlam = 0.0;
     bool bad = false;
     if constexpr (!(E16_SKIP & 4)) bad = e16_twisted(d, e, lam, bl, bh, v, dlam) && j < n;

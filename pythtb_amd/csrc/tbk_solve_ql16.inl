@@ -685,6 +685,17 @@ static int launch_ql16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
     TBK_REQUIRE(nk * 16 < (int64_t)0x7fffffff * 256, TBK_EUNSUPPORTED, "too many k-points for one launch");
     const unsigned blocks = (unsigned)((nk * 16 + 255) / 256);
     if constexpr (!VEC && MODE != 1) {
+        // round 5: eigenvalues only through the fused kernel (k_e16<MODE, false>: tridiagonalisation on DPP, every lane its own
+        // eigenvalue, nothing listed) at every count -- the pair of kernels below was slower than the fused kernel WITH its
+        // eigenvectors (cubic16: 5.1 against 3.7 ns per point; TBK_E16_EVALS=0 keeps the pair)
+        if (tbk_knobs().e16 != 0 && tbk_knobs().e16_evals != 0 && !ctx->qlw_off && (MODE == 2 || mv.nR > 0)) {
+            const int64_t cmax = ((int64_t)0x7fffffff / 16 - 4) & ~(int64_t)3;
+            for (int64_t id0 = 0; id0 < nk; id0 += cmax) {
+                const int rc = tbk_e16_launch_evals(MODE, ctx->stream, mv, nk, L, id0, std::min<int64_t>(cmax, nk - id0));
+                if (rc) return rc;
+            }
+            return TBK_OK;
+        }
         // (from ~8 k matrices on: below that the second kernel's one-matrix-per-lane QL is a single under-filled wavefront
         // and its latency exceeds what the replication costs; TBK_QL16_EVONLY=0: always the single replicated kernel)
         if (tbk_knobs().ql16_evonly != 0 && nk >= 8192) {

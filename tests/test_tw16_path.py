@@ -111,6 +111,49 @@ def test_supplied_matrices_against_lapack(tb, n):
         assert max(q) < 2e-14, (i, q)
 
 
+@pytest.mark.parametrize("n", [9, 12, 16])
+def test_eigenvalues_only_through_the_fused_kernel(tb, n):
+    """round 5: eigenvalue-only calls of 9..16 states (supplied matrices and k lists, any count) run k_e16<.., false> -- no reflector
+    record, no vectors, nothing listed (a lane whose Newton iteration does not settle bisects on the exact count).  Against LAPACK,
+    against round 3's pair of kernels (TBK_E16_EVALS=0), sorted, the same bits for a matrix whatever shares its batch, and a NaN raises."""
+    from pythtb_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(300 + n)
+    nk = 9000
+    h = rng.standard_normal((nk, n, n)) + 1j * rng.standard_normal((nk, n, n))
+    h = h + h.conj().transpose(0, 2, 1)
+    sp = special_matrices(n, rng)
+    h[:len(sp)] = np.array(sp)
+
+    def evals(hh):
+        ev = np.zeros((n, len(hh)))
+        hc = np.ascontiguousarray(hh)
+        _lib.check(_lib.lib.tbk_eigh_batch(ctx.handle, n, _lib.dptr(hc.view(float)), len(hh), _lib.dptr(ev), None))
+        return ev
+    with _lib.knob("TBK_E16", 1), _lib.knob("TBK_E16_EVALS", 1):
+        ev = evals(h)
+        few = evals(h[:len(sp) + 5])                      # another batch size, other neighbours in the wavefront
+        shuffled = evals(h[::-1])
+    with _lib.knob("TBK_E16_EVALS", 0):
+        ev0 = evals(h)
+    ref = np.linalg.eigvalsh(h)
+    nrm = np.maximum(np.abs(ref).max(axis=1), 1e-300)
+    assert np.all(np.diff(ev, axis=0) >= 0.0)
+    err = np.abs(ev.T - ref).max(axis=1) / nrm
+    err[0] = 0.0                                          # (the zero matrix: |T| = 0)
+    assert err.max() < 1e-14, (err.argmax(), err.max())
+    assert np.abs(ev[:, 0]).max() < 1e-30
+    assert np.max(np.abs(ev - ev0).max(axis=0)[1:] / nrm[1:]) < 1e-14
+    assert np.array_equal(few, ev[:, :few.shape[1]])
+    assert np.array_equal(shuffled[:, ::-1], ev)
+    bad = h[:40].copy()
+    bad[7, 2, 3] = bad[7, 3, 2] = np.nan
+    with _lib.knob("TBK_E16", 1), _lib.knob("TBK_E16_EVALS", 1):
+        with pytest.raises(_lib.TbkError):
+            evals(bad)
+        assert np.array_equal(evals(h[:40]), ev[:, :40])   # (the flag does not stick)
+
+
 def test_tridiagonal_newton_schulz_step_against_the_full_one(tb):
     """round 5: k_e16 takes the Newton-Schulz step with V^T V - I cut to its tridiagonal part unless T splits or eigenvalues crowd;
     TBK_E16_NS_FULL=1 is round 4's form (the full step on the matrix cores for every matrix).  Same eigenvalues bit for bit (the
