@@ -613,8 +613,14 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
         // walks along (padding rows sit at 2: they add nothing below it).
         // (... and so does a lane whose eigenvalue has a neighbour within 1e-5 |T|: Newton's last step leaves step^2 / gap behind, which
         // the eigenvector form repairs by listing the matrix and by the Rayleigh quotient -- neither exists here)
+        // (neighbours in ONE unreduced block only: the Kramers pairs of a cleanly split T are simple roots of their own blocks)
         const double xup = e16_next(x), xdn = e16_prev(x);
-        const bool crowded = (j + 1 < n && !(xup - x >= 1e-5)) || (j >= 1 && j < n && !(x - xdn >= 1e-5));
+        const int bl_up = __builtin_amdgcn_update_dpp(0, bl, 0x101, 0xf, 0xf, true), bl_dn = __builtin_amdgcn_update_dpp(0, bl, 0x111, 0xf, 0xf, true);
+        // (... and not the numerically double ones, gap below 1e-13 |T| -- spin-degenerate bands: the multiplicity-2 Newton step
+        // has taken both members to their mean at rounding level; bisecting them costs twice the kernel, profiles/evals16_twins_probe.py)
+        const double gup = xup - x, gdn = x - xdn;
+        const bool crowded = (j + 1 < n && bl_up == bl && !(gup >= 1e-5) && !(gup < 1e-13)) ||
+                             (j >= 1 && j < n && bl_dn == bl && !(gdn >= 1e-5) && !(gdn < 1e-13));
         const bool need = (flag || !conv || crowded) && j < n;
         if (__builtin_amdgcn_ballot_w64(need) != 0) {
             E16_ORDER();
@@ -1150,10 +1156,12 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         const int64_t id3 = id0 + (live3 ? slot_u3 : nc - 1);
         double lam_o = lam;
         if (__builtin_amdgcn_ballot_w64((split & 0x7fffu & ((1u << (n - 1)) - 1u)) != 0) != 0) {
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
+            // (the eigenvalues of different blocks of a split T that agree to rounding may come out in any order: a full odd-even
+            // transposition sort along the row -- values only, there are no vectors to keep in step)
+#pragma unroll 1
+            for (int pass = 0; pass < 16; ++pass) {
                 const double up = e16_next(lam_o), dn = e16_prev(lam_o);
-                if ((j & 1) == pass) {
+                if ((j & 1) == (pass & 1)) {
                     if (j + 1 < n && up < lam_o) lam_o = up;
                 } else {
                     if (j >= 1 && j < n && dn > lam_o) lam_o = dn;
