@@ -608,28 +608,27 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
     }
 #endif
     if constexpr (RESCUE) {
-        // eigenvalues only: nothing is listed -- a lane that is not done (no convergence in E16_NEWTON_MAX steps, inconsistent counts
-        // of a split T) bisects on the exact count from the Gershgorin interval down to rounding level.  Rare; the whole wavefront
-        // walks along (padding rows sit at 2: they add nothing below it).
-        // (... and so does a lane whose eigenvalue has a neighbour within 1e-5 |T|: Newton's last step leaves step^2 / gap behind, which
-        // the eigenvector form repairs by listing the matrix and by the Rayleigh quotient -- neither exists here)
-        // (neighbours in ONE unreduced block only: the Kramers pairs of a cleanly split T are simple roots of their own blocks)
-        const double xup = e16_next(x), xdn = e16_prev(x);
-        const int bl_up = __builtin_amdgcn_update_dpp(0, bl, 0x101, 0xf, 0xf, true), bl_dn = __builtin_amdgcn_update_dpp(0, bl, 0x111, 0xf, 0xf, true);
-        // (... and not the numerically double ones, gap below 1e-13 |T| -- spin-degenerate bands: the multiplicity-2 Newton step
-        // has taken both members to their mean at rounding level; bisecting them costs twice the kernel, profiles/evals16_twins_probe.py)
-        const double gup = xup - x, gdn = x - xdn;
-        const bool crowded = (j + 1 < n && bl_up == bl && !(gup >= 1e-5) && !(gup < 1e-13)) ||
-                             (j >= 1 && j < n && bl_dn == bl && !(gdn >= 1e-5) && !(gdn < 1e-13));
-        const bool need = (flag || !conv || crowded) && j < n;
-        if (__builtin_amdgcn_ballot_w64(need) != 0) {
-            E16_ORDER();
+        // eigenvalues only: nothing is listed, so nothing may be left to the list.  EVERY lane's result is checked against the exact
+        // pivot count (reciprocal refined to full precision, dstebz's recurrence: backward stable): eigenvalue j must lie inside
+        // (x - 3e-15, x + 3e-15] |T|.  Newton's answer passes unless the spectrum crowds (a pair merged to its mean, a cluster
+        // the bracket did not separate, a graded T) or the iteration did not settle; a lane that fails bisects on the same count
+        // from the Gershgorin interval down to rounding level.  Two counts per lane, 7 % of this form; the rest is rare.
+        E16_ORDER();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const e16_d2 t = xd[i];
-                d[i] = t.x;
-                e2[i] = fmax(t.y * t.y, 1e-300);
-            }
+        for (int i = 0; i < 16; ++i) {
+            const e16_d2 t = xd[i];
+            d[i] = t.x;
+            e2[i] = fmax(t.y * t.y, 1e-300);
+        }
+        unsigned c_below = 0, c_above = 0;
+        {
+            double q = 1.0;
+            e16_count_step_exact<0>(d, e2, x - 3e-15, q, c_below);
+            q = 1.0;
+            e16_count_step_exact<0>(d, e2, x + 3e-15, q, c_above);
+        }
+        const bool need = (flag || !conv || !(c_below <= (unsigned)j && (unsigned)j < c_above)) && j < n;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
             double blo = gl, bhi = gu;
 #pragma unroll 1
             for (int it = 0; it < 64; ++it) {
@@ -642,9 +641,9 @@ __device__ __forceinline__ void e16_eigenvalue(const double dd, const double ee_
                 bhi = left ? bhi : mid;
             }
             if (need) x = 0.5 * (blo + bhi);
-            conv = true;
-            flag = false;
         }
+        conv = true;
+        flag = false;
         // (a matrix with a NaN or an infinity in it has no eigenvalues to bisect for: the caller raises like the reference's eigh.
         // fmax drops NaNs, so the norm above does not show them: ask d and e themselves, any position of the row)
         const unsigned long long nb = __builtin_amdgcn_ballot_w64(!(fabs(dd) < INFINITY) || !(fabs(ee_in) < INFINITY));
