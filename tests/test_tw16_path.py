@@ -154,6 +154,41 @@ def test_eigenvalues_only_through_the_fused_kernel(tb, n):
         assert np.array_equal(evals(h[:40]), ev[:, :40])   # (the flag does not stick)
 
 
+@pytest.mark.parametrize("n", [9, 13, 16])
+def test_eigenvalues_only_on_hard_spectra(tb, n):
+    """profiles/evals16_stress.py in small: spectra on which a Newton iteration that is trusted goes wrong (pairs split by 1e-15..1e-3
+    merge to their mean, a triple within 1e-6, graded over twelve decades, an (n - 2)-fold level) -- the eigenvalue-only form checks
+    every result against the exact Sturm count and bisects where it fails: rounding level on all of them, and sorted."""
+    from pythtb_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(900 + n)
+    nk = 400
+
+    def conj_unitary(lev):
+        a = rng.standard_normal((len(lev), n, n)) + 1j * rng.standard_normal((len(lev), n, n))
+        q = np.linalg.qr(a)[0]
+        h = (q * lev[:, None, :]) @ q.conj().transpose(0, 2, 1)
+        return 0.5 * (h + h.conj().transpose(0, 2, 1))
+    base = np.sort(rng.standard_normal((nk, (n + 1) // 2)), axis=1)
+    split = 10.0 ** rng.uniform(-15, -3, size=(nk, 1))
+    fam = {
+        "pairs": conj_unitary(np.repeat(base, 2, axis=1)[:, :n] + np.tile([0.0, 1.0], (n + 1) // 2)[:n] * split),
+        "graded": conj_unitary(np.sort(10.0 ** rng.uniform(-6, 6, size=(nk, n)), axis=1)),
+        "rank2": conj_unitary(np.concatenate([np.ones((nk, n - 2)), 1.0 + rng.standard_normal((nk, 2))], axis=1)),
+        "triple": conj_unitary(np.sort(rng.standard_normal((nk, n)), axis=1) * np.r_[np.ones(n - 3), 0, 0, 0] +
+                               np.r_[np.zeros(n - 3), 0.5, 0.5 + 1e-6, 0.5 + 2e-6]),
+    }
+    with _lib.knob("TBK_E16", 1), _lib.knob("TBK_E16_EVALS", 1):
+        for name, h in fam.items():
+            ev = np.zeros((n, nk))
+            hc = np.ascontiguousarray(h)
+            _lib.check(_lib.lib.tbk_eigh_batch(ctx.handle, n, _lib.dptr(hc.view(float)), nk, _lib.dptr(ev), None))
+            ref = np.linalg.eigvalsh(h)
+            err = (np.abs(ev.T - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+            assert np.all(np.diff(ev, axis=0) >= 0.0), name
+            assert err < 2e-14, (name, err)
+
+
 def test_tridiagonal_newton_schulz_step_against_the_full_one(tb):
     """round 5: k_e16 takes the Newton-Schulz step with V^T V - I cut to its tridiagonal part unless T splits or eigenvalues crowd;
     TBK_E16_NS_FULL=1 is round 4's form (the full step on the matrix cores for every matrix).  Same eigenvalues bit for bit (the
