@@ -728,7 +728,7 @@ __device__ __forceinline__ bool e16_twisted(const double (&d0)[16], const double
     dlam = gam_r * inz * inz;
     // residual |(T - lambda) z| / |z| = |gamma_r| / |z|: a few eps |T| for an eigenvalue that accurate
     const double tn = tnorm + fabs(lam);
-    return !(fabs(gam_r) * inz <= 1e-11 * tn);
+    return !(fabs(gam_r) * inz <= 1e-13 * tn);   // (1e-11 until round 5: pairs split by a little more than gaptol kept vectors with residuals of 1e-12, profiles/evecs_stress.py)
 }
 
 // The SECOND eigenvector of a pair of eigenvalues of one block closer than gaptol |T| (twins: Kramers pairs, spin-degenerate bands,
