@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
 #pragma unroll
             for (int c = 0; c < 16; ++c)
                 if (sidx[c] >= 0) a[c] = e16_get(wxch + sidx[c]);
-        } else {
+        } else if (lastax >= 0) {                           // (k lists have no row part: no walk over the table for nothing)
             for (int r = 0; r < nRr; ++r)
                 if (in_row_part(mv.rvec[r])) stage_and_add(r);
         }
