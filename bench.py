@@ -717,7 +717,10 @@ def main():
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC passes (rocprofv3 --pmc), per launch
         if os.path.exists(tpath):
-            tj = json.load(open(tpath)).get(dom, {})
+            tj = json.load(open(tpath)).get(dom)
+            if tj is None:                          # an empty / clobbered table must be seen, not read as "no counters"
+                sys.stderr.write("[bench] profiles/traffic.json has no entry for %r: roofline.traffic is null\n" % dom)
+                tj = {}
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = "profiles/traffic.json <- %s (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % tj.get("source")
         roofs = {}
@@ -746,7 +749,8 @@ def main():
                                "tbk_berry_flux_async); the one-pass extension is reported under fused_extension",
                        "global_mesh": [MESH * world, MESH], "start_k": [-0.5, -0.5],
                        "sharding": "k-slabs along mesh axis 0, halo row recomputed", "gather": gather},
-            "roofline": dict(roofs.get(dom, {}), kernel=dom, traffic=traffic, traffic_source=traffic_source),
+            "roofline": dict(roofs.get(dom, {}), kernel=dom, traffic=traffic, traffic_source=traffic_source,
+                             traffic_over_algorithmic=(traffic / alg[dom]) if traffic else None),
             "kernels": kern, "empty_bracket_ms": ev_ms,
             "roofline_all": roofs,
             "solve_kpts_per_s": npt / (kern["solve_grid"]["avg_bracket_ms"] * 1e-3) if "solve_grid" in kern else None,
