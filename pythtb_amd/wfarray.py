@@ -9,6 +9,7 @@ to the caller, after which the device copy is refreshed before its next use).
 """
 import copy
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -50,12 +51,13 @@ class _PointLedger(object):
     view of the storage).  Each point has a snapshot of what the device held when it was handed out (or last synchronised);
     `changed()` is one vectorised bit-compare per chunk of 256 points.  With `own` the ledger also owns the memory the
     caller's arrays view (chunks that are never reallocated), so a write made through a temporary -- `wf[i,j][0] *= z` --
-    is still there when the next device use looks; otherwise the live rows are rows of the host mirror."""
+    is still there when the next device use looks; otherwise the live rows are rows of the host mirror.
+    A chunk is a record [snap, live or None, ids]; `slot[fi]` = (record, row)."""
     CHUNK = 256
 
     def __init__(self, pt_shape, own):
         self.pt_shape, self.own = tuple(pt_shape), own
-        self.slot, self.idx, self.snap, self.live, self.n = {}, [], [], [], 0
+        self.slot, self.chunks, self.n = {}, [], 0
 
     def __len__(self):
         return self.n
@@ -63,49 +65,47 @@ class _PointLedger(object):
     def __contains__(self, fi):
         return fi in self.slot
 
+    @property
+    def idx(self):
+        return [fi for ch in self.chunks for fi in ch[2]]
+
     def add(self, fi, value):
-        c, r = divmod(self.n, self.CHUNK)
-        if r == 0:
-            self.snap.append(np.empty((self.CHUNK,) + self.pt_shape, dtype=complex))
-            if self.own:
-                self.live.append(np.empty((self.CHUNK,) + self.pt_shape, dtype=complex))
-        self.snap[c][r] = value
+        if not self.chunks or len(self.chunks[-1][2]) == self.CHUNK:
+            self.chunks.append([np.empty((self.CHUNK,) + self.pt_shape, dtype=complex),
+                                np.empty((self.CHUNK,) + self.pt_shape, dtype=complex) if self.own else None, []])
+        ch = self.chunks[-1]
+        r = len(ch[2])
+        ch[0][r] = value
         if self.own:
-            self.live[c][r] = value
-        self.slot[fi] = self.n
-        self.idx.append(fi)
+            ch[1][r] = value
+        ch[2].append(fi)
+        self.slot[fi] = (ch, r)
         self.n += 1
 
     def view(self, fi):
-        c, r = divmod(self.slot[fi], self.CHUNK)
-        return self.live[c][r]
+        ch, r = self.slot[fi]
+        return ch[1][r]
 
     def set(self, fi, value):
         """The storage at this point was assigned: snapshot (and the caller's arrays of it) follow."""
-        c, r = divmod(self.slot[fi], self.CHUNK)
-        self.snap[c][r] = value
+        ch, r = self.slot[fi]
+        ch[0][r] = value
         if self.own:
-            self.live[c][r] = value
+            ch[1][r] = value
 
     def indices(self):
         return np.array(self.idx, dtype=np.int64)
-
-    def _chunks(self, rows):
-        ids = self.indices()
-        for c in range(len(self.snap)):
-            lo = c * self.CHUNK
-            m = min(self.CHUNK, self.n - lo)
-            cid = ids[lo:lo + m]
-            yield cid, (self.live[c][:m] if self.own else rows[cid]), self.snap[c][:m]
 
     def changed(self, rows=None):
         """(flat indices, values) of the points whose live array differs bit for bit from its snapshot; the snapshots
         are brought up to date.  `rows`: the mirror as [point][...] for a ledger that does not own its live rows."""
         out_i, out_v = [], []
-        for cid, live, snap in self._chunks(rows):
-            m = len(cid)
+        for snap, live, ids in self.chunks:
+            m = len(ids)
+            cid = np.array(ids, dtype=np.int64)
+            live = live[:m] if self.own else rows[cid]
             diff = np.flatnonzero((np.ascontiguousarray(live).view(np.uint64).reshape(m, -1)
-                                   != snap.view(np.uint64).reshape(m, -1)).any(axis=1))
+                                   != snap[:m].view(np.uint64).reshape(m, -1)).any(axis=1))
             if len(diff):
                 out_i.append(cid[diff])
                 out_v.append(np.array(live[diff]))
@@ -116,16 +116,42 @@ class _PointLedger(object):
 
     def refresh(self, pos, buf, rows=None):
         """The device copy was rewritten: live rows and snapshots take buf[pos[fi]]."""
-        ids = self.indices()
-        for c in range(len(self.snap)):
-            lo = c * self.CHUNK
-            m = min(self.CHUNK, self.n - lo)
-            src = buf[[pos[int(i)] for i in ids[lo:lo + m]]]
-            self.snap[c][:m] = src
+        for snap, live, ids in self.chunks:
+            m = len(ids)
+            src = buf[[pos[int(i)] for i in ids]]
+            snap[:m] = src
             if self.own:
-                self.live[c][:m] = src
+                live[:m] = src
             else:
-                rows[ids[lo:lo + m]] = src
+                rows[np.array(ids, dtype=np.int64)] = src
+
+    def recycle(self):
+        """Forget the pool chunks no array outside the ledger views any more; returns the number of points dropped.
+        To be called right after `changed()` was carried to the device (so nothing a temporary wrote is lost).  Every
+        array handed out -- and every view derived from one: NumPy collapses `.base` to the owner of the memory -- holds a
+        reference to its CHUNK, so a chunk whose only referrer is this ledger has no live handle left: a read loop
+        `for i, j: x = wf[i, j]` keeps at most the chunk of its last point (without this the loop ran the pool
+        to its cap and then gave up device residency for good)."""
+        if not self.own:
+            return 0
+        keep, dropped = [], 0
+        while self.chunks:
+            ch = self.chunks.pop()
+            live = ch[1]
+            ch[1] = None                                    # referrers now: `live` here + getrefcount's argument (+ user views)
+            if sys.getrefcount(live) > 2:
+                ch[1] = live
+                keep.append(ch)
+            else:
+                for fi in ch[2]:
+                    del self.slot[fi]
+                dropped += len(ch[2])
+            del live
+        keep.reverse()
+        # (a kept chunk that is not full stays as it is -- its rows never move; add() opens a new chunk after it)
+        self.chunks = keep
+        self.n -= dropped
+        return dropped
 
 
 class wf_array(object):
@@ -368,9 +394,6 @@ class wf_array(object):
                 "\nnot specify the nsta_arr parameter when initializing this object.\n\n")
         self._start_k = start_k
         m = self._model
-        for d in range(self._dim_arr):                       # impose_pbc's guard (pythtb.py:2725)
-            if m._per[d] not in m._per:
-                raise Exception("Periodic boundary condition can be specified only along periodic directions!")
         sk = np.array(start_k, dtype=float)
         if sk.size != self._dim_arr:
             raise Exception("\n\nk-vector of wrong shape!")
@@ -417,6 +440,8 @@ class wf_array(object):
         from ._lib import TbkError
         m = self._model
         occ_arr = self._occ(occ)
+        if occ_arr.ndim == 1:
+            occ_arr = self._wrap_occ(occ_arr)
         if (self._dim_arr == 2 and self._dim_arr == m._dim_k and self._nsta_arr == m._nsta and m._nsta in (2, 4)
                 and 1 <= len(occ_arr) <= 2):
             start = np.ascontiguousarray(np.array(start_k, dtype=float).reshape(-1))
@@ -578,6 +603,11 @@ class wf_array(object):
             led = self._pt_copies
             if led is not None and fi in led:
                 return led.view(fi)
+            if led is not None and len(led) >= self._pt_cap():
+                # the pool is full: carry what was written through it to the device, then forget the chunks nobody holds an
+                # array of any more (a read loop over the mesh stays resident: no whole-array download, no sticky export)
+                self._sync_point_writes()
+                led.recycle()
             if led is None or len(led) < self._pt_cap():
                 if self._pt_views is not None and fi in self._pt_views and self._host is not None:
                     return self._host[key]                     # (handed out as a mirror row earlier: that row is the live one)
@@ -595,19 +625,29 @@ class wf_array(object):
             self._host_exported = True
             self._pt_views = None
         out = self._host_array()[key]
+        if self._pt_copies is not None and self._dev_valid and self._dev is not None:
+            fi = self._flat_index(key)
+            if fi in self._pt_copies:
+                # a point lives in ONE buffer: its pool array stays the live one, also once the mirror has been exported
+                # (two unrelated live buffers for one point lost the first of two writes: ADVICE r5)
+                return self._pt_copies.view(fi)
         if self._dev_valid and self._dev is not None and not self._host_exported:
             fi = self._flat_index(key)
-            if self._pt_copies is not None and fi in self._pt_copies:
-                return self._pt_copies.view(fi)                # (a point lives in one ledger: its pool array is the live one)
             if self._pt_views is None:
                 self._pt_views = _PointLedger(pt_shape, own=False)
             if fi not in self._pt_views:
                 if len(self._pt_views) >= self._pt_cap():
                     self._sync_point_writes()
-                    self._host_array()
-                    self._host_exported = True
-                    self._pt_views = None
-                    return out
+                    # every handed-out row is a view whose base is the mirror: none left (besides `out`) => start afresh
+                    host = self._host
+                    if self._host_valid and host.base is None and sys.getrefcount(host) <= 4:   # self._host, `host`, out.base, the argument
+                        self._pt_views = _PointLedger(pt_shape, own=False)
+                    else:
+                        del host
+                        self._host_array()
+                        self._host_exported = True
+                        self._pt_views = None
+                        return out
                 self._pt_views.add(fi, out)
         return out
 
@@ -723,6 +763,16 @@ class wf_array(object):
             return np.arange(self._nsta_arr, dtype=np.int32)
         return np.array(occ, dtype=int)
 
+    def _wrap_occ(self, occ):
+        """The band list as NumPy's fancy index reads it (the reference takes `_wfs[:, occ, :]` / `plane_wfs[:, :, occ]`,
+        pythtb.py:2981, :2989-2996, :3141): entries in [-nsta_arr, nsta_arr) count from the end when negative, anything
+        else is NumPy's IndexError."""
+        n = self._nsta_arr
+        bad = (occ < -n) | (occ >= n)
+        if np.any(bad):
+            raise IndexError("index %d is out of bounds for axis 1 with size %d" % (int(occ[bad][0]), n))
+        return np.where(occ < 0, occ + n, occ)
+
     def berry_phase(self, occ="All", dir=None, contin=True, berry_evals=False):
         """Berry phase (or Wilson-loop eigenphases) of every string along `dir`
         (pythtb.py:2863-3066).  Link overlaps, polar factors, ordered products and
@@ -741,6 +791,7 @@ class wf_array(object):
             use_dir = int(dir)
         else:
             raise Exception("\n\nWrong dimensionality!")
+        occ = self._wrap_occ(occ)
         h = self._ensure_dev()
         nocc = len(occ)
         other = [int(self._mesh_arr[d]) for d in range(self._dim_arr) if d != use_dir]
@@ -773,21 +824,6 @@ class wf_array(object):
     def berry_flux(self, occ="All", dirs=None, individual_phases=False):
         """Berry flux through the (dirs[0],dirs[1]) planes (pythtb.py:3068-3205):
         plaquette phases and their deterministic sum are computed on the device."""
-        # (the occupied-band list as a ctypes pointer is kept per distinct list: building it anew is 3 us of a 40 us call)
-        b = self._call_bufs(self._nsta_arr)
-        try:
-            okey = occ if isinstance(occ, str) or occ is None else tuple(occ)
-            o = b["occ"].get(okey)
-        except TypeError:
-            okey, o = None, None
-        if o is None:
-            occ_arr = self._occ(occ)
-            occ32 = np.ascontiguousarray(occ_arr, dtype=np.int32)
-            o = (occ32, _lib.iptr(occ32), len(occ32))
-            if okey is not None and occ_arr.ndim == 1:
-                if len(b["occ"]) > 64:
-                    b["occ"].clear()
-                b["occ"][okey] = o
         if self._model._assume_position_operator_diagonal == False:  # noqa: E712
             raise Exception("\n\nBerry-like objects of Wannier90 models need "
                             "my_model.ignore_position_operator_offdiagonal()")
@@ -799,6 +835,23 @@ class wf_array(object):
             raise Exception("Direction for Berry flux calculation out of bounds.")
         if self._dim_arr not in (2, 3, 4):
             raise Exception("\n\nWrong dimensionality!")
+        # (the occupied-band list as a ctypes pointer is kept per distinct list: building it anew is 3 us of a 40 us call)
+        b = self._call_bufs(self._nsta_arr)
+        try:
+            okey = occ if isinstance(occ, str) or occ is None else tuple(occ)
+            o = b["occ"].get(okey)
+        except TypeError:
+            okey, o = None, None
+        if o is None:
+            occ_arr = self._occ(occ)
+            if occ_arr.ndim == 1:
+                occ_arr = self._wrap_occ(occ_arr)
+            occ32 = np.ascontiguousarray(occ_arr, dtype=np.int32)
+            o = (occ32, _lib.iptr(occ32), len(occ32))
+            if okey is not None and occ_arr.ndim == 1:
+                if len(b["occ"]) > 64:
+                    b["occ"].clear()
+                b["occ"][okey] = o
         h = self._ensure_dev()
         if self._dim_arr == 2:
             rest, nsl = [], 1

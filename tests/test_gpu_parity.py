@@ -449,6 +449,47 @@ def test_mesh_berry_vs_oracle(tb, case):
                     assert np.max(np.abs(wrap(got - ref))) < TOL_P
 
 
+def test_signed_band_indices_like_numpy(tb):
+    """occ is a NumPy fancy index in the reference (pythtb.py:2981, :2989-2996, :3141): negative entries count from the top
+    band, an entry outside [-nsta, nsta) is IndexError -- in berry_phase, berry_flux and the fused extension alike."""
+    from oracle import tb_oracle as orc
+    rng = np.random.default_rng(11)
+    for m, mesh, start in ((hp.haldane(tb.tb_model, 0.0), [33, 33], [-0.5, -0.5]),
+                           (hp.kane_mele(tb.tb_model, "odd"), [21, 17], [0.1, 0.2]),
+                           (hp.cubic16(tb.tb_model), [9, 9, 9], [0.0, 0.0, 0.0])):
+        n, D = m._nsta, len(mesh)
+        w = tb.wf_array(m, mesh)
+        w.solve_on_grid(start)
+        owfs, _ = orc.solve_on_grid(m, mesh, start, vectorised=True)
+        occs = [[-1], [-2, -1], range(-2, 0), [0, -1]] + [list(rng.choice(np.arange(-n, n), size=int(rng.integers(1, min(n, 4) + 1)),
+                                                                       replace=False)) for _ in range(4)]
+        for occ in occs:
+            pos = [int(o) % n for o in occ]
+            if len(set(pos)) != len(pos):
+                continue                                   # a band twice: a singular overlap, nothing to compare
+            for d in range(D):
+                got = w.berry_phase(occ, d, contin=False)
+                ref = orc.berry_phase(owfs, D, list(occ), d, contin=False)
+                assert np.max(np.abs(wrap(got - ref))) < TOL_P
+                assert np.array_equal(got, w.berry_phase(pos, d, contin=False))
+            gotp = w.berry_flux(occ, individual_phases=True)
+            refp = orc.berry_flux(owfs, D, list(occ), [0, 1], individual_phases=True, vectorised=True)
+            assert np.max(np.abs(wrap(gotp - refp))) < TOL_P
+            assert np.max(np.abs(w.berry_flux(occ) - refp.sum(axis=(-2, -1)))) < 1e-9
+            assert np.array_equal(gotp, w.berry_flux(pos, individual_phases=True))
+        for bad in ([n], [-n - 1], [0, n + 3]):
+            with pytest.raises(IndexError):
+                w.berry_phase(bad, 0, contin=False)
+            with pytest.raises(IndexError):
+                w.berry_flux(bad)
+        if D == 2:
+            w2 = tb.wf_array(m, mesh)
+            g, f = w2.solve_on_grid_flux(start, occ=[-n])       # the bottom band by its negative index
+            assert abs(f - w.berry_flux([0])) < 1e-9
+            with pytest.raises(IndexError):
+                w2.solve_on_grid_flux(start, occ=[n])
+
+
 def test_upload_roundtrip_and_user_written_arrays(tb):
     """A wf_array filled on the host (oracle eigenvectors, different gauge) gives the
     same gauge-invariant numbers; download(upload(x)) is the identity."""

@@ -491,7 +491,9 @@ class _FakeWfsLib(object):
         self.next = 1
 
     def _arr(self, ptr, n):
-        return np.ctypeslib.as_array(ptr, shape=(n,))
+        # (np.ctypeslib.as_array on a pointer leaves a reference CYCLE that keeps the caller's array referenced until the next
+        # gc pass; the real library holds nothing, and the ledger's chunk recycling reads reference counts)
+        return np.frombuffer((ctypes.c_double * n).from_address(ctypes.addressof(ptr.contents)), dtype=float)
 
     def tbk_wfs_create(self, ctx, dim, mesh, nsta, ncomp, out):
         m = np.ctypeslib.as_array(mesh, shape=(dim,))
@@ -624,11 +626,73 @@ def test_point_ledger_gives_way_to_the_whole_mirror_past_its_cap(monkeypatch):
     w._PT_TRACK_MAX = 64
     w._PT_TRACK_BYTES = 1 << 40
     first = w[0, 1]
-    for j in range(70):
-        w[1 + j // 20, j % 20]
-    assert w._host_exported and len(w._pt_copies) == 64
+    held = [w[1 + j // 20, j % 20] for j in range(70)]      # arrays the caller keeps: their chunk cannot be recycled
+    assert w._host_exported and len(w._pt_copies) == 64 and len(held) == 70
+    assert np.shares_memory(w[0, 1], first)         # a pool point stays ONE buffer once the mirror is exported
     first[0, 0] = 11.0
     late = w[15, 15]                                # a view of the exported mirror
     late[1, 0] = 12.0
     w._ensure_dev()
     assert d[1, 0] == 11.0 and d[15 * 20 + 15, 2] == 12.0
+
+
+@pytest.mark.parametrize("pool", [False, True])
+def test_read_loop_past_the_cap_keeps_device_residency(monkeypatch, pool):
+    """`for i, j: x = wf[i, j]` over more points than the ledger follows ran the pool to its cap, downloaded
+    the whole array and left `_host_exported` set for good, so every later berry_* call re-uploaded the mirror.  Chunks (pool)
+    or the mirror (small arrays) that no caller array views any more are forgotten instead; writes made on the way -- also
+    through temporaries -- still reach the device; an array the caller keeps across the recycling stays live."""
+    w, fake, d, device_write = _fake_resident(monkeypatch, [40, 40], small_mirror_bytes=0 if pool else None)
+    w._PT_TRACK_MAX = 64 if not pool else 768       # (pool chunks hold 256 points; two stay referenced below)
+    w._PT_TRACK_BYTES = 1 << 40
+    # held across the whole loop (small arrays hand out rows of ONE mirror: an array kept there means the mirror stays the
+    # live copy past the cap, as before -- at most 32 MB per device use)
+    keep = w[0, 0] if pool else None
+    want = d.copy()
+    acc = 0.0
+    for i in range(40):
+        for j in range(40):
+            if pool:
+                x = w[i, j]                         # (the previous point's array is alive during the next access)
+                acc += x[0, 0].real
+            else:
+                acc += w[i, j][0, 0].real
+            if (i * 40 + j) % 97 == 0:
+                w[i, j][1, 1] = -3.0                # a write through a temporary
+                want[i * 40 + j, 3] = -3.0
+    assert acc == float(np.sum(want[:, 0].real))
+    x = None
+    assert not w._host_exported
+    assert len(w._pt_copies if pool else w._pt_views) <= w._pt_cap()
+    if pool:
+        assert fake.calls["down"] == 0              # never the whole array
+    ups = fake.calls["up"]
+    w._ensure_dev()
+    w._ensure_dev()
+    assert fake.calls["up"] == ups == 0             # berry_* twice: no full-array upload
+    assert np.array_equal(d, want)
+    if pool:
+        keep[0, 1] = 5.5                            # the array held since before the recycling is still live
+        w._ensure_dev()
+        assert d[0, 1] == 5.5 and fake.calls["up"] == 0
+        assert np.shares_memory(w[0, 0], keep)
+
+
+def test_band_lists_wrap_like_a_numpy_fancy_index():
+    """occ of berry_phase / berry_flux is `_wfs[:, occ, :]` in the reference (pythtb.py:2981, :3141): differential check of
+    wf_array._wrap_occ against NumPy's own indexing on random signed lists, incl. the exception class."""
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 4, 16):
+        w = tb.wf_array(hp.haldane(tb.tb_model, 0.0), [3, 3], nsta_arr=n)
+        ref = np.arange(n)
+        for _ in range(200):
+            occ = rng.integers(-n - 2, n + 2, size=int(rng.integers(1, 6)))
+            try:
+                want = ref[occ]
+            except IndexError:
+                with pytest.raises(IndexError, match="out of bounds for axis 1 with size %d" % n):
+                    w._wrap_occ(w._occ(occ))
+                continue
+            assert np.array_equal(w._wrap_occ(w._occ(list(occ))), want)
+        assert np.array_equal(w._wrap_occ(w._occ(range(-n, 0))), ref)
+        assert np.array_equal(w._wrap_occ(w._occ("All")), ref)

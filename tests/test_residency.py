@@ -123,6 +123,30 @@ def test_getitem_is_writable_like_the_reference(tb, mesh):
     assert np.array_equal(w.to_host()[11, 3], ref2)
 
 
+def test_read_loop_over_more_points_than_the_pool_follows_stays_resident(tb):
+    """`for i, j: x = wf[i, j]` past the pool's cap used to download the whole array and leave it exported, so
+    every later berry_* call re-uploaded it.  Chunks nobody holds an array of are recycled instead: after reading 3 000 points
+    of a 1024^2 array (cap lowered to 1 024 points) two berry_flux calls move no array in either direction, and a write made on
+    the way still counts."""
+    m = hp.haldane(tb.tb_model, 0.3)
+    w = tb.wf_array(m, [1025, 1025])                 # 67 MB: past _SMALL_MIRROR_BYTES, points are fetched into the pool
+    w.solve_on_grid([0.0, 0.0])
+    w._PT_TRACK_MAX = 1024
+    f0 = w.berry_flux([0])
+    stats(tb, reset=True)
+    acc = 0.0
+    for i in range(3):
+        for j in range(1000):
+            x = w[i, j]
+            acc += abs(x[0, 0])
+    w[2, 500][0] *= -1.0                             # (a band's sign: gauge only, the flux is unchanged; it must still be uploaded)
+    assert not w._host_exported and len(w._pt_copies) <= 1024
+    assert abs(w.berry_flux([0]) - f0) < 1e-9 and abs(w.berry_flux([0]) - f0) < 1e-9
+    st = stats(tb)
+    assert st["h2d_bytes"] == 2 * 2 * 16 and st["h2d_calls"] == 1          # the one changed point
+    assert st["d2h_bytes"] < 3100 * 64 + 4096                              # the points read (+ the small results), never 67 MB
+
+
 def test_exported_mirror_stays_live(tb):
     """A script may keep the array it got from `_wfs` and write to it at any time: every later
     device call must see those writes, and device-side writes must show up in the held array."""
