@@ -742,6 +742,7 @@ static int fill_occ(const tbk_wfs* w, const int32_t* occ, int nocc, int* dst) {
 }
 
 #include "tbk_berry_big.inl"   // nocc > TBK_MAX_NOCC: link determinants by LU, one workgroup per link
+#include "tbk_berry_lanes.inl" // Wilson loops of 3 and 4 bands: a lane per string / per link, vectors through LDS
 
 // scratch of the large-nocc paths: [occ | dets of ndirs directions | LU workspace]
 static int big_scratch(tbk_wfs* w, const int32_t* occ, int nocc, int ndirs, size_t extra, int** occ_dev, cd** dets,
@@ -1879,10 +1880,37 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 A.flags = ctx->flags_dev;
             }
         }
-        // 3 or 4 bands: a thread per segment (k_wilson_seg_reg); segments sized on the whole call
+        // 3 or 4 bands whose occupied vectors fit the LDS tile: a lane per string or per link, vectors through LDS (tbk_berry_lanes.inl;
+        // TBK_WILSON_REG=3, the default; 1: round 4's thread per segment, 2: a thread per link + the product tree, 0: the workgroup kernels)
         const int wreg = tbk_knobs().wilson_reg;
-        const bool seg_route = !mfma_route && nocc >= 3 && nocc <= 4 && wreg != 0 && wreg != 2 && A.nstrings * L < (int64_t)0x7fffffff * 128;
+        bool lanes_route = false, lanes_l = false;
+        size_t lanes_lds = 0;
+        int lanes_res = 1;                                // wavefronts of the S form resident per CU (LDS-bound)
+        if (nocc >= 3 && nocc <= 4 && wreg == 3 && v.npts < (int64_t)0x7fffffff && v.ncomp <= 21) {
+            // L: the string runs along the fastest axis, or there are too few strings to give every lane one
+            lanes_l = (A.sdir == 1 && L >= 32) || (A.nstrings < 32 && L >= 32);
+            lanes_lds = lanes_l ? (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd) : (size_t)2 * nocc * 64 * v.ncomp * sizeof(cd);
+            lanes_route = lanes_lds <= 64 * 1024;
+            lanes_res = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lanes_lds, 1)));
+        }
+        if (lanes_route) mfma_route = false;
+        // else 3 or 4 bands: a thread per segment (k_wilson_seg_reg); segments sized on the whole call
+        const bool seg_route = !lanes_route && !mfma_route && nocc >= 3 && nocc <= 4 && wreg != 0 && wreg != 2 && A.nstrings * L < (int64_t)0x7fffffff * 128;
         int seg_len_r = L, nseg_r = 1;
+        int64_t lanes_ntile = 1;
+        if (lanes_route && lanes_l) {
+            seg_len_r = 64;
+            nseg_r = (L + 63) / 64;
+        } else if (lanes_route) {
+            // S: one round of resident wavefronts when the strings allow it (a longer segment pays its first row once), else about four
+            const int64_t nsb_guess = A.nstrings;          // (tiles are counted per batch below; the segment length is set once, on the call)
+            lanes_ntile = (nsb_guess + 63) / 64;
+            const int64_t R = (int64_t)ctx->cus * lanes_res;
+            int64_t nseg = lanes_ntile * 2 <= R ? R / lanes_ntile : (4 * R + lanes_ntile - 1) / lanes_ntile;
+            nseg = std::max<int64_t>(1, std::min<int64_t>(nseg, std::max(1, L / 2)));
+            seg_len_r = (int)((L + nseg - 1) / nseg);
+            nseg_r = (L + seg_len_r - 1) / seg_len_r;
+        }
         if (seg_route) {
             const int64_t want = (int64_t)ctx->cus * 512;
             const int64_t nseg = std::max<int64_t>(1, std::min<int64_t>((L + 3) / 4, (want + A.nstrings - 1) / A.nstrings));
@@ -1890,7 +1918,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             nseg_r = (L + seg_len_r - 1) / seg_len_r;
         }
         // matrices per string that the buffers hold: every link (the workgroup kernels), or one per segment
-        const int Lb = mfma_route ? A.nseg : (seg_route ? nseg_r : L);
+        const int Lb = mfma_route ? A.nseg : (seg_route || lanes_route ? nseg_r : L);
         size_t batch_bytes = (size_t)1 << 30;
         if (tbk_knobs().wilson_batch_bytes >= 0) batch_bytes = (size_t)std::max(1ll, tbk_knobs().wilson_batch_bytes);   // test hook
         const int64_t cap = std::max<int64_t>(1, (int64_t)(batch_bytes / (2 * (size_t)Lb * nn * sizeof(cd))));
@@ -1971,6 +1999,34 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
 #undef TBK_WILP
                 TBK_HIP(hipGetLastError());
                 Lt = A.nseg;
+            } else if (lanes_route) {
+                WilsonLanesArgs S{};
+                S.W = W;
+                S.seg_len = seg_len_r;
+                S.nseg = nseg_r;
+                S.ntile = (ns + 63) / 64;
+                S.magic = (unsigned)((65536 + v.ncomp - 1) / v.ncomp);
+                S.segs = buf1;                     // [ns][nseg][nn]
+                S.prod = buf0;                     // string s at buf0 + s nseg nn, where the tree leaves a string's product
+                S.pstride = (size_t)Lb * nn;
+                {
+                    ProfScope ps(ctx, lanes_l ? "wilson_lanes_l" : "wilson_lanes_s");
+                    const dim3 g((unsigned)(lanes_l ? ns * S.nseg : S.ntile * S.nseg)), b(64);
+                    if (lanes_l) {
+                        if (nocc == 3) hipLaunchKernelGGL((k_wilson_lanes_l<3>), g, b, lanes_lds, ctx->stream, S);
+                        else hipLaunchKernelGGL((k_wilson_lanes_l<4>), g, b, lanes_lds, ctx->stream, S);
+                    } else {
+                        if (nocc == 3) hipLaunchKernelGGL((k_wilson_lanes_s<3>), g, b, lanes_lds, ctx->stream, S);
+                        else hipLaunchKernelGGL((k_wilson_lanes_s<4>), g, b, lanes_lds, ctx->stream, S);
+                    }
+                    TBK_HIP(hipGetLastError());
+                }
+                {
+                    ProfScope ps(ctx, "wilson_lanes_combine");
+                    if (nocc == 3) hipLaunchKernelGGL((k_wilson_lanes_combine<3>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, S);
+                    else hipLaunchKernelGGL((k_wilson_lanes_combine<4>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, S);
+                    TBK_HIP(hipGetLastError());
+                }
             } else
             if (nocc >= 3 && nocc <= 4 && wreg != 0 && !mfma_route && A.nstrings * L < (int64_t)0x7fffffff * 128) {
                 // 3 or 4 bands in registers (tbk_berry_big.inl): a thread per SEGMENT of a string forms its links, their polar
@@ -2012,7 +2068,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 hipLaunchKernelGGL(k_link_polar_big, dim3((unsigned)std::min<int64_t>(ns * L, nblk)), dim3(256), 0, ctx->stream, W);
                 TBK_HIP(hipGetLastError());
             }
-            const bool tree = !seg_route;
+            const bool tree = !seg_route && !lanes_route;
             for (int st = 1; tree && st < Lt; st *= 2) {
                 WilsonTreeArgs T{cur, nxt, nocc, Lt, st, ns};
                 const int64_t items = ns * ((Lt + 2 * st - 1) / (2 * st));

@@ -1,0 +1,237 @@
+// tbk_berry_lanes.inl -- Wilson-loop eigenphases of 3 and 4 bands, the link stage (pythtb.py:3823-3838: per link
+// `U, s, Vh = svd(M); P = P (U Vh)`).  Round 6, replacing the thread-per-segment kernel of round 4 (k_wilson_seg_reg, kept behind
+// TBK_WILSON_REG=1) on arrays whose occupied vectors fit the tile below.
+//
+// What was wrong with a thread per segment (profiles/r05fcfg): every lane fetched its own points 16 bytes at a time, 96 bytes from
+// its neighbour's -- 7.7 M L2 requests for 76 MB of vectors (a whole 128-byte line per 16 bytes used: the 36 KB a wavefront touches
+// per link do not survive in a 32 KB L1), 77 % of a wavefront's life waiting at one wavefront per SIMD; and the segments of a string
+// were then multiplied by ONE thread (257 threads on the chip, a serial chain of dependent loads: 167 us of the 281).
+//
+// Here a wavefront (one per workgroup: no barriers, the LDS operations of a wavefront execute in order) moves the occupied vectors
+// of a TILE of 64 mesh points into LDS with global_load_lds_dwordx4 -- the 64 lanes of a transfer fetch 64 CONSECUTIVE 16-byte
+// units of a band's plane, so every line is requested once -- and each lane then reads its own points from LDS:
+//   * S form (strings across the lanes; the array's fastest axis is not the string axis): lane = string, the wavefront walks a
+//     SEGMENT of links; two row buffers, the row of link i + 2 is requested as soon as the overlap matrix of link i has been formed
+//     and lands behind the polar iteration; each lane keeps the ordered product of its segment.
+//   * L form (the string along the lanes; the string axis is the fastest one, or there are too few strings to fill lanes): lane =
+//     link of one 64-link tile of a string, 65 points in LDS; the 64 polar factors are multiplied by an ORDERED shuffle tree (the
+//     left operand always from the lower lane), six levels.
+// k_wilson_lanes_combine multiplies a string's segment products the same way: a wavefront per string, a contiguous run of segments
+// per lane, the same tree.  The polar iteration (Newton-Schulz, wilson_polar_reg) and the tail of the pipeline (Cayley transform,
+// Hermitian eigen-solve, phases) are those of tbk_berry_big.inl.
+
+struct WilsonLanesArgs {
+    WilsonBigArgs W;
+    int seg_len;       // S: links a lane multiplies in order; L: 64
+    int nseg;          // matrices per string in `segs`: segments (S) or tiles (L)
+    int64_t ntile;     // S: tiles of 64 strings (per segment)
+    unsigned magic;    // ceil(65536 / ncomp): u / ncomp = (u * magic) >> 16 for the unit numbers of a tile
+    cd* segs;          // [ns][nseg][nocc^2]
+    cd* prod;          // combine: string s at prod + s * pstride
+    size_t pstride;
+};
+
+typedef __attribute__((address_space(3))) void* lanes_lds_ptr;
+
+// One band's components at the tile's points -> row[u], u = j * ncomp + c (j: point of the tile, c: component).  `pt(j)`: the mesh
+// point of tile point j.  CONTIG: pt(j) = pt0 + j, the units are consecutive in memory and no division is needed.  A lane whose
+// unit lies past the tile fetches the last unit again (every transfer complete: vmcnt counts them).
+template <bool CONTIG, class PT>
+__device__ __forceinline__ void lanes_issue_row(const WfsView& v, const int band, const int64_t pt0, PT pt, const int npt, cd* row,
+                                                const int lane, const unsigned magic) {
+    const int ncomp = v.ncomp;
+    const int nunit = npt * ncomp;
+    const cd* const plane = v.data + (int64_t)band * v.npts * ncomp;
+    for (int u0 = 0; u0 < nunit; u0 += 64) {
+        const int u = min(u0 + lane, nunit - 1);
+        const cd* src;
+        if constexpr (CONTIG) {
+            src = plane + pt0 * ncomp + u;
+        } else {
+            const int j = (int)(((unsigned)u * magic) >> 16);
+            src = plane + pt(j) * ncomp + (u - j * ncomp);
+        }
+        __builtin_amdgcn_global_load_lds((const void*)src, (lanes_lds_ptr)(row + u0), 16, 0, 0);
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void lanes_identity(cd (&R)[M][M]) {
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) R[a][b] = cd{a == b ? 1.0 : 0.0, 0.0};
+}
+template <int M>
+__device__ __forceinline__ void lanes_mul(cd (&R)[M][M], const cd (&X)[M][M]) {      // R <- R X
+    cd T[M][M];
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            cd acc{0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < M; ++k) cfma(acc, R[a][k], X[k][b]);
+            T[a][b] = acc;
+        }
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) R[a][b] = T[a][b];
+}
+// X_ab = <u_a(p) | u_b(q)> from two row sets in LDS: band a of tile point j at rows[a * rowsz + j * ncomp + c]
+template <int M>
+__device__ __forceinline__ void lanes_overlap(const cd* P, const int jp, const cd* Q, const int jq, const int rowsz, const int ncomp,
+                                              cd (&X)[M][M]) {
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) X[a][b] = cd{0.0, 0.0};
+    const cd* p = P + jp * ncomp;
+    const cd* q = Q + jq * ncomp;
+    for (int c = 0; c < ncomp; ++c) {
+        cd pc[M], qc[M];
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            pc[a] = p[a * rowsz + c];
+            qc[a] = q[a * rowsz + c];
+        }
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+#pragma unroll
+            for (int b = 0; b < M; ++b) cfmac(X[a][b], pc[a], qc[b]);
+    }
+}
+// ordered product over the lanes: lane 0 ends with R_0 R_1 ... R_63 (the left operand always from the lower lane; lanes that hold
+// nothing carry the identity)
+template <int M>
+__device__ __forceinline__ void lanes_tree(cd (&R)[M][M]) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        cd O[M][M];
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+#pragma unroll
+            for (int b = 0; b < M; ++b) O[a][b] = cd{__shfl_down(R[a][b].x, off), __shfl_down(R[a][b].y, off)};
+        lanes_mul<M>(R, O);        // (lanes that are not a multiple of 2 off form products nobody reads)
+    }
+}
+
+// ---- S form: lane = string, a wavefront walks one segment of links for 64 neighbouring strings
+template <int M>
+__global__ __launch_bounds__(64) void k_wilson_lanes_s(const WilsonLanesArgs S) {
+    extern __shared__ __align__(16) unsigned char lds_lanes[];
+    const WilsonBigArgs& A = S.W;
+    const int lane = threadIdx.x;
+    const int ncomp = A.v.ncomp;
+    const int64_t seg = blockIdx.x / S.ntile, ts = blockIdx.x - seg * S.ntile;    // (neighbouring workgroups: neighbouring tiles of one segment)
+    const int64_t s = ts * 64 + lane;
+    const bool live = s < A.ns;
+    const int npt = (int)min((int64_t)64, A.ns - ts * 64);
+    const int i0 = (int)seg * S.seg_len, len = min(S.seg_len, A.nlinks - i0);    // wave-uniform
+    const int64_t base = axis_offset(A.other, A.s0 + (live ? s : A.ns - 1)) + (int64_t)i0 * A.sdir;
+    const int64_t base0 = (int64_t)__shfl((long long)base, 0);
+    const bool contig = __builtin_amdgcn_ballot_w64(live && base != base0 + lane) == 0;
+    const int rowsz = 64 * ncomp;
+    cd* const buf = reinterpret_cast<cd*>(lds_lanes);            // [2][M][rowsz]
+    int occ[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) occ[a] = A.occ[a];
+    auto issue = [&](const int li, const int b) __attribute__((always_inline)) {       // row of string point i0 + li -> buffer b
+        const int64_t shift = (int64_t)li * A.sdir;
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            cd* row = buf + (b * M + a) * rowsz;
+            if (contig) lanes_issue_row<true>(A.v, occ[a], base0 + shift, [](int) { return (int64_t)0; }, npt, row, lane, S.magic);
+            else lanes_issue_row<false>(A.v, occ[a], 0, [&](const int j) { return (int64_t)__shfl((long long)base, j) + shift; }, npt, row, lane, S.magic);
+        }
+    };
+    issue(0, 0);
+    issue(1, 1);
+    cd R[M][M];
+    lanes_identity<M>(R);
+    bool all_ok = true;
+    for (int li = 0; li < len; ++li) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        cd X[M][M];
+        lanes_overlap<M>(buf + (li & 1) * M * rowsz, lane, buf + ((li + 1) & 1) * M * rowsz, lane, rowsz, ncomp, X);
+        // the row of link li is not needed any more: its buffer takes the row of link li + 2, which lands behind the polar iteration
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (li + 2 <= len) issue(li + 2, li & 1);
+        if (!live) lanes_identity<M>(X);           // (a lane past the last string reads repeated units: not a link matrix)
+        all_ok = wilson_polar_reg<M>(X) && all_ok;
+        lanes_mul<M>(R, X);
+    }
+    if (!live) return;
+    if (!all_ok) atomicExch(A.flags + 1, 1);
+    cd* const o = S.segs + ((size_t)s * S.nseg + seg) * (M * M);
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) o[a * M + b] = R[a][b];
+}
+
+// ---- L form: lane = link, a wavefront takes 64 consecutive links of one string
+template <int M>
+__global__ __launch_bounds__(64) void k_wilson_lanes_l(const WilsonLanesArgs S) {
+    extern __shared__ __align__(16) unsigned char lds_lanes[];
+    const WilsonBigArgs& A = S.W;
+    const int lane = threadIdx.x;
+    const int ncomp = A.v.ncomp;
+    const int64_t s = blockIdx.x / S.nseg;
+    const int t = (int)(blockIdx.x - s * S.nseg);
+    const int i0 = t * 64, nl = min(64, A.nlinks - i0), npt = nl + 1;
+    const int64_t base = axis_offset(A.other, A.s0 + s) + (int64_t)i0 * A.sdir;
+    const int rowsz = (65 * ncomp + 63) & ~63;                   // (whole transfers: the repeated units of a row's last transfer stay inside it)
+    cd* const buf = reinterpret_cast<cd*>(lds_lanes);            // [M][rowsz]
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const int band = A.occ[a];
+        if (A.sdir == 1) lanes_issue_row<true>(A.v, band, base, [](int) { return (int64_t)0; }, npt, buf + a * rowsz, lane, S.magic);
+        else lanes_issue_row<false>(A.v, band, 0, [&](const int j) { return base + (int64_t)j * A.sdir; }, npt, buf + a * rowsz, lane, S.magic);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    cd X[M][M];
+    const bool act = lane < nl;
+    lanes_overlap<M>(buf, act ? lane : 0, buf, act ? lane + 1 : 0, rowsz, ncomp, X);
+    if (!act) lanes_identity<M>(X);
+    if (!wilson_polar_reg<M>(X)) atomicExch(A.flags + 1, 1);
+    lanes_tree<M>(X);
+    if (lane != 0) return;
+    cd* const o = S.segs + ((size_t)s * S.nseg + t) * (M * M);
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) o[a * M + b] = X[a][b];
+}
+
+// ---- the segments of a string in order: a wavefront per string, a contiguous run of segments per lane, the ordered tree
+template <int M>
+__global__ __launch_bounds__(64) void k_wilson_lanes_combine(const WilsonLanesArgs S) {
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int run = (S.nseg + 63) / 64;
+    const int g0 = lane * run, g1 = min(g0 + run, S.nseg);
+    const cd* const segs = S.segs + (size_t)s * S.nseg * (M * M);
+    cd R[M][M];
+    lanes_identity<M>(R);
+    for (int g = g0; g < g1; ++g) {
+        cd X[M][M];
+        const cd* x = segs + (size_t)g * (M * M);
+#pragma unroll
+        for (int a = 0; a < M; ++a)
+#pragma unroll
+            for (int b = 0; b < M; ++b) X[a][b] = x[a * M + b];
+        lanes_mul<M>(R, X);
+    }
+    lanes_tree<M>(R);
+    if (lane != 0) return;
+    cd* const o = S.prod + (size_t)s * S.pstride;
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) o[a * M + b] = R[a][b];
+}

@@ -89,7 +89,8 @@ struct TbkKnobs {
     int chain_wave_from = -1;   // TBK_CHAIN_WAVE_FROM  smallest band count of the wave-per-string link kernels (default 1)
     int det_big_from = -1;      // TBK_DET_BIG_FROM  smallest band count of the workgroup-level link determinants
     int wilson_mfma = 1;        // TBK_WILSON_MFMA   0: Wilson loops of 5..8 wide bands on the workgroup-per-link kernels instead of k_chain_prod_tile<.., POLAR>
-    int wilson_reg = 1;         // TBK_WILSON_REG    0: link polar factors of 3-4 bands by the workgroup-per-link kernel (A/B)
+    int wilson_reg = 3;         // TBK_WILSON_REG    Wilson loops of 3-4 bands: 3 a lane per string / link, vectors through LDS (tbk_berry_lanes.inl);
+                                //                   1 round 4's thread per segment; 2 a thread per link + product tree; 0 the workgroup-per-link kernel
     int wilson_big_from = -1;   // TBK_WILSON_BIG_FROM  ... of the workgroup-level Wilson-loop pipeline
     long long wilson_batch_bytes = -1;   // TBK_WILSON_BATCH_BYTES  test hook: workspace bound per batch of strings
     double wilson_alpha = 0.0;  // TBK_WILSON_ALPHA  test hook: first Cayley angle

@@ -327,7 +327,9 @@ __device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N]
             };
             const double dlt = 0.5 * (d[L + 1] - d[L]), el2 = e[L] * e[L];
             const double t1 = fma(dlt, dlt, el2);
-            const double hh = t1 * rsqrt_full(t1);
+            // (dlt^2 + e_L^2 underflows to 0 for a block of denormal scale whose e_L is still not negligible: 0 * rsqrt(0) would
+            // be NaN and the lane would spin its 30 sweeps; any h of the right magnitude does there -- ADVICE r5)
+            const double hh = t1 > 0.0 ? t1 * rsqrt_full(t1) : fmax(fabs(dlt), fabs(e[L]));
             double g = dm - d[L] + el2 * recip(dlt + copysign(hh, dlt));
             if (first && m == N - 1) g = dm - first_shift;
             first = false;
@@ -371,7 +373,7 @@ __device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N]
                 if (j == m) e[j] = 0.0;
         }
     }
-    return !work;
+    return negligible(L);                      // (the state AFTER the last sweep, not the test made before it)
 }
 
 // The two LOWEST eigenvalues of the 4 x 4 symmetric tridiagonal (d, e) in closed form, to ~1e-6 |T|: first-sweep shifts for
@@ -928,7 +930,7 @@ __global__ __launch_bounds__(256) void k_solve_small_multi(const ModelView mv, c
 }
 
 // ---- per-axis tables of a regular mesh: one thread per (axis, index)
-__global__ __launch_bounds__(256) void k_grid_tables(const ModelView mv, const GridArgs G, cd* tz0, cd* tf0) {
+__global__ __launch_bounds__(256) void k_grid_tables(const ModelView mv, const GridArgs G, cd* tz0, cd* tf0, cd* tf_first = nullptr) {
     int t = blockIdx.x * 256 + threadIdx.x;
     int d = 0;
     int64_t zoff = 0, foff = 0;
@@ -951,6 +953,16 @@ __global__ __launch_bounds__(256) void k_grid_tables(const ModelView mv, const G
         cd f = cconj(expi2pi(kd * td));
         if (wrap) f = cmul(f, G.pbc[d * mv.nsta + o]);
         tf0[foff + (int64_t)t * mv.nsta + o] = f;
+    }
+    // the last axis' phases at GLOBAL index 0 (k_d = start_k[d] + 0 / (nd - 1): the expression above at g = 0, the same bits a
+    // window that holds column 0 has in tf[last][0..n)), for a window whose last column is the image but that starts later
+    if (tf_first && t == 0 && d == G.wv.dim_arr - 1) {
+        const double k0 = G.start_k[d] + (double)(int64_t)0 / (double)(nd - 1);
+        for (int o = 0; o < mv.nsta; ++o) {
+            const double4 tau = mv.orb[o];
+            const double td = d == 0 ? tau.x : d == 1 ? tau.y : d == 2 ? tau.z : tau.w;
+            tf_first[o] = cconj(expi2pi(k0 * td));
+        }
     }
 }
 
@@ -1164,6 +1176,12 @@ __global__ __launch_bounds__(256) TBK_ROWS_OCC void k_grid_rows(const ModelView 
                 const cd t = cmulc_x(G.tf[last][(int64_t)(nlast - 1) * N + o], G.tf[last][(int64_t)o]);
                 ips[o] = cd{uniform_d(t.x), uniform_d(t.y)};
             }
+        } else if (G.img_win && jc1 == G.cpr) {       // (this tile solves the image column itself: the same factor, column 0's phases from tf0)
+#pragma unroll
+            for (int o = 0; o < N; ++o) {
+                const cd t = cmulc_x(G.tf[last][(int64_t)(nlast - 1) * N + o], G.tf0[o]);
+                ips[o] = cd{uniform_d(t.x), uniform_d(t.y)};
+            }
         }
     }
     if (TBK_ABLATE(G.ablate) == 4) {   // diagnostics: tile set-up only
@@ -1351,6 +1369,10 @@ __global__ __launch_bounds__(256) TBK_ROWS_OCC void k_grid_rows(const ModelView 
             cd fo[N];
 #pragma unroll
             for (int o = 0; o < N; ++o) fo[o] = G.tf[last][(int64_t)jj * N + o];
+            if (G.img_win && jc == G.cpr - 1 && jj == nlast - 1) {   // the image column solved on its own: column 0's phases first
+#pragma unroll
+                for (int o = 0; o < N; ++o) fo[o] = G.tf0[o];
+            }
             if (jc + 1 < jc1) zl_next = G.tz[last][min((jc + 1) * 64 + lane, ncol - 1)];
 #pragma unroll
             for (int o = 0; o < N; ++o) fo[o] = cmul_x(frow[o], fo[o]);
@@ -1430,6 +1452,14 @@ __global__ __launch_bounds__(256) TBK_ROWS_OCC void k_grid_rows(const ModelView 
                 }
             } else {
                 small_vector<N, r>(F, z);
+            }
+            if (G.img_win && jc == G.cpr - 1) {        // (wave-uniform) ... then x (tf_image conj tf_0), as the lane of column 0 does
+                const bool wl = jc * 64 + lane_here >= nlast - 1;
+#pragma unroll
+                for (int o = 0; o < N; ++o) {
+                    const cd zi = cmul_x(z[o], ips[o]);
+                    z[o] = cd{wl ? zi.x : z[o].x, wl ? zi.y : z[o].y};
+                }
             }
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -2816,7 +2846,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
     key.insert(key.end(), pbc_phase, pbc_phase + (size_t)D * n * 2);
     int64_t ntab = 0;
     for (int d = 0; d < D; ++d) ntab += v.mesh[d];
-    const int64_t need = ntab * (1 + n);
+    const int64_t need = ntab * (1 + n) + n;           // (+ n: the last axis' phases at global index 0, GridArgs::tf0)
     if (w->tab_cap < need) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
         if (w->tab_dev) TBK_HIP(hipFree(w->tab_dev));
@@ -2834,6 +2864,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
             zo += v.mesh[d];
             fo += (int64_t)v.mesh[d] * n;
         }
+        G.tf0 = w->tab_dev + ntab * (1 + n);
     }
     if (key != w->tab_key) {
         std::vector<cd> st((size_t)TBK_MAX_DIM * n, cd{0.0, 0.0});
@@ -2844,7 +2875,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
         TBK_HIP(hipStreamSynchronize(ctx->stream));  // st is a local: finish before it dies
         ProfScope ps(ctx, "grid_tables");
         hipLaunchKernelGGL(k_grid_tables, dim3((unsigned)((ntab + 255) / 256)), dim3(256), 0, ctx->stream, m->view, G,
-                           w->tab_dev, w->tab_dev + ntab);
+                           w->tab_dev, w->tab_dev + ntab, w->tab_dev + ntab * (1 + n));
         TBK_HIP(hipGetLastError());
         w->tab_key = key;
     }
@@ -2992,6 +3023,7 @@ static int solve_window_impl(tbk_wfs* w, tbk_model* m, const double* start_k, co
             G.cpr = (v.mesh[D - 1] - 1 + 63) / 64;
             G.nchunks = nrows * G.cpr;
         }
+        G.img_win = rows_kernel && n > 2 && !G.img_last && G.off[D - 1] + v.mesh[D - 1] == G.gmesh[D - 1] ? 1 : 0;
         G.seg = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, G.cpr), G.nchunks / want));
         if (tbk_knobs().grid_seg >= 0) G.seg = std::max(1, std::min(tbk_knobs().grid_seg, G.cpr));
         G.tpr = (G.cpr + G.seg - 1) / G.seg;

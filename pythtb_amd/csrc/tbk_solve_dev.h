@@ -35,6 +35,11 @@ struct GridArgs {
     int* flags;              // the context's sticky status words ([0]: an eigen-solver ran into its iteration cap)
     int img_last;            // k_grid_rows: the window's last column is the periodic image of its first (the whole last axis is
                              // inside the window): it is not chunked, the lane that solves column 0 stores it too
+    int img_win;             // k_grid_rows, n = 3, 4: the window's last column is the global mesh's periodic image but column 0 is
+                             // not solved with it (a window that starts past column 0, or TBK_GRID_IMG=0): the lane that solves
+                             // it forms the image exactly as the lane of column 0 would -- column 0's vector under column 0's
+                             // phases (tf0), then x (tf_image conj tf_0) -- so windows stay bit-identical to the whole array
+    const cd* tf0;           // [nsta]: the last axis' orbital phases at GLOBAL index 0 (= tf[last][0..n) of a window that holds column 0)
     int seg;                 // chunks per wave tile (k_grid_rows)
     int tpr;                 // wave tiles per row
     int64_t ntiles;
@@ -312,8 +317,14 @@ __device__ __forceinline__ double qle_pick(const double (&a)[16], const int idx,
 }
 
 // tbk_solve_e16.hip: the fused n = 9..16 solver with eigenvectors (one kernel, reflectors in LDS)
+// `form`: E16_F_* bits.  They select a FORM of the kernel and must depend on the model and the knobs alone, never on the window:
+// the bit-identity of windows and shards rests on every window of a mesh taking the same form.
+enum : int {
+    E16_F_NS_FULL = 1,    // TBK_E16_NS_FULL=1: the full Newton-Schulz step (matrix cores) for EVERY matrix, as round 4 did
+    E16_F_NO_CELLS = 2,   // TBK_E16_CELLS=0: S(k) from the tiled sum over the lattice vectors, not from the row's coefficient cells
+};
 int tbk_e16_launch(int mode, hipStream_t stream, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G, int64_t id0,
-                   int64_t nc, int* list, int* count, double gaptol, int ns_full);
+                   int64_t nc, int* list, int* count, double gaptol, int form);
 int tbk_e16_launch_evals(int mode, hipStream_t stream, const ModelView& mv, int64_t nk, const ListArgs& L, int64_t id0, int64_t nc);
 
 #endif  // TBK_SOLVE_DEV_H

@@ -6,15 +6,15 @@
 #include "tbk_solve_e16.inl"
 
 // The matrices [id0, id0 + nc) of a k list (mode 0), a mesh window (1) or supplied matrices (2) on `stream`; the matrices left to
-// the QL-replay kernels come back as list[0 .. *count) (positions relative to id0; *count must be zero on the stream before).
+// the QL-replay kernels come back as list[0 .. *count) (positions relative to id0; *count must be zero on the stream before).  `form`: E16_F_* bits (tbk_solve_dev.h).
 int tbk_e16_launch(int mode, hipStream_t stream, const ModelView& mv, int64_t nk, const ListArgs& L, const GridArgs& G, int64_t id0,
-                   int64_t nc, int* list, int* count, double gaptol, int ns_full) {
+                   int64_t nc, int* list, int* count, double gaptol, int form) {
     TBK_REQUIRE(mode >= 0 && mode <= 2 && nc >= 1 && nc < (int64_t)0x7fffffff / 16 && mv.nsta >= 2 && mv.nsta <= 16, TBK_EINVAL,
                 "tbk_e16_launch: mode %d, %lld matrices of %d states", mode, (long long)nc, mv.nsta);
     const unsigned blocks = (unsigned)((nc * 16 + 255) / 256);
-    if (mode == 0) hipLaunchKernelGGL((k_e16<0>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol, ns_full);
-    else if (mode == 1) hipLaunchKernelGGL((k_e16<1>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol, ns_full);
-    else hipLaunchKernelGGL((k_e16<2>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol, ns_full);
+    if (mode == 0) hipLaunchKernelGGL((k_e16<0>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol, form);
+    else if (mode == 1) hipLaunchKernelGGL((k_e16<1>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol, form);
+    else hipLaunchKernelGGL((k_e16<2>), dim3(blocks), dim3(256), 0, stream, mv, nk, L, G, id0, nc, list, count, gaptol, form);
     TBK_HIP(hipGetLastError());
     return TBK_OK;
 }

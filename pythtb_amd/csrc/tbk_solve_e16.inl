@@ -839,7 +839,7 @@ __device__ __forceinline__ bool e16_twin(const e16_lcd* xd, const double lam, co
 template <int MODE, bool VEC = true>
 __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_t nk, const ListArgs Lst, const GridArgs G, const int64_t id0,
                                                 const int64_t nc, int* __restrict__ list, int* __restrict__ count, const double gaptol,
-                                                const int ns_all) {
+                                                const int form) {
 #ifndef E16_LDS_PAD   // (profiles/microbench/e16_bench.hip only: extra LDS per block, to run the kernel at a lower occupancy)
 #define E16_LDS_PAD 0
 #endif
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         // The choice depends on the model alone (nR), so windows and shards stay bit-identical; cubic16 (7 vectors) keeps the form below.
         bool cells_done = false;
         if constexpr (MODE == 1) {
-            if (nRr > E16_CELLS_MIN_NR && lastax >= 0 && (ns_all & 2) == 0) {       // ((ns_all & 2): TBK_E16_CELLS=0)
+            if (nRr > E16_CELLS_MIN_NR && lastax >= 0 && (form & E16_F_NO_CELLS) == 0) {
                 cells_done = true;
                 const int pmax = mv.pmax;
                 // z_last by 0 / 1 weights (a select on `lastax` would turn zk[] into an indexed array in scratch memory)
@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(256, 3) void k_e16(const ModelView mv, const int64_
         // rest of the spectrum, not only towards each other)
         const double lam_up1 = e16_next(lam_o);
         const bool near = (j + 2 < n && !(lam_up2 - lam_o >= E16_NS_TRIPLE * tmax)) || (j + 1 < n && !(lam_up1 - lam_o >= E16_NS_PAIR * tmax));
-        ns_full = __builtin_amdgcn_ballot_w64(live2 && (splits_here || near || (ns_all & 1) != 0));   // (ns_all & 1: TBK_E16_NS_FULL=1, round 4's form)
+        ns_full = __builtin_amdgcn_ballot_w64(live2 && (splits_here || near || (form & E16_F_NS_FULL) != 0));
         if ((((unsigned)(ns_full >> (lane & 48))) & 0xffffu) == 0) {      // (row-uniform) this lane's matrix: the tridiagonal part
             double vn[16];
             double s_up = 0.0, s_self = 0.0;                              // v_j . v_{j+1} (0 in lane 15), v_j . v_j

@@ -704,7 +704,7 @@ static int launch_tw16(tbk_ctx* ctx, const ModelView& mv, int64_t nk, const List
             TBK_HIP(hipMemsetAsync(w.count, 0, sizeof(int), sq));
             if (fused) {
                 ProfScope ps(brackets ? ctx : nullptr, "e16");
-                const int rc = tbk_e16_launch(MODE, sq, mv, nk, L, G, id0, nc, w.list, w.count, K.tw16_gaptol, (K.e16_ns_full ? 1 : 0) | (K.e16_cells ? 0 : 2));
+                const int rc = tbk_e16_launch(MODE, sq, mv, nk, L, G, id0, nc, w.list, w.count, K.tw16_gaptol, (K.e16_ns_full ? E16_F_NS_FULL : 0) | (K.e16_cells ? 0 : E16_F_NO_CELLS));
                 if (rc) return rc;
             } else {
             {

@@ -455,7 +455,8 @@ def test_signed_band_indices_like_numpy(tb):
     from oracle import tb_oracle as orc
     rng = np.random.default_rng(11)
     for m, mesh, start in ((hp.haldane(tb.tb_model, 0.0), [33, 33], [-0.5, -0.5]),
-                           (hp.kane_mele(tb.tb_model, "odd"), [21, 17], [0.1, 0.2]),
+                           (hp.kane_mele(tb.tb_model, "odd"), [21, 17], [0.13, 0.21]),   # (no mesh line through a time-reversal invariant
+                           # coordinate: on k_0 = 0 a single band's links across k_1 = 0, 1/2 join Kramers partners -- overlap 0, no phase)
                            (hp.cubic16(tb.tb_model), [9, 9, 9], [0.0, 0.0, 0.0])):
         n, D = m._nsta, len(mesh)
         w = tb.wf_array(m, mesh)
@@ -1009,13 +1010,15 @@ def test_sharded_windows_equal_unsharded(tb):
             w.solve_on_grid_window(start, [0, b], mesh)
             wl.append(w.berry_phase([0, 1], 0, contin=False, berry_evals=True)[:e - b])
             bp.append(w.berry_phase([2, 3], 0, contin=False)[:e - b])
-        # Bit for bit -- except the string at the periodic-image column.  In the full array that column is column 0's vectors
-        # times (image phase / column-0 phase), written by the lanes that hold column 0 (k_grid_rows, n = 3, 4: the phases are
-        # folded into the solver's factors, round 5); a window that holds the image column without column 0 solves it as a column
-        # of its own.  The same numbers to rounding, not the same bits.
+        # Bit for bit, the string at the periodic-image column included: a window that holds the image column without column 0
+        # forms it as the lanes of column 0 do in the full array -- column 0's vector under column 0's phases, then times
+        # (image phase conj column-0 phase) (GridArgs::img_win; it was "to rounding" in round 5)
         wl, bp = np.concatenate(wl), np.concatenate(bp)
-        assert np.array_equal(wl[:-1], ref_wl[:-1]) and np.array_equal(bp[:-1], ref_bp[:-1])
-        assert np.max(np.abs(wl[-1] - ref_wl[-1])) < 1e-13 and abs(bp[-1] - ref_bp[-1]) < 1e-13
+        assert np.array_equal(wl, ref_wl) and np.array_equal(bp, ref_bp)
+        # ... and the eigenvectors themselves, for a window that starts past column 0 and for every column solved on its own
+        w = tb.wf_array(m, [mesh[0], mesh[1] - 5])
+        w.solve_on_grid_window(start, [0, 5], mesh)
+        assert np.array_equal(w._wfs, host[:, 5:])
 
 
 @pytest.mark.parametrize("half,mesh", [(3, [23, 53]), (6, [41, 53]), (7, [41, 53]), (8, [41, 53]), (12, [41, 53])])

@@ -333,7 +333,7 @@ def test_degenerate_bands_above_64_states_stay_on_the_direct_method(tb):
 def test_periodic_image_column_is_stored_by_the_lane_of_column_zero(tb, n):
     """k_grid_rows does not chunk the last column of a closed mesh row: it is the periodic image of the first (pythtb.py:2729-2747)
     and the lane that solves column 0 stores it with the image's orbital phase.  The same bits as solving it on its own
-    (TBK_GRID_IMG=0) for n <= 2, the same numbers to rounding for n = 3, 4, on row lengths around the chunk size, on 1-D / 2-D / 3-D arrays, with a start point off the origin; min
+    (TBK_GRID_IMG=0), on row lengths around the chunk size, on 1-D / 2-D / 3-D arrays, with a start point off the origin; min
     gaps equal; windows that do not hold the whole last axis are unaffected (tests/test_tw16_path.py, test_gpu_parity.py)."""
     from pythtb_amd import _lib
     if n == 4:
@@ -355,17 +355,10 @@ def test_periodic_image_column_is_stored_by_the_lane_of_column_zero(tb, n):
                 w = tb.wf_array(m, mesh)
                 gaps = w.solve_on_grid(start)
                 out[img] = (None if gaps is None else np.array(gaps), w.to_host().copy())
-        if n <= 2:
-            assert np.array_equal(out[0][1], out[1][1]), mesh
-        else:
-            # n = 3, 4 (round 5): the orbital phases are folded into the solver's factors, and the image is column 0's stored vector
-            # times (image phase / column-0 phase) -- the same numbers as the column solved on its own to rounding, every other
-            # column bit for bit
-            D = len(mesh)
-            a0 = np.moveaxis(out[0][1], D - 1, 0)
-            a1 = np.moveaxis(out[1][1], D - 1, 0)
-            assert np.array_equal(a0[:-1], a1[:-1]), mesh
-            assert np.max(np.abs(a0[-1] - a1[-1])) < 4e-15, mesh
+        # n = 3, 4: the orbital phases are folded into the solver's factors and the image is column 0's vector (under column 0's
+        # phases) times (image phase conj column-0 phase); the column solved on its own is formed in the same two steps
+        # (GridArgs::img_win), so it is the same bits for every n again (round 5 had "to rounding" here)
+        assert np.array_equal(out[0][1], out[1][1]), mesh
         if out[0][0] is not None:
             assert np.array_equal(out[0][0], out[1][0]), mesh
 
@@ -476,24 +469,29 @@ def test_mesh_rows_of_5_to_8_states_from_coefficient_cells(tb, n, rmax, mesh):
     assert np.array_equal(ww.to_host(), host[tuple(slice(a, a + b) for a, b in zip(lo, sub))])
 
 
-@pytest.mark.parametrize("n,nocc,mesh", [(6, 3, [23, 37]), (8, 4, [70, 19]), (8, 3, [5, 6, 41]), (9, 4, [12, 11, 9])])
+@pytest.mark.parametrize("n,nocc,mesh", [(6, 3, [23, 37]), (8, 4, [70, 19]), (8, 3, [5, 6, 41]), (9, 4, [12, 11, 9]),
+                                         (6, 3, [131, 70]), (8, 4, [67, 200]), (5, 3, [3, 150]), (7, 4, [140, 3]), (4, 4, [9, 9, 70]),
+                                         (10, 3, [66, 5, 7])])
 def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
-    """Wilson-loop eigenphases (berry_phase(..., berry_evals=True), pythtb.py:3798-3838) of 3 and 4 bands: the string's links,
-    their polar factors and their ordered product in registers (k_wilson_seg_reg, the default), the polar factors alone in
-    registers followed by the product tree (TBK_WILSON_REG=2), and the workgroup-per-link kernels (=0): the same phases along
-    every direction, on string counts and lengths that are no multiples of the wavefront or the segment."""
+    """Wilson-loop eigenphases (berry_phase(..., berry_evals=True), pythtb.py:3798-3838) of 3 and 4 bands: a lane per string or per
+    link with the occupied vectors staged through LDS (tbk_berry_lanes.inl: TBK_WILSON_REG=3, the default since round 6), the
+    string's links, their polar factors and their ordered product in a thread per segment (k_wilson_seg_reg, =1), the polar
+    factors alone in registers followed by the product tree (=2), and the workgroup-per-link kernels (=0): the same phases along
+    every direction, on string counts and lengths that are no multiples of the wavefront, the tile or the segment -- strings
+    across the lanes (S form, contiguous and gathered tiles, ragged last tile), strings along the lanes (L form: the fastest
+    axis, several 64-link tiles, few strings), short strings, the occupied bands not the lowest."""
     from pythtb_amd import _lib
     m = hp.random_model(tb.tb_model, n, len(mesh), 1, seed=70 + n + nocc, nhop=4 * n, rmax=1)
     w = tb.wf_array(m, mesh)
     w.solve_on_grid([0.03, -0.2, 0.1][:len(mesh)])
-    occ = list(range(nocc))
+    occ = list(range(nocc)) if n % 2 == 0 else list(range(n - nocc, n))[::-1]
     for d in range(len(mesh)):
         got = {}
-        for route in (1, 2, 0):
+        for route in (1, 2, 0, 3):
             with _lib.knob("TBK_WILSON_REG", route), _lib.knob("TBK_WILSON_MFMA", 2):     # (MFMA=2: wide states stay off the tile kernel)
                 got[route] = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
-        got["default"] = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))   # (>= 8 components: the matrix-core kernel)
-        for route in (2, 0, "default"):
+        got["default"] = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
+        for route in (2, 0, 3, "default"):
             diff = np.angle(np.exp(1j * (got[1] - got[route])))
             assert np.max(np.abs(diff)) < 1e-10, (d, route)
         # the sum of the eigenphases is the determinant form's phase
