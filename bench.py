@@ -36,11 +36,13 @@ of 2048 plaquette rows starting at global row 2048*r and recomputes its one halo
 row, so there is no data-path collective.  `python bench.py --gpus N` starts its own N
 ranks (pythtb_amd/launch.py; the parent makes no GPU call) and behaves the same under
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.  The ranks
-rendezvous through gloo (barriers only), bring the RCCL communicator up FIRST, and the
+rendezvous on the launcher's own TCP socket (launch.Rendezvous: barriers, one-word agreements and
+RCCL's 128-byte id; no torch -- TBK_RENDEZVOUS=gloo takes torch.distributed instead), bring the RCCL
+communicator up FIRST, and the
 gather of [partial flux, min gap, elapsed] per rank after the timed loop -- the path's
 one collective -- is tbk_comm_allgather_f64 (RCCL over xGMI): `config.gather` says
 `rccl_allgather`.  Every RCCL call runs under a time limit; if RCCL is unavailable the
-line is still printed, through gloo and labelled FALLBACK, and the exit status is 4.
+line is still printed, through the rendezvous socket and labelled FALLBACK, and the exit status is 4.
 (configs[1]/[3]/[4] at N > 1: bench_configs.py --gpus N.)
 
 Prints ONE JSON line on rank 0.
@@ -470,13 +472,13 @@ class _StubGrid(object):
 
 
 class _StubComm(object):
-    """--stub: a communicator with RcclComm's interface over gloo; TBK_BENCH_STUB_COMM=fail makes its gather raise
-    (on every rank: the stand-in shares gloo with the fallback, so a one-sided failure would wedge gloo itself)."""
+    """--stub: a communicator with RcclComm's interface over the rendezvous; TBK_BENCH_STUB_COMM=fail makes its gather raise
+    (on every rank: the stand-in shares the rendezvous with the fallback, so a one-sided failure would wedge it)."""
     name = "stub"
 
     def __init__(self, dist):
         from pythtb_amd import multi
-        self.g = multi.GlooComm(dist)
+        self.g = multi.SocketComm(dist) if hasattr(dist, "allgather_bytes") else multi.GlooComm(dist)
         self.world = self.g.world
 
     def allgather(self, mine):
@@ -517,7 +519,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: start the N ranks ourselves.  This process has made no GPU call (nothing
         # GPU-side is imported before this point) and only waits; rank 0's JSON line is the children's stdout.
-        sys.exit(_load_launcher().spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        sys.exit(_load_launcher().spawn_ranks(os.environ.get("TBK_BENCH_SELF") or os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -528,10 +530,14 @@ def main():
         cpu = cpu_baseline()                        # forks workers: must precede every GPU call of this process
 
     dist = None
-    if world > 1:                                   # rendezvous + barriers only; no tensors on the GPU
-        import datetime
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    rdzv_kind = os.environ.get("TBK_RENDEZVOUS", "socket")
+    if world > 1:                                   # rendezvous + barriers + RCCL's 128-byte id; nothing of the data path
+        if rdzv_kind == "gloo":                     # (optional: torch.distributed on the host, as rounds 2-5 did)
+            import datetime
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        else:                                       # the launcher's own TCP rendezvous: no torch anywhere in the run
+            dist = _load_launcher().Rendezvous(rank=rank, world=world, timeout=600.0)
 
     status = 0                                      # exit status of this rank (non-zero: the line is still printed)
     hung = False                                    # an RCCL call was left behind on its thread: finish with os._exit
@@ -690,13 +696,11 @@ def main():
             elif ok:
                 comm_err = "all-gather failed on another rank"
         if allv is None:
-            import torch
-            buf = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(buf, torch.from_numpy(mine))
-            allv = np.stack([b.numpy() for b in buf])
-            gather = "gloo (FALLBACK: rccl %s)" % (comm_err or "unavailable")
+            host = multi.SocketComm(dist) if hasattr(dist, "allgather_bytes") else multi.GlooComm(dist)
+            allv = host.allgatherv(mine, [3] * world).reshape(world, 3)
+            gather = "%s (FALLBACK: rccl %s)" % (host.name, comm_err or "unavailable")
             status = 4                              # the line is printed, the run is not a success
-            sys.stderr.write("[bench] rank %d: RCCL gather unavailable (%s); reported through gloo\n" % (rank, comm_err))
+            sys.stderr.write("[bench] rank %d: RCCL gather unavailable (%s); reported through %s\n" % (rank, comm_err, host.name))
 
     def build_line(gather):
         """Pure host arithmetic on numbers already in hand."""
@@ -771,7 +775,9 @@ def main():
             status = status or 5
     if dist is not None:
         dist.barrier()
-        if not hung:
+        if hasattr(dist, "close"):
+            dist.close()
+        elif not hung:
             dist.destroy_process_group()
     if not hung:
         grid.free()

@@ -1888,8 +1888,13 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         int lanes_res = 1;                                // wavefronts of the S form resident per CU (LDS-bound)
         if (nocc >= 3 && nocc <= 4 && wreg == 3 && v.npts < (int64_t)0x7fffffff && v.ncomp <= 21) {
             // L: the string runs along the fastest axis, or there are too few strings to give every lane one
+            const size_t lds_l = (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd), lds_s = (size_t)2 * nocc * 64 * v.ncomp * sizeof(cd);
             lanes_l = (A.sdir == 1 && L >= 32) || (A.nstrings < 32 && L >= 32);
-            lanes_lds = lanes_l ? (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd) : (size_t)2 * nocc * 64 * v.ncomp * sizeof(cd);
+            // ... or the two row buffers of the S form leave fewer than four wavefronts on a compute unit (a SIMD without one):
+            // 4 bands of 8 components, 1025 x 257 along axis 0: S 118 us (2 per CU), L with gathered points 104 (profiles/r06w)
+            if (lds_s > 40 * 1024 && lds_l <= 40 * 1024 && L >= 32) lanes_l = true;
+            if (tbk_knobs().wilson_form >= 0) lanes_l = tbk_knobs().wilson_form != 0;
+            lanes_lds = lanes_l ? lds_l : lds_s;
             lanes_route = lanes_lds <= 64 * 1024;
             lanes_res = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lanes_lds, 1)));
         }
@@ -1900,7 +1905,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         int64_t lanes_ntile = 1;
         if (lanes_route && lanes_l) {
             seg_len_r = 64;
-            nseg_r = (L + 63) / 64;
+            nseg_r = ((L + 63) / 64) * (64 / LANES_L_SPAN);        // (a tile leaves the products of its 16-link quarters)
         } else if (lanes_route) {
             // S: one round of resident wavefronts when the strings allow it (a longer segment pays its first row once), else about four
             const int64_t nsb_guess = A.nstrings;          // (tiles are counted per batch below; the segment length is set once, on the call)
@@ -1909,6 +1914,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             int64_t nseg = lanes_ntile * 2 <= R ? R / lanes_ntile : (4 * R + lanes_ntile - 1) / lanes_ntile;
             nseg = std::max<int64_t>(1, std::min<int64_t>(nseg, std::max(1, L / 2)));
             seg_len_r = (int)((L + nseg - 1) / nseg);
+            if (tbk_knobs().wilson_seg > 0) seg_len_r = std::min(L, tbk_knobs().wilson_seg);
             nseg_r = (L + seg_len_r - 1) / seg_len_r;
         }
         if (seg_route) {
@@ -2006,12 +2012,14 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 S.nseg = nseg_r;
                 S.ntile = (ns + 63) / 64;
                 S.magic = (unsigned)((65536 + v.ncomp - 1) / v.ncomp);
+                S.swz = v.ncomp == 4 ? 2 : v.ncomp == 8 ? 1 : v.ncomp == 16 ? 0 : -1;
+                if (tbk_knobs().wilson_swz == 0) S.swz = -1;
                 S.segs = buf1;                     // [ns][nseg][nn]
                 S.prod = buf0;                     // string s at buf0 + s nseg nn, where the tree leaves a string's product
                 S.pstride = (size_t)Lb * nn;
                 {
                     ProfScope ps(ctx, lanes_l ? "wilson_lanes_l" : "wilson_lanes_s");
-                    const dim3 g((unsigned)(lanes_l ? ns * S.nseg : S.ntile * S.nseg)), b(64);
+                    const dim3 g((unsigned)(lanes_l ? ns * (S.nseg / (64 / LANES_L_SPAN)) : S.ntile * S.nseg)), b(64);
                     if (lanes_l) {
                         if (nocc == 3) hipLaunchKernelGGL((k_wilson_lanes_l<3>), g, b, lanes_lds, ctx->stream, S);
                         else hipLaunchKernelGGL((k_wilson_lanes_l<4>), g, b, lanes_lds, ctx->stream, S);

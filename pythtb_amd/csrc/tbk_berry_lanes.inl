@@ -26,31 +26,35 @@ struct WilsonLanesArgs {
     int nseg;          // matrices per string in `segs`: segments (S) or tiles (L)
     int64_t ntile;     // S: tiles of 64 strings (per segment)
     unsigned magic;    // ceil(65536 / ncomp): u / ncomp = (u * magic) >> 16 for the unit numbers of a tile
+    int swz;           // >= 0 (ncomp = 4, 8, 16): component c of tile point j sits at unit j ncomp + (c ^ ((j >> swz) & (ncomp - 1))) --
+                       // a lane reads its point with a stride of ncomp 16-byte units, 4- to 16-way bank conflicts of ds_read_b128 for
+                       // these ncomp (k_wilson_lanes_s<4> on 8 components: 87 % of its LDS cycles, 41 % of a wavefront's life); with
+                       // the exclusive-or the 16 lanes of a read group hit 16 different units.  The transfer fetches the permuted
+                       // component (the same 16 ncomp bytes of the point: coalescing is untouched), LDS stays linear.  -1: none
     cd* segs;          // [ns][nseg][nocc^2]
     cd* prod;          // combine: string s at prod + s * pstride
     size_t pstride;
 };
 
 typedef __attribute__((address_space(3))) void* lanes_lds_ptr;
+#define LANES_L_SPAN 16      // L form: links per matrix it leaves in `segs` (64 / LANES_L_SPAN matrices per tile)
 
 // One band's components at the tile's points -> row[u], u = j * ncomp + c (j: point of the tile, c: component).  `pt(j)`: the mesh
 // point of tile point j.  CONTIG: pt(j) = pt0 + j, the units are consecutive in memory and no division is needed.  A lane whose
 // unit lies past the tile fetches the last unit again (every transfer complete: vmcnt counts them).
 template <bool CONTIG, class PT>
 __device__ __forceinline__ void lanes_issue_row(const WfsView& v, const int band, const int64_t pt0, PT pt, const int npt, cd* row,
-                                                const int lane, const unsigned magic) {
+                                                const int lane, const unsigned magic, const int swz) {
     const int ncomp = v.ncomp;
     const int nunit = npt * ncomp;
     const cd* const plane = v.data + (int64_t)band * v.npts * ncomp;
     for (int u0 = 0; u0 < nunit; u0 += 64) {
         const int u = min(u0 + lane, nunit - 1);
+        const int j = (int)(((unsigned)u * magic) >> 16);
+        const int us = swz >= 0 ? u ^ ((j >> swz) & (ncomp - 1)) : u;     // (ncomp a power of two: the exclusive-or stays inside the point)
         const cd* src;
-        if constexpr (CONTIG) {
-            src = plane + pt0 * ncomp + u;
-        } else {
-            const int j = (int)(((unsigned)u * magic) >> 16);
-            src = plane + pt(j) * ncomp + (u - j * ncomp);
-        }
+        if constexpr (CONTIG) src = plane + pt0 * ncomp + us;
+        else src = plane + pt(j) * ncomp + (us - j * ncomp);
         __builtin_amdgcn_global_load_lds((const void*)src, (lanes_lds_ptr)(row + u0), 16, 0, 0);
     }
 }
@@ -82,19 +86,20 @@ __device__ __forceinline__ void lanes_mul(cd (&R)[M][M], const cd (&X)[M][M]) { 
 // X_ab = <u_a(p) | u_b(q)> from two row sets in LDS: band a of tile point j at rows[a * rowsz + j * ncomp + c]
 template <int M>
 __device__ __forceinline__ void lanes_overlap(const cd* P, const int jp, const cd* Q, const int jq, const int rowsz, const int ncomp,
-                                              cd (&X)[M][M]) {
+                                              const int swz, cd (&X)[M][M]) {
 #pragma unroll
     for (int a = 0; a < M; ++a)
 #pragma unroll
         for (int b = 0; b < M; ++b) X[a][b] = cd{0.0, 0.0};
     const cd* p = P + jp * ncomp;
     const cd* q = Q + jq * ncomp;
+    const int fp = swz >= 0 ? (jp >> swz) & (ncomp - 1) : 0, fq = swz >= 0 ? (jq >> swz) & (ncomp - 1) : 0;
     for (int c = 0; c < ncomp; ++c) {
         cd pc[M], qc[M];
 #pragma unroll
         for (int a = 0; a < M; ++a) {
-            pc[a] = p[a * rowsz + c];
-            qc[a] = q[a * rowsz + c];
+            pc[a] = p[a * rowsz + (c ^ fp)];
+            qc[a] = q[a * rowsz + (c ^ fq)];
         }
 #pragma unroll
         for (int a = 0; a < M; ++a)
@@ -104,10 +109,10 @@ __device__ __forceinline__ void lanes_overlap(const cd* P, const int jp, const c
 }
 // ordered product over the lanes: lane 0 ends with R_0 R_1 ... R_63 (the left operand always from the lower lane; lanes that hold
 // nothing carry the identity)
-template <int M>
-__device__ __forceinline__ void lanes_tree(cd (&R)[M][M]) {
+template <int M, int SPAN = 64>
+__device__ __forceinline__ void lanes_tree(cd (&R)[M][M]) {      // SPAN < 64: the lanes that are multiples of SPAN end with the product of their SPAN lanes
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
+    for (int off = 1; off < SPAN; off <<= 1) {
         cd O[M][M];
 #pragma unroll
         for (int a = 0; a < M; ++a)
@@ -142,8 +147,8 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_s(const WilsonLanesArgs S) 
 #pragma unroll
         for (int a = 0; a < M; ++a) {
             cd* row = buf + (b * M + a) * rowsz;
-            if (contig) lanes_issue_row<true>(A.v, occ[a], base0 + shift, [](int) { return (int64_t)0; }, npt, row, lane, S.magic);
-            else lanes_issue_row<false>(A.v, occ[a], 0, [&](const int j) { return (int64_t)__shfl((long long)base, j) + shift; }, npt, row, lane, S.magic);
+            if (contig) lanes_issue_row<true>(A.v, occ[a], base0 + shift, [](int) { return (int64_t)0; }, npt, row, lane, S.magic, S.swz);
+            else lanes_issue_row<false>(A.v, occ[a], 0, [&](const int j) { return (int64_t)__shfl((long long)base, j) + shift; }, npt, row, lane, S.magic, S.swz);
         }
     };
     issue(0, 0);
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_s(const WilsonLanesArgs S) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         cd X[M][M];
-        lanes_overlap<M>(buf + (li & 1) * M * rowsz, lane, buf + ((li + 1) & 1) * M * rowsz, lane, rowsz, ncomp, X);
+        lanes_overlap<M>(buf + (li & 1) * M * rowsz, lane, buf + ((li + 1) & 1) * M * rowsz, lane, rowsz, ncomp, S.swz, X);
         // the row of link li is not needed any more: its buffer takes the row of link li + 2, which lands behind the polar iteration
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -180,8 +185,9 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_l(const WilsonLanesArgs S) 
     const WilsonBigArgs& A = S.W;
     const int lane = threadIdx.x;
     const int ncomp = A.v.ncomp;
-    const int64_t s = blockIdx.x / S.nseg;
-    const int t = (int)(blockIdx.x - s * S.nseg);
+    const int ntile = S.nseg / (64 / LANES_L_SPAN);
+    const int64_t s = blockIdx.x / ntile;
+    const int t = (int)(blockIdx.x - s * ntile);
     const int i0 = t * 64, nl = min(64, A.nlinks - i0), npt = nl + 1;
     const int64_t base = axis_offset(A.other, A.s0 + s) + (int64_t)i0 * A.sdir;
     const int rowsz = (65 * ncomp + 63) & ~63;                   // (whole transfers: the repeated units of a row's last transfer stay inside it)
@@ -189,19 +195,22 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_l(const WilsonLanesArgs S) 
 #pragma unroll
     for (int a = 0; a < M; ++a) {
         const int band = A.occ[a];
-        if (A.sdir == 1) lanes_issue_row<true>(A.v, band, base, [](int) { return (int64_t)0; }, npt, buf + a * rowsz, lane, S.magic);
-        else lanes_issue_row<false>(A.v, band, 0, [&](const int j) { return base + (int64_t)j * A.sdir; }, npt, buf + a * rowsz, lane, S.magic);
+        if (A.sdir == 1) lanes_issue_row<true>(A.v, band, base, [](int) { return (int64_t)0; }, npt, buf + a * rowsz, lane, S.magic, S.swz);
+        else lanes_issue_row<false>(A.v, band, 0, [&](const int j) { return base + (int64_t)j * A.sdir; }, npt, buf + a * rowsz, lane, S.magic, S.swz);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     cd X[M][M];
     const bool act = lane < nl;
-    lanes_overlap<M>(buf, act ? lane : 0, buf, act ? lane + 1 : 0, rowsz, ncomp, X);
+    lanes_overlap<M>(buf, act ? lane : 0, buf, act ? lane + 1 : 0, rowsz, ncomp, S.swz, X);
     if (!act) lanes_identity<M>(X);
     if (!wilson_polar_reg<M>(X)) atomicExch(A.flags + 1, 1);
-    lanes_tree<M>(X);
-    if (lane != 0) return;
-    cd* const o = S.segs + ((size_t)s * S.nseg + t) * (M * M);
+    // four levels of the tree here (the products of 16 links: lanes 0, 16, 32, 48), the rest with the string's other tiles in
+    // k_wilson_lanes_combine -- a level costs the wavefront a whole matrix product however few lanes still need it, and the
+    // combine pays its levels once per string, not once per tile
+    lanes_tree<M, LANES_L_SPAN>(X);
+    if ((lane & (LANES_L_SPAN - 1)) != 0) return;
+    cd* const o = S.segs + ((size_t)s * S.nseg + (size_t)t * (64 / LANES_L_SPAN) + lane / LANES_L_SPAN) * (M * M);
 #pragma unroll
     for (int a = 0; a < M; ++a)
 #pragma unroll

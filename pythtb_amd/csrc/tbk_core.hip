@@ -88,6 +88,9 @@ static void knobs_parse() {
     geti("TBK_DET_BIG_FROM", k.det_big_from);
     geti("TBK_WILSON_BIG_FROM", k.wilson_big_from);
     geti("TBK_WILSON_REG", k.wilson_reg);
+    geti("TBK_WILSON_SEG", k.wilson_seg);
+    geti("TBK_WILSON_SWZ", k.wilson_swz);
+    geti("TBK_WILSON_FORM", k.wilson_form);
     geti("TBK_WILSON_MFMA", k.wilson_mfma);
     getl("TBK_WILSON_BATCH_BYTES", k.wilson_batch_bytes);
     if (const char* e = getenv("TBK_WILSON_ALPHA")) {

@@ -91,6 +91,9 @@ struct TbkKnobs {
     int wilson_mfma = 1;        // TBK_WILSON_MFMA   0: Wilson loops of 5..8 wide bands on the workgroup-per-link kernels instead of k_chain_prod_tile<.., POLAR>
     int wilson_reg = 3;         // TBK_WILSON_REG    Wilson loops of 3-4 bands: 3 a lane per string / link, vectors through LDS (tbk_berry_lanes.inl);
                                 //                   1 round 4's thread per segment; 2 a thread per link + product tree; 0 the workgroup-per-link kernel
+    int wilson_seg = -1;        // TBK_WILSON_SEG    test / probe hook: links per lane segment of the S form of tbk_berry_lanes.inl
+    int wilson_swz = 1;         // TBK_WILSON_SWZ    0: no LDS swizzle of the components in tbk_berry_lanes.inl (A/B of the bank conflicts)
+    int wilson_form = -1;       // TBK_WILSON_FORM   test / probe hook: 0 forces the S form (lane = string), 1 the L form (lane = link)
     int wilson_big_from = -1;   // TBK_WILSON_BIG_FROM  ... of the workgroup-level Wilson-loop pipeline
     long long wilson_batch_bytes = -1;   // TBK_WILSON_BATCH_BYTES  test hook: workspace bound per batch of strings
     double wilson_alpha = 0.0;  // TBK_WILSON_ALPHA  test hook: first Cayley angle

@@ -18,9 +18,11 @@ Nothing is exchanged while computing: every rank solves its own window of the gl
 (`wf_array.solve_on_grid_window`; periodic images and halo planes are recomputed, bit-identically).  The one
 collective is the gather of the per-rank results at the end, through a `Comm` object:
 
-    RcclComm   tbk_comm_allgatherv_f64 on device buffers (RCCL over xGMI) -- the product path
-    GlooComm   torch.distributed (gloo) on host arrays -- rendezvous, CPU tests, and the fallback the bench
-               drivers report through while the RCCL leg is being validated
+    RcclComm    tbk_comm_allgatherv_f64 on device buffers (RCCL over xGMI) -- the product path
+    SocketComm  the launcher's own TCP rendezvous (launch.Rendezvous: no torch) on host arrays -- hands round RCCL's
+                unique id, the one-word agreements, and is the labelled fallback gather when RCCL is unavailable
+    GlooComm    torch.distributed (gloo) on host arrays -- the CPU test-suite's stand-in and an optional fallback
+                (TBK_RENDEZVOUS=gloo); nothing in the product path needs torch
 
 The drivers take the `wf_array` class to use, so the CPU test-suite can run them (2 ranks, gloo, uneven
 counts) with an oracle-backed stand-in where no GPU exists; the library itself never does that.
@@ -32,7 +34,7 @@ import numpy as np
 
 from . import shard
 
-__all__ = ["GlooComm", "RcclComm", "plan_strings", "plan_slabs", "plan_list", "wilson_loops_sharded",
+__all__ = ["GlooComm", "SocketComm", "RcclComm", "plan_strings", "plan_slabs", "plan_list", "wilson_loops_sharded",
            "mesh_phases_sharded", "solve_all_sharded", "solve_all_mesh_sharded", "call_with_timeout", "agree",
            "rccl_bring_up", "GridSlab", "berry_flux_sharded", "combine_flux_blocks"]
 
@@ -127,6 +129,37 @@ class GlooComm(object):
         out = np.empty((nrows, int(sum(counts))))
         for b, c, d in zip(buf, counts, _displs(counts)):
             out[:, d:d + c] = b.numpy()[:nrows * c].reshape(nrows, c)
+        return out
+
+
+class SocketComm(GlooComm):
+    """The same host-array collectives over the launcher's TCP rendezvous (launch.Rendezvous): float64 blocks as byte
+    strings through rank 0.  No torch.  Small results only (phases, partial fluxes, status words) -- the fallback when the
+    RCCL communicator is unavailable, and what carries RCCL's unique id."""
+
+    def __init__(self, rdzv):
+        self.dist = rdzv
+        self.rank, self.world = rdzv.rank, rdzv.world
+        self.name = "socket"
+
+    def allgatherv(self, mine, counts):
+        mine = np.ascontiguousarray(mine, dtype=np.float64).reshape(-1)
+        assert mine.size == counts[self.rank]
+        parts = self.dist.allgather_bytes(mine.tobytes())
+        return np.concatenate([np.frombuffer(p, dtype=np.float64, count=int(c)) for p, c in zip(parts, counts)]) \
+            if sum(counts) else np.zeros(0)
+
+    def gatherv_rows(self, mine, counts, root=0):
+        """Rooted form: only `root` assembles (nrows, sum(counts)); the other ranks return None."""
+        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        nrows = mine.shape[0]
+        assert mine.shape[1] == counts[self.rank]
+        parts = self.dist.allgather_bytes(mine.tobytes())    # (a star through rank 0: the bytes pass there either way)
+        if self.rank != root:
+            return None
+        out = np.empty((nrows, int(sum(counts))))
+        for p, c, d in zip(parts, counts, _displs(counts)):
+            out[:, d:d + c] = np.frombuffer(p, dtype=np.float64, count=nrows * int(c)).reshape(nrows, int(c))
         return out
 
 
@@ -297,16 +330,29 @@ def call_with_timeout(fn, seconds):
 
 
 def agree(dist, ok):
-    """Every rank takes the same branch: true only if `ok` everywhere (one gloo all-reduce of a flag)."""
+    """Every rank takes the same branch: true only if `ok` everywhere -- one word through the launcher's rendezvous
+    (launch.Rendezvous.all_min), or a gloo all-reduce when `dist` is torch.distributed."""
+    if hasattr(dist, "all_min"):
+        return bool(dist.all_min(1 if ok else 0))
     import torch
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(flag.item())
 
 
+def _broadcast_bytes(dist, payload, src=0):
+    """`payload` (bytes or None) of rank `src` on every rank, through either kind of rendezvous; None stays None."""
+    if hasattr(dist, "broadcast_bytes"):
+        out = dist.broadcast_bytes(b"\x01" + payload if payload is not None else b"\x00", src=src)
+        return out[1:] if out[:1] == b"\x01" else None
+    box = [payload]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def rccl_bring_up(ctx, dist, rank, world, timeout=120.0):
     """The RCCL communicator of a one-process-per-GPU run, brought up FIRST (before any measurement): rank 0 creates the
-    id, gloo hands it round, every rank joins on a worker thread with a time limit, and the ranks agree on the outcome.
+    id, the rendezvous (the launcher's TCP socket, or gloo) hands it round, every rank joins on a worker thread with a time limit, and the ranks agree on the outcome.
     Returns (RcclComm or None, message, hung)."""
     from . import _lib
     err, uid = "", None
@@ -317,8 +363,7 @@ def rccl_bring_up(ctx, dist, rank, world, timeout=120.0):
             uid = bytes(buf)
         except Exception as e:                          # noqa: BLE001
             err = "unique_id: %s" % " ".join(str(e).split())
-    box = [uid]
-    dist.broadcast_object_list(box, src=0)
+    box = [_broadcast_bytes(dist, uid, src=0)]
     ok, comm, hung = box[0] is not None, None, False
     if ok:
         ok, val, hung = call_with_timeout(lambda: RcclComm(ctx, box[0], world, rank), timeout)
