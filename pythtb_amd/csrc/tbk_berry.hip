@@ -2017,6 +2017,9 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 S.segs = buf1;                     // [ns][nseg][nn]
                 S.prod = buf0;                     // string s at buf0 + s nseg nn, where the tree leaves a string's product
                 S.pstride = (size_t)Lb * nn;
+                S.herm = herm;                     // (the Cayley transform for the first angle comes out of the combine)
+                S.ca = cos(alphas[0]);
+                S.sa = sin(alphas[0]);
                 {
                     ProfScope ps(ctx, lanes_l ? "wilson_lanes_l" : "wilson_lanes_s");
                     const dim3 g((unsigned)(lanes_l ? ns * (S.nseg / (64 / LANES_L_SPAN)) : S.ntile * S.nseg)), b(64);
@@ -2090,7 +2093,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             for (int attempt = 0; attempt < 4; ++attempt) {
                 const double alpha = alphas[attempt];
                 CayleyArgs C{cur, (size_t)Lb * nn, ab, herm, nocc, cos(alpha), sin(alpha)};
-                {
+                if (!(lanes_route && attempt == 0)) {
                     ProfScope ps(ctx, "wilson_cayley");
                     hipLaunchKernelGGL(k_wilson_cayley, dim3((unsigned)ns), dim3(256), 0, ctx->stream, C);
                     TBK_HIP(hipGetLastError());

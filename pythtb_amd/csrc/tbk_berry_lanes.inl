@@ -34,6 +34,8 @@ struct WilsonLanesArgs {
     cd* segs;          // [ns][nseg][nocc^2]
     cd* prod;          // combine: string s at prod + s * pstride
     size_t pstride;
+    cd* herm;          // combine, non-null: [ns][nocc^2] Cayley transform of e^{-i alpha} (string product), Hermitian part (k_wilson_cayley's
+    double ca, sa;     // output for the pipeline's FIRST angle alpha: cos, sin) -- one launch less in front of the eigen-solve
 };
 
 typedef __attribute__((address_space(3))) void* lanes_lds_ptr;
@@ -243,4 +245,70 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_combine(const WilsonLanesAr
     for (int a = 0; a < M; ++a)
 #pragma unroll
         for (int b = 0; b < M; ++b) o[a * M + b] = R[a][b];
+    if (S.herm == nullptr) return;
+    // H = Hermitian part of i (I - Q) (I + Q)^-1, Q = e^{-i alpha} P (k_wilson_cayley's arithmetic, in the registers of the lane
+    // that holds P): Gauss-Jordan on [I + Q | i (I - Q)] with partial pivoting, row exchanges as selects
+    cd A[M][M], B[M][M];
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) {
+            const cd pv = R[a][b];
+            const cd q{S.ca * pv.x + S.sa * pv.y, S.ca * pv.y - S.sa * pv.x};
+            const double d = a == b ? 1.0 : 0.0;
+            A[a][b] = cd{d + q.x, q.y};
+            B[a][b] = cd{q.y, d - q.x};
+        }
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        int r = k;
+        double best = cabs2(A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) {
+            const double v = cabs2(A[i][k]);
+            if (v > best) {
+                best = v;
+                r = i;
+            }
+        }
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) {
+            const bool sw = r == i;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const cd ta = A[k][j], tb = B[k][j];
+                A[k][j] = cd{sw ? A[i][j].x : ta.x, sw ? A[i][j].y : ta.y};
+                A[i][j] = cd{sw ? ta.x : A[i][j].x, sw ? ta.y : A[i][j].y};
+                B[k][j] = cd{sw ? B[i][j].x : tb.x, sw ? B[i][j].y : tb.y};
+                B[i][j] = cd{sw ? tb.x : B[i][j].x, sw ? tb.y : B[i][j].y};
+            }
+        }
+        const cd piv = A[k][k];
+        const double ip = 1.0 / fmax(cabs2(piv), 1e-300);
+        const cd inv{piv.x * ip, -piv.y * ip};
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            if (j > k) A[k][j] = cmul(A[k][j], inv);
+            B[k][j] = cmul(B[k][j], inv);
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i == k) continue;
+            const cd f = A[i][k];
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                if (j > k) {
+                    const cd t = cmul(f, A[k][j]);
+                    A[i][j] = cd{A[i][j].x - t.x, A[i][j].y - t.y};
+                }
+                const cd t = cmul(f, B[k][j]);
+                B[i][j] = cd{B[i][j].x - t.x, B[i][j].y - t.y};
+            }
+        }
+    }
+    cd* const H = S.herm + (size_t)s * (M * M);
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+        for (int b = 0; b < M; ++b) H[a * M + b] = cd{0.5 * (B[a][b].x + B[b][a].x), 0.5 * (B[a][b].y - B[b][a].y)};
 }

@@ -499,6 +499,30 @@ def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
         assert np.max(np.abs(np.angle(np.exp(1j * (got[1].sum(axis=-1) - det))))) < 1e-9
 
 
+@pytest.mark.parametrize("nocc,mesh,d", [(3, [40, 70], 0), (4, [9, 90], 1)])
+def test_wilson_lanes_cayley_pole_is_noticed_and_redone(tb, nocc, mesh, d):
+    """The lanes route forms the Cayley transform of the FIRST angle inside its combine kernel (one launch less); the transform has
+    a pole at theta = alpha + pi.  With the pole put exactly on one string's eigenphase the call must notice (max |h|), redo
+    that string with the next angle through k_wilson_cayley, and return the same phases."""
+    from pythtb_amd import _lib
+    m = hp.random_model(tb.tb_model, 2 * nocc, 2, 1, seed=91 + nocc, nhop=8 * nocc, rmax=1)
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid([0.05, 0.15])
+    occ = list(range(nocc))
+    got = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
+    ctx = _lib.default_context()
+    ctx.prof_enable(1)
+    ctx.prof_reset()
+    try:
+        with _lib.knob("TBK_WILSON_ALPHA", repr(float(-got[5, 1] - np.pi))):
+            again = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
+        rep = ctx.prof_report()
+    finally:
+        ctx.prof_enable(0)
+    assert rep["wilson_lanes_combine"]["launches"] == 1 and rep["wilson_cayley"]["launches"] == 1     # first angle fused, second alone
+    assert np.max(np.abs(np.angle(np.exp(1j * (np.sort(again, axis=1) - np.sort(got, axis=1)))))) < 1e-10
+
+
 @pytest.mark.parametrize("n,nocc,mesh", [(16, 8, [9, 7, 40]), (16, 5, [6, 33, 5]), (12, 7, [21, 19]), (10, 6, [5, 4, 70])])
 def test_wilson_loops_of_5_to_8_wide_bands_on_the_matrix_cores(tb, n, nocc, mesh):
     """Wilson-loop eigenphases of 5..8 bands of states with >= 8 components: k_chain_prod_tile<.., POLAR> forms a string's link
