@@ -2,7 +2,8 @@
 """Secondary measurements: the other BASELINE.json configs (device-resident timings from HIP events on the
 library's stream; not the driver's headline line -- that is bench.py).  One JSON object per config.
 
-    python bench_configs.py [B] [C] [D] [E] [R] [W] [H] [P] [--reps 5] one GPU (not in BASELINE.json: R ribbons / mid-size meshes, P late Berry kernels, W the
+    python bench_configs.py [B] [C] [D] [E] [R] [W] [H] [P] [L] [--reps 5] one GPU (not in BASELINE.json: R ribbons / mid-size meshes, P late Berry kernels, L the k-list
+                                                                        kernels on an 8192^2 list, W the
                                                                         Wannier90 silicon model, H hybrid Wannier centres (8f-1))
     python bench_configs.py --gpus N [B] [D] [E] [--side 257]           N GPUs, one process each (starts its own ranks; the
                                                                         same under torch.distributed.run --nproc-per-node N)
@@ -16,7 +17,8 @@ Multi-GPU legs (BASELINE configs[1], [3] and [4]; drivers in pytht
   E  cubic16 wf_array([257]*3): slabs along axis 0 with a recomputed halo plane, berry_phase(range(8), dir=2) per slab,
      the (257, 257) phase array and the min gaps assembled by the gather.
 The RCCL communicator is brought up first and the gathers of the reported runs are tbk_comm_allgatherv[_rows]_f64 (RCCL over
-xGMI); every RCCL call runs under a time limit, gloo is the labelled fallback (exit status 4).  Time per config = max over
+xGMI); every RCCL call runs under a time limit, the rendezvous socket (launch.Rendezvous; TBK_RENDEZVOUS=gloo: torch) is the
+labelled fallback (exit status 4).  Time per config = max over
 ranks of one pass including its gather.
 """
 import contextlib
@@ -99,6 +101,47 @@ def single_gpu(which, reps):
                     "python_call_list_path_s": t_list, "mesh_path_kernels_ms": prof_mesh,
                     "mesh_evals_hbm_GBs": 32 * nk / prof_mesh["mesh_evals"] / 1e6 if "mesh_evals" in prof_mesh else None,
                     "solve_all_mesh_call_s": t_mesh, "dos_mesh_call_s": t_dos, "kpts_per_s_dos_call": nk / t_dos})
+    if "L" in which:
+        # (not a BASELINE config) the k-list kernels PAST the last-level cache: configs[1]'s leg moves
+        # 33.5 MB -- 4 us at HBM peak, so its 17 us mostly measure launch + completion latency.  Here the same kernels on an 8192^2
+        # list: 1.07 GB of k read, 1.07 GB (2 states) / 2.15 GB (4 states) of eigenvalues written, everything resident, the list made
+        # on the device (tbk_k_uniform_mesh_dev).  Algorithmic bytes 8 (d + n) per k-point.
+        HBM = 8000.0
+        side = 8192
+        nk = side * side
+        mesh32 = np.array([side, side], dtype=np.int32)
+        kd = C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 16, C.byref(kd)))
+        _lib.check(lib.tbk_k_uniform_mesh_dev(ctx.handle, 2, _lib.iptr(mesh32), kd))
+        legs = []
+        for tag, model in (("haldane_2states", hp.haldane(tb.tb_model, 0.2)), ("kane_mele_4states", hp.kane_mele(tb.tb_model, "odd"))):
+            n = model._nsta
+            hm = model._device_model()
+            ed = C.c_void_p()
+            _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * n * 8, C.byref(ed)))
+            t = timed(ctx, lambda: _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None)), reps)
+            ctx.prof_enable(1)
+            ctx.prof_reset()
+            _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None))
+            kern = {kk: v["total_ms"] / max(v["launches"], 1) for kk, v in ctx.prof_report().items()}
+            ctx.prof_enable(0)
+            # spot check against the same kernel on a short list (the first and the last 4096 points)
+            probe = np.zeros((n, 4096))
+            chk = []
+            for first in (0, nk - 4096):
+                for b in range(n):
+                    _lib.check(lib.tbk_dev_download(ctx.handle, probe[b].ctypes.data_as(C.c_void_p),
+                                                    C.c_void_p(ed.value + 8 * (b * nk + first)), 8 * 4096))
+                kk = np.array([[(i // side) / side, (i % side) / side] for i in range(first, first + 4096)])
+                chk.append(float(np.max(np.abs(probe - model.solve_all(kk)))))
+            nbytes = 8 * (2 + n) * nk
+            legs.append({"leg": "list_%s_%dsq" % (tag, side), "nk": nk, "n": n, "eval_only_ms": t, "kernels_ms": kern,
+                         "kpts_per_s": nk / t * 1e3, "max_abs_diff_vs_short_list": max(chk),
+                         "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / (t * 1e-3) / 1e9, "peak": HBM,
+                                      "unit": "GB/s", "frac": nbytes / (t * 1e-3) / 1e9 / HBM}})
+            _lib.check(lib.tbk_dev_free(ctx.handle, ed))
+        _lib.check(lib.tbk_dev_free(ctx.handle, kd))
+        out.append({"config": "L: k-list kernels past the last-level cache (8192^2 k list, eigenvalues only, resident)", "legs": legs})
     if "C" in which or "D" in which:
         for tag, model, mesh, occ in (("C: Haldane 2048^2", hp.haldane(tb.tb_model, 0.0), [2049, 2049], [0]),
                                       ("D: Kane-Mele 4096x512", hp.kane_mele(tb.tb_model, "odd"), [4097, 513], [0, 1])):
@@ -338,21 +381,25 @@ def multi_gpu(which, side):
     BEFORE anything touches the GPU, then the RCCL communicator, then the legs.  The gathers inside the drivers of
     pythtb_amd/multi.py -- the path's one collective each -- run through RCCL (tbk_comm_allgatherv[_rows]_f64); gloo is the
     labelled fallback, and then the exit status is 4."""
-    import datetime
-    import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
     import pythtb_amd as tb
-    from pythtb_amd import _lib, multi
+    from pythtb_amd import _lib, multi, launch
+    if os.environ.get("TBK_RENDEZVOUS", "socket") == "gloo":  # (optional: torch.distributed on the host, as rounds 2-5 did)
+        import datetime
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+        gloo = multi.GlooComm(dist)
+    else:                                                     # the launcher's own TCP rendezvous: no torch in the run
+        dist = launch.Rendezvous(rank=rank, world=world, timeout=900.0)
+        gloo = multi.SocketComm(dist)
     import helpers as hp
     ctx = _lib.default_context()                              # device = LOCAL_RANK
     limit = float(os.environ.get("TBK_BENCH_RCCL_TIMEOUT", "120"))
-    gloo = multi.GlooComm(dist)
     comm, err, hung = multi.rccl_bring_up(ctx, dist, rank, world, limit)
     status = 0
     if comm is None:
-        sys.stderr.write("[bench_configs] rank %d: RCCL communicator unavailable (%s); gathers go through gloo\n" % (rank, err))
-        comm, gather, status = gloo, "gloo (FALLBACK: rccl %s)" % err, 4
+        sys.stderr.write("[bench_configs] rank %d: RCCL communicator unavailable (%s); gathers go through %s\n" % (rank, err, gloo.name))
+        comm, gather, status = gloo, "%s (FALLBACK: rccl %s)" % (gloo.name, err), 4
     else:
         gather = "rccl gather-v / all-gather-v (tbk_comm_gatherv_rows_f64, tbk_comm_allgatherv_f64, RCCL over xGMI)"
     lines = []
@@ -479,7 +526,10 @@ def multi_gpu(which, side):
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(status or 3)
-    dist.destroy_process_group()
+    if hasattr(dist, "close"):
+        dist.close()
+    else:
+        dist.destroy_process_group()
 
 
 def main():

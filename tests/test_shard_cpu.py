@@ -181,16 +181,26 @@ class OracleWf(object):
         return orc.berry_flux(self.wfs, len(self.mesh), list(occ), dirs=dirs, individual_phases=individual_phases, vectorised=True)
 
 
-class Counting(multi.GlooComm):
+SOCKET = os.environ.get("TBK_TEST_RDZV") == "socket"      # the launcher's TCP rendezvous instead of torch.distributed (no torch)
+Base = multi.SocketComm if SOCKET else multi.GlooComm
+
+
+class Counting(Base):
     '''counts the collectives a driver issues (north_star: ONE gather per driver)'''
     calls = 0
     def allgatherv(self, mine, counts):
         Counting.calls += 1
-        return multi.GlooComm.allgatherv(self, mine, counts)
+        return Base.allgatherv(self, mine, counts)
 
 
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
+if SOCKET:
+    from pythtb_amd import launch
+    dist = launch.Rendezvous(timeout=300.0)
+    dist.destroy_process_group = dist.close
+    rank, world = dist.rank, dist.world
+else:
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
 comm = Counting(dist)
 # solve_all on a k list (configs[1] / the solve_all leg of configs[4]) in small: 11 k-points do not divide by 2 or 3
 hal = hp.haldane(tb.tb_model, 0.2)
@@ -266,6 +276,8 @@ for occ2 in ([0], [0, 1]):
 assert abs(multi.berry_flux_sharded(OracleWf, hal0, mesh2, start2, [0], comm, rank, world)[0] / (2 * np.pi) + 1.0) < 1e-10   # Chern -1
 if rank == 0:
     print("MULTI_DRIVERS_OK", world, counts)
+    if os.environ.get("TBK_TEST_OUT"):
+        open(os.environ["TBK_TEST_OUT"], "a").write("MULTI_DRIVERS_OK %d\n" % world)
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -288,6 +300,22 @@ def test_multi_gpu_drivers_on_gloo_with_uneven_counts(tmp_path, world):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "MULTI_DRIVERS_OK %d" % world in res.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_gpu_drivers_on_the_socket_rendezvous(tmp_path, world):
+    """The same drivers with multi.SocketComm over launch.Rendezvous (what bench.py / bench_configs.py --gpus N use since round 6
+    for the control plane and the labelled fallback): started by our own launcher, no torch.distributed in the ranks."""
+    from pythtb_amd import launch
+    script = tmp_path / "multi_worker.py"
+    script.write_text(MULTI_WORKER.replace("import torch.distributed as dist\n", "dist = None\n"))
+    env = dict(os.environ, TBK_ROOT=ROOT, OMP_NUM_THREADS="1", TBK_TEST_RDZV="socket")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    out = tmp_path / "out.txt"
+    rc = launch.spawn_ranks(str(script), [], world, env=dict(env, TBK_TEST_OUT=str(out)), timeout=600)
+    assert rc == 0
+    assert "MULTI_DRIVERS_OK %d" % world in open(out).read()
 
 
 def test_multi_plans_cover_every_string_and_plane_once():
