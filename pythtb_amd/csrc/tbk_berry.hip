@@ -1881,7 +1881,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             }
         }
         // 3 or 4 bands whose occupied vectors fit the LDS tile: a lane per string or per link, vectors through LDS (tbk_berry_lanes.inl;
-        // TBK_WILSON_REG=3, the default; 1: round 4's thread per segment, 2: a thread per link + the product tree, 0: the workgroup kernels)
+        // TBK_WILSON_REG=3, the default; 1: round 4's thread per segment, 0: the workgroup kernels)
         const int wreg = tbk_knobs().wilson_reg;
         bool lanes_route = false, lanes_l = false;
         size_t lanes_lds = 0;
@@ -1900,7 +1900,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         }
         if (lanes_route) mfma_route = false;
         // else 3 or 4 bands: a thread per segment (k_wilson_seg_reg); segments sized on the whole call
-        const bool seg_route = !lanes_route && !mfma_route && nocc >= 3 && nocc <= 4 && wreg != 0 && wreg != 2 && A.nstrings * L < (int64_t)0x7fffffff * 128;
+        const bool seg_route = !lanes_route && !mfma_route && nocc >= 3 && nocc <= 4 && wreg != 0 && A.nstrings * L < (int64_t)0x7fffffff * 128;
         int seg_len_r = L, nseg_r = 1;
         int64_t lanes_ntile = 1;
         if (lanes_route && lanes_l) {
@@ -2041,17 +2041,9 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             } else
             if (nocc >= 3 && nocc <= 4 && wreg != 0 && !mfma_route && A.nstrings * L < (int64_t)0x7fffffff * 128) {
                 // 3 or 4 bands in registers (tbk_berry_big.inl): a thread per SEGMENT of a string forms its links, their polar
-                // factors and their ordered product; the segments of a string are multiplied by k_wilson_seg_combine.  (TBK_WILSON_REG=2:
-                // only the polar factors in registers, one thread per link, then the product tree; 0: the workgroup kernels.)
-                if (wreg == 2) {
-                    {
-                        ProfScope ps(ctx, "link_polar_reg");
-                        const dim3 g((unsigned)((ns * L + 255) / 256)), b(256);
-                        if (nocc == 3) hipLaunchKernelGGL((k_link_polar_reg<3>), g, b, 0, ctx->stream, W);
-                        else hipLaunchKernelGGL((k_link_polar_reg<4>), g, b, 0, ctx->stream, W);
-                        TBK_HIP(hipGetLastError());
-                    }
-                } else {
+                // factors and their ordered product; the segments of a string are multiplied by k_wilson_lanes_combine.  (TBK_WILSON_REG=0:
+                // the workgroup kernels.)
+                {
                     WilsonSegArgs S{};
                     S.W = W;
                     S.seg_len = seg_len_r;         // (segments: enough threads to fill the chip, none shorter than 4 links)
@@ -2067,10 +2059,16 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                         TBK_HIP(hipGetLastError());
                     }
                     {
-                        ProfScope ps(ctx, "wilson_seg_combine");
-                        const dim3 g((unsigned)((ns + 63) / 64)), b(64);
-                        if (nocc == 3) hipLaunchKernelGGL((k_wilson_seg_combine<3>), g, b, 0, ctx->stream, S);
-                        else hipLaunchKernelGGL((k_wilson_seg_combine<4>), g, b, 0, ctx->stream, S);
+                        // (a wavefront per string and the ordered tree of tbk_berry_lanes.inl: round 4's one-thread-per-string
+                        // combine walked 256 matrices through dependent loads -- 167 of a call's 281 us)
+                        WilsonLanesArgs C2{};
+                        C2.nseg = S.nseg;
+                        C2.segs = S.segs;
+                        C2.prod = S.prod;
+                        C2.pstride = S.pstride;
+                        ProfScope ps(ctx, "wilson_lanes_combine");
+                        if (nocc == 3) hipLaunchKernelGGL((k_wilson_lanes_combine<3>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, C2);
+                        else hipLaunchKernelGGL((k_wilson_lanes_combine<4>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, C2);
                         TBK_HIP(hipGetLastError());
                     }
                 }

@@ -322,94 +322,8 @@ __global__ __launch_bounds__(256) void k_link_polar_big(const WilsonBigArgs A) {
     }
 }
 
-// The same for 3 and 4 bands with the link matrix in REGISTERS, one thread per link (round 4): a 256-thread workgroup iterating
-// on a 4 x 4 matrix through global memory was 80-87 % of a Wilson-loop call of 3-4 bands (link_polar_big 4.1 of 5.1 ms for 4 of
-// 8 bands on a 65^3 array, profiles/wilson_stage_probe.py).  Same iteration, same stopping rule, same report of a singular link;
-// a wavefront runs until its slowest link has converged (neighbouring k-points: 3-4 steps).
-template <int M>
-__global__ __launch_bounds__(256) void k_link_polar_reg(const WilsonBigArgs A) {
-    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = item < A.ns * A.nlinks;
-    const int64_t it0 = live ? item : A.ns * A.nlinks - 1;
-    const int64_t s = it0 / A.nlinks;
-    const int i = (int)(it0 - s * A.nlinks);
-    const int ncomp = A.v.ncomp;
-    const int64_t p = axis_offset(A.other, A.s0 + s) + (int64_t)i * A.sdir, q = p + A.sdir;
-    cd X[M][M];
-#pragma unroll
-    for (int a = 0; a < M; ++a)
-#pragma unroll
-        for (int b = 0; b < M; ++b) X[a][b] = cd{0.0, 0.0};
-    {
-        const cd* up[M];
-        const cd* uq[M];
-#pragma unroll
-        for (int a = 0; a < M; ++a) {
-            up[a] = wf_at(A.v, A.occ[a], p);
-            uq[a] = wf_at(A.v, A.occ[a], q);
-        }
-        for (int c = 0; c < ncomp; ++c) {
-            cd pc[M], qc[M];
-#pragma unroll
-            for (int a = 0; a < M; ++a) {
-                pc[a] = up[a][c];
-                qc[a] = uq[a][c];
-            }
-#pragma unroll
-            for (int a = 0; a < M; ++a)
-#pragma unroll
-                for (int b = 0; b < M; ++b) cfmac(X[a][b], pc[a], qc[b]);
-        }
-    }
-    bool converged = false;
-    for (int it = 0; it < 200; ++it) {
-        // Y = X^H X (Hermitian: the upper triangle), r2 = ||Y - I||_F^2
-        cd Y[M][M];
-        double r2 = 0.0;
-#pragma unroll
-        for (int a = 0; a < M; ++a)
-#pragma unroll
-            for (int b = a; b < M; ++b) {
-                cd acc{0.0, 0.0};
-#pragma unroll
-                for (int k = 0; k < M; ++k) cfmac(acc, X[k][a], X[k][b]);
-                if (a == b) acc.y = 0.0;
-                Y[a][b] = acc;
-                Y[b][a] = cconj(acc);
-                const double dx = acc.x - (a == b ? 1.0 : 0.0);
-                r2 += (a == b ? 1.0 : 2.0) * (dx * dx + acc.y * acc.y);
-            }
-        if (!converged) {
-            // X <- (3 X - X Y) / 2
-            cd Z[M][M];
-#pragma unroll
-            for (int a = 0; a < M; ++a)
-#pragma unroll
-                for (int b = 0; b < M; ++b) {
-                    cd acc{0.0, 0.0};
-#pragma unroll
-                    for (int k = 0; k < M; ++k) cfma(acc, X[a][k], Y[k][b]);
-                    Z[a][b] = cd{1.5 * X[a][b].x - 0.5 * acc.x, 1.5 * X[a][b].y - 0.5 * acc.y};
-                }
-#pragma unroll
-            for (int a = 0; a < M; ++a)
-#pragma unroll
-                for (int b = 0; b < M; ++b) X[a][b] = Z[a][b];
-            if (r2 < 1e-14) converged = true;     // residual 1e-7 before this update, its square after it
-        }
-        if (__builtin_amdgcn_ballot_w64(!converged) == 0) break;
-    }
-    if (!live) return;
-    if (!converged) atomicExch(A.flags + 1, 1);
-    cd* const home = A.buf0 + (size_t)item * (M * M);
-#pragma unroll
-    for (int a = 0; a < M; ++a)
-#pragma unroll
-        for (int b = 0; b < M; ++b) home[a * M + b] = X[a][b];
-}
-
-// ... and the whole string in registers: a thread owns a SEGMENT of a string, forms each link matrix, iterates it to its polar
-// factor and multiplies it onto the segment's ordered product; k_wilson_seg_combine multiplies a string's segments in order.  No
+// 3 or 4 bands, the whole string in registers: a thread owns a SEGMENT of a string, forms each link matrix, iterates it to its polar
+// factor and multiplies it onto the segment's ordered product; k_wilson_lanes_combine (tbk_berry_lanes.inl) multiplies a string's segments in order.  No
 // link factors in memory, no product tree (log2 L launches of workgroup matmuls: 0.5 of the 1.16 ms that were left after
 // k_link_polar_reg).  The polar iteration of a link ends when every lane of the wavefront has converged.
 struct WilsonSegArgs {
@@ -537,40 +451,6 @@ __global__ __launch_bounds__(256) void k_wilson_seg_reg(const WilsonSegArgs S) {
 #pragma unroll
         for (int b = 0; b < M; ++b) o[a * M + b] = R[a][b];
 }
-template <int M>
-__global__ __launch_bounds__(64) void k_wilson_seg_combine(const WilsonSegArgs S) {
-    const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (s >= S.W.ns) return;
-    cd R[M][M];
-    const cd* g0 = S.segs + (size_t)s * S.nseg * (M * M);
-#pragma unroll
-    for (int a = 0; a < M; ++a)
-#pragma unroll
-        for (int b = 0; b < M; ++b) R[a][b] = g0[a * M + b];
-    for (int g = 1; g < S.nseg; ++g) {
-        const cd* X = g0 + (size_t)g * (M * M);
-        cd T[M][M];
-#pragma unroll
-        for (int a = 0; a < M; ++a)
-#pragma unroll
-            for (int b = 0; b < M; ++b) {
-                cd acc{0.0, 0.0};
-#pragma unroll
-                for (int k = 0; k < M; ++k) cfma(acc, R[a][k], X[k * M + b]);
-                T[a][b] = acc;
-            }
-#pragma unroll
-        for (int a = 0; a < M; ++a)
-#pragma unroll
-            for (int b = 0; b < M; ++b) R[a][b] = T[a][b];
-    }
-    cd* const o = S.prod + (size_t)s * S.pstride;
-#pragma unroll
-    for (int a = 0; a < M; ++a)
-#pragma unroll
-        for (int b = 0; b < M; ++b) o[a * M + b] = R[a][b];
-}
-
 struct WilsonTreeArgs {
     const cd* in;
     cd* out;

@@ -98,9 +98,13 @@ static void knobs_parse() {
         k.wilson_alpha_set = true;
     }
     getl("TBK_BIG_BATCH", k.big_batch);
-    geti("TBK_REG_LANES", k.reg_lanes);
-    geti("TBK_ABLATE_GRID", k.ablate_grid);
+#ifdef TBK_REG_MULTILANE
+    geti("TBK_REG_LANES", k.reg_lanes);          // (the multi-lane instantiations of k_solve_reg exist in that build only)
+#endif
+#ifdef TBK_DIAG
+    geti("TBK_ABLATE_GRID", k.ablate_grid);      // (the ablation branches are compiled into diagnostic builds only)
     geti("TBK_ABLATE_FLUX", k.ablate_flux);
+#endif
     g_knobs = k;
     g_knobs_parsed = true;
 }

@@ -90,7 +90,7 @@ struct TbkKnobs {
     int det_big_from = -1;      // TBK_DET_BIG_FROM  smallest band count of the workgroup-level link determinants
     int wilson_mfma = 1;        // TBK_WILSON_MFMA   0: Wilson loops of 5..8 wide bands on the workgroup-per-link kernels instead of k_chain_prod_tile<.., POLAR>
     int wilson_reg = 3;         // TBK_WILSON_REG    Wilson loops of 3-4 bands: 3 a lane per string / link, vectors through LDS (tbk_berry_lanes.inl);
-                                //                   1 round 4's thread per segment; 2 a thread per link + product tree; 0 the workgroup-per-link kernel
+                                //                   1 round 4's thread per segment (still what wide states that fit neither tile take); 0 the workgroup-per-link kernel
     int wilson_seg = -1;        // TBK_WILSON_SEG    test / probe hook: links per lane segment of the S form of tbk_berry_lanes.inl
     int wilson_swz = 1;         // TBK_WILSON_SWZ    0: no LDS swizzle of the components in tbk_berry_lanes.inl (A/B of the bank conflicts)
     int wilson_form = -1;       // TBK_WILSON_FORM   test / probe hook: 0 forces the S form (lane = string), 1 the L form (lane = link)

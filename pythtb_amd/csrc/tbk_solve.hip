@@ -2221,12 +2221,6 @@ static int launch_small(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
     if constexpr (MODE == 0) {
         const int kpt = tbk_knobs().small_kpt;
         const bool many = kpt == 2 || (kpt < 0 && !VEC && nk >= ((int64_t)1 << 19));
-        if (kpt == 4 && n == 2 && !VEC) {       // (probe: four points per lane, profiles/r06 leg L)
-            hipLaunchKernelGGL((k_solve_small_multi<2, false, 4>), dim3((unsigned)((nk + 1023) / 1024)), dim3(256), rlds, ctx->stream, mv, nk, L);
-            if (L.done.word) hipLaunchKernelGGL(k_signal_only, dim3(1), dim3(64), 0, ctx->stream, L.done);
-            TBK_HIP(hipGetLastError());
-            return TBK_OK;
-        }
         if (many && (n == 2 || (!VEC && (n == 3 || n == 4)))) {
             const unsigned b2 = (unsigned)((nk + 511) / 512);
             if (n == 2) hipLaunchKernelGGL((k_solve_small_multi<2, VEC, 2>), dim3(b2), dim3(256), rlds, ctx->stream, mv, nk, L);

@@ -84,6 +84,18 @@ REGIMES = [
     (100, 12, {"TBK_TRIGV": 0, "TBK_BLOCKED": 0}, "workgroup / whole-chip Jacobi"),
     (130, 6, {"TBK_TRIGV": 0, "TBK_BIG_FROM": 65}, "whole-chip Jacobi rounds"),
     (257, 2, {"TBK_TRIGV": 0}, "whole-chip Jacobi rounds"),
+    # launch shapes of the paths above (every knob forced somewhere)
+    (30, 8, {"TBK_FEW_NT": 512}, "small batch: workgroup LDS Jacobi on 512 threads"),
+    (30, 8, {"TBK_FEW_WARM": 0}, "small batch: workgroup LDS Jacobi, always cold"),
+    (13, 200, {"TBK_QL16": 0, "TBK_ROW16": 0, "TBK_FEW_MAX": 0, "TBK_WAVE_RUN": 1}, "wavefront LDS Jacobi, chains of one (cold)"),
+    (70, 170, {"TBK_TRIGV": 0, "TBK_WG_NT": 512}, "workgroup per L2-resident matrix on 512 threads"),
+    (24, 100, {"TBK_QLW_MIN": 0, "TBK_QLW_NT": 64}, "tridiagonal path, 64 threads per matrix"),
+    (24, 100, {"TBK_QLW_MIN": 0, "TBK_QLW_NT": 256}, "tridiagonal path, 256 threads per matrix"),
+    (100, 12, {"TBK_TRIGV_NC": 4}, "direct method, 4-column strips"),
+    (100, 12, {"TBK_TRIGV_NC": 16}, "direct method, 16-column strips"),
+    (24, 100, {"TBK_TRIGV_FROM": 17}, "direct method of 65+ states from 17 on"),
+    (12, 200, {"TBK_QL16_MIN": 0, "TBK_QL16_SPLIT_MIN": 0, "TBK_TW16_STREAMS": 2}, "fused 9..16 kernel, two chunks in flight"),
+    (12, 200, {"TBK_QL16_MIN": 0, "TBK_QL16_SPLIT_MIN": 0, "TBK_TW16_STREAMS": 1, "TBK_E16": 0}, "three-kernel 9..16 form on the context's stream"),
 ]
 EVAL_ONLY = [
     (12, 200, {}, "tridiagonalise + lane-per-matrix QL (any count)"),
@@ -95,6 +107,8 @@ EVAL_ONLY = [
     (90, 10, {"TBK_TRIG": 0}, "Jacobi"),
     (90, 10, {"TBK_TRIG": 0, "TBK_BLOCKED": 1}, "block Jacobi, eigenvalues only"),
     (300, 3, {}, "tridiagonalise in L2 + bisection"),
+    (90, 10, {"TBK_TRIG_NT": 256}, "tridiagonalise in L2 on 256 threads + bisection"),
+    (300, 3, {"TBK_TRIG_NT": 512}, "tridiagonalise in L2 on 512 threads + bisection"),
 ]
 
 
@@ -475,8 +489,8 @@ def test_mesh_rows_of_5_to_8_states_from_coefficient_cells(tb, n, rmax, mesh):
 def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
     """Wilson-loop eigenphases (berry_phase(..., berry_evals=True), pythtb.py:3798-3838) of 3 and 4 bands: a lane per string or per
     link with the occupied vectors staged through LDS (tbk_berry_lanes.inl: TBK_WILSON_REG=3, the default since round 6), the
-    string's links, their polar factors and their ordered product in a thread per segment (k_wilson_seg_reg, =1), the polar
-    factors alone in registers followed by the product tree (=2), and the workgroup-per-link kernels (=0): the same phases along
+    string's links, their polar factors and their ordered product in a thread per segment (k_wilson_seg_reg, =1) and the
+    workgroup-per-link kernels (=0): the same phases along
     every direction, on string counts and lengths that are no multiples of the wavefront, the tile or the segment -- strings
     across the lanes (S form, contiguous and gathered tiles, ragged last tile), strings along the lanes (L form: the fastest
     axis, several 64-link tiles, few strings), short strings, the occupied bands not the lowest."""
@@ -487,11 +501,11 @@ def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
     occ = list(range(nocc)) if n % 2 == 0 else list(range(n - nocc, n))[::-1]
     for d in range(len(mesh)):
         got = {}
-        for route in (1, 2, 0, 3):
+        for route in (1, 0, 3):
             with _lib.knob("TBK_WILSON_REG", route), _lib.knob("TBK_WILSON_MFMA", 2):     # (MFMA=2: wide states stay off the tile kernel)
                 got[route] = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
         got["default"] = np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True))
-        for route in (2, 0, 3, "default"):
+        for route in (0, 3, "default"):
             diff = np.angle(np.exp(1j * (got[1] - got[route])))
             assert np.max(np.abs(diff)) < 1e-10, (d, route)
         # the sum of the eigenphases is the determinant form's phase
