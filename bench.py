@@ -415,6 +415,27 @@ def extra_configs(tb, _lib, lib, ctx, ev_ms, valu):
                                                      kernel="chain_prod" if "chain_prod" in kt else "chain_links + chain_lu")},
                     "check": {"gap78": float(gaps[7]), "phase_checksum": float(np.sum(np.cos(phases)))}})
         g.free()
+        # ---- ... and its solve_all leg: eigenvalues of the k_uniform_mesh([side - 1] * 3) list, list and results resident
+        # (eigenvalue-only form of the fused kernel, k_e16<0, false>; algorithmic bytes 8 (d + n) per k-point)
+        nk = (side - 1) ** 3
+        mesh32 = np.array([side - 1] * 3, dtype=np.int32)
+        kd, ed = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 24, C.byref(kd)))
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 16 * 8, C.byref(ed)))
+        _lib.check(lib.tbk_k_uniform_mesh_dev(ctx.handle, 3, _lib.iptr(mesh32), kd))
+        hm = m._device_model()
+        _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None))
+        ctx.sync()
+        ka = kernel_times(ctx, lambda: _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None)), 2, ev_ms)
+        t_all = sum(v["avg_bracket_ms"] for v in ka.values())
+        ev0 = np.zeros(16)
+        for b in range(16):
+            _lib.check(lib.tbk_dev_download(ctx.handle, ev0[b:b + 1].ctypes.data_as(C.c_void_p), C.c_void_p(ed.value + 8 * b * nk), 8))
+        out[-1]["solve_all"] = {"kpts": nk, "kernels": ka, "ns_per_point": t_all * 1e6 / nk, "kpts_per_s": nk / (t_all * 1e-3),
+                                "roofline": roof(8 * (3 + 16) * nk, t_all, "k_e16<0,false>", nk, valu),
+                                "first_point_max_abs_diff_vs_solve_one": float(np.max(np.abs(ev0 - m.solve_one([0.0, 0.0, 0.0]))))}
+        for ptr in (kd, ed):
+            _lib.check(lib.tbk_dev_free(ctx.handle, ptr))
     except Exception as e:
         out.append({"config": "configs[4]", "error": " ".join(str(e).split())[:300]})
     return out

@@ -202,7 +202,22 @@ def single_gpu(which, reps):
             _lib.check(lib.tbk_berry_phase(hw, _lib.iptr(occ32), 8, 2, 1, _lib.dptr(wil)))
             t_wil = min(t_wil, time.perf_counter() - t0)
         wil = wil.reshape(-1, 8)
+        # configs[4]'s solve_all leg: eigenvalues of the k_uniform_mesh list, list and results resident (k_e16<0, false>)
+        mesh64 = np.array([64, 64, 64], dtype=np.int32)
+        kd, ed = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 24, C.byref(kd)))
+        _lib.check(lib.tbk_dev_alloc(ctx.handle, nk * 16 * 8, C.byref(ed)))
+        _lib.check(lib.tbk_k_uniform_mesh_dev(ctx.handle, 3, _lib.iptr(mesh64), kd))
+        t_all = timed(ctx, lambda: _lib.check(lib.tbk_solve_list_dev(hm, kd, nk, ed, None)), max(1, reps // 2))
+        ev0 = np.zeros(16)
+        for b in range(16):
+            _lib.check(lib.tbk_dev_download(ctx.handle, ev0[b:b + 1].ctypes.data_as(C.c_void_p), C.c_void_p(ed.value + 8 * b * nk), 8))
+        ev_ref = model.solve_all(np.zeros((1, 3)), eig_vectors=True)[0][:, 0]      # (another kernel: the counters of k_e16<0, false> stay those of the leg)
+        _lib.check(lib.tbk_dev_free(ctx.handle, kd))
+        _lib.check(lib.tbk_dev_free(ctx.handle, ed))
         out.append({"config": "E: cubic16 (888 hops) 64^3 sub-mesh", "nk": nk, "solve_grid_ms": t_solve,
+                    "solve_all_eigenvalues_ms": t_all, "solve_all_ns_per_point": t_all * 1e6 / nk,
+                    "solve_all_first_point_max_abs_diff": float(np.max(np.abs(ev0 - ev_ref))),
                     "kpts_per_s": nk / t_solve * 1e3, "berry_phase_8band_call_ms": t_phase * 1e3,
                     "links_per_s": 65 * 65 * 64 / t_phase, "wilson_loop_8band_call_ms": t_wil * 1e3,
                     "wilson_links_per_s": 65 * 65 * 64 / t_wil,

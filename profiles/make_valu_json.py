@@ -11,6 +11,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernel as bench.py names it, summary file, key inside it, mesh points per dispatch of that run)
 # (a key "a+b+c" sums the per-dispatch counts of several kernels that each cover the same points)
 SOURCES = [
+    # round 6, final build: r06a (the two-call headline step), r06f (--fused-headline), r06bcfg (bench_configs.py B D E P L W H R),
+    # r06ecfg (bench_configs.py E alone: clean per-dispatch counts of k_e16<1,true>, k_e16<0,false>, k_chain_prod_tile<8,2,false>)
+    ("k_grid_rows<2,1>", "r06a/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
+    ("k_flux_rows<1,2>", "r06a/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),
+    ("k_grid_rows_flux<2,1,1>", "r06f/pmc_per_dispatch.json", "k_grid_rows_flux<2,1,1>", 2049 * 2049),
+    ("k_grid_rows<4,1>", "r06bcfg/pmc_per_dispatch.json", "k_grid_rows<4,1>", 4097 * 513),
+    ("k_flux_rows<2,4>", "r06bcfg/pmc_per_dispatch.json", "k_flux_rows<2,4>", 4097 * 513),
+    ("k_e16<1>", "r06ecfg/pmc_per_dispatch.json", "k_e16<1,true>", 65 ** 3),
+    ("k_e16<0,false>", "r06ecfg/pmc_per_dispatch.json", "k_e16<0,false>", 64 ** 3),
+    ("k_chain_prod_tile<8,2>", "r06ecfg/pmc_per_dispatch.json", "k_chain_prod_tile<8,2,false>", 65 ** 3),
     # round 5, final build: r05c (the two-call headline step), r05ccfg (bench_configs.py B D E), r05p (leg P)
     ("k_grid_rows<2,1>", "r05c/pmc_per_dispatch.json", "k_grid_rows<2,1>", 2049 * 2049),
     ("k_flux_rows<1,2>", "r05c/pmc_per_dispatch.json", "k_flux_rows<1,2>", 2049 * 2049),

@@ -306,7 +306,7 @@ __device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N]
     auto negligible = [&](const int j) { return fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1])); };
     bool work = true;
     bool first = guided;                       // (a per-lane flag, not "iter == 0": the compiler peels a loop on the latter and keeps two copies of everything)
-    for (int iter = 0; iter < 30; ++iter) {
+    for (int iter = 0; iter < 31; ++iter) {
         work = !negligible(L);
         if (__builtin_amdgcn_ballot_w64(work) == 0) break;
         if (work) {
@@ -373,7 +373,11 @@ __device__ __forceinline__ bool ql_deflate_small(SmallFact<N>& F, double (&e)[N]
                 if (j == m) e[j] = 0.0;
         }
     }
-    return negligible(L);                      // (the state AFTER the last sweep, not the test made before it)
+    // `work` is the test made BEFORE a sweep: with 31 passes of the loop it is the state after the 30th sweep (LAPACK's limit; the
+    // 31st sweep of a lane that still has work is harmless and its outcome is not reported).  Re-evaluating negligible(L) here
+    // instead keeps d, e live across the divergent loop in a second copy: k_grid_rows<4,1> 128 -> 192 VGPRs, four -> two wavefronts
+    // per SIMD, 152 -> 215 us per 4097 x 513 mesh (profiles/r06cfg caught it)
+    return !work;
 }
 
 // The two LOWEST eigenvalues of the 4 x 4 symmetric tridiagonal (d, e) in closed form, to ~1e-6 |T|: first-sweep shifts for
