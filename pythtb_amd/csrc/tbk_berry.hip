@@ -1905,7 +1905,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         int64_t lanes_ntile = 1;
         if (lanes_route && lanes_l) {
             seg_len_r = 64;
-            nseg_r = ((L + 63) / 64) * (64 / LANES_L_SPAN);        // (a tile leaves the products of its 16-link quarters)
+            nseg_r = ((L + 63) / 64) * (64 / LANES_L_SPAN);        // (a tile leaves the products of its LANES_L_SPAN-link groups)
         } else if (lanes_route) {
             // S: one round of resident wavefronts when the strings allow it (a longer segment pays its first row once), else about four
             const int64_t nsb_guess = A.nstrings;          // (tiles are counted per batch below; the segment length is set once, on the call)

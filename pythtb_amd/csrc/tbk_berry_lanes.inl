@@ -15,7 +15,7 @@
 //     and lands behind the polar iteration; each lane keeps the ordered product of its segment.
 //   * L form (the string along the lanes; the string axis is the fastest one, or there are too few strings to fill lanes): lane =
 //     link of one 64-link tile of a string, 65 points in LDS; the 64 polar factors are multiplied by an ORDERED shuffle tree (the
-//     left operand always from the lower lane), six levels.
+//     left operand always from the lower lane): two levels per tile, the rest per string in the combine.
 // k_wilson_lanes_combine multiplies a string's segment products the same way: a wavefront per string, a contiguous run of segments
 // per lane, the same tree.  The polar iteration (Newton-Schulz, wilson_polar_reg) and the tail of the pipeline (Cayley transform,
 // Hermitian eigen-solve, phases) are those of tbk_berry_big.inl.
@@ -39,7 +39,8 @@ struct WilsonLanesArgs {
 };
 
 typedef __attribute__((address_space(3))) void* lanes_lds_ptr;
-#define LANES_L_SPAN 16      // L form: links per matrix it leaves in `segs` (64 / LANES_L_SPAN matrices per tile)
+#define LANES_L_SPAN 4       // L form: links per matrix it leaves in `segs` (64 / LANES_L_SPAN matrices per tile; 4 bands of 8 components,
+                             // 257 x 1024: kernel + combine 103 us at 16, 101 at 8, 97 at 4, 100 at 2)
 
 // One band's components at the tile's points -> row[u], u = j * ncomp + c (j: point of the tile, c: component).  `pt(j)`: the mesh
 // point of tile point j.  CONTIG: pt(j) = pt0 + j, the units are consecutive in memory and no division is needed.  A lane whose
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_l(const WilsonLanesArgs S) 
     lanes_overlap<M>(buf, act ? lane : 0, buf, act ? lane + 1 : 0, rowsz, ncomp, S.swz, X);
     if (!act) lanes_identity<M>(X);
     if (!wilson_polar_reg<M>(X)) atomicExch(A.flags + 1, 1);
-    // four levels of the tree here (the products of 16 links: lanes 0, 16, 32, 48), the rest with the string's other tiles in
+    // two levels of the tree here (the products of 4 links: lanes 0, 4, 8, ...), the rest with the string's other tiles in
     // k_wilson_lanes_combine -- a level costs the wavefront a whole matrix product however few lanes still need it, and the
     // combine pays its levels once per string, not once per tile
     lanes_tree<M, LANES_L_SPAN>(X);
