@@ -8,8 +8,8 @@
 // through LDS, three workgroup barriers per reflection and two more per reflector of the accumulation.  At 17..32 states that is
 // all latency: 36 k matrices of 32 states took 2.3 ms of the path's 4.3 (17 states: 0.71 of 1.4 ms; profiles/n17_probe.py, round 6)
 // -- 80 us per matrix for 0.6 M multiply-adds.  Here ONE wavefront owns a matrix and nothing but the broadcasts goes through LDS:
-//   * tridiagonalisation: lane (x, h) = row x, columns h HC .. h HC + HC - 1 of A in registers (HC = NMAX / 2: the two halves of
-//     the wavefront split the columns).  Reflection K (a compile-time constant: every register index is static): the column
+//   * tridiagonalisation: lane (x, h) = row x, columns h, h + 2, h + 4, ... of A in registers (the two halves of the wavefront
+//     take the columns in turn, so the live ones stay evenly split as the reflections advance and a step's loops start at slot K / 2).  Reflection K (a compile-time constant: every register index is static): the column
 //     below the diagonal is a[K % HC] of the half that owns column K, handed to the other half by one cross-half shuffle; u and
 //     q reach the columns as broadcast LDS reads (every lane of a half reads the same address); p = A u and the rank-2 update
 //     run over a lane's own columns, the halves' partial sums meet in one shuffle.  No workgroup barrier (one wavefront per
@@ -22,6 +22,14 @@
 // diagonal unitary D): (d, e) go to the same workspace, Z to the same place, and stages 2 and 3 (k_tridiag_ql_lanes, k_ql_replay_reg)
 // follow unchanged.  Not the same bits as k_tridiag_lds (the partial sums are cut differently); every point is still solved on its
 // own, so periodic images, halo rows and shard windows stay bit-identical.  TBK_HH32=0: k_tridiag_lds as before.
+//
+// Measured (profiles/hh32_sweep.py, 33^3 points, the whole three-stage call): n = 18 1.42 ms (k_tridiag_lds: 1.46), 20 1.57 (1.72),
+// 24 1.87 (2.24), 28 3.00 (3.18), 32 3.68 (4.05) -- 3 to 17 %; at 17 states a tie, left on the old kernel.  The stage itself: 1.76
+// against 2.32 ms at 32 states.  It is not the 2-3 x its arithmetic allows: a wavefront's step is a chain of ~6 dependent LDS round
+// trips, two 32-lane sums and two reciprocal square roots (~1.5 k cycles of latency for ~130 instructions), and 19 KB of LDS (the
+// staged matrix / the record / Z on its way out) leave two wavefronts per SIMD to hide it behind (k_e16 keeps twelve matrices per
+// SIMD in flight).  The first version, with the columns split in two blocks instead of in turn, did 60 % more multiply-adds on dead
+// columns and was no faster than k_tridiag_lds at all (profiles/HISTORY.md).
 
 // the value the lane 32 away holds: two v_permlane32_swap_b32 (vector ALU; __shfl_xor(v, 32) is a ds_bpermute round trip)
 __device__ __forceinline__ double hh32_xhalf(const double v, const bool upper) {
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
     cd a[HC];
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
-        const int c = h * HC + j;
+        const int c = 2 * j + h;
         a[j] = (x < n && c < n) ? A[x * ld + c] : cd{0.0, 0.0};
     }
     HH32_SYNC();                       // (the region takes the reflector record from here on)
@@ -112,10 +120,10 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
         // dependence TREE of a value -- sixteen operands per level here -- and took a minute for six steps, exponentially more beyond)
 #pragma unroll
         for (int j = 0; j < HC; ++j) asm("" : "+v"(a[j].x), "+v"(a[j].y));
-        const cd own = a[K % HC];
+        const cd own = a[K / 2];
         const cd oth{hh32_xhalf(own.x, h != 0), hh32_xhalf(own.y, h != 0)};
         const bool below = x > K && x < n;
-        const bool mine = h == K / HC;
+        const bool mine = h == (K & 1);
         const cd colx = below ? cd{mine ? own.x : oth.x, mine ? own.y : oth.y} : cd{0.0, 0.0};
         const cd alpha{hh32_lane(colx.x, K + 1), hh32_lane(colx.y, K + 1)};
         // |rows > K+1 of the column|^2: a reflection is needed iff this is non-zero (like LAPACK's zlarfg)
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
         cd p{0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < HC; ++j) {
-            if (HC + j > K) cfma(p, a[j], ubuf[h * HC + j]);          // (columns <= K: u is zero there; both halves' dead ones skipped)
+            if (2 * j + 1 > K) cfma(p, a[j], ubuf[2 * j + h]);          // (columns <= K: u is zero there; both halves' dead ones skipped)
         }
         p = cd{p.x + hh32_xhalf(p.x, h != 0), p.y + hh32_xhalf(p.y, h != 0)};
         const cd ps{p.x * beta, p.y * beta};
@@ -152,8 +160,8 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
         HH32_SYNC();
 #pragma unroll
         for (int j = 0; j < HC; ++j) {
-            if (HC + j > K) {      // A[x][c] -= u_x conj(q_c) + q_x conj(u_c)
-                const cd uc = ubuf[h * HC + j], qc = qbuf[h * HC + j];
+            if (2 * j + 1 > K) {   // A[x][c] -= u_x conj(q_c) + q_x conj(u_c)
+                const cd uc = ubuf[2 * j + h], qc = qbuf[2 * j + h];
                 a[j].x -= (u.x * qc.x + u.y * qc.y) + (q.x * uc.x + q.y * uc.y);
                 a[j].y -= (u.y * qc.x - u.x * qc.y) + (q.y * uc.x - q.x * uc.y);
             }
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
     // the diagonal: A[x][x] sits in the half that owns column x
     double dx = 0.0;
 #pragma unroll
-    for (int j = 0; j < HC; ++j) dx = (h * HC + j == x) ? a[j].x : dx;
+    for (int j = 0; j < HC; ++j) dx = (2 * j + h == x) ? a[j].x : dx;
     dx += hh32_xhalf(dx, h != 0);
     HH32_SYNC();
     // subdiagonal moduli and the phases D_{k+1} = D_k t_k / |t_k|
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
     // ---- 2. Z = H_0 (H_1 ( ... (H_{n-3} D))): lane (c, h) holds rows h HC .. of column c = x
     cd z[HC];
 #pragma unroll
-    for (int j = 0; j < HC; ++j) z[j] = (h * HC + j == x && x < n) ? dphase[x] : cd{0.0, 0.0};
+    for (int j = 0; j < HC; ++j) z[j] = (2 * j + h == x && x < n) ? dphase[x] : cd{0.0, 0.0};
     static_for<0, NMAX - 2>([&](auto it) __attribute__((always_inline)) {
         constexpr int K = NMAX - 3 - decltype(it)::value;
         if (K + 2 >= n) return;            // (uniform) no reflector with this number
@@ -213,8 +221,8 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
             cd t{0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < HC; ++j) {
-                if (HC + j > K) {          // (rows <= K of the record are zero; the dead rows of BOTH halves are skipped)
-                    const int r = h * HC + j;
+                if (2 * j + 1 > K) {       // (rows <= K of the record are zero; the dead rows of BOTH halves are skipped)
+                    const int r = 2 * j + h;
                     const cd ur = r < n && K + 2 < n ? A[K * n + r] : cd{0.0, 0.0};
                     cfmac(t, ur, z[j]);                        // t_c += conj(u_r) Z[r][c]
                 }
@@ -223,8 +231,8 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
             const cd ts{t.x * beta, t.y * beta};
 #pragma unroll
             for (int j = 0; j < HC; ++j) {
-                if (HC + j > K) {          // Z[r][c] -= u_r (beta t_c)
-                    const int r = h * HC + j;
+                if (2 * j + 1 > K) {       // Z[r][c] -= u_r (beta t_c)
+                    const int r = 2 * j + h;
                     const cd ur = r < n && K + 2 < n ? A[K * n + r] : cd{0.0, 0.0};
                     z[j].x -= ur.x * ts.x - ur.y * ts.y;
                     z[j].y -= ur.x * ts.y + ur.y * ts.x;
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
     HH32_SYNC();                       // the record has been read: the region takes Z, row-major with stride ld
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
-        const int r = h * HC + j;
+        const int r = 2 * j + h;
         if (r < n && x < n) A[r * ld + x] = z[j];
     }
     HH32_SYNC();

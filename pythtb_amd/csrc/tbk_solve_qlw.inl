@@ -696,6 +696,14 @@ __global__ __launch_bounds__(128) void k_ql_replay_reg64(const int n, const int6
     }
 }
 
+#include "tbk_solve_hh32.inl"   // k_hh32: stage 1 for n <= 32 with the matrix in registers
+static size_t hh32_lds_bytes(int n, int nR) {
+    size_t b = (size_t)n * (n | 1) * sizeof(cd);                  // H(k) | reflector record | Z
+    b += (size_t)(64 + std::max(n, nR) + 2 * n) * sizeof(cd);     // ubuf, qbuf, eo / phases, dphase, tsub
+    b += (size_t)2 * n * sizeof(double);                          // tau, eb
+    return (b + 15) & ~(size_t)15;
+}
+
 template <int MODE, bool VEC>
 static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, const ListArgs& L, const GridArgs& G) {
     const TbkKnobs& K = tbk_knobs();
@@ -758,13 +766,23 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         TBK_HIP(hipFuncSetAttribute((const void*)k_ql_backtransform<MODE, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     cd* evec = MODE == 1 ? nullptr : L.evec;
+    // n <= 32: the tridiagonalisation (and Z) with the matrix in the registers of ONE wavefront (k_hh32, tbk_solve_hh32.inl; round 6)
+    // (33^3 points, ms per call, k_hh32 / k_tridiag_lds: n = 17 1.41 / 1.37, 18 1.42 / 1.46, 20 1.57 / 1.72, 24 1.87 / 2.24, 28 3.00 / 3.18, 32 3.68 / 4.05
+    // -- profiles/hh32_sweep.py; TBK_HH32=2 forces it at 17 too, 0 never)
+    const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && n >= 18));
+    const size_t lds_hh = hh32_lds_bytes(n, MODE == 2 ? 0 : mv.nR);
     for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
+        if (hh32) {
+            if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, VEC, 24>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de);
+            else hipLaunchKernelGGL((k_hh32<MODE, VEC, 32>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de);
+        } else {
 #define TBK_QLW_K1(RW_, NT_)                                                                                                    \
     if (rw == RW_ && nt == NT_)                                                                                                 \
         hipLaunchKernelGGL((k_tridiag_lds<MODE, VEC, RW_, NT_>), dim3((unsigned)nc), dim3(NT_), lds1, ctx->stream, mv, nk, L, G, id0, nc, W.de);
         TBK_QLW_K1(32, 64) TBK_QLW_K1(32, 128) TBK_QLW_K1(32, 256) TBK_QLW_K1(64, 128) TBK_QLW_K1(64, 256) TBK_QLW_K1(64, 512)
 #undef TBK_QLW_K1
+        }
         // eigenvalues only, batches that leave the lane-per-matrix QL kernel a few wavefronts of pure latency: one thread per
         // EIGENVALUE instead (bisection, tbk_solve_trig.inl); TBK_QLW_BISECT=0 | 1 forces either
         bool bisect = false;

@@ -65,7 +65,13 @@ REGIMES = [
     (16, 200, {"TBK_QL16": 0, "TBK_FEW_MAX": 0}, "DPP-row Jacobi (n = 15, 16)"),
     (13, 200, {"TBK_QL16": 0, "TBK_ROW16": 0, "TBK_FEW_MAX": 0}, "wavefront LDS Jacobi"),
     (17, 100, {}, "small batch: workgroup Jacobi"),
-    (24, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, register replay (32 lanes)"),
+    (24, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path (k_hh32: matrix in registers), register replay (32 lanes)"),
+    (17, 100, {"TBK_QLW_MIN": 0, "TBK_HH32": 2}, "tridiagonal path, k_hh32<24> forced at 17"),
+    (18, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<24>"),
+    (25, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<32>"),
+    (32, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<32>"),
+    (24, 100, {"TBK_QLW_MIN": 0, "TBK_HH32": 0}, "tridiagonal path, LDS workgroup tridiagonalisation (round 2)"),
+    (31, 100, {"TBK_QLW_MIN": 0, "TBK_HH32": 0}, "tridiagonal path, LDS workgroup tridiagonalisation (round 2)"),
     (33, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, LDS replay"),
     (48, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, register replay (two wavefronts)"),
     (64, 60, {"TBK_QLW_MIN": 0}, "tridiagonal path, register replay (two wavefronts)"),
@@ -102,6 +108,8 @@ EVAL_ONLY = [
     (12, 200, {"TBK_QL16_EVONLY": 0}, "single replicated kernel"),
     (24, 100, {}, "tridiagonalise in LDS + bisection"),
     (24, 100, {"TBK_QLW_BISECT": 0}, "tridiagonalise in LDS + lane-per-matrix QL"),
+    (29, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<32, eigenvalues only> + lane-per-matrix QL"),
+    (19, 100, {"TBK_HH32": 0}, "k_tridiag_lds + bisection"),
     (48, 100, {"TBK_QLW": 0}, "Jacobi"),
     (90, 10, {}, "tridiagonalise in L2 + bisection"),
     (90, 10, {"TBK_TRIG": 0}, "Jacobi"),
