@@ -788,7 +788,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         bool bisect = false;
         if constexpr (!VEC && MODE != 1) bisect = K.qlw_bisect >= 0 ? K.qlw_bisect == 1 : nc < (int64_t)ctx->cus * 16;
         if (bisect)
-            hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(64), (size_t)n * sizeof(double2) + 8 * sizeof(double), ctx->stream, n,
+            hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(64), (size_t)n * sizeof(double2) + 32 * sizeof(double), ctx->stream, n,
                                nk, id0, (const double2*)W.de, L.eval, (int64_t)1, nc, ctx->flags_dev);
         else
             hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0,

@@ -224,16 +224,19 @@ __global__ __launch_bounds__(NT) void k_tridiag_glb(const ModelView mv, const in
 }
 
 // (d_j, e_j) of matrix idc at de[idc * si + j * sj]  ->  eval[j][id] ascending.  One block per matrix, thread j <-> eigenvalue j (+ 256, ...).
-__global__ __launch_bounds__(256) void k_tridiag_bisect(const int n, const int64_t nk, const int64_t id0, const double2* __restrict__ de,
+// threads per matrix of k_tridiag_bisect: one per eigenvalue up to 1024 (round 6: with 256 threads a matrix of 257..512 states ran its
+// bisections in two rounds -- 101 x n = 300: 2.8 ms of the 17 ms call)
+static inline int trig_bisect_nt(const int n) { return n <= 256 ? 256 : std::min(1024, (n + 63) & ~63); }
+__global__ __launch_bounds__(1024) void k_tridiag_bisect(const int n, const int64_t nk, const int64_t id0, const double2* __restrict__ de,
                                                         double* __restrict__ eval, const int64_t si, const int64_t sj, int* flags) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double2* T = (double2*)lds_raw;           // [n] (d_j, e_{j-1}^2)   (e_{-1} = 0)
-    double* red = (double*)(T + n);           // [8]
+    double* red = (double*)(T + n);           // [32]: (lo, hi) per wavefront
     const int tid = threadIdx.x;
     const int64_t idc = blockIdx.x, id = id0 + idc;
     const double2* src = de + idc * si;
     double glo = INFINITY, ghi = -INFINITY, emax = 0.0;
-    const int nt = blockDim.x;                // 64 | 256
+    const int nt = blockDim.x;                // 64 | 256 | ... | 1024
     for (int j = tid; j < n; j += nt) {
         const double2 v = src[j * sj];
         const double em = j > 0 ? src[(j - 1) * sj].y : 0.0;
@@ -330,7 +333,7 @@ static int launch_trig(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
     TBK_TRIG_K1(false, 256) TBK_TRIG_K1(false, 512) TBK_TRIG_K1(false, 1024) TBK_TRIG_K1(true, 256) TBK_TRIG_K1(true, 512) TBK_TRIG_K1(true, 1024)
 #undef TBK_TRIG_K1
     if (lds1 > 64 * 1024) TBK_HIP(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const size_t lds2 = (size_t)n * sizeof(double2) + 8 * sizeof(double);
+    const size_t lds2 = (size_t)n * sizeof(double2) + 32 * sizeof(double);
     for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
         // (the workspace stride is n x n complex, rounded: keep the kernels' own stride n * n -- chunks are packed)
@@ -339,7 +342,7 @@ static int launch_trig(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, con
         hipLaunchKernelGGL((k_tridiag_glb<MODE, AL_, NT_>), dim3((unsigned)nc), dim3(NT_), lds1, ctx->stream, mv, nk, L, id0, nc, work, de);
         TBK_TRIG_K1(false, 256) TBK_TRIG_K1(false, 512) TBK_TRIG_K1(false, 1024) TBK_TRIG_K1(true, 256) TBK_TRIG_K1(true, 512) TBK_TRIG_K1(true, 1024)
 #undef TBK_TRIG_K1
-        hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(256), lds2, ctx->stream, n, nk, id0, (const double2*)de, L.eval,
+        hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(trig_bisect_nt(n)), lds2, ctx->stream, n, nk, id0, (const double2*)de, L.eval,
                            (int64_t)n, (int64_t)1, ctx->flags_dev);
         TBK_HIP(hipGetLastError());
     }

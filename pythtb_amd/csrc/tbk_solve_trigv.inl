@@ -422,7 +422,7 @@ static int launch_trigv(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
     const int nt = n <= 160 ? 512 : 1024;
     const void* f1 = nt == 512 ? (const void*)k_tridiag_glb<MODE, false, 512, true> : (const void*)k_tridiag_glb<MODE, false, 1024, true>;
     if (lds1 > 64 * 1024) TBK_HIP(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const size_t lds2 = (size_t)n * sizeof(double2) + 8 * sizeof(double);
+    const size_t lds2 = (size_t)n * sizeof(double2) + 32 * sizeof(double);
     const size_t lds3 = (size_t)n * (sizeof(double2) + sizeof(double));
     // columns per strip of the back-transformation: n x NC complex (+ reflector, D, partial sums) within 160 KB of LDS
     // (ms for the back-transformation, 16 | 8 | 4 columns: 512 x n=128 1.3 | 2.0 | 4.9, 101 x n=300 6.6 | 4.1 | 7.0 -- a strip should
@@ -448,7 +448,7 @@ static int launch_trigv(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, co
         const int64_t lam_nk = MODE == 1 ? nc : nk, lam_id0 = MODE == 1 ? 0 : id0;
         {
             ProfScope ps(ctx, "trigv_bisect");
-            hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(256), lds2, ctx->stream, n, lam_nk, lam_id0, (const double2*)de, lam,
+            hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(trig_bisect_nt(n)), lds2, ctx->stream, n, lam_nk, lam_id0, (const double2*)de, lam,
                                (int64_t)n, (int64_t)1, ctx->flags_dev);
         }
         if constexpr (MODE == 1) hipLaunchKernelGGL(k_trigv_gaps, dim3((unsigned)(n - 1)), dim3(256), 0, ctx->stream, n, nc, (const double*)evb, G);
