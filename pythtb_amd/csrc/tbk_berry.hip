@@ -789,6 +789,8 @@ static void launch_flux(tbk_ctx* ctx, const FluxArgs& A, int64_t nslices) {
 }
 
 static int chain_wave_link_dets(tbk_wfs* w, const int32_t* occ, int nocc, int dir, cd* dets_out);   // defined with its kernels below
+static bool lanes_dets_applies(const WfsView& v, int nocc);
+static int lanes_link_dets(tbk_wfs* w, const int32_t* occ, int nocc, int dir, cd* dets_out);          // (tbk_berry_lanes.inl kernels, OUT = 2)
 static bool chain_wave_applies(const WfsView& v, int nocc);
 
 extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, int dir0, int dir1,
@@ -903,7 +905,8 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         A.plaq = w->flux_plaq_dev;
     }
     A.partial = w->flux_partial_dev;
-    if (!big && chain_wave_applies(v, nocc)) {
+    const bool lanes_flux = !big && !rows && !chain_wave_applies(v, nocc) && lanes_dets_applies(v, nocc);
+    if (!big && (chain_wave_applies(v, nocc) || lanes_flux)) {
         // 5..8 bands of wide states: every lane of the plaquette kernel would walk its own 256-byte rows; instead the link
         // determinants along both directions come from the wave-per-string kernels (coalesced), then the same combine
         // kernel as for large band sets
@@ -912,9 +915,11 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         rc = tbk_ctx_scratch(ctx, 256 + 2 * db, &base);
         if (rc) return rc;
         cd* dets = (cd*)((unsigned char*)base + 256);
-        rc = chain_wave_link_dets(w, occ, nocc, dir0, dets);
+        // (1..4 bands of states with fewer than 8 components, round 6: the LDS-tile kernels of tbk_berry_lanes.inl)
+        rc = lanes_flux ? lanes_link_dets(w, occ, nocc, dir0, dets) : chain_wave_link_dets(w, occ, nocc, dir0, dets);
         if (rc) return rc;
-        rc = chain_wave_link_dets(w, occ, nocc, dir1, (cd*)((unsigned char*)dets + db));
+        rc = lanes_flux ? lanes_link_dets(w, occ, nocc, dir1, (cd*)((unsigned char*)dets + db))
+                        : chain_wave_link_dets(w, occ, nocc, dir1, (cd*)((unsigned char*)dets + db));
         if (rc) return rc;
         PlaqDetArgs P{};
         P.d0 = dets;
@@ -1811,6 +1816,96 @@ __global__ __launch_bounds__(64) void k_chain_final_wave(const ChainArgs A) {
     }
 }
 
+// ---- the LDS-tile kernels (tbk_berry_lanes.inl) for determinants: which arrays they take, how a call is cut into tiles
+struct LanesPlan {
+    bool ok, l;          // applies; L form (lane = link) instead of S (lane = string)
+    size_t lds;
+    int seg_len, nseg;   // S: links per lane segment, segments per string; L: 64, tiles per string
+    int64_t ntile;       // S: tiles of 64 strings
+};
+static bool lanes_dets_applies(const WfsView& v, int nocc) {
+    // 1..4 bands; not the up-to-two bands of up-to-four components the register kernels serve; the tile must fit 64 KB of LDS
+    return nocc >= 1 && nocc <= 4 && !(nocc <= 2 && v.ncomp <= 4) && tbk_knobs().wilson_reg == 3 && v.npts < (int64_t)0x7fffffff &&
+           v.ncomp <= 21 && (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd) <= 64 * 1024;
+}
+static LanesPlan lanes_plan(tbk_ctx* ctx, const WfsView& v, int nocc, int64_t sdir, int L, int64_t nstrings) {
+    LanesPlan P{};
+    const size_t lds_l = (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd), lds_s = (size_t)2 * nocc * 64 * v.ncomp * sizeof(cd);
+    P.l = (sdir == 1 && L >= 32) || (nstrings < 32 && L >= 32) || (lds_s > 40 * 1024 && lds_l <= 40 * 1024 && L >= 32) || lds_s > 64 * 1024;
+    if (tbk_knobs().wilson_form >= 0 && !(lds_s > 64 * 1024)) P.l = tbk_knobs().wilson_form != 0;
+    P.lds = P.l ? lds_l : lds_s;
+    P.ok = P.lds <= 64 * 1024;
+    P.ntile = 1;
+    if (P.l) {
+        P.seg_len = 64;
+        P.nseg = (L + 63) / 64;
+    } else {
+        const int res = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(P.lds, 1)));
+        P.ntile = (nstrings + 63) / 64;
+        const int64_t R = (int64_t)ctx->cus * res;
+        int64_t ns_ = P.ntile * 2 <= R ? R / P.ntile : (4 * R + P.ntile - 1) / P.ntile;
+        ns_ = std::max<int64_t>(1, std::min<int64_t>(ns_, std::max(1, L / 2)));
+        P.seg_len = (int)((L + ns_ - 1) / ns_);
+        if (tbk_knobs().wilson_seg > 0) P.seg_len = std::min(L, tbk_knobs().wilson_seg);
+        P.nseg = (L + P.seg_len - 1) / P.seg_len;
+    }
+    return P;
+}
+static void lanes_fill(WilsonLanesArgs& S, tbk_ctx* ctx, const WfsView& v, const int* occ, int nocc, int L, int64_t sdir, const AxisSet& other,
+                       int64_t nstrings, const LanesPlan& P) {
+    S = WilsonLanesArgs{};
+    S.W.v = v;
+    S.W.occ = nullptr;
+    S.W.nocc = nocc;
+    S.W.nlinks = L;
+    S.W.sdir = sdir;
+    S.W.other = other;
+    S.W.s0 = 0;
+    S.W.ns = nstrings;
+    S.W.flags = ctx->flags_dev;
+    for (int a = 0; a < 4; ++a) S.occ_inl[a] = a < nocc ? occ[a] : 0;
+    S.seg_len = P.seg_len;
+    S.nseg = P.nseg;
+    S.ntile = P.ntile;
+    S.magic = (unsigned)((65536 + v.ncomp - 1) / v.ncomp);
+    S.swz = v.ncomp == 4 ? 2 : v.ncomp == 8 ? 1 : v.ncomp == 16 ? 0 : -1;
+    if (tbk_knobs().wilson_swz == 0) S.swz = -1;
+}
+#define TBK_LANES_LAUNCH(OUT_, S_, P_, nstr_)                                                                                \
+    {                                                                                                                        \
+        const dim3 g_((unsigned)((P_).l ? (nstr_) * (P_).nseg : (P_).ntile * (P_).nseg)), b_(64);                            \
+        switch ((S_).W.nocc) {                                                                                               \
+            case 1: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<1, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+                    else hipLaunchKernelGGL((k_wilson_lanes_s<1, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
+            case 2: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<2, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+                    else hipLaunchKernelGGL((k_wilson_lanes_s<2, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
+            case 3: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<3, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+                    else hipLaunchKernelGGL((k_wilson_lanes_s<3, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
+            default: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);         \
+                     else hipLaunchKernelGGL((k_wilson_lanes_s<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;        \
+        }                                                                                                                    \
+    }
+// dets_out[p] = det of the link matrix from mesh point p to its neighbour along `dir`, for every string along that axis
+static int lanes_link_dets(tbk_wfs* w, const int32_t* occ, int nocc, int dir, cd* dets_out) {
+    tbk_ctx* ctx = w->ctx;
+    const WfsView& v = w->view;
+    AxisSet other{};
+    int64_t nstrings = 1;
+    other_axes(v, dir, -1, &other, &nstrings);
+    const int L = v.mesh[dir] - 1;
+    const LanesPlan P = lanes_plan(ctx, v, nocc, v.stride[dir], L, nstrings);
+    TBK_REQUIRE(P.ok, TBK_EUNSUPPORTED, "lanes_link_dets: %d bands of %d components do not fit the LDS tile", nocc, v.ncomp);
+    int occ4[4] = {0, 0, 0, 0};
+    for (int a = 0; a < nocc; ++a) occ4[a] = occ[a];
+    WilsonLanesArgs S;
+    lanes_fill(S, ctx, v, occ4, nocc, L, v.stride[dir], other, nstrings, P);
+    S.dets = dets_out;
+    ProfScope ps(ctx, "lanes_link_dets");
+    TBK_LANES_LAUNCH(2, S, P, nstrings)
+    TBK_HIP(hipGetLastError());
+    return TBK_OK;
+}
+
 extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir, int berry_evals, double* out) {
     TBK_REQUIRE(w && out, TBK_EINVAL, "tbk_berry_phase: null argument");
     const WfsView& v = w->view;
@@ -2140,6 +2235,17 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     A.nseg = (A.nlinks + A.seg_len - 1) / A.seg_len;
     if (wave_chain) chain_wave_segments(ctx, A);
     const bool ev = berry_evals != 0;
+    // determinant form of 1..4 bands of NARROW states (fewer than 8 components, where the wave-per-string kernels above do not
+    // apply): the LDS-tile kernels of tbk_berry_lanes.inl without the polar iteration (round 6).  Not for up to two bands of up
+    // to four components: k_chain_partial keeps a link's shared point in registers there (13 us for Kane-Mele-sized states).
+    // TBK_WILSON_REG != 3 keeps k_chain_partial.
+    LanesPlan LP{};
+    const bool lanes_det = !ev && !wave_chain && lanes_dets_applies(v, nocc);
+    if (lanes_det) {
+        LP = lanes_plan(ctx, v, nocc, A.sdir, A.nlinks, A.nstrings);
+        A.seg_len = LP.seg_len;
+        A.nseg = LP.nseg;
+    }
     const int64_t per = ev ? (int64_t)nocc * nocc : 1;
     const int64_t nout = A.nstrings * (ev ? nocc : 1);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -2158,6 +2264,12 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         if (wave_chain) {
             rc = launch_chain_wave(ctx, v, A, nocc, nullptr);
             if (rc) return rc;
+        } else if (lanes_det) {
+            WilsonLanesArgs S;
+            lanes_fill(S, ctx, v, A.occ, nocc, A.nlinks, A.sdir, A.other, A.nstrings, LP);
+            S.dets = A.partial;
+            S.det_stride = A.nstrings;
+            TBK_LANES_LAUNCH(1, S, LP, A.nstrings)
         } else if (!ev) {
             switch (nocc) {
                 case 1: hipLaunchKernelGGL((k_chain_partial<1, 1, false>), grid, blk, 0, ctx->stream, A); break;

@@ -34,6 +34,9 @@ struct WilsonLanesArgs {
     cd* segs;          // [ns][nseg][nocc^2]
     cd* prod;          // combine: string s at prod + s * pstride
     size_t pstride;
+    int occ_inl[4];    // the occupied bands when W.occ is null (the determinant form: the list travels with the arguments)
+    cd* dets;          // POLAR = false: [nseg][det_stride] products of the link determinants, what k_chain_final(_wave) reads
+    int64_t det_stride;
     cd* herm;          // combine, non-null: [ns][nocc^2] Cayley transform of e^{-i alpha} (string product), Hermitian part (k_wilson_cayley's
     double ca, sa;     // output for the pipeline's FIRST angle alpha: cos, sin) -- one launch less in front of the eigen-solve
 };
@@ -126,8 +129,17 @@ __device__ __forceinline__ void lanes_tree(cd (&R)[M][M]) {      // SPAN < 64: t
 }
 
 // ---- S form: lane = string, a wavefront walks one segment of links for 64 neighbouring strings
-template <int M>
+// POLAR = false (round 6): the DETERMINANT form of berry_phase (pythtb.py:3829-3831: -angle(det of the product) = the product of the
+// link determinants) for 1..4 bands of states with fewer than 8 components -- the same tiles, no polar iteration: a lane multiplies
+// the determinants of its links and leaves ONE complex number per (segment, string) where k_chain_final(_wave) expects it.  The
+// thread-per-(string, segment) kernel it replaces there (k_chain_partial) fetched its points 16 bytes per lane like round 4's
+// Wilson kernel: 3 bands of 6 components, 257 x 1024 links: 52-74 us, 4 bands 80-124 (profiles/det_narrow_probe.py).
+// OUT = 2 (berry_flux of the same bands): every link's determinant on its own, at dets[mesh point the link starts from] -- the
+// array k_flux_from_dets combines into plaquette phases (the thread-per-plaquette kernel took 78 (1 band) to 327 us (4 bands) for
+// the 263 k plaquettes of a 1025 x 257 array of 6-component states: profiles/flux_narrow_probe.py).
+template <int M, int OUT = 0>
 __global__ __launch_bounds__(64) void k_wilson_lanes_s(const WilsonLanesArgs S) {
+    constexpr bool POLAR = OUT == 0;
     extern __shared__ __align__(16) unsigned char lds_lanes[];
     const WilsonBigArgs& A = S.W;
     const int lane = threadIdx.x;
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_s(const WilsonLanesArgs S) 
     cd* const buf = reinterpret_cast<cd*>(lds_lanes);            // [2][M][rowsz]
     int occ[M];
 #pragma unroll
-    for (int a = 0; a < M; ++a) occ[a] = A.occ[a];
+    for (int a = 0; a < M; ++a) occ[a] = A.occ ? A.occ[a] : S.occ_inl[a];
     auto issue = [&](const int li, const int b) __attribute__((always_inline)) {       // row of string point i0 + li -> buffer b
         const int64_t shift = (int64_t)li * A.sdir;
 #pragma unroll
@@ -169,10 +181,21 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_s(const WilsonLanesArgs S) 
         __builtin_amdgcn_wave_barrier();
         if (li + 2 <= len) issue(li + 2, li & 1);
         if (!live) lanes_identity<M>(X);           // (a lane past the last string reads repeated units: not a link matrix)
-        all_ok = wilson_polar_reg<M>(X) && all_ok;
-        lanes_mul<M>(R, X);
+        if constexpr (POLAR) {
+            all_ok = wilson_polar_reg<M>(X) && all_ok;
+            lanes_mul<M>(R, X);
+        } else if constexpr (OUT == 1) {
+            R[0][0] = cmul(R[0][0], det_small<M>(X));      // (the running product of the link determinants sits in R[0][0])
+        } else {
+            if (live) S.dets[base + (int64_t)li * A.sdir] = det_small<M>(X);
+        }
     }
     if (!live) return;
+    if constexpr (OUT == 2) return;
+    if constexpr (OUT == 1) {
+        S.dets[seg * S.det_stride + A.s0 + s] = R[0][0];
+        return;
+    }
     if (!all_ok) atomicExch(A.flags + 1, 1);
     cd* const o = S.segs + ((size_t)s * S.nseg + seg) * (M * M);
 #pragma unroll
@@ -182,13 +205,14 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_s(const WilsonLanesArgs S) 
 }
 
 // ---- L form: lane = link, a wavefront takes 64 consecutive links of one string
-template <int M>
+template <int M, int OUT = 0>
 __global__ __launch_bounds__(64) void k_wilson_lanes_l(const WilsonLanesArgs S) {
+    constexpr bool POLAR = OUT == 0;
     extern __shared__ __align__(16) unsigned char lds_lanes[];
     const WilsonBigArgs& A = S.W;
     const int lane = threadIdx.x;
     const int ncomp = A.v.ncomp;
-    const int ntile = S.nseg / (64 / LANES_L_SPAN);
+    const int ntile = POLAR ? S.nseg / (64 / LANES_L_SPAN) : S.nseg;
     const int64_t s = blockIdx.x / ntile;
     const int t = (int)(blockIdx.x - s * ntile);
     const int i0 = t * 64, nl = min(64, A.nlinks - i0), npt = nl + 1;
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_l(const WilsonLanesArgs S) 
     cd* const buf = reinterpret_cast<cd*>(lds_lanes);            // [M][rowsz]
 #pragma unroll
     for (int a = 0; a < M; ++a) {
-        const int band = A.occ[a];
+        const int band = A.occ ? A.occ[a] : S.occ_inl[a];
         if (A.sdir == 1) lanes_issue_row<true>(A.v, band, base, [](int) { return (int64_t)0; }, npt, buf + a * rowsz, lane, S.magic, S.swz);
         else lanes_issue_row<false>(A.v, band, 0, [&](const int j) { return base + (int64_t)j * A.sdir; }, npt, buf + a * rowsz, lane, S.magic, S.swz);
     }
@@ -207,6 +231,18 @@ __global__ __launch_bounds__(64) void k_wilson_lanes_l(const WilsonLanesArgs S) 
     const bool act = lane < nl;
     lanes_overlap<M>(buf, act ? lane : 0, buf, act ? lane + 1 : 0, rowsz, ncomp, S.swz, X);
     if (!act) lanes_identity<M>(X);
+    if constexpr (OUT == 2) {                      // every link's determinant at the mesh point it starts from
+        if (act) S.dets[base + (int64_t)lane * A.sdir] = det_small<M>(X);
+        return;
+    }
+    if constexpr (OUT == 1) {                      // determinant form: the product of the tile's link determinants (any order)
+        cd dt = det_small<M>(X);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) dt = cmul(dt, cd{__shfl_xor(dt.x, off), __shfl_xor(dt.y, off)});
+        if (lane == 0) S.dets[(int64_t)t * S.det_stride + A.s0 + s] = dt;
+        return;
+    }
+    if constexpr (!POLAR) return;                  // (nothing below is instantiated for use; kept out of the determinant form's code)
     if (!wilson_polar_reg<M>(X)) atomicExch(A.flags + 1, 1);
     // two levels of the tree here (the products of 4 links: lanes 0, 4, 8, ...), the rest with the string's other tiles in
     // k_wilson_lanes_combine -- a level costs the wavefront a whole matrix product however few lanes still need it, and the

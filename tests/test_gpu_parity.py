@@ -491,6 +491,39 @@ def test_signed_band_indices_like_numpy(tb):
                 w2.solve_on_grid_flux(start, occ=[n])
 
 
+@pytest.mark.parametrize("n,nspin,mesh", [(5, 1, [40, 23]), (3, 2, [19, 70]), (7, 1, [9, 8, 35]), (6, 1, [5, 66, 4])])
+def test_narrow_states_berry_calls_on_the_lds_tile_kernels(tb, n, nspin, mesh):
+    """1..4 bands of states with 5..7 components (round 6): berry_phase in its determinant form and berry_flux take the LDS-tile
+    kernels of tbk_berry_lanes.inl (products of link determinants / every link's determinant + k_flux_from_dets) -- against the
+    oracle on the oracle's own eigenvectors, every direction and plane, both forms of the tile (strings across / along the lanes:
+    the meshes put the string axis first, last and in the middle), and against the kernels they replace (TBK_WILSON_REG=1)."""
+    from oracle import tb_oracle as orc
+    from pythtb_amd import _lib
+    m = hp.random_model(tb.tb_model, n, len(mesh), nspin, seed=200 + n, nhop=4 * n * nspin, rmax=1)
+    D = len(mesh)
+    start = [0.07, -0.31, 0.2][:D]
+    w = tb.wf_array(m, mesh)
+    w.solve_on_grid(start)
+    owfs, _ = orc.solve_on_grid(m, mesh, start, vectorised=True)
+    for occ in ([0], [1, 0], [0, 2, 3], [1, 2, 3, 4]):
+        for d in range(D):
+            got = np.asarray(w.berry_phase(occ, d, contin=False))
+            ref = np.asarray(orc.berry_phase(owfs, D, occ, d, contin=False))
+            assert got.shape == ref.shape and np.max(np.abs(wrap(got - ref))) < TOL_P, (occ, d)
+            with _lib.knob("TBK_WILSON_REG", 1):
+                old = np.asarray(w.berry_phase(occ, d, contin=False))
+            assert np.max(np.abs(wrap(got - old))) < 1e-11, (occ, d)
+        for dirs in ([0, 1], [1, 0]) + (([1, 2], [2, 0]) if D == 3 else ()):
+            got = w.berry_flux(occ, dirs=list(dirs), individual_phases=True)
+            ref = orc.berry_flux(owfs, D, occ, list(dirs), individual_phases=True, vectorised=True)
+            assert got.shape == ref.shape and np.max(np.abs(wrap(got - ref))) < TOL_P, (occ, dirs)
+            tot = w.berry_flux(occ, dirs=list(dirs))
+            assert np.max(np.abs(tot - got.sum(axis=(-2, -1)))) < 1e-9
+            with _lib.knob("TBK_WILSON_REG", 1):
+                old = w.berry_flux(occ, dirs=list(dirs), individual_phases=True)
+            assert np.max(np.abs(wrap(got - old))) < 1e-11, (occ, dirs)
+
+
 def test_upload_roundtrip_and_user_written_arrays(tb):
     """A wf_array filled on the host (oracle eigenvectors, different gauge) gives the
     same gauge-invariant numbers; download(upload(x)) is the identity."""

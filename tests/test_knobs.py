@@ -65,7 +65,7 @@ def test_mesh_and_flux_launch_shapes(tb, knob, value):
         assert abs(a[2] - b[2]) < 1e-10 and abs(a[5] - b[5]) < 1e-10 and abs(a[2] - a[5]) < 1e-9
 
 
-CHAIN_KNOBS = [("TBK_CHAIN_WAVE", 0), ("TBK_CHAIN_WAVE_FROM", 3), ("TBK_CHAIN_WS_MB", 1), ("TBK_DET_BIG_FROM", 2), ("TBK_DET_BIG_FROM", 4),
+CHAIN_KNOBS = [("TBK_WILSON_REG", 1), ("TBK_CHAIN_WAVE", 0), ("TBK_CHAIN_WAVE_FROM", 3), ("TBK_CHAIN_WS_MB", 1), ("TBK_DET_BIG_FROM", 2), ("TBK_DET_BIG_FROM", 4),
                ("TBK_WILSON_BIG_FROM", 2), ("TBK_WILSON_BIG_FROM", 5), ("TBK_WILSON_FORM", 0), ("TBK_WILSON_FORM", 1),
                ("TBK_WILSON_SEG", 1), ("TBK_WILSON_SEG", 5), ("TBK_WILSON_SWZ", 0)]
 
@@ -77,11 +77,14 @@ def test_berry_phase_route_knobs(tb, knob, value):
     forces against the default route: every direction, determinant and eigenphase form."""
     from pythtb_amd import _lib
     cases = ((hp.cubic16(tb.tb_model), [7, 6, 40], [0.1, 0.2, 0.3]),
-             (hp.random_model(tb.tb_model, 8, 2, 1, seed=77, nhop=24, rmax=1), [70, 45], [0.05, -0.1]))
+             (hp.random_model(tb.tb_model, 8, 2, 1, seed=77, nhop=24, rmax=1), [70, 45], [0.05, -0.1]),
+             # narrow states (fewer than 8 components): the determinant form of 1..4 bands on the LDS-tile kernels (round 6)
+             (hp.random_model(tb.tb_model, 6, 2, 1, seed=78, nhop=20, rmax=1), [131, 45], [0.02, 0.3]),
+             (hp.random_model(tb.tb_model, 5, 3, 1, seed=79, nhop=15, rmax=1), [9, 8, 70], [0.1, 0.0, -0.2]))
     for m, mesh, start in cases:
         w = tb.wf_array(m, mesh)
         w.solve_on_grid(start)
-        for occ in ([0, 1], [0, 1, 2], [1, 2, 3, 4]):
+        for occ in ([0], [0, 1], [0, 1, 2], [1, 2, 3, 4]):
             for d in range(len(mesh)):
                 ref_det = np.asarray(w.berry_phase(occ, d, contin=False))
                 ref_ev = np.sort(np.asarray(w.berry_phase(occ, d, contin=False, berry_evals=True)), axis=-1)
