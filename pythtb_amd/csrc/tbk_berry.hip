@@ -905,7 +905,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         A.plaq = w->flux_plaq_dev;
     }
     A.partial = w->flux_partial_dev;
-    const bool lanes_flux = !big && !rows && !chain_wave_applies(v, nocc) && lanes_dets_applies(v, nocc);
+    const bool lanes_flux = !big && !rows && lanes_dets_applies(v, nocc) && tbk_knobs().chain_wave != 2;
     if (!big && (chain_wave_applies(v, nocc) || lanes_flux)) {
         // 5..8 bands of wide states: every lane of the plaquette kernel would walk its own 256-byte rows; instead the link
         // determinants along both directions come from the wave-per-string kernels (coalesced), then the same combine
@@ -1824,8 +1824,10 @@ struct LanesPlan {
     int64_t ntile;       // S: tiles of 64 strings
 };
 static bool lanes_dets_applies(const WfsView& v, int nocc) {
-    // 1..4 bands; not the up-to-two bands of up-to-four components the register kernels serve; the tile must fit 64 KB of LDS
-    return nocc >= 1 && nocc <= 4 && !(nocc <= 2 && v.ncomp <= 4) && tbk_knobs().wilson_reg == 3 && v.npts < (int64_t)0x7fffffff &&
+    // 1..7 bands (a lane holds the link matrix in registers); not the up-to-two bands of up-to-four components the register kernels
+    // serve; the tile must fit 64 KB of LDS.  Wide states too (round 6, profiles/berry_cliff_sweep.py: the wave-per-string kernels
+    // have a floor of ~100 us per 132 k points whatever the band count -- 1 band of 8 components 99 us against 15 us for 7).
+    return nocc >= 1 && nocc <= 7 && !(nocc <= 2 && v.ncomp <= 4) && tbk_knobs().wilson_reg == 3 && v.npts < (int64_t)0x7fffffff &&
            v.ncomp <= 21 && (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd) <= 64 * 1024;
 }
 static LanesPlan lanes_plan(tbk_ctx* ctx, const WfsView& v, int nocc, int64_t sdir, int L, int64_t nstrings) {
@@ -1863,7 +1865,7 @@ static void lanes_fill(WilsonLanesArgs& S, tbk_ctx* ctx, const WfsView& v, const
     S.W.s0 = 0;
     S.W.ns = nstrings;
     S.W.flags = ctx->flags_dev;
-    for (int a = 0; a < 4; ++a) S.occ_inl[a] = a < nocc ? occ[a] : 0;
+    for (int a = 0; a < 8; ++a) S.occ_inl[a] = a < nocc ? occ[a] : 0;
     S.seg_len = P.seg_len;
     S.nseg = P.nseg;
     S.ntile = P.ntile;
@@ -1881,8 +1883,14 @@ static void lanes_fill(WilsonLanesArgs& S, tbk_ctx* ctx, const WfsView& v, const
                     else hipLaunchKernelGGL((k_wilson_lanes_s<2, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
             case 3: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<3, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
                     else hipLaunchKernelGGL((k_wilson_lanes_s<3, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
-            default: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);         \
-                     else hipLaunchKernelGGL((k_wilson_lanes_s<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;        \
+            case 4: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+                    else hipLaunchKernelGGL((k_wilson_lanes_s<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
+            case 5: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<5, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+                    else hipLaunchKernelGGL((k_wilson_lanes_s<5, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
+            case 6: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<6, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+                    else hipLaunchKernelGGL((k_wilson_lanes_s<6, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
+            default: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<7, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);         \
+                     else hipLaunchKernelGGL((k_wilson_lanes_s<7, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;        \
         }                                                                                                                    \
     }
 // dets_out[p] = det of the link matrix from mesh point p to its neighbour along `dir`, for every string along that axis
@@ -1895,7 +1903,7 @@ static int lanes_link_dets(tbk_wfs* w, const int32_t* occ, int nocc, int dir, cd
     const int L = v.mesh[dir] - 1;
     const LanesPlan P = lanes_plan(ctx, v, nocc, v.stride[dir], L, nstrings);
     TBK_REQUIRE(P.ok, TBK_EUNSUPPORTED, "lanes_link_dets: %d bands of %d components do not fit the LDS tile", nocc, v.ncomp);
-    int occ4[4] = {0, 0, 0, 0};
+    int occ4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int a = 0; a < nocc; ++a) occ4[a] = occ[a];
     WilsonLanesArgs S;
     lanes_fill(S, ctx, v, occ4, nocc, L, v.stride[dir], other, nstrings, P);
@@ -1988,7 +1996,8 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
             // ... or the two row buffers of the S form leave fewer than four wavefronts on a compute unit (a SIMD without one):
             // 4 bands of 8 components, 1025 x 257 along axis 0: S 118 us (2 per CU), L with gathered points 104 (profiles/r06w)
             if (lds_s > 40 * 1024 && lds_l <= 40 * 1024 && L >= 32) lanes_l = true;
-            if (tbk_knobs().wilson_form >= 0) lanes_l = tbk_knobs().wilson_form != 0;
+            if (lds_s > 64 * 1024 && lds_l <= 64 * 1024) lanes_l = true;                  // (the only form that fits: 3 bands of 16 components)
+            if (tbk_knobs().wilson_form >= 0 && lds_s <= 64 * 1024) lanes_l = tbk_knobs().wilson_form != 0;
             lanes_lds = lanes_l ? lds_l : lds_s;
             lanes_route = lanes_lds <= 64 * 1024;
             lanes_res = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lanes_lds, 1)));
@@ -2240,7 +2249,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     // to four components: k_chain_partial keeps a link's shared point in registers there (13 us for Kane-Mele-sized states).
     // TBK_WILSON_REG != 3 keeps k_chain_partial.
     LanesPlan LP{};
-    const bool lanes_det = !ev && !wave_chain && lanes_dets_applies(v, nocc);
+    const bool lanes_det = !ev && !big && lanes_dets_applies(v, nocc) && tbk_knobs().chain_wave != 2;   // (TBK_CHAIN_WAVE=2: wide states stay on the wave-per-string kernels)
     if (lanes_det) {
         LP = lanes_plan(ctx, v, nocc, A.sdir, A.nlinks, A.nstrings);
         A.seg_len = LP.seg_len;
@@ -2261,7 +2270,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     const dim3 grid((unsigned)((nthreads + 255) / 256)), blk(256);
     {
         ProfScope ps(ctx, ev ? "chain_partial_evals" : "chain_partial_det");
-        if (wave_chain) {
+        if (wave_chain && !lanes_det) {
             rc = launch_chain_wave(ctx, v, A, nocc, nullptr);
             if (rc) return rc;
         } else if (lanes_det) {

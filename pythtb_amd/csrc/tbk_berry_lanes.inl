@@ -34,7 +34,7 @@ struct WilsonLanesArgs {
     cd* segs;          // [ns][nseg][nocc^2]
     cd* prod;          // combine: string s at prod + s * pstride
     size_t pstride;
-    int occ_inl[4];    // the occupied bands when W.occ is null (the determinant form: the list travels with the arguments)
+    int occ_inl[8];    // the occupied bands when W.occ is null (the determinant form: the list travels with the arguments)
     cd* dets;          // POLAR = false: [nseg][det_stride] products of the link determinants, what k_chain_final(_wave) reads
     int64_t det_stride;
     cd* herm;          // combine, non-null: [ns][nocc^2] Cayley transform of e^{-i alpha} (string product), Hermitian part (k_wilson_cayley's
