@@ -1989,7 +1989,9 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
         bool lanes_route = false, lanes_l = false;
         size_t lanes_lds = 0;
         int lanes_res = 1;                                // wavefronts of the S form resident per CU (LDS-bound)
-        if (nocc >= 3 && nocc <= 4 && wreg == 3 && v.npts < (int64_t)0x7fffffff && v.ncomp <= 21) {
+        // (5 and 6 bands too, round 6: 256 VGPRs + accumulation registers, one wavefront per SIMD -- still 3-20 x the workgroup
+        // pipeline on narrow states and 2-3 x the matrix-core tile kernel on wide ones, profiles/berry_cliff_sweep.py)
+        if (nocc >= 3 && nocc <= 6 && wreg == 3 && v.npts < (int64_t)0x7fffffff && v.ncomp <= 21) {
             // L: the string runs along the fastest axis, or there are too few strings to give every lane one
             const size_t lds_l = (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd), lds_s = (size_t)2 * nocc * 64 * v.ncomp * sizeof(cd);
             lanes_l = (A.sdir == 1 && L >= 32) || (A.nstrings < 32 && L >= 32);
@@ -2127,19 +2129,26 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
                 {
                     ProfScope ps(ctx, lanes_l ? "wilson_lanes_l" : "wilson_lanes_s");
                     const dim3 g((unsigned)(lanes_l ? ns * (S.nseg / (64 / LANES_L_SPAN)) : S.ntile * S.nseg)), b(64);
-                    if (lanes_l) {
-                        if (nocc == 3) hipLaunchKernelGGL((k_wilson_lanes_l<3>), g, b, lanes_lds, ctx->stream, S);
-                        else hipLaunchKernelGGL((k_wilson_lanes_l<4>), g, b, lanes_lds, ctx->stream, S);
-                    } else {
-                        if (nocc == 3) hipLaunchKernelGGL((k_wilson_lanes_s<3>), g, b, lanes_lds, ctx->stream, S);
-                        else hipLaunchKernelGGL((k_wilson_lanes_s<4>), g, b, lanes_lds, ctx->stream, S);
+#define TBK_WL(MM)                                                                                          \
+    if (lanes_l) hipLaunchKernelGGL((k_wilson_lanes_l<MM>), g, b, lanes_lds, ctx->stream, S);              \
+    else hipLaunchKernelGGL((k_wilson_lanes_s<MM>), g, b, lanes_lds, ctx->stream, S);
+                    switch (nocc) {
+                        case 3: TBK_WL(3) break;
+                        case 4: TBK_WL(4) break;
+                        case 5: TBK_WL(5) break;
+                        default: TBK_WL(6) break;
                     }
+#undef TBK_WL
                     TBK_HIP(hipGetLastError());
                 }
                 {
                     ProfScope ps(ctx, "wilson_lanes_combine");
-                    if (nocc == 3) hipLaunchKernelGGL((k_wilson_lanes_combine<3>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, S);
-                    else hipLaunchKernelGGL((k_wilson_lanes_combine<4>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, S);
+                    switch (nocc) {
+                        case 3: hipLaunchKernelGGL((k_wilson_lanes_combine<3>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, S); break;
+                        case 4: hipLaunchKernelGGL((k_wilson_lanes_combine<4>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, S); break;
+                        case 5: hipLaunchKernelGGL((k_wilson_lanes_combine<5>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, S); break;
+                        default: hipLaunchKernelGGL((k_wilson_lanes_combine<6>), dim3((unsigned)ns), dim3(64), 0, ctx->stream, S); break;
+                    }
                     TBK_HIP(hipGetLastError());
                 }
             } else

@@ -493,7 +493,7 @@ def test_mesh_rows_of_5_to_8_states_from_coefficient_cells(tb, n, rmax, mesh):
 
 @pytest.mark.parametrize("n,nocc,mesh", [(6, 3, [23, 37]), (8, 4, [70, 19]), (8, 3, [5, 6, 41]), (9, 4, [12, 11, 9]),
                                          (6, 3, [131, 70]), (8, 4, [67, 200]), (5, 3, [3, 150]), (7, 4, [140, 3]), (4, 4, [9, 9, 70]),
-                                         (10, 3, [66, 5, 7])])
+                                         (10, 3, [66, 5, 7]), (6, 5, [40, 70]), (7, 6, [70, 9]), (10, 6, [9, 8, 66]), (12, 5, [131, 6])])
 def test_wilson_loops_of_3_and_4_bands_three_routes(tb, n, nocc, mesh):
     """Wilson-loop eigenphases (berry_phase(..., berry_evals=True), pythtb.py:3798-3838) of 3 and 4 bands: a lane per string or per
     link with the occupied vectors staged through LDS (tbk_berry_lanes.inl: TBK_WILSON_REG=3, the default since round 6), the
