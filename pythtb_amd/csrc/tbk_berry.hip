@@ -789,7 +789,12 @@ static void launch_flux(tbk_ctx* ctx, const FluxArgs& A, int64_t nslices) {
 }
 
 static int chain_wave_link_dets(tbk_wfs* w, const int32_t* occ, int nocc, int dir, cd* dets_out);   // defined with its kernels below
-static bool lanes_dets_applies(const WfsView& v, int nocc);
+// Largest L-form tile (above 64 KB the launch sets the kernel's dynamic-LDS attribute).  Products of determinants gain up to 128 KB
+// (16 components: 4 bands 152 -> 61 us, 6 bands 222 -> 160 per 513 x 257 array); the two per-link passes of berry_flux only up to ~72 KB
+// (4 bands of 16 components 144 -> 121 us; 5 bands, 87 KB: 172 -> 249) -- profiles/berry_cliff_sweep.py
+#define TBK_LANES_DET_LDS_MAX ((size_t)128 * 1024)
+#define TBK_LANES_FLUX_LDS_MAX ((size_t)72 * 1024)
+static bool lanes_dets_applies(const WfsView& v, int nocc, size_t lds_max);
 static int lanes_link_dets(tbk_wfs* w, const int32_t* occ, int nocc, int dir, cd* dets_out);          // (tbk_berry_lanes.inl kernels, OUT = 2)
 static bool chain_wave_applies(const WfsView& v, int nocc);
 
@@ -905,7 +910,7 @@ extern "C" int tbk_berry_flux_async(tbk_wfs* w, const int32_t* occ, int nocc, in
         A.plaq = w->flux_plaq_dev;
     }
     A.partial = w->flux_partial_dev;
-    const bool lanes_flux = !big && !rows && lanes_dets_applies(v, nocc) && tbk_knobs().chain_wave != 2;
+    const bool lanes_flux = !big && !rows && lanes_dets_applies(v, nocc, TBK_LANES_FLUX_LDS_MAX) && tbk_knobs().chain_wave != 2;
     if (!big && (chain_wave_applies(v, nocc) || lanes_flux)) {
         // 5..8 bands of wide states: every lane of the plaquette kernel would walk its own 256-byte rows; instead the link
         // determinants along both directions come from the wave-per-string kernels (coalesced), then the same combine
@@ -1823,12 +1828,12 @@ struct LanesPlan {
     int seg_len, nseg;   // S: links per lane segment, segments per string; L: 64, tiles per string
     int64_t ntile;       // S: tiles of 64 strings
 };
-static bool lanes_dets_applies(const WfsView& v, int nocc) {
+static bool lanes_dets_applies(const WfsView& v, int nocc, const size_t lds_max) {
     // 1..7 bands (a lane holds the link matrix in registers); not the up-to-two bands of up-to-four components the register kernels
     // serve; the tile must fit 64 KB of LDS.  Wide states too (round 6, profiles/berry_cliff_sweep.py: the wave-per-string kernels
     // have a floor of ~100 us per 132 k points whatever the band count -- 1 band of 8 components 99 us against 15 us for 7).
     return nocc >= 1 && nocc <= 7 && !(nocc <= 2 && v.ncomp <= 4) && tbk_knobs().wilson_reg == 3 && v.npts < (int64_t)0x7fffffff &&
-           v.ncomp <= 21 && (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd) <= 64 * 1024;
+           v.ncomp <= 21 && (size_t)nocc * ((65 * v.ncomp + 63) & ~63) * sizeof(cd) <= lds_max;
 }
 static LanesPlan lanes_plan(tbk_ctx* ctx, const WfsView& v, int nocc, int64_t sdir, int L, int64_t nstrings) {
     LanesPlan P{};
@@ -1836,7 +1841,7 @@ static LanesPlan lanes_plan(tbk_ctx* ctx, const WfsView& v, int nocc, int64_t sd
     P.l = (sdir == 1 && L >= 32) || (nstrings < 32 && L >= 32) || (lds_s > 40 * 1024 && lds_l <= 40 * 1024 && L >= 32) || lds_s > 64 * 1024;
     if (tbk_knobs().wilson_form >= 0 && !(lds_s > 64 * 1024)) P.l = tbk_knobs().wilson_form != 0;
     P.lds = P.l ? lds_l : lds_s;
-    P.ok = P.lds <= 64 * 1024;
+    P.ok = P.lds <= (P.l ? TBK_LANES_DET_LDS_MAX : (size_t)64 * 1024);
     P.ntile = 1;
     if (P.l) {
         P.seg_len = 64;
@@ -1873,23 +1878,24 @@ static void lanes_fill(WilsonLanesArgs& S, tbk_ctx* ctx, const WfsView& v, const
     S.swz = v.ncomp == 4 ? 2 : v.ncomp == 8 ? 1 : v.ncomp == 16 ? 0 : -1;
     if (tbk_knobs().wilson_swz == 0) S.swz = -1;
 }
+#define TBK_LANES_BIG(M_, OUT_, P_) if ((P_).lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wilson_lanes_l<M_, OUT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define TBK_LANES_LAUNCH(OUT_, S_, P_, nstr_)                                                                                \
     {                                                                                                                        \
         const dim3 g_((unsigned)((P_).l ? (nstr_) * (P_).nseg : (P_).ntile * (P_).nseg)), b_(64);                            \
         switch ((S_).W.nocc) {                                                                                               \
-            case 1: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<1, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+            case 1: if ((P_).l) { TBK_LANES_BIG(1, OUT_, P_) hipLaunchKernelGGL((k_wilson_lanes_l<1, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); } \
                     else hipLaunchKernelGGL((k_wilson_lanes_s<1, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
-            case 2: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<2, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+            case 2: if ((P_).l) { TBK_LANES_BIG(2, OUT_, P_) hipLaunchKernelGGL((k_wilson_lanes_l<2, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); } \
                     else hipLaunchKernelGGL((k_wilson_lanes_s<2, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
-            case 3: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<3, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+            case 3: if ((P_).l) { TBK_LANES_BIG(3, OUT_, P_) hipLaunchKernelGGL((k_wilson_lanes_l<3, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); } \
                     else hipLaunchKernelGGL((k_wilson_lanes_s<3, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
-            case 4: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+            case 4: if ((P_).l) { TBK_LANES_BIG(4, OUT_, P_) hipLaunchKernelGGL((k_wilson_lanes_l<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); } \
                     else hipLaunchKernelGGL((k_wilson_lanes_s<4, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
-            case 5: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<5, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+            case 5: if ((P_).l) { TBK_LANES_BIG(5, OUT_, P_) hipLaunchKernelGGL((k_wilson_lanes_l<5, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); } \
                     else hipLaunchKernelGGL((k_wilson_lanes_s<5, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
-            case 6: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<6, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);          \
+            case 6: if ((P_).l) { TBK_LANES_BIG(6, OUT_, P_) hipLaunchKernelGGL((k_wilson_lanes_l<6, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); } \
                     else hipLaunchKernelGGL((k_wilson_lanes_s<6, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;         \
-            default: if ((P_).l) hipLaunchKernelGGL((k_wilson_lanes_l<7, OUT_>), g_, b_, (P_).lds, ctx->stream, S_);         \
+            default: if ((P_).l) { TBK_LANES_BIG(7, OUT_, P_) hipLaunchKernelGGL((k_wilson_lanes_l<7, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); } \
                      else hipLaunchKernelGGL((k_wilson_lanes_s<7, OUT_>), g_, b_, (P_).lds, ctx->stream, S_); break;        \
         }                                                                                                                    \
     }
@@ -2258,7 +2264,7 @@ extern "C" int tbk_berry_phase(tbk_wfs* w, const int32_t* occ, int nocc, int dir
     // to four components: k_chain_partial keeps a link's shared point in registers there (13 us for Kane-Mele-sized states).
     // TBK_WILSON_REG != 3 keeps k_chain_partial.
     LanesPlan LP{};
-    const bool lanes_det = !ev && !big && lanes_dets_applies(v, nocc) && tbk_knobs().chain_wave != 2;   // (TBK_CHAIN_WAVE=2: wide states stay on the wave-per-string kernels)
+    const bool lanes_det = !ev && !big && lanes_dets_applies(v, nocc, TBK_LANES_DET_LDS_MAX) && tbk_knobs().chain_wave != 2;   // (TBK_CHAIN_WAVE=2: wide states stay on the wave-per-string kernels)
     if (lanes_det) {
         LP = lanes_plan(ctx, v, nocc, A.sdir, A.nlinks, A.nstrings);
         A.seg_len = LP.seg_len;
