@@ -111,6 +111,78 @@ __global__ __launch_bounds__(256) void k_position_matrix_tile(const EvecSrc ev, 
 }
 
 // band-major eigen-solver outputs -> [k][i] / [k][i][x] in the requested basis
+// The same for 17..32 states (round 6; profiles/position_cliff_sweep.py: the thread-per-entry kernel took 5.6 x the time of 16 states
+// for 20, 28 x for 32 -- 2.3 ms per 33 k points): one point per wavefront, a 4 x 4 block of X per lane (NT4 = ceil(nsub / 4) = 5..8:
+// NT4^2 <= 64 lanes), eight LDS reads for sixteen complex multiply-adds per component; two wavefronts per workgroup (17 KB of LDS each).
+template <int NT4>
+__global__ __launch_bounds__(128) void k_position_matrix_tile4(const EvecSrc ev, const double* __restrict__ pos, const int64_t nk,
+                                                               const int nsub, const int ncomp, cd* __restrict__ xmat) {
+    extern __shared__ __align__(16) unsigned char pos_lds[];
+    const int wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t p0 = (int64_t)blockIdx.x * 2 + wib;
+    if (p0 >= nk) return;                              // (no workgroup barrier below: the wavefronts are independent)
+    const int ldp = ncomp + 1, pbuf = nsub * ldp;
+    const int wstride = pbuf + (ncomp + 1) / 2;        // the point + the coordinates
+    cd* const buf = reinterpret_cast<cd*>(pos_lds) + (size_t)wib * wstride;
+    {   // rows (state) of ncomp contiguous components: sixteen lanes per row, all loads of a 16-component slice before the first write
+        const int j0 = lane & 15;
+        for (int jc = 0; jc < ncomp; jc += 16) {
+            const int j = jc + j0;
+            cd r[8];
+            int dsto[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int b = (lane >> 4) + 4 * i;
+                const bool ok = b < nsub && j < ncomp;
+                dsto[i] = ok ? b * ldp + j : -1;
+                r[i] = ok ? ev.at(p0, b)[j] : cd{0.0, 0.0};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (dsto[i] >= 0) buf[dsto[i]] = r[i];
+        }
+    }
+    {
+        double* const pl = reinterpret_cast<double*>(buf + pbuf);
+        for (int j = lane; j < ncomp; j += 64) pl[j] = pos[j];
+    }
+    pos_lds_sync_wave();
+    const int ta = lane / NT4, tb = lane - ta * NT4;
+    if (lane >= NT4 * NT4) return;
+    const cd* ar[4];
+    const cd* br[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ar[i] = buf + min(4 * ta + i, nsub - 1) * ldp;
+        br[i] = buf + min(4 * tb + i, nsub - 1) * ldp;
+    }
+    cd x[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[i][k] = cd{0.0, 0.0};
+    const double* const posl = reinterpret_cast<const double*>(buf + pbuf);
+    for (int j = 0; j < ncomp; ++j) {
+        const double r = posl[j];
+        cd u[4], v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u[i] = ar[i][j];
+            v[i] = cscale(br[i][j], r);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cfmac(x[i][k], u[i], v[k]);
+    }
+    cd* const o = xmat + p0 * (int64_t)nsub * nsub;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * ta + i < nsub && 4 * tb + k < nsub) o[(4 * ta + i) * nsub + 4 * tb + k] = x[i][k];
+}
+
 __global__ __launch_bounds__(256) void k_hwf_out(const double* __restrict__ ev, const cd* __restrict__ vw,
                                                  const EvecSrc src, int64_t nk, int nsub, int ncomp,
                                                  int orbital, double* __restrict__ hwfc, cd* __restrict__ hwf) {
@@ -198,6 +270,18 @@ static int position_run(tbk_ctx* ctx, const double* host_evec, EvecSrc src, cons
                 default: TBK_PT(8); break;
             }
 #undef TBK_PT
+        } else if (nsub > 16 && nsub <= 32 && nk >= 64 && (size_t)2 * (nsub * (ncomp + 1) + (ncomp + 1) / 2) * sizeof(cd) <= 64 * 1024 &&
+                   tbk_knobs().pos_tile != 0) {
+            const size_t lds4 = (size_t)2 * (nsub * (ncomp + 1) + (ncomp + 1) / 2) * sizeof(cd);
+            const dim3 g((unsigned)((nk + 1) / 2)), b(128);
+#define TBK_PT4(NN) hipLaunchKernelGGL((k_position_matrix_tile4<NN>), g, b, lds4, ctx->stream, src, (const double*)d_pos, nk, nsub, ncomp, d_x)
+            switch ((nsub + 3) / 4) {
+                case 5: TBK_PT4(5); break;
+                case 6: TBK_PT4(6); break;
+                case 7: TBK_PT4(7); break;
+                default: TBK_PT4(8); break;
+            }
+#undef TBK_PT4
         } else {
             hipLaunchKernelGGL(k_position_matrix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                                src, (const double*)d_pos, nk, nsub, ncomp, d_x);

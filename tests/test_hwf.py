@@ -189,9 +189,10 @@ def test_gpu_position_matrix_tile_kernel_equals_the_entry_kernel(nsub):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nl,nocc", [(16, 16), (16, 13), (20, 11)])
+@pytest.mark.parametrize("nl,nocc", [(16, 16), (16, 13), (20, 11), (20, 17), (24, 24), (29, 26), (32, 32), (33, 21)])
 def test_gpu_position_hwf_mesh_9_to_16_states(nl, nocc):
-    """9..16 states: k_position_matrix_tile with all 64 lanes on one point.  The centres of a slab on a mesh against the
+    """9..16 states: k_position_matrix_tile with all 64 lanes on one point; 17..32 states (round 6): k_position_matrix_tile4, a 4 x 4
+    block of X per lane.  The centres of a slab on a mesh against the
     thread-per-entry kernel (TBK_POS_TILE=0) and against numpy on the position matrix built from the downloaded states."""
     import pythtb_amd as tb
     from pythtb_amd import _lib
