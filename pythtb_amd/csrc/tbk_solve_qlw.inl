@@ -53,6 +53,12 @@ struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
     int* rank;             // [n][nchunk]      rank[b][id] = ascending rank of the eigenvalue of column b
     int64_t cap;
     int scap;
+    // n <= 32 with eigenvectors (tbk_solve_tw32.inl): what k_tw32_vectors needs from the QL kernel; lam == nullptr: not asked for
+    double* lam;           // [n][nchunk]      the eigenvalue left at position j
+    uint2* meta;           // [nchunk]         {split mask of T (bit i: e_i negligible), 1 = two eigenvalues of one block closer than gaptol |T|}
+    int* list;             // [nchunk]         matrices left to the rotation replay
+    int* count;            //                  their number
+    double gaptol;
 };
 
 static size_t qlw_lds1_bytes(int n, int nR, int rw, int nt) {
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
         }
     };
     rescan();
+    const unsigned split0 = (unsigned)negl;              // (n <= 32 where it is used) T as it splits before the first sweep
     for (int iter = 0;; ++iter) {
         int m = n - 1;
         if (!done) {
@@ -417,14 +424,31 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
         if (overflow) atomicExch(flags + 2, 1);
     }
     // stable ascending ranks; E is free now: E[r] <- the column of rank r (as a double)
+    const bool tw = REC && W.lam != nullptr;             // (uniform) positions, splitting and close pairs for k_tw32_vectors
+    bool flagged = false;
+    double thr = 0.0;
+    if (tw) {
+        double tnorm = 0.0;
+        for (int a = 0; a < n; ++a) tnorm = fmax(tnorm, fabs(D[a * 64 + lane]));
+        thr = W.gaptol * tnorm;
+    }
     for (int a = 0; a < n; ++a) {
         const double da = D[a * 64 + lane];
         int r = 0;
         for (int b = 0; b < n; ++b) {
             const double db = D[b * 64 + lane];
             r += (db < da || (db == da && b < a)) ? 1 : 0;
+            // two eigenvalues of one unreduced block (no split between positions a and b) closer than gaptol |T|: their
+            // twisted-factorisation vectors would be nearly parallel
+            if (tw && b > a) flagged = flagged || (((split0 >> a) & ((1u << (b - a)) - 1u)) == 0 && !(fabs(da - db) >= thr));
         }
         E[r * 64 + lane] = (double)a;
+        if (tw && has) W.lam[(int64_t)a * nchunk + idc] = da;
+    }
+    if (tw && has) {
+        flagged = flagged || overflow;                   // (no record to replay: the caller repeats the call anyway)
+        W.meta[idc] = uint2{split0, flagged ? 1u : 0u};
+        if (flagged) W.list[atomicAdd(W.count, 1)] = (int)idc;
     }
     double prev = 0.0;
     for (int r = 0; r < n; ++r) {
@@ -563,15 +587,24 @@ __device__ __forceinline__ void qlw_replay_pos(cd (&z)[NMAX], const double2* __r
     if constexpr (I > 0) qlw_replay_pos<I - 1, NMAX>(z, xg, on, ilo, ihi);
 }
 
-template <int MODE, int NMAX>
+// LIST: the matrices W.list[0 .. *W.count) instead of the whole chunk (what k_tw32_vectors left: tbk_solve_tw32.inl); the grid is
+// sized for the chunk and the blocks past the count leave at once.
+template <int MODE, int NMAX, bool LIST = false>
 __global__ __launch_bounds__(256) void k_ql_replay_reg(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
                                                         const QlwWork W, cd* __restrict__ evec, const WfsView wv) {
     __shared__ double2 xch[4][2][32];
     const int lane = threadIdx.x & 63, x = lane & 31;
     double2* xg = xch[threadIdx.x >> 6][lane >> 5];
     const int64_t idc0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
-    const bool live = idc0 < nchunk;
-    const int64_t idc = live ? idc0 : nchunk - 1, id = id0 + idc;
+    int64_t nlive = nchunk;
+    if constexpr (LIST) {
+        nlive = *W.count;
+        if ((int64_t)blockIdx.x * 8 >= nlive) return;
+    }
+    const bool live = idc0 < nlive;
+    int64_t idc = live ? idc0 : nlive - 1;
+    if constexpr (LIST) idc = W.list[idc];
+    const int64_t id = id0 + idc;
     const bool real_row = x < n;
     const int xr = real_row ? x : n - 1;
     cd z[NMAX];
@@ -697,6 +730,7 @@ __global__ __launch_bounds__(128) void k_ql_replay_reg64(const int n, const int6
 }
 
 #include "tbk_solve_hh32.inl"   // k_hh32: stage 1 for n <= 32 with the matrix in registers
+#include "tbk_solve_tw32.inl"   // k_tw32_vectors: stage 3 for n <= 32 without the rotation replay
 static size_t hh32_lds_bytes(int n, int nR) {
     size_t b = (size_t)n * (n | 1) * sizeof(cd);                  // H(k) | reflector record | Z
     b += (size_t)(64 + std::max(n, nR) + 2 * n) * sizeof(cd);     // ubuf, qbuf, eo / phases, dphase, tsub
@@ -715,8 +749,11 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     int64_t chunk = std::max<int64_t>(1024, (int64_t)(budget / per));
     chunk = std::min<int64_t>(chunk, nk);
     chunk = (nk + (nk + chunk - 1) / chunk - 1) / ((nk + chunk - 1) / chunk);   // equal chunks (the QL kernel's time hardly depends on the count)
+    // n <= 32 with eigenvectors: the vectors from the twisted factorisation (k_tw32_vectors), the replay for the listed matrices only
+    const bool tw32 = VEC && n <= 32 && K.tw32 != 0 && K.qlw_replay_reg != 0;
     const size_t wbytes = al((size_t)chunk * n * sizeof(double2)) + 256 + al((size_t)chunk * cap * sizeof(double2)) +
-                          al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n * sizeof(int)) + 1024;
+                          al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n * sizeof(int)) + 1024 +
+                          (tw32 ? al((size_t)chunk * n * sizeof(double)) + al((size_t)chunk * sizeof(uint2)) + al((size_t)chunk * sizeof(int)) + 256 : 0);
     if (wbytes > ctx->work_bytes) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->work) TBK_HIP(hipFree(ctx->work));
@@ -738,8 +775,19 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     W.nsw = (int*)p;
     p += al((size_t)chunk * sizeof(int));
     W.rank = (int*)p;
+    p += al((size_t)chunk * n * sizeof(int));
     W.cap = cap;
     W.scap = scap;
+    if (tw32) {
+        W.lam = (double*)p;
+        p += al((size_t)chunk * n * sizeof(double));
+        W.meta = (uint2*)p;
+        p += al((size_t)chunk * sizeof(uint2));
+        W.list = (int*)p;
+        p += al((size_t)chunk * sizeof(int));
+        W.count = (int*)p;
+        W.gaptol = K.tw16_gaptol;
+    }
 
     const int rw = n <= 32 ? 32 : 64;
     int nt = rw == 32 ? 128 : 256;
@@ -790,11 +838,22 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         if (bisect)
             hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(64), (size_t)n * sizeof(double2) + 32 * sizeof(double), ctx->stream, n,
                                nk, id0, (const double2*)W.de, L.eval, (int64_t)1, nc, ctx->flags_dev);
-        else
+        else {
+            if (tw32) TBK_HIP(hipMemsetAsync(W.count, 0, sizeof(int), ctx->stream));
             hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0,
                                nc, W, L.eval, G, ctx->flags_dev);
+        }
         if (VEC) {
-            if (rw == 32 && K.qlw_replay_reg != 0) {
+            if (tw32) {
+                const unsigned b2 = (unsigned)((nc + 1) / 2), b32 = (unsigned)((nc * 32 + 255) / 256);
+                if (n <= 24) {
+                    hipLaunchKernelGGL((k_tw32_vectors<MODE, 24>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24, true>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                } else {
+                    hipLaunchKernelGGL((k_tw32_vectors<MODE, 32>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32, true>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                }
+            } else if (rw == 32 && K.qlw_replay_reg != 0) {
                 const unsigned b32 = (unsigned)((nc * 32 + 255) / 256);
                 if (n <= 24)
                     hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);

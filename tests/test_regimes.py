@@ -70,6 +70,11 @@ REGIMES = [
     (18, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<24>"),
     (25, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<32>"),
     (32, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<32>"),
+    (24, 100, {"TBK_QLW_MIN": 0, "TBK_TW32": 0}, "tridiagonal path, the rotations replayed on every matrix (rounds 2-5) instead of k_tw32_vectors<24>"),
+    (29, 100, {"TBK_QLW_MIN": 0, "TBK_TW32": 0}, "tridiagonal path, the rotations replayed on every matrix instead of k_tw32_vectors<32>"),
+    (21, 101, {"TBK_QLW_MIN": 0, "TBK_TW16_GAPTOL": "1e300"}, "k_tw32_vectors<24> lists every matrix: replay over the list"),
+    (32, 101, {"TBK_QLW_MIN": 0, "TBK_TW16_GAPTOL": "1e300"}, "k_tw32_vectors<32> lists every matrix: replay over the list"),
+    (27, 101, {"TBK_QLW_MIN": 0, "TBK_TW16_GAPTOL": "3e-2"}, "k_tw32_vectors<32>: some matrices listed, some not"),
     (24, 100, {"TBK_QLW_MIN": 0, "TBK_HH32": 0}, "tridiagonal path, LDS workgroup tridiagonalisation (round 2)"),
     (31, 100, {"TBK_QLW_MIN": 0, "TBK_HH32": 0}, "tridiagonal path, LDS workgroup tridiagonalisation (round 2)"),
     (33, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, LDS replay"),
