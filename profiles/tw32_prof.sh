@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/tw32prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tw32prof -- python3 $R/profiles/n17_probe.py > $R/gpurun_out/tw32prof.out 2> $R/gpurun_out/tw32prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tw32prof -- python3 $R/profiles/${1:-n17_probe.py} > $R/gpurun_out/tw32prof.out 2> $R/gpurun_out/tw32prof.err
 cd $R
 python3 - <<PY
 import csv,glob

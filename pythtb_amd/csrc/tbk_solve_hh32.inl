@@ -57,9 +57,16 @@ __device__ __forceinline__ double hh32_allsum(double v) {
 #ifndef HH32_OCC
 #define HH32_OCC __attribute__((amdgpu_waves_per_eu(3, 8)))
 #endif
-template <int MODE, bool VEC, int NMAX>
+// the reflector record k_hh32<.., 2, NMAX> leaves per matrix for k_tw32_vectors<.., NMAX, true> (16-byte entries): sqrt(beta_K) u_K[r],
+// r = K + 1 .. NMAX - 1, packed reflector after reflector (zeros past n), then the phases D[NMAX], then the orbital phases [NMAX]
+__host__ __device__ constexpr int hh32_rec_off(const int K, const int NMAX) { return (NMAX - 1) * K - K * (K - 1) / 2; }
+__host__ __device__ constexpr int hh32_rec_size(const int NMAX) { return hh32_rec_off(NMAX - 2, NMAX) + 2 * NMAX; }
+
+// VEC 0: (d, e) only; 1: Z = H_0 .. H_{n-3} D with the orbital phases on its rows into the output array; 2: the reflector record
+// into `refl` (round 6: the accumulation of Z was 0.67 of this kernel's 1.75 ms per 36 k matrices of 32 states)
+template <int MODE, int VEC, int NMAX>
 __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const int64_t nk, const ListArgs L, const GridArgs G, const int64_t id0,
-                                              const int64_t nchunk, double2* __restrict__ de) {
+                                              const int64_t nchunk, double2* __restrict__ de, cd* __restrict__ refl = nullptr) {
     static_assert(NMAX == 24 || NMAX == 32, "k_hh32: 17..24 or 25..32 states");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int HC = NMAX / 2;
@@ -204,8 +211,27 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
         }
     }
     if (tid < n) de[(int64_t)tid * nchunk + idc] = double2{dx, eb[tid]};
-    if constexpr (!VEC) return;
+    if constexpr (VEC == 0) return;
     HH32_SYNC();
+    if constexpr (VEC == 2) {
+        constexpr int P = hh32_rec_off(NMAX - 2, NMAX);
+        cd* out = refl + idc * hh32_rec_size(NMAX);
+        for (int K = h; K < NMAX - 2; K += 2) {           // (the two halves take the reflectors in turn)
+            const int r = K + 1 + x;
+            if (r < NMAX) {
+                cd v{0.0, 0.0};
+                if (K + 2 < n && r < n) {
+                    const double beta = tau[K];
+                    const double sb = beta > 0.0 ? beta * rsqrt_full(beta) : 0.0;
+                    const cd u = A[K * n + r];
+                    v = cd{u.x * sb, u.y * sb};
+                }
+                out[hh32_rec_off(K, NMAX) + x] = v;
+            }
+        }
+        if (x < NMAX) out[P + h * NMAX + x] = x < n ? (h == 0 ? dphase[x] : eo[x]) : cd{0.0, 0.0};
+        return;
+    }
 
     // ---- 2. Z = H_0 (H_1 ( ... (H_{n-3} D))): lane (c, h) holds rows h HC .. of column c = x
     cd z[HC];

@@ -59,6 +59,7 @@ struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
     int* list;             // [nchunk]         matrices left to the rotation replay
     int* count;            //                  their number
     double gaptol;
+    cd* refl;              // [nchunk][hh32_rec_size(NM)]  the reflector records of k_hh32<.., 2, NM> (nullptr: Q sits in the output array)
 };
 
 static size_t qlw_lds1_bytes(int n, int nR, int rw, int nt) {
@@ -744,16 +745,25 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     const int64_t cap = VEC ? (K.qlw_cap > 0 ? (int64_t)K.qlw_cap : (int64_t)3 * n * n + 64) : 0;   // rotations recorded per matrix (~1.2 n^2 are typical)
     const int scap = VEC ? 8 * n : 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + (size_t)n * sizeof(int);
+    const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + (size_t)n * sizeof(int) +
+                       (VEC && n <= 32 ? (size_t)n * sizeof(double) + 16 + (size_t)hh32_rec_size(n <= 24 ? 24 : 32) * sizeof(cd) : 0);
     const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 4096) << 20;
     int64_t chunk = std::max<int64_t>(1024, (int64_t)(budget / per));
     chunk = std::min<int64_t>(chunk, nk);
     chunk = (nk + (nk + chunk - 1) / chunk - 1) / ((nk + chunk - 1) / chunk);   // equal chunks (the QL kernel's time hardly depends on the count)
     // n <= 32 with eigenvectors: the vectors from the twisted factorisation (k_tw32_vectors), the replay for the listed matrices only
     const bool tw32 = VEC && n <= 32 && K.tw32 != 0 && K.qlw_replay_reg != 0;
+    // n <= 32: the tridiagonalisation with the matrix in the registers of ONE wavefront (k_hh32, tbk_solve_hh32.inl; round 6)
+    // (33^3 points, ms per call, k_hh32 / k_tridiag_lds: n = 17 1.41 / 1.37, 18 1.42 / 1.46, 20 1.57 / 1.72, 24 1.87 / 2.24, 28 3.00 / 3.18, 32 3.68 / 4.05
+    // -- profiles/hh32_sweep.py; TBK_HH32=2 forces it at 17 too, 0 never).  With k_tw32_vectors behind it k_hh32 leaves the reflector
+    // record instead of Z (TBK_TW32=2: Z as before, the back-transformation as a matrix product) and is used at 17 as well.
+    const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && (n >= 18 || (tw32 && K.tw32 != 2))));
+    const bool refl = tw32 && hh32 && K.tw32 != 2;
+    const int nm32 = n <= 24 ? 24 : 32;
     const size_t wbytes = al((size_t)chunk * n * sizeof(double2)) + 256 + al((size_t)chunk * cap * sizeof(double2)) +
                           al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n * sizeof(int)) + 1024 +
-                          (tw32 ? al((size_t)chunk * n * sizeof(double)) + al((size_t)chunk * sizeof(uint2)) + al((size_t)chunk * sizeof(int)) + 256 : 0);
+                          (tw32 ? al((size_t)chunk * n * sizeof(double)) + al((size_t)chunk * sizeof(uint2)) + al((size_t)chunk * sizeof(int)) + 256 : 0) +
+                          (refl ? al((size_t)chunk * hh32_rec_size(nm32) * sizeof(cd)) : 0);
     if (wbytes > ctx->work_bytes) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->work) TBK_HIP(hipFree(ctx->work));
@@ -786,7 +796,9 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         W.list = (int*)p;
         p += al((size_t)chunk * sizeof(int));
         W.count = (int*)p;
+        p += 256;
         W.gaptol = K.tw16_gaptol;
+        if (refl) W.refl = (cd*)p;
     }
 
     const int rw = n <= 32 ? 32 : 64;
@@ -814,16 +826,15 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         TBK_HIP(hipFuncSetAttribute((const void*)k_ql_backtransform<MODE, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     cd* evec = MODE == 1 ? nullptr : L.evec;
-    // n <= 32: the tridiagonalisation (and Z) with the matrix in the registers of ONE wavefront (k_hh32, tbk_solve_hh32.inl; round 6)
-    // (33^3 points, ms per call, k_hh32 / k_tridiag_lds: n = 17 1.41 / 1.37, 18 1.42 / 1.46, 20 1.57 / 1.72, 24 1.87 / 2.24, 28 3.00 / 3.18, 32 3.68 / 4.05
-    // -- profiles/hh32_sweep.py; TBK_HH32=2 forces it at 17 too, 0 never)
-    const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && n >= 18));
     const size_t lds_hh = hh32_lds_bytes(n, MODE == 2 ? 0 : mv.nR);
     for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
-        if (hh32) {
-            if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, VEC, 24>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de);
-            else hipLaunchKernelGGL((k_hh32<MODE, VEC, 32>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de);
+        if (hh32 && refl) {
+            if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, 2, 24>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de, W.refl);
+            else hipLaunchKernelGGL((k_hh32<MODE, 2, 32>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de, W.refl);
+        } else if (hh32) {
+            if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, VEC ? 1 : 0, 24>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
+            else hipLaunchKernelGGL((k_hh32<MODE, VEC ? 1 : 0, 32>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
         } else {
 #define TBK_QLW_K1(RW_, NT_)                                                                                                    \
     if (rw == RW_ && nt == NT_)                                                                                                 \
@@ -847,10 +858,12 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
             if (tw32) {
                 const unsigned b2 = (unsigned)((nc + 1) / 2), b32 = (unsigned)((nc * 32 + 255) / 256);
                 if (n <= 24) {
-                    hipLaunchKernelGGL((k_tw32_vectors<MODE, 24>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, true>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    else hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, false>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
                     hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24, true>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
                 } else {
-                    hipLaunchKernelGGL((k_tw32_vectors<MODE, 32>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, true>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    else hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, false>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
                     hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32, true>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
                 }
             } else if (rw == 32 && K.qlw_replay_reg != 0) {

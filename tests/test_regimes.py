@@ -70,6 +70,11 @@ REGIMES = [
     (18, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<24>"),
     (25, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<32>"),
     (32, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<32>"),
+    (17, 101, {"TBK_QLW_MIN": 0}, "tridiagonal path: k_hh32<24> leaves the reflector record, k_tw32_vectors<24, record>"),
+    (23, 101, {"TBK_QLW_MIN": 0, "TBK_TW32": 2}, "k_hh32<24> accumulates Z, k_tw32_vectors<24> multiplies by it (matrix cores)"),
+    (30, 101, {"TBK_QLW_MIN": 0, "TBK_TW32": 2}, "k_hh32<32> accumulates Z, k_tw32_vectors<32> multiplies by it (matrix cores)"),
+    (26, 101, {"TBK_QLW_MIN": 0, "TBK_TW32": 2, "TBK_TW16_GAPTOL": "3e-2"}, "... some matrices listed: Q left in place, replay"),
+    (22, 101, {"TBK_QLW_MIN": 0, "TBK_HH32": 0}, "k_tridiag_lds leaves Z, k_tw32_vectors<24> multiplies by it"),
     (24, 100, {"TBK_QLW_MIN": 0, "TBK_TW32": 0}, "tridiagonal path, the rotations replayed on every matrix (rounds 2-5) instead of k_tw32_vectors<24>"),
     (29, 100, {"TBK_QLW_MIN": 0, "TBK_TW32": 0}, "tridiagonal path, the rotations replayed on every matrix instead of k_tw32_vectors<32>"),
     (21, 101, {"TBK_QLW_MIN": 0, "TBK_TW16_GAPTOL": "1e300"}, "k_tw32_vectors<24> lists every matrix: replay over the list"),
