@@ -273,17 +273,27 @@ __global__ __launch_bounds__(NT) void k_tridiag_lds(const ModelView mv, const in
 }
 
 // ---- one lane per matrix: implicit-shift QL (EISPACK tql2 recurrences) on (d, e)
-template <int MODE, bool REC>
+// RECM 0: eigenvalues only; 1: the rotations recorded for the replay; 2: no record, but what k_tw32_vectors needs (ranks, the eigenvalue
+// of every position, the splitting of T, close pairs listed).  LIST: the matrices W.list[0 .. *W.count) instead of the chunk (the record
+// for the matrices k_tw32_vectors left to the replay; the grid is sized for the chunk, blocks past the count leave at once).
+template <int MODE, int RECM, bool LIST = false>
 __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk,
                                                          const QlwWork W, double* __restrict__ eval, const GridArgs G,
                                                          int* flags) {
+    constexpr bool REC = RECM == 1;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double* D = (double*)lds_raw;          // [n][64]
     double* E = D + n * 64;                // [n][64]
     const int lane = threadIdx.x;
-    const int64_t idc = (int64_t)blockIdx.x * 64 + lane;
-    const bool has = idc < nchunk;
-    const int64_t ic = has ? idc : nchunk - 1;
+    int64_t nlive = nchunk;
+    if constexpr (LIST) {
+        nlive = *W.count;
+        if ((int64_t)blockIdx.x * 64 >= nlive) return;
+    }
+    const int64_t it = (int64_t)blockIdx.x * 64 + lane;
+    const bool has = it < nlive;
+    const int64_t ic = LIST ? (int64_t)W.list[has ? it : nlive - 1] : (has ? it : nchunk - 1);
+    const int64_t idc = ic;                // (every write below is under `has`)
     for (int j = 0; j < n; ++j) {
         const double2 v = W.de[(int64_t)j * nchunk + ic];
         D[j * 64 + lane] = v.x;
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
         if (overflow) atomicExch(flags + 2, 1);
     }
     // stable ascending ranks; E is free now: E[r] <- the column of rank r (as a double)
-    const bool tw = REC && W.lam != nullptr;             // (uniform) positions, splitting and close pairs for k_tw32_vectors
+    constexpr bool tw = RECM == 2;                       // positions, splitting and close pairs for k_tw32_vectors
     bool flagged = false;
     double thr = 0.0;
     if (tw) {
@@ -447,7 +457,6 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
         if (tw && has) W.lam[(int64_t)a * nchunk + idc] = da;
     }
     if (tw && has) {
-        flagged = flagged || overflow;                   // (no record to replay: the caller repeats the call anyway)
         W.meta[idc] = uint2{split0, flagged ? 1u : 0u};
         if (flagged) W.list[atomicAdd(W.count, 1)] = (int)idc;
     }
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
     for (int r = 0; r < n; ++r) {
         const int a = (int)E[r * 64 + lane];
         const double v = D[a * 64 + lane];
-        if (REC && has) W.rank[(int64_t)a * nchunk + idc] = r;
+        if (RECM != 0 && has) W.rank[(int64_t)a * nchunk + idc] = r;
         if constexpr (MODE == 1) {
             if (r > 0) {
                 double gap = has ? v - prev : INFINITY;
@@ -820,7 +829,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     TBK_REQUIRE(f1, TBK_EINVAL, "launch_qlw: no kernel for %d rows x %d threads", rw, nt);
     if (lds1 > 64 * 1024) TBK_HIP(hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (lds2 > 64 * 1024)
-        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_ql_lanes<MODE, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TBK_HIP(hipFuncSetAttribute((const void*)k_tridiag_ql_lanes<MODE, VEC ? 1 : 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (VEC && lds3 > 64 * 1024) {
         TBK_HIP(hipFuncSetAttribute((const void*)k_ql_backtransform<MODE, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         TBK_HIP(hipFuncSetAttribute((const void*)k_ql_backtransform<MODE, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -851,19 +860,30 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
                                nk, id0, (const double2*)W.de, L.eval, (int64_t)1, nc, ctx->flags_dev);
         else {
             if (tw32) TBK_HIP(hipMemsetAsync(W.count, 0, sizeof(int), ctx->stream));
-            hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0,
-                               nc, W, L.eval, G, ctx->flags_dev);
+            // (tw32: no rotation record here -- 0.60 against 0.42 ms per 36 k matrices of 32 states -- the listed matrices get theirs below)
+            if (tw32)
+                hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, 2>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0, nc, W,
+                                   L.eval, G, ctx->flags_dev);
+            else
+                hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC ? 1 : 0>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk,
+                                   id0, nc, W, L.eval, G, ctx->flags_dev);
         }
         if (VEC) {
             if (tw32) {
                 const unsigned b2 = (unsigned)((nc + 1) / 2), b32 = (unsigned)((nc * 32 + 255) / 256);
+                auto listed_ql = [&]() {
+                    hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, 1, true>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0, nc,
+                                       W, L.eval, G, ctx->flags_dev);
+                };
                 if (n <= 24) {
                     if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, true>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
                     else hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, false>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    listed_ql();
                     hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24, true>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
                 } else {
                     if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, true>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
                     else hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, false>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    listed_ql();
                     hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32, true>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
                 }
             } else if (rw == 32 && K.qlw_replay_reg != 0) {
