@@ -1754,7 +1754,8 @@ int tbk_mesh_evals_rows(tbk_model* m, const int32_t* mesh, double* e_dev, bool* 
 // S(k) of one point (or the supplied matrix, MODE 2) into the LDS matrix A[n][ld], by the NT threads of a
 // workgroup; `ph` is scratch for max(nR, 1) phases.  The last writes are NOT followed by a barrier.
 // ---------------------------------------------------------------------------
-template <int MODE, int NT>
+// TRI: only the upper triangle, packed by columns -- entry (a, b), a <= b, at b (b + 1) / 2 + a (k_hh32, whose LDS sets its occupancy).
+template <int MODE, int NT, bool TRI = false>
 __device__ __forceinline__ void assemble_lds(const ModelView& mv, const ListArgs& L, const int64_t id, const double (&kk)[4],
                                              cd* __restrict__ A, const int ld, cd* __restrict__ ph, const int lane) {
     const int n = mv.nsta;
@@ -1765,7 +1766,11 @@ __device__ __forceinline__ void assemble_lds(const ModelView& mv, const ListArgs
             // use the upper triangle, mirror it (the reference's eigh reads one triangle)
             cd v = a <= b ? h[a * n + b] : cconj(h[b * n + a]);
             if (a == b) v.y = 0.0;
-            A[a * ld + b] = v;
+            if constexpr (TRI) {
+                if (a <= b) A[b * (b + 1) / 2 + a] = v;
+            } else {
+                A[a * ld + b] = v;
+            }
         }
     } else {
         cd z[4];
@@ -1783,7 +1788,11 @@ __device__ __forceinline__ void assemble_lds(const ModelView& mv, const ListArgs
                 cd acc{0.0, 0.0};
 #pragma unroll 4
                 for (int r = 0; r < mv.nR; ++r) cfma(acc, u[(size_t)r * mv.nslot], ph[r]);
-                if (a == b) {
+                if constexpr (TRI) {
+                    if (a == b) A[a * (a + 1) / 2 + a] = cd{acc.x, 0.0};
+                    else if (a < b) A[b * (b + 1) / 2 + a] = acc;
+                    else A[a * (a + 1) / 2 + b] = cconj(acc);
+                } else if (a == b) {
                     A[a * ld + a] = cd{acc.x, 0.0};
                 } else {
                     A[a * ld + b] = acc;
@@ -1793,14 +1802,18 @@ __device__ __forceinline__ void assemble_lds(const ModelView& mv, const ListArgs
             __syncthreads();   // phases consumed before the caller reuses `ph`
         } else {
             // sparse model (ribbons, slabs): clear A, then walk the non-empty slots only
-            for (int e = lane; e < n * ld; e += NT) A[e] = cd{0.0, 0.0};
+            for (int e = lane; e < (TRI ? n * (n + 1) / 2 : n * ld); e += NT) A[e] = cd{0.0, 0.0};
             __syncthreads();
             for (int i = lane; i < mv.nnz; i += NT) {
                 const int4 s = mv.nz[i];
                 const int a = s.x & 0xffff, b = s.x >> 16;
                 cd acc{0.0, 0.0};
                 for (int t = s.y; t < s.z; ++t) cfma(acc, mv.term_amp[t], phase_of_R(z, mv.term_R[t]));
-                if (a == b) {
+                if constexpr (TRI) {
+                    if (a == b) A[a * (a + 1) / 2 + a] = cd{acc.x, 0.0};
+                    else if (a < b) A[b * (b + 1) / 2 + a] = acc;
+                    else A[a * (a + 1) / 2 + b] = cconj(acc);
+                } else if (a == b) {
                     A[a * ld + a] = cd{acc.x, 0.0};
                 } else {
                     A[a * ld + b] = acc;

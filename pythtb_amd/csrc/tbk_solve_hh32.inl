@@ -72,8 +72,11 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
     constexpr int HC = NMAX / 2;
     const int n = mv.nsta, ld = n | 1;
     const int tid = threadIdx.x, x = tid & 31, h = tid >> 5;
-    cd* A = (cd*)lds_raw;                  // [n][ld]: H(k) as assembled; then the reflector record U[K][r] (stride n); then Z on its way out
-    cd* ubuf = A + n * ld;                 // [32]
+    // VEC == 1: [n][ld]: H(k) as assembled; then the reflector record U[K][r] (stride n); then Z on its way out.  Otherwise only the upper
+    // triangle of H(k), packed (8.4 instead of 16.9 KB at 32 states: three wavefronts per SIMD instead of two)
+    constexpr bool TRI = VEC != 1;
+    cd* A = (cd*)lds_raw;
+    cd* ubuf = A + (TRI ? n * (n + 1) / 2 : n * ld);   // [32]
     cd* qbuf = ubuf + 32;                  // [32]
     cd* eo = qbuf + 32;                    // [max(n, nR)]: assembly scratch, then the orbital phases
     cd* dphase = eo + (n > mv.nR ? n : mv.nR);
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
     } else if constexpr (MODE == 1) {
         grid_point(G, id, kk, wrap);
     }
-    assemble_lds<MODE, 64>(mv, L, id, kk, A, ld, eo, tid);
+    assemble_lds<MODE, 64, TRI>(mv, L, id, kk, A, ld, eo, tid);
     __syncthreads();
     if (VEC && tid < n) {
         cd f{1.0, 0.0};
@@ -108,8 +111,10 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
 #pragma unroll
     for (int j = 0; j < HC; ++j) {
         const int c = 2 * j + h;
-        a[j] = (x < n && c < n) ? A[x * ld + c] : cd{0.0, 0.0};
+        if constexpr (TRI) a[j] = (x < n && c < n) ? (c <= x ? cconj(A[x * (x + 1) / 2 + c]) : A[c * (c + 1) / 2 + x]) : cd{0.0, 0.0};
+        else a[j] = (x < n && c < n) ? A[x * ld + c] : cd{0.0, 0.0};
     }
+    cd* const rec_out = VEC == 2 ? refl + idc * hh32_rec_size(NMAX) : nullptr;
     HH32_SYNC();                       // (the region takes the reflector record from here on)
     if (tid < n) {
         tau[tid] = 0.0;
@@ -151,7 +156,15 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
         const cd tK{refl ? -ph.x * nrm : alpha.x, refl ? -ph.y * nrm : alpha.y};
         if (h == 0) {
             ubuf[x] = u;
-            if (x < n && K + 2 < n) A[K * n + x] = u;  // the record the accumulation reads ((n - 2) n entries: the region holds n (n | 1))
+            if constexpr (VEC == 1) {
+                if (x < n && K + 2 < n) A[K * n + x] = u;  // the record the accumulation reads ((n - 2) n entries: the region holds n (n | 1))
+            }
+            if constexpr (VEC == 2) {                  // sqrt(beta) u_K straight into the record of k_tw32_vectors (zeros past n)
+                if (K + 2 < NMAX && x > K && x < NMAX) {
+                    const double sb = beta > 0.0 ? beta * rsqrt_full(beta) : 0.0;
+                    rec_out[hh32_rec_off(K, NMAX) + x - K - 1] = cd{u.x * sb, u.y * sb};
+                }
+            }
         }
         HH32_SYNC();
         cd p{0.0, 0.0};
@@ -216,18 +229,9 @@ __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const 
     if constexpr (VEC == 2) {
         constexpr int P = hh32_rec_off(NMAX - 2, NMAX);
         cd* out = refl + idc * hh32_rec_size(NMAX);
-        for (int K = h; K < NMAX - 2; K += 2) {           // (the two halves take the reflectors in turn)
+        for (int K = (n > 1 ? n - 1 : 0) + h; K < NMAX - 2; K += 2) {   // the reflectors that do not exist (steps the loop above left out): zeros
             const int r = K + 1 + x;
-            if (r < NMAX) {
-                cd v{0.0, 0.0};
-                if (K + 2 < n && r < n) {
-                    const double beta = tau[K];
-                    const double sb = beta > 0.0 ? beta * rsqrt_full(beta) : 0.0;
-                    const cd u = A[K * n + r];
-                    v = cd{u.x * sb, u.y * sb};
-                }
-                out[hh32_rec_off(K, NMAX) + x] = v;
-            }
+            if (r < NMAX) out[hh32_rec_off(K, NMAX) + x] = cd{0.0, 0.0};
         }
         if (x < NMAX) out[P + h * NMAX + x] = x < n ? (h == 0 ? dphase[x] : eo[x]) : cd{0.0, 0.0};
         return;

@@ -741,8 +741,8 @@ __global__ __launch_bounds__(128) void k_ql_replay_reg64(const int n, const int6
 
 #include "tbk_solve_hh32.inl"   // k_hh32: stage 1 for n <= 32 with the matrix in registers
 #include "tbk_solve_tw32.inl"   // k_tw32_vectors: stage 3 for n <= 32 without the rotation replay
-static size_t hh32_lds_bytes(int n, int nR) {
-    size_t b = (size_t)n * (n | 1) * sizeof(cd);                  // H(k) | reflector record | Z
+static size_t hh32_lds_bytes(int n, int nR, bool tri) {
+    size_t b = (size_t)(tri ? n * (n + 1) / 2 : n * (n | 1)) * sizeof(cd);   // H(k) | reflector record | Z; or the packed triangle of H(k)
     b += (size_t)(64 + std::max(n, nR) + 2 * n) * sizeof(cd);     // ubuf, qbuf, eo / phases, dphase, tsub
     b += (size_t)2 * n * sizeof(double);                          // tau, eb
     return (b + 15) & ~(size_t)15;
@@ -835,7 +835,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         TBK_HIP(hipFuncSetAttribute((const void*)k_ql_backtransform<MODE, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     cd* evec = MODE == 1 ? nullptr : L.evec;
-    const size_t lds_hh = hh32_lds_bytes(n, MODE == 2 ? 0 : mv.nR);
+    const size_t lds_hh = hh32_lds_bytes(n, MODE == 2 ? 0 : mv.nR, !VEC || refl);
     for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
         if (hh32 && refl) {
