@@ -740,6 +740,7 @@ __global__ __launch_bounds__(128) void k_ql_replay_reg64(const int n, const int6
 }
 
 #include "tbk_solve_hh32.inl"   // k_hh32: stage 1 for n <= 32 with the matrix in registers
+#include "tbk_solve_ql32.inl"   // k_ql32_lanes: stage 2 for n <= 32 with (d, e) in registers
 #include "tbk_solve_tw32.inl"   // k_tw32_vectors: stage 3 for n <= 32 without the rotation replay
 static size_t hh32_lds_bytes(int n, int nR, bool tri) {
     size_t b = (size_t)(tri ? n * (n + 1) / 2 : n * (n | 1)) * sizeof(cd);   // H(k) | reflector record | Z; or the packed triangle of H(k)
@@ -861,7 +862,13 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         else {
             if (tw32) TBK_HIP(hipMemsetAsync(W.count, 0, sizeof(int), ctx->stream));
             // (tw32: no rotation record here -- 0.60 against 0.42 ms per 36 k matrices of 32 states -- the listed matrices get theirs below)
-            if (tw32)
+            const bool ql32 = n <= 32 && K.ql32 != 0 && (tw32 || !VEC);
+            const dim3 gq((unsigned)((nc + 63) / 64));
+            if (ql32 && tw32 && n <= 24) hipLaunchKernelGGL((k_ql32_lanes<MODE, 2, 24>), gq, dim3(64), 0, ctx->stream, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
+            else if (ql32 && tw32) hipLaunchKernelGGL((k_ql32_lanes<MODE, 2, 32>), gq, dim3(64), 0, ctx->stream, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
+            else if (ql32 && n <= 24) hipLaunchKernelGGL((k_ql32_lanes<MODE, 0, 24>), gq, dim3(64), 0, ctx->stream, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
+            else if (ql32) hipLaunchKernelGGL((k_ql32_lanes<MODE, 0, 32>), gq, dim3(64), 0, ctx->stream, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
+            else if (tw32)
                 hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, 2>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0, nc, W,
                                    L.eval, G, ctx->flags_dev);
             else
