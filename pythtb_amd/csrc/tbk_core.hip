@@ -44,6 +44,7 @@ static void knobs_parse() {
     geti("TBK_HH32", k.hh32);
     geti("TBK_TW32", k.tw32);
     geti("TBK_QL32", k.ql32);
+    geti("TBK_QLW_STREAMS", k.qlw_streams);
     geti("TBK_QLW_BISECT", k.qlw_bisect);
     geti("TBK_QLW_REPLAY_REG", k.qlw_replay_reg);
     geti("TBK_QLW_WS_MB", k.qlw_ws_mb);

@@ -49,6 +49,7 @@ struct TbkKnobs {
     int hh32 = 1;               // TBK_HH32          0: n = 18..32 tridiagonalised by the LDS workgroup kernel k_tridiag_lds instead of k_hh32 (matrix in registers); 2: k_hh32 from 17
     int tw32 = 1;               // TBK_TW32          0: eigenvectors of 17..32 states by replaying the QL rotations on every matrix (k_ql_replay_reg) instead of k_tw32_vectors; 2: k_tw32_vectors on Q (k_hh32 accumulates Z) instead of on the reflector record
     int ql32 = 1;               // TBK_QL32          0: the QL iteration of 17..32 states with (d, e) in LDS and dynamic positions (k_tridiag_ql_lanes) instead of registers (k_ql32_lanes)
+    int qlw_streams = 0;        // TBK_QLW_STREAMS   chunks of a 17..32-state batch in flight on side streams (default: 2 from 16384 matrices with eigenvectors; 1: one after the other)
     int qlw_nt = -1;            // TBK_QLW_NT        threads per matrix of the tridiagonalisation kernel (64 | 128 | 256 | 512)
     long long qlw_cap = -1;     // TBK_QLW_CAP       tests: rotations recorded per matrix (default 3 n^2 + 64)
     int qlw_ws_mb = -1;         // TBK_QLW_WS_MB     workspace budget of the tridiagonal paths in MiB (default 4096; 8192 for the n = 9..16 eigenvector path)

@@ -3,7 +3,7 @@
 // position of a sweep unrolled under a per-lane predicate -- the form k_tw16_eigvals has for 9..16 states (qle_pos, tbk_solve_dev.h).
 // k_tridiag_ql_lanes keeps d, e in LDS and walks the union of the 64 lanes' ranges with dynamic positions: ~450 cycles per position
 // (36 k matrices of 32 states: 0.39 ms on half a wavefront per SIMD, a pure latency chain); here a position is its ~12 dependent
-// double-precision operations.  No rotation record: eigenvalues only (RECM 0), or what k_tw32_vectors needs (RECM 2: ranks, the
+// double-precision operations.  No rotation record: eigenvalues only, or also what k_tw32_vectors needs (W.lam set: ranks, the
 // eigenvalue of every position, the splitting of T, close pairs listed) -- the matrices k_tw32_vectors leaves to the replay get
 // their record from k_tridiag_ql_lanes<.., 1, LIST>.  Restates the reference's numpy.linalg.eigh (pythtb.py:939-947); same
 // recurrences as EISPACK tql2, LAPACK's limit of 30 shifts per eigenvalue.  TBK_QL32=0: k_tridiag_ql_lanes for every matrix.
@@ -43,11 +43,14 @@ __device__ __forceinline__ double ql32_pick(const double (&a)[NM], const int idx
     else return r;
 }
 
-template <int MODE, int RECM, int NM>
+// ONE instantiation serves the eigenvalue-only calls and the calls with eigenvectors (W.lam != nullptr: the extra outputs), so that the
+// eigenvalues of the two forms of a call are the same bits (two instantiations differed in the last place on an already tridiagonal
+// chain: the compiler contracts multiply-adds per instantiation).
+template <int MODE, int NM>
 __global__ __launch_bounds__(64) void k_ql32_lanes(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk, const QlwWork W,
                                                    double* __restrict__ eval, const GridArgs G, int* flags) {
-    static_assert(RECM == 0 || RECM == 2, "k_ql32_lanes records no rotations");
-    __shared__ double S[NM][64];                         // the eigenvalues by rank, on their way out
+    const bool tw = W.lam != nullptr;                    // (uniform)
+    __shared__ double S[NM][64], T[NM][64];              // the eigenvalues by position / by rank, on their way out
     const int lane = threadIdx.x;
     const int64_t idc = (int64_t)blockIdx.x * 64 + lane;
     const bool has = idc < nchunk;
@@ -105,41 +108,40 @@ __global__ __launch_bounds__(64) void k_ql32_lanes(const int n, const int64_t nk
         }
         ql32_pos<NM - 2, NM>(d, e, sn, cs, pp, g, alive, !done, l, m);
     }
-    // stable ascending ranks among the n real entries; S[r] <- the eigenvalue of rank r
+    // stable ascending ranks among the n real entries; T[r] <- the eigenvalue of rank r.  (Through LDS with rolled loops: the
+    // unrolled n^2 comparisons on registers were 3 k instructions, and the compiler put d in scratch memory for them once the loop
+    // could not be unrolled fully.)
+#pragma unroll
+    for (int a = 0; a < NM; ++a) S[a][lane] = d[a];
+    asm volatile("" ::: "memory");                      // (a lane reads back its own column: no barrier)
     double tnorm = 0.0;
-#pragma unroll
-    for (int a = 0; a < NM; ++a)
-        if (a < n) tnorm = fmax(tnorm, fabs(d[a]));
-    const double thr = RECM == 2 ? W.gaptol * tnorm : 0.0;
+    for (int a = 0; a < n; ++a) tnorm = fmax(tnorm, fabs(S[a][lane]));
+    const double thr = tw ? W.gaptol * tnorm : 0.0;
     bool flagged = false;
-#pragma unroll
-    for (int a = 0; a < NM; ++a) {
-        if (a < n) {                                     // (uniform)
-            int r = 0;
-#pragma unroll
-            for (int b = 0; b < NM; ++b) {
-                if (b < n) {
-                    r += (d[b] < d[a] || (d[b] == d[a] && b < a)) ? 1 : 0;
-                    // two eigenvalues of one unreduced block (no split between positions a and b) closer than gaptol |T|: their
-                    // twisted-factorisation vectors would be nearly parallel
-                    if (RECM == 2 && b > a) flagged = flagged || (((split >> a) & ((1u << (b - a)) - 1u)) == 0 && !(fabs(d[a] - d[b]) >= thr));
-                }
-            }
-            S[r][lane] = d[a];
-            if (RECM == 2 && has) {
-                W.rank[(int64_t)a * nchunk + idc] = r;
-                W.lam[(int64_t)a * nchunk + idc] = d[a];
-            }
+    for (int a = 0; a < n; ++a) {
+        const double da = S[a][lane];
+        int r = 0;
+        for (int b = 0; b < n; ++b) {
+            const double db = S[b][lane];
+            r += (db < da || (db == da && b < a)) ? 1 : 0;
+            // two eigenvalues of one unreduced block (no split between positions a and b) closer than gaptol |T|: their
+            // twisted-factorisation vectors would be nearly parallel
+            if (tw && b > a) flagged = flagged || (((split >> a) & ((1u << (b - a)) - 1u)) == 0 && !(fabs(da - db) >= thr));
+        }
+        T[r][lane] = da;
+        if (tw && has) {
+            W.rank[(int64_t)a * nchunk + idc] = r;
+            W.lam[(int64_t)a * nchunk + idc] = da;
         }
     }
-    if (RECM == 2 && has) {
+    if (tw && has) {
         W.meta[idc] = uint2{split, flagged ? 1u : 0u};
         if (flagged) W.list[atomicAdd(W.count, 1)] = (int)idc;
     }
     asm volatile("" ::: "memory");                      // (a lane reads back its own column of S: no barrier)
     double prev = 0.0;
     for (int r = 0; r < n; ++r) {
-        const double v = S[r][lane];
+        const double v = T[r][lane];
         if constexpr (MODE == 1) {
             if (r > 0) {
                 double gap = has ? v - prev : INFINITY;

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(64) void k_tridiag_ql_lanes(const int n, const int6
         const int a = (int)E[r * 64 + lane];
         const double v = D[a * 64 + lane];
         if (RECM != 0 && has) W.rank[(int64_t)a * nchunk + idc] = r;
+        if constexpr (LIST) continue;                    // (the eigenvalues and the gaps went out with the main launch: both forms of a call keep the same bits)
         if constexpr (MODE == 1) {
             if (r > 0) {
                 double gap = has ? v - prev : INFINITY;
@@ -758,22 +759,34 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + (size_t)n * sizeof(int) +
                        (VEC && n <= 32 ? (size_t)n * sizeof(double) + 16 + (size_t)hh32_rec_size(n <= 24 ? 24 : 32) * sizeof(cd) : 0);
     const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 4096) << 20;
-    int64_t chunk = std::max<int64_t>(1024, (int64_t)(budget / per));
-    chunk = std::min<int64_t>(chunk, nk);
-    chunk = (nk + (nk + chunk - 1) / chunk - 1) / ((nk + chunk - 1) / chunk);   // equal chunks (the QL kernel's time hardly depends on the count)
     // n <= 32 with eigenvectors: the vectors from the twisted factorisation (k_tw32_vectors), the replay for the listed matrices only
     const bool tw32 = VEC && n <= 32 && K.tw32 != 0 && K.qlw_replay_reg != 0;
     // n <= 32: the tridiagonalisation with the matrix in the registers of ONE wavefront (k_hh32, tbk_solve_hh32.inl; round 6)
     // (33^3 points, ms per call, k_hh32 / k_tridiag_lds: n = 17 1.41 / 1.37, 18 1.42 / 1.46, 20 1.57 / 1.72, 24 1.87 / 2.24, 28 3.00 / 3.18, 32 3.68 / 4.05
     // -- profiles/hh32_sweep.py; TBK_HH32=2 forces it at 17 too, 0 never).  With k_tw32_vectors behind it k_hh32 leaves the reflector
     // record instead of Z (TBK_TW32=2: Z as before, the back-transformation as a matrix product) and is used at 17 as well.
-    const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && (n >= 18 || (tw32 && K.tw32 != 2))));
+    // (at 17 states with AND without eigenvectors: the eigenvalues of the two forms of a call stay the same bits)
+    const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && (n >= 18 || (K.tw32 == 1 && K.qlw_replay_reg != 0))));
     const bool refl = tw32 && hh32 && K.tw32 != 2;
     const int nm32 = n <= 24 ? 24 : 32;
-    const size_t wbytes = al((size_t)chunk * n * sizeof(double2)) + 256 + al((size_t)chunk * cap * sizeof(double2)) +
+    // n <= 32 on k_ql32_lanes: the QL kernel is ONE dependent chain per wavefront on half a wavefront per SIMD -- a quarter of the call during
+    // which the chip idles.  Chunks on the context's side streams (the scheme of launch_tw16): a chunk's QL runs beside its
+    // neighbours' tridiagonalisation and vectors.  (Round 6 tried this with the replay kernels and gained nothing: every stage was
+    // throughput-bound then.)  Measured (profiles/qlw_streams_probe.py, 1 / 2 / 3 chunks in flight, ms): 33^3 points with vectors n = 17
+    // 1.03 / 0.98 / 0.95, 24: 1.22 / 1.10 / 1.09, 32: 1.81 / 1.64 / 1.66; 49^3: 2.52 / 2.43 / 2.46, 2.97 / 2.86 / 2.99, 5.01 / 4.60 / 4.66;
+    // eigenvalues only LOSE (32 states: 1.48 / 1.75 / 1.98 -- two stages only, and every chunk's QL lasts as long as the whole batch's).
+    // So: two chunks with eigenvectors, one without.  TBK_QLW_STREAMS=1: one chunk after the other on the context's stream.
+    const bool ql32 = n <= 32 && K.ql32 != 0 && (tw32 || !VEC);
+    int ns = ql32 && tw32 && nk >= 16384 ? 2 : 1;
+    if (K.qlw_streams >= 1) ns = ql32 ? std::min(K.qlw_streams, 3) : 1;
+    int64_t chunk = std::max<int64_t>(1024, (int64_t)(budget / ns / per));
+    chunk = std::min<int64_t>(chunk, (nk + ns - 1) / ns);
+    chunk = (nk + (nk + chunk - 1) / chunk - 1) / ((nk + chunk - 1) / chunk);   // equal chunks (the QL kernel's time hardly depends on the count)
+    const size_t wone = al((size_t)chunk * n * sizeof(double2)) + 256 + al((size_t)chunk * cap * sizeof(double2)) +
                           al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n * sizeof(int)) + 1024 +
                           (tw32 ? al((size_t)chunk * n * sizeof(double)) + al((size_t)chunk * sizeof(uint2)) + al((size_t)chunk * sizeof(int)) + 256 : 0) +
                           (refl ? al((size_t)chunk * hh32_rec_size(nm32) * sizeof(cd)) : 0);
+    const size_t wbytes = wone * ns;
     if (wbytes > ctx->work_bytes) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->work) TBK_HIP(hipFree(ctx->work));
@@ -783,8 +796,10 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         TBK_REQUIRE(e == hipSuccess, TBK_ENOMEM, "tridiagonal-path workspace of %zu bytes: %s", wbytes, hipGetErrorString(e));
         ctx->work_bytes = wbytes;
     }
+    QlwWork Wsl[3];
+    for (int sl = 0; sl < ns; ++sl) {
     QlwWork W{};
-    unsigned char* p = (unsigned char*)ctx->work;
+    unsigned char* p = (unsigned char*)ctx->work + (size_t)sl * wone;
     W.de = (double2*)p;
     p += al((size_t)chunk * n * sizeof(double2));
     p += 256;                                  // (the back-transform's eight-entry loads may start before a sweep's first entry)
@@ -809,6 +824,19 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         p += 256;
         W.gaptol = K.tw16_gaptol;
         if (refl) W.refl = (cd*)p;
+    }
+    Wsl[sl] = W;
+    }
+    hipStream_t st[3] = {ctx->stream, ctx->stream, ctx->stream};
+    if (ns > 1) {
+        if (!ctx->side_ev[0])
+            for (int i = 0; i < 4; ++i) TBK_HIP(hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming));
+        TBK_HIP(hipEventRecord(ctx->side_ev[0], ctx->stream));
+        for (int sl = 0; sl < ns; ++sl) {
+            if (!ctx->side[sl]) TBK_HIP(hipStreamCreateWithFlags(&ctx->side[sl], hipStreamNonBlocking));
+            st[sl] = ctx->side[sl];
+            TBK_HIP(hipStreamWaitEvent(st[sl], ctx->side_ev[0], 0));
+        }
     }
 
     const int rw = n <= 32 ? 32 : 64;
@@ -837,18 +865,23 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     }
     cd* evec = MODE == 1 ? nullptr : L.evec;
     const size_t lds_hh = hh32_lds_bytes(n, MODE == 2 ? 0 : mv.nR, !VEC || refl);
-    for (int64_t id0 = 0; id0 < nk; id0 += chunk) {
+    // the chunks; an error inside leaves through the join below like success does (see launch_tw16)
+    auto run_chunks = [&]() -> int {
+    int which = 0;
+    for (int64_t id0 = 0; id0 < nk; id0 += chunk, which = (which + 1) % ns) {
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
+        const QlwWork& W = Wsl[which];
+        hipStream_t sq = st[which];
         if (hh32 && refl) {
-            if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, 2, 24>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de, W.refl);
-            else hipLaunchKernelGGL((k_hh32<MODE, 2, 32>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de, W.refl);
+            if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, 2, 24>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
+            else hipLaunchKernelGGL((k_hh32<MODE, 2, 32>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
         } else if (hh32) {
-            if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, VEC ? 1 : 0, 24>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
-            else hipLaunchKernelGGL((k_hh32<MODE, VEC ? 1 : 0, 32>), dim3((unsigned)nc), dim3(64), lds_hh, ctx->stream, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
+            if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, VEC ? 1 : 0, 24>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
+            else hipLaunchKernelGGL((k_hh32<MODE, VEC ? 1 : 0, 32>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
         } else {
 #define TBK_QLW_K1(RW_, NT_)                                                                                                    \
     if (rw == RW_ && nt == NT_)                                                                                                 \
-        hipLaunchKernelGGL((k_tridiag_lds<MODE, VEC, RW_, NT_>), dim3((unsigned)nc), dim3(NT_), lds1, ctx->stream, mv, nk, L, G, id0, nc, W.de);
+        hipLaunchKernelGGL((k_tridiag_lds<MODE, VEC, RW_, NT_>), dim3((unsigned)nc), dim3(NT_), lds1, sq, mv, nk, L, G, id0, nc, W.de);
         TBK_QLW_K1(32, 64) TBK_QLW_K1(32, 128) TBK_QLW_K1(32, 256) TBK_QLW_K1(64, 128) TBK_QLW_K1(64, 256) TBK_QLW_K1(64, 512)
 #undef TBK_QLW_K1
         }
@@ -857,64 +890,77 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         bool bisect = false;
         if constexpr (!VEC && MODE != 1) bisect = K.qlw_bisect >= 0 ? K.qlw_bisect == 1 : nc < (int64_t)ctx->cus * 16;
         if (bisect)
-            hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(64), (size_t)n * sizeof(double2) + 32 * sizeof(double), ctx->stream, n,
+            hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(64), (size_t)n * sizeof(double2) + 32 * sizeof(double), sq, n,
                                nk, id0, (const double2*)W.de, L.eval, (int64_t)1, nc, ctx->flags_dev);
         else {
-            if (tw32) TBK_HIP(hipMemsetAsync(W.count, 0, sizeof(int), ctx->stream));
+            if (tw32) TBK_HIP(hipMemsetAsync(W.count, 0, sizeof(int), sq));
             // (tw32: no rotation record here -- 0.60 against 0.42 ms per 36 k matrices of 32 states -- the listed matrices get theirs below)
-            const bool ql32 = n <= 32 && K.ql32 != 0 && (tw32 || !VEC);
             const dim3 gq((unsigned)((nc + 63) / 64));
-            if (ql32 && tw32 && n <= 24) hipLaunchKernelGGL((k_ql32_lanes<MODE, 2, 24>), gq, dim3(64), 0, ctx->stream, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
-            else if (ql32 && tw32) hipLaunchKernelGGL((k_ql32_lanes<MODE, 2, 32>), gq, dim3(64), 0, ctx->stream, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
-            else if (ql32 && n <= 24) hipLaunchKernelGGL((k_ql32_lanes<MODE, 0, 24>), gq, dim3(64), 0, ctx->stream, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
-            else if (ql32) hipLaunchKernelGGL((k_ql32_lanes<MODE, 0, 32>), gq, dim3(64), 0, ctx->stream, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
+            if (ql32 && n <= 24) hipLaunchKernelGGL((k_ql32_lanes<MODE, 24>), gq, dim3(64), 0, sq, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
+            else if (ql32) hipLaunchKernelGGL((k_ql32_lanes<MODE, 32>), gq, dim3(64), 0, sq, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
             else if (tw32)
-                hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, 2>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0, nc, W,
+                hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, 2>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, sq, n, nk, id0, nc, W,
                                    L.eval, G, ctx->flags_dev);
             else
-                hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC ? 1 : 0>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk,
+                hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, VEC ? 1 : 0>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, sq, n, nk,
                                    id0, nc, W, L.eval, G, ctx->flags_dev);
         }
         if (VEC) {
             if (tw32) {
                 const unsigned b2 = (unsigned)((nc + 1) / 2), b32 = (unsigned)((nc * 32 + 255) / 256);
                 auto listed_ql = [&]() {
-                    hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, 1, true>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, ctx->stream, n, nk, id0, nc,
+                    hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, 1, true>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, sq, n, nk, id0, nc,
                                        W, L.eval, G, ctx->flags_dev);
                 };
                 if (n <= 24) {
-                    if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, true>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
-                    else hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, false>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
+                    else hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, false>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                     listed_ql();
-                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24, true>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24, true>), dim3(b32), dim3(256), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                 } else {
-                    if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, true>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
-                    else hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, false>), dim3(b2), dim3(64), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
+                    else hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, false>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                     listed_ql();
-                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32, true>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32, true>), dim3(b32), dim3(256), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                 }
             } else if (rw == 32 && K.qlw_replay_reg != 0) {
                 const unsigned b32 = (unsigned)((nc * 32 + 255) / 256);
                 if (n <= 24)
-                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24>), dim3(b32), dim3(256), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                 else
-                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32>), dim3(b32), dim3(256), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32>), dim3(b32), dim3(256), 0, sq, n, nk, id0, nc, W, evec, G.wv);
             } else if (rw == 64 && K.qlw_replay_reg != 0 && n >= 40) {   // (33..39: the 40-row form wastes more than it gains)
                 if (n <= 40)
-                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 40>), dim3((unsigned)nc), dim3(128), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 40>), dim3((unsigned)nc), dim3(128), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                 else if (n <= 48)
-                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 48>), dim3((unsigned)nc), dim3(128), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 48>), dim3((unsigned)nc), dim3(128), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                 else if (n <= 56)
-                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 56>), dim3((unsigned)nc), dim3(128), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 56>), dim3((unsigned)nc), dim3(128), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                 else
-                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 64>), dim3((unsigned)nc), dim3(128), 0, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                    hipLaunchKernelGGL((k_ql_replay_reg64<MODE, 64>), dim3((unsigned)nc), dim3(128), 0, sq, n, nk, id0, nc, W, evec, G.wv);
             } else if (rw == 32)
-                hipLaunchKernelGGL((k_ql_backtransform<MODE, 64>), dim3((unsigned)nc), dim3(64), lds3, ctx->stream, n, nk, id0, nc, W, evec, G.wv);
+                hipLaunchKernelGGL((k_ql_backtransform<MODE, 64>), dim3((unsigned)nc), dim3(64), lds3, sq, n, nk, id0, nc, W, evec, G.wv);
             else
-                hipLaunchKernelGGL((k_ql_backtransform<MODE, 128>), dim3((unsigned)nc), dim3(128), lds3, ctx->stream, n, nk, id0, nc, W, evec,
+                hipLaunchKernelGGL((k_ql_backtransform<MODE, 128>), dim3((unsigned)nc), dim3(128), lds3, sq, n, nk, id0, nc, W, evec,
                                    G.wv);
         }
         TBK_HIP(hipGetLastError());
     }
     return TBK_OK;
+    };
+    const int rc_chunks = run_chunks();
+    int rc_join = TBK_OK;
+    if (ns > 1) {
+        for (int sl = 0; sl < ns; ++sl) {
+            hipError_t e = hipEventRecord(ctx->side_ev[1 + sl], st[sl]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->side_ev[1 + sl], 0);
+            if (e != hipSuccess && rc_join == TBK_OK) {
+                (void)hipStreamSynchronize(st[sl]);                                  // (the ordering could not be expressed: wait here)
+                tbk_set_error("joining the side streams of the n = 17..32 solver: %s", hipGetErrorString(e));
+                rc_join = TBK_EHIP;
+            }
+        }
+    }
+    if (rc_chunks) return rc_chunks;
+    return rc_join;
 }

@@ -94,7 +94,12 @@ __global__ __launch_bounds__(64) void k_tw32_vectors(const int n, const int64_t 
     const double lam = j < n ? W.lam[(int64_t)j * nchunk + slot] : 0.0;
     TW_LDS_ORDER();
     bool bad = false;
-    {
+    double lamv = lam;
+    // (a second pass with the Rayleigh-quotient correction lambda + gamma_r / |z|^2 when a vector of the wavefront fails the residual
+    // test: a listed matrix costs a whole lane-per-matrix QL chain with its record, ~0.15 ms per chunk whatever their number)
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const double lam = lamv;
         const double2* xd = Xd + mat * 32;
         // lp in registers; um_k goes to slot k + 1 of this lane's column of the V image -- where z_{k+1} = -um_k z_k will stand
         // (lp AND um in registers, then z: 218 VGPRs, one wavefront per SIMD)
@@ -172,6 +177,10 @@ __global__ __launch_bounds__(64) void k_tw32_vectors(const int n, const int64_t 
         const double inz = rsqrt_full(nz2);
         const double tn = tnorm + fabs(lam);
         bad = !(fabs(gam_r) * inz <= 1e-13 * tn) && j < n;
+        if (pass == 0 && __any(bad && live && mt.y == 0)) {
+            lamv = bad ? fma(gam_r * inz, inz, lam) : lam;
+            continue;
+        }
         if (j < NM) {
 #pragma unroll
             for (int i = 0; i < NM; i += 2) {
@@ -182,6 +191,7 @@ __global__ __launch_bounds__(64) void k_tw32_vectors(const int n, const int64_t 
 #pragma unroll
         for (int i = 0; i < 32; i += 2)                   // rows past NM; the whole column of a lane past NM (a unit vector: V stays orthogonal)
             if (i >= NM || j >= NM) *reinterpret_cast<double2*>(mine + i) = double2{i == j ? 1.0 : 0.0, i + 1 == j ? 1.0 : 0.0};
+        break;
     }
     // a matrix one of whose vectors failed the residual test joins the list (once; not if the QL kernel listed it already)
     const unsigned long long bal = __ballot(bad && live);

@@ -230,9 +230,12 @@ def test_chunked_mesh_equals_one_batch(tb):
     assert np.max(np.abs(np.min(ev[1:] - ev[:-1], axis=1) - g1)) < 1e-12
 
 
-def test_rotation_record_overflow_falls_back_to_jacobi(tb):
+@pytest.mark.parametrize("route", [{"TBK_TW32": 0}, {"TBK_TW16_GAPTOL": "1e300"}],
+                         ids=["replay-on-every-matrix", "every-matrix-listed-by-k_tw32_vectors"])
+def test_rotation_record_overflow_falls_back_to_jacobi(tb, route):
     """The QL kernel records at most 3 n^2 rotations per matrix (4 x the usual count).  If a matrix needs more, the call is
-    repeated on the Jacobi kernels; TBK_QLW_CAP=64 provokes that for every matrix here."""
+    repeated on the Jacobi kernels; TBK_QLW_CAP=64 provokes that for every matrix here -- on the replay path of rounds 2-5, and
+    (round 6) for the matrices k_tw32_vectors lists, whose record comes from the list-mode launch of the QL kernel."""
     from pythtb_amd import _lib
     rng = np.random.default_rng(12)
     n, nk = 24, 70
@@ -240,7 +243,8 @@ def test_rotation_record_overflow_falls_back_to_jacobi(tb):
     h = h + h.conj().transpose(0, 2, 1)
     m = _ribbon(tb, 10)
     k = np.linspace(-0.5, 0.5, 33)
-    with _lib.knob("TBK_QLW_MIN", 0), _lib.knob("TBK_QLW_CAP", 64):
+    (rk, rv), = route.items()
+    with _lib.knob("TBK_QLW_MIN", 0), _lib.knob("TBK_QLW_CAP", 64), _lib.knob(rk, rv):
         ev, vec = _eigh_batch(h)
         mev, mvec = m.solve_all(k, eig_vectors=True)
         w = tb.wf_array(m, [41])
