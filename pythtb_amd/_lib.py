@@ -195,7 +195,7 @@ class Context(object):
         return dict(h2d_bytes=v[0].value, d2h_bytes=v[1].value, h2d_calls=v[2].value, d2h_calls=v[3].value)
 
     def solver_stats(self, reset=False):
-        """dict(listed_matrices=...): matrices of 9..16 states the direct kernels handed to their fallback since the last reset."""
+        """dict(listed_matrices=...): matrices of 9..32 states the direct kernels handed to their fallback (the QL replay) since the last reset."""
         v = C.c_int64(0)
         check(lib.tbk_ctx_solver_stats(self.handle, C.byref(v), 1 if reset else 0))
         return dict(listed_matrices=v.value)

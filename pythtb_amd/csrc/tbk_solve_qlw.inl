@@ -59,6 +59,7 @@ struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
     int* list;             // [nchunk]         matrices left to the rotation replay
     int* count;            //                  their number
     double gaptol;
+    unsigned long long* listed;   // the context's count of listed matrices (tbk_ctx_solver_stats)
     cd* refl;              // [nchunk][hh32_rec_size(NM)]  the reflector records of k_hh32<.., 2, NM> (nullptr: Q sits in the output array)
 };
 
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(256) void k_ql_replay_reg(const int n, const int64_
     int64_t nlive = nchunk;
     if constexpr (LIST) {
         nlive = *W.count;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && nlive > 0) atomicAdd(W.listed, (unsigned long long)nlive);
         if ((int64_t)blockIdx.x * 8 >= nlive) return;
     }
     const bool live = idc0 < nlive;
@@ -823,6 +825,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         W.count = (int*)p;
         p += 256;
         W.gaptol = K.tw16_gaptol;
+        W.listed = (unsigned long long*)(ctx->flags_dev + TBK_FLAG_LISTED);
         if (refl) W.refl = (cd*)p;
     }
     Wsl[sl] = W;

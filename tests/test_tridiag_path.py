@@ -175,6 +175,39 @@ def test_windows_reproduce_the_whole_mesh(tb):
     assert np.max(np.abs(host[-1, 3] - host[0, 3] * ph0)) < 1e-15
 
 
+def test_direct_vectors_of_17_to_32_states_list_next_to_nothing_and_chunks_in_flight_change_no_bit(tb):
+    """Round 6 (k_hh32 + k_ql32_lanes + k_tw32_vectors): on a generic model hardly any matrix goes on the list for the QL replay
+    (the context's counter, tbk_ctx_solver_stats); TBK_TW16_GAPTOL=1e300 lists every one; and two or three chunks in flight on the
+    side streams (the default from 16384 matrices) leave every bit of the array and of the minimal gaps where it was."""
+    from pythtb_amd import _lib
+    ctx = _lib.default_context()
+    m = hp.random_model(tb.tb_model, 22, 3, 1, seed=8, nhop=120, rmax=1)
+    mesh, start = [17, 16, 18], [0.0, 0.1, -0.2]
+    npt = int(np.prod(mesh))
+    w = tb.wf_array(m, mesh)
+    ctx.solver_stats(reset=True)
+    gaps = w.solve_on_grid(start)
+    host = w.to_host().copy()
+    assert ctx.solver_stats(reset=True)["listed_matrices"] <= npt // 100
+    for knobs in ({"TBK_QLW_STREAMS": 2}, {"TBK_QLW_STREAMS": 3}, {"TBK_QLW_STREAMS": 1}):
+        (kn, kv), = knobs.items()
+        with _lib.knob(kn, kv):
+            w2 = tb.wf_array(m, mesh)
+            g2 = w2.solve_on_grid(start)
+        assert np.array_equal(g2, gaps) and np.array_equal(w2.to_host(), host), knobs
+    with _lib.knob("TBK_TW16_GAPTOL", "1e300"):
+        w3 = tb.wf_array(m, mesh)
+        g3 = w3.solve_on_grid(start)
+    assert ctx.solver_stats(reset=True)["listed_matrices"] == npt
+    assert np.array_equal(g3, gaps)                               # (the eigenvalues come from the same kernel either way)
+    k = np.array([start]) + np.array([[3 / 16.0, 5 / 15.0, 7 / 17.0]])
+    H = m._gen_ham(k[0])
+    for arr in (host, w3.to_host()):
+        V = arr[3, 5, 7]
+        ev = np.linalg.eigvalsh(H)
+        assert np.max(np.abs(H @ V.T - V.T * ev)) < 1e-12 and np.max(np.abs(V.conj() @ V.T - np.eye(22))) < 1e-12
+
+
 def test_large_batch_takes_the_path_by_default(tb):
     """Above 8 x CUs matrices no knob is needed: 4096 k-points of a 20-orbital ribbon, against LAPACK on H(k)."""
     m = _ribbon(tb, 10)
