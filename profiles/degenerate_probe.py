@@ -38,6 +38,11 @@ out = {}
 for tw in (1, 0):
     with _lib.knob("TBK_TW32", tw):
         out[tw] = timed(lambda: w.solve_on_grid([0.0, 0.0, 0.0]))
+        ctx.solver_stats(reset=True)
+        w.solve_on_grid([0.0, 0.0, 0.0]); ctx.sync()
+        if tw:
+            print("matrices listed for the replay: %d of %d" % (ctx.solver_stats(reset=True)["listed_matrices"], 33 ** 3))
+            ctx.prof_enable(1); ctx.prof_reset(); w.solve_on_grid([0.0, 0.0, 0.0]); rep = ctx.prof_report(); ctx.prof_enable(0)
 k = rng.uniform(-0.5, 0.5, (300, 3))
 ev, vec = m.solve_all(k, eig_vectors=True)
 H = np.array([m._gen_ham(kk) for kk in k])

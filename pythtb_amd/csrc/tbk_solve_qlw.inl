@@ -58,7 +58,8 @@ struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
     uint2* meta;           // [nchunk]         {split mask of T (bit i: e_i negligible), 1 = two eigenvalues of one block closer than gaptol |T|}
     int* list;             // [nchunk]         matrices left to the rotation replay
     int* count;            //                  their number
-    double gaptol;
+    double gaptol;         //                  (0 since k_tw32_vectors looks for the close pairs itself: it repairs isolated ones)
+    double pair_tol;       //                  relative distance below which k_tw32_vectors treats two eigenvalues of one block as twins
     unsigned long long* listed;   // the context's count of listed matrices (tbk_ctx_solver_stats)
     cd* refl;              // [nchunk][hh32_rec_size(NM)]  the reflector records of k_hh32<.., 2, NM> (nullptr: Q sits in the output array)
 };
@@ -824,7 +825,8 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         p += al((size_t)chunk * sizeof(int));
         W.count = (int*)p;
         p += 256;
-        W.gaptol = K.tw16_gaptol;
+        W.gaptol = 0.0;
+        W.pair_tol = K.tw16_gaptol;
         W.listed = (unsigned long long*)(ctx->flags_dev + TBK_FLAG_LISTED);
         if (refl) W.refl = (cd*)p;
     }
