@@ -1,6 +1,7 @@
-"""Round 6: the 17..32-state path on spectra it cannot serve directly -- every level doubly degenerate at every k (two decoupled
-identical copies of a random 12-orbital model, orbitals interleaved): how many matrices go on k_tw32_vectors' list and what the call
-costs against the replay on every matrix (TBK_TW32=0).  Also a spinful model with Kramers pairs (inversion-symmetric, 12 sites)."""
+"""Round 6: the 17..32-state path on a spectrum the twisted-factorisation vectors cannot serve -- every level doubly degenerate at
+every k (two decoupled identical copies of a random 12-orbital model, orbitals interleaved: the situation of spin-degenerate and
+Kramers-paired bands).  Default (the library notices the pairs at upload and takes the rotation replay), TBK_TW32=3 (k_tw32_vectors
+forced: every matrix listed) and TBK_TW32=0, with the context's count of listed matrices."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -35,19 +36,16 @@ while len(seen) < 6 * half:
         m.set_hop(amp, 2 * i + c, 2 * j + c, list(R))
 w = tb.wf_array(m, [33] * 3)
 out = {}
-for tw in (1, 0):
+for tw in (0, 1, 3, 0, 1):
     with _lib.knob("TBK_TW32", tw):
         out[tw] = timed(lambda: w.solve_on_grid([0.0, 0.0, 0.0]))
         ctx.solver_stats(reset=True)
         w.solve_on_grid([0.0, 0.0, 0.0]); ctx.sync()
-        if tw:
-            print("matrices listed for the replay: %d of %d" % (ctx.solver_stats(reset=True)["listed_matrices"], 33 ** 3))
-            ctx.prof_enable(1); ctx.prof_reset(); w.solve_on_grid([0.0, 0.0, 0.0]); rep = ctx.prof_report(); ctx.prof_enable(0)
+        print("TBK_TW32=%d: %.3f ms, matrices listed for the replay: %d of %d" % (tw, out[tw], ctx.solver_stats(reset=True)["listed_matrices"], 33 ** 3))
 k = rng.uniform(-0.5, 0.5, (300, 3))
 ev, vec = m.solve_all(k, eig_vectors=True)
 H = np.array([m._gen_ham(kk) for kk in k])
 V = vec.transpose(1, 0, 2)
 res = np.abs(np.einsum("kij,kbj->kbi", H, V) - V * ev.T[:, :, None]).max()
 orth = np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.eye(2 * half)).max()
-print("two decoupled copies, n = 24, 33^3 points: default %.3f ms, TBK_TW32=0 %.3f ms; residual %.1e, orthonormality %.1e (300 listed points)"
-      % (out[1], out[0], res, orth))
+print("two decoupled copies, n = 24: residual %.1e, orthonormality %.1e (300 k-points of a list, default path)" % (res, orth))

@@ -884,6 +884,19 @@ extern "C" int tbk_model_upload(tbk_ctx* ctx, int dim_k, int norb, int nspin, co
     m->view.rblock = (const cd*)(base + o_rblk);
     m->view.nnz = nnz;
     m->view.nz = (const int4*)(base + o_nz);
+    // 17..32 states: does the spectrum hold paired levels at a generic k?  (ModelView::pairs_hint)
+    m->view.pairs_hint = 0;
+    if (n >= 17 && n <= 32 && dim_k >= 1) {
+        const double kprobe[4] = {0.1234567, 0.2718281, 0.3141592, 0.4142135};
+        double ev[32];
+        if (tbk_solve_list(m, kprobe, 1, ev, nullptr) == TBK_OK) {
+            double tmax = 0.0;
+            for (int i = 0; i < n; ++i) tmax = std::max(tmax, std::fabs(ev[i]));
+            const double thr = 1e-5 * tmax;       // (the default of TBK_TW16_GAPTOL -- not the knob: tests set that to list every matrix)
+            for (int i = 0; i + 1 < n; ++i)
+                if (!(ev[i + 1] - ev[i] >= thr)) m->view.pairs_hint = 1;
+        }
+    }
     *out = m;
     return TBK_OK;
 }

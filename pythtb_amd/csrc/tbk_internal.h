@@ -47,7 +47,7 @@ struct TbkKnobs {
     int qlw_replay_reg = 1;     // TBK_QLW_REPLAY_REG  0: n <= 32 replays the rotations on Z in LDS (the form n = 33..64 uses) instead of in registers
     int qlw_bisect = -1;        // TBK_QLW_BISECT    eigenvalue-only n = 17..64: 1 bisection, 0 lane-per-matrix QL (default: bisection below 16 x CUs matrices)
     int hh32 = 1;               // TBK_HH32          0: n = 18..32 tridiagonalised by the LDS workgroup kernel k_tridiag_lds instead of k_hh32 (matrix in registers); 2: k_hh32 from 17
-    int tw32 = 1;               // TBK_TW32          0: eigenvectors of 17..32 states by replaying the QL rotations on every matrix (k_ql_replay_reg) instead of k_tw32_vectors; 2: k_tw32_vectors on Q (k_hh32 accumulates Z) instead of on the reflector record
+    int tw32 = 1;               // TBK_TW32          0: eigenvectors of 17..32 states by replaying the QL rotations on every matrix (k_ql_replay_reg) instead of k_tw32_vectors (what models with paired levels at a generic k get by themselves; 3: not even those); 2: k_tw32_vectors on Q (k_hh32 accumulates Z) instead of on the reflector record
     int ql32 = 1;               // TBK_QL32          0: the QL iteration of 17..32 states with (d, e) in LDS and dynamic positions (k_tridiag_ql_lanes) instead of registers (k_ql32_lanes)
     int qlw_streams = 0;        // TBK_QLW_STREAMS   chunks of a 17..32-state batch in flight on side streams (default: 2 from 16384 matrices with eigenvectors; 1: one after the other)
     int qlw_nt = -1;            // TBK_QLW_NT        threads per matrix of the tridiagonalisation kernel (64 | 128 | 256 | 512)
@@ -334,6 +334,11 @@ struct ModelView {
     // the non-empty slots only: {a | b<<16, t0, t1, 0}
     int nnz;
     const int4* nz;           // [nnz]
+    // 17..32 states: 1 when the spectrum at a fixed generic k holds two levels closer than gaptol |H| -- spin-degenerate or Kramers-
+    // paired bands: degenerate at EVERY k, and every matrix would go on k_tw32_vectors' list.  Found once, at upload (one k-point
+    // solved); such models take the rotation replay from the start (launch_qlw).  A property of the model alone: every window and
+    // every shard of a mesh decides the same way.
+    int pairs_hint;
 };
 
 struct tbk_model {

@@ -58,8 +58,7 @@ struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
     uint2* meta;           // [nchunk]         {split mask of T (bit i: e_i negligible), 1 = two eigenvalues of one block closer than gaptol |T|}
     int* list;             // [nchunk]         matrices left to the rotation replay
     int* count;            //                  their number
-    double gaptol;         //                  (0 since k_tw32_vectors looks for the close pairs itself: it repairs isolated ones)
-    double pair_tol;       //                  relative distance below which k_tw32_vectors treats two eigenvalues of one block as twins
+    double gaptol;
     unsigned long long* listed;   // the context's count of listed matrices (tbk_ctx_solver_stats)
     cd* refl;              // [nchunk][hh32_rec_size(NM)]  the reflector records of k_hh32<.., 2, NM> (nullptr: Q sits in the output array)
 };
@@ -763,13 +762,14 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
                        (VEC && n <= 32 ? (size_t)n * sizeof(double) + 16 + (size_t)hh32_rec_size(n <= 24 ? 24 : 32) * sizeof(cd) : 0);
     const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 4096) << 20;
     // n <= 32 with eigenvectors: the vectors from the twisted factorisation (k_tw32_vectors), the replay for the listed matrices only
-    const bool tw32 = VEC && n <= 32 && K.tw32 != 0 && K.qlw_replay_reg != 0;
+    // (not for models whose levels come in pairs at a generic k -- ModelView::pairs_hint -- unless TBK_TW32=3: every matrix would be listed)
+    const bool tw32 = VEC && n <= 32 && K.tw32 != 0 && K.qlw_replay_reg != 0 && (MODE == 2 || !mv.pairs_hint || K.tw32 == 3);
     // n <= 32: the tridiagonalisation with the matrix in the registers of ONE wavefront (k_hh32, tbk_solve_hh32.inl; round 6)
     // (33^3 points, ms per call, k_hh32 / k_tridiag_lds: n = 17 1.41 / 1.37, 18 1.42 / 1.46, 20 1.57 / 1.72, 24 1.87 / 2.24, 28 3.00 / 3.18, 32 3.68 / 4.05
     // -- profiles/hh32_sweep.py; TBK_HH32=2 forces it at 17 too, 0 never).  With k_tw32_vectors behind it k_hh32 leaves the reflector
     // record instead of Z (TBK_TW32=2: Z as before, the back-transformation as a matrix product) and is used at 17 as well.
     // (at 17 states with AND without eigenvectors: the eigenvalues of the two forms of a call stay the same bits)
-    const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && (n >= 18 || (K.tw32 == 1 && K.qlw_replay_reg != 0))));
+    const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && (n >= 18 || ((K.tw32 == 1 || K.tw32 == 3) && K.qlw_replay_reg != 0))));
     const bool refl = tw32 && hh32 && K.tw32 != 2;
     const int nm32 = n <= 24 ? 24 : 32;
     // n <= 32 on k_ql32_lanes: the QL kernel is ONE dependent chain per wavefront on half a wavefront per SIMD -- a quarter of the call during
@@ -825,8 +825,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         p += al((size_t)chunk * sizeof(int));
         W.count = (int*)p;
         p += 256;
-        W.gaptol = 0.0;
-        W.pair_tol = K.tw16_gaptol;
+        W.gaptol = K.tw16_gaptol;
         W.listed = (unsigned long long*)(ctx->flags_dev + TBK_FLAG_LISTED);
         if (refl) W.refl = (cd*)p;
     }

@@ -21,7 +21,7 @@
 // windows stay bit-identical.  TBK_TW32=0 restores the replay for every matrix.
 
 #define TW32_LD 34            // doubles per column of the V image (even: double2 stores; 2-way bank conflicts at most)
-#define TW32_WAVE_LDS (2 * 32 * TW32_LD * 8 + 2 * 32 * 16 + 2 * 32 * 4 + 2 * 32 * 8 + 2 * 32 * 4)
+#define TW32_WAVE_LDS (2 * 32 * TW32_LD * 8 + 2 * 32 * 16 + 2 * 32 * 4)
 
 // y <- H_K y for K = K0 .. 0, H_K = I - us_K us_K^+, for ONE matrix on the whole wavefront: lane (j, h) holds rows 2 i + h of vector j
 // (the rows dealt in turn, like the columns in k_hh32: the live ones stay evenly split); the entries of us_K are broadcast reads of the
@@ -65,14 +65,12 @@ __device__ __forceinline__ void tw32_reflect(cd (&y)[NM / 2], const cd* R, const
 // holding its vector (the form k_tw16_vectors has), transposed through LDS on the way out; listed matrices get V = I, i.e. Q in the
 // output array for the replay.
 template <int MODE, int NM, bool REFL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_tw32_vectors(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk, const QlwWork W,
+__global__ __launch_bounds__(64) void k_tw32_vectors(const int n, const int64_t nk, const int64_t id0, const int64_t nchunk, const QlwWork W,
                                                      cd* evec, const WfsView wv) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[TW32_WAVE_LDS];
     double* const Vs = reinterpret_cast<double*>(lds_all);                                  // [2][32][TW32_LD]
     double2* const Xd = reinterpret_cast<double2*>(lds_all + 2 * 32 * TW32_LD * 8);          // [2][32] (d_i, e_i | 0 at a split)
     int* const Rk = reinterpret_cast<int*>(lds_all + 2 * 32 * TW32_LD * 8 + 2 * 32 * 16);   // [2][32] ascending rank of position j
-    double* const Lam = reinterpret_cast<double*>(lds_all + 2 * 32 * TW32_LD * 8 + 2 * 32 * 16 + 2 * 32 * 4);   // [2][32] the eigenvalue of position j
-    int* const Cn = reinterpret_cast<int*>(lds_all + 2 * 32 * TW32_LD * 8 + 2 * 32 * 16 + 2 * 32 * 4 + 2 * 32 * 8);   // [2][32] close partners of position j
     const int lane = threadIdx.x, mat = lane >> 5, j = lane & 31;
     const int64_t slot0 = (int64_t)blockIdx.x * 2;
     const int64_t slot_u = slot0 + mat;
@@ -94,7 +92,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
         Rk[mat * 32 + j] = rk;
     }
     const double lam = j < n ? W.lam[(int64_t)j * nchunk + slot] : 0.0;
-    Lam[mat * 32 + j] = lam;
     TW_LDS_ORDER();
     bool bad = false;
     double lamv = lam;
@@ -194,133 +191,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 #pragma unroll
         for (int i = 0; i < 32; i += 2)                   // rows past NM; the whole column of a lane past NM (a unit vector: V stays orthogonal)
             if (i >= NM || j >= NM) *reinterpret_cast<double2*>(mine + i) = double2{i == j ? 1.0 : 0.0, i + 1 == j ? 1.0 : 0.0};
-        TW_LDS_ORDER();
-        // ---- twins (Kramers pairs, spin-degenerate bands, or merely close levels): two eigenvalues of one unreduced block closer than
-        // pair_tol |T| get (nearly) the same vector from the twisted factorisation.  An ISOLATED pair is repaired here the way k_e16
-        // does it (xSTEIN's remedy): the second member's vector by inverse iteration on T - lambda = L D L^T (lp from above, the pivots
-        // recomputed from it), orthogonalised against the first member's, two rounds, accepted if it is an eigenvector to 1e-13 |T|.
-        // Three or more eigenvalues that close, or a repair that fails, list the matrix.
-        {
-            const double* Lm = Lam + mat * 32;
-            const double lam_in = Lm[j];
-            double tmaxm = 0.0;
-#pragma unroll
-            for (int i = 0; i < NM; ++i) tmaxm = fmax(tmaxm, i < n ? fabs(Lm[i]) : 0.0);
-            const double thr = W.pair_tol * tmaxm;
-            int cnt = 0, p = j;
-#pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                const bool close = i < n && j < n && i != j && i >= bl && i <= bh && !(fabs(Lm[i] - lam_in) >= thr);
-                cnt += close ? 1 : 0;
-                p = close ? i : p;
-            }
-            Cn[mat * 32 + j] = cnt;
-            TW_LDS_ORDER();
-            const int cntp = Cn[mat * 32 + p];
-            const double lam_p = Lm[p];
-            const bool second = cnt == 1 && cntp == 1 && (lam_in > lam_p || (lam_in == lam_p && j > p)) && !bad;
-#ifdef TW32_REASONS
-            if (bad && live) atomicAdd(W.listed, 1ull << 34);
-            if ((cnt >= 2 || (cnt == 1 && cntp != 1)) && live) atomicAdd(W.listed, 1ull << 20);
-#endif
-            bad = bad || cnt >= 2 || (cnt == 1 && cntp != 1);
-            if (second) {
-                const double* wc = Vs + (mat * 32 + p) * TW32_LD;         // the first member's unit vector (its lane leaves it alone)
-                constexpr double cgen[32] = {0.61, -0.37, 0.93, 0.28, -0.75, 0.49, 0.17, -0.88, 0.55, -0.23, 0.71, 0.39, -0.64, 0.82, -0.12, 0.45,
-                                             -0.58, 0.33, 0.77, -0.41, 0.26, 0.95, -0.69, 0.14, 0.52, -0.86, 0.31, 0.67, -0.19, 0.43, 0.89, -0.47};
-                // start: a fixed generic vector on the rows of the block (the lane's own twisted-factorisation vector is the first
-                // member's bit for bit when the two eigenvalues came out equal).  x in registers, w re-read from LDS at every use.
-                double x[NM];
-#pragma unroll
-                for (int i = 0; i < NM; ++i) x[i] = i >= bl && i <= bh ? cgen[i] : 0.0;
-                auto orth = [&]() {
-                    double c = 0.0;
-                    TW_LDS_ORDER();
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) {
-                        c = fma(wc[i], x[i], c);
-                        if ((i & 3) == 3) TW_LDS_ORDER();          // (a few reads in flight, not all NM: registers)
-                    }
-                    TW_LDS_ORDER();
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) {
-                        x[i] = fma(-c, wc[i], x[i]);
-                        if ((i & 3) == 3) TW_LDS_ORDER();
-                    }
-                    TW_LDS_ORDER();
-                };
-                auto normalise = [&]() {
-                    double mx = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) mx = fmax(mx, fabs(x[i]));
-                    int ex = 0;
-                    (void)frexp(mx, &ex);
-                    const double sc = mx > 0.0 && mx < INFINITY ? ldexp(1.0, -ex) : 1.0;   // (the solve grows by up to 1 / pivot)
-                    double nz = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) {
-                        x[i] *= sc;
-                        nz = fma(x[i], x[i], nz);
-                    }
-                    const double f = nz > 0.0 ? rsqrt_full(nz) : 0.0;
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) x[i] *= f;
-                };
-#pragma unroll 1
-                for (int it = 0; it < 2; ++it) {
-                    orth();
-                    normalise();
-                    {   // (L D L^T) x = b in place: forward, the pivots recomputed from lp (no chain: dp_{i+1} needs lp_i only), back
-#pragma unroll
-                        for (int i = 0; i < NM - 1; ++i) x[i + 1] = fma(-lp[i], x[i], x[i + 1]);
-                        TW_LDS_ORDER();
-                        x[0] *= tw_rcp(tw_guard(xd[0].x - lam));
-#pragma unroll
-                        for (int i = 0; i < NM - 1; ++i) {
-                            x[i + 1] *= tw_rcp(tw_guard(fma(-xd[i].y, lp[i], xd[i + 1].x - lam)));
-                            if ((i & 3) == 3) TW_LDS_ORDER();        // (a few reciprocals side by side, not 31: registers)
-                        }
-                        TW_LDS_ORDER();
-#pragma unroll
-                        for (int i = NM - 2; i >= 0; --i) x[i] = fma(-lp[i], x[i + 1], x[i]);
-                    }
-                    normalise();
-                    orth();
-                    normalise();
-                }
-                // r = (T - lam) x, rq = x.r (Rayleigh correction), residual of (lam + rq, x)
-                double rq = 0.0, r2 = 0.0, cw = 0.0, nv2 = 0.0, rr = 0.0;
-                {
-                    TW_LDS_ORDER();
-                    double eprev = 0.0;
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) {
-                        const double2 t = xd[i];
-                        double r = fma(t.x - lam, x[i], i > 0 ? eprev * x[i > 0 ? i - 1 : 0] : 0.0);
-                        if (i < NM - 1) r = fma(t.y, x[i + 1], r);
-                        eprev = t.y;
-                        rq = fma(x[i], r, rq);
-                        rr = fma(r, r, rr);
-                        cw = fma(wc[i], x[i], cw);
-                        nv2 = fma(x[i], x[i], nv2);
-                        if ((i & 3) == 3) TW_LDS_ORDER();
-                    }
-                    // |r - rq x|^2 = |r|^2 - rq^2 (2 - |x|^2)   (one pass: the residual vector is not kept)
-                    r2 = fmax(fma(-rq * rq, 2.0 - nv2, rr), 0.0);
-                }
-                TW_LDS_ORDER();
-#pragma unroll
-                for (int i = 0; i < NM; i += 2) *reinterpret_cast<double2*>(mine + i) = double2{x[i], x[i + 1]};
-                const double tl = 1e-13 * tn;                 // (the bound the twisted-factorisation vectors are held to)
-#ifdef TW32_REASONS
-                if (!(r2 <= tl * tl)) atomicAdd(W.listed, 1ull << 48);
-                if (!(fabs(cw) <= 1e-12)) atomicAdd(W.listed, 1ull << 52);
-                if (!(fabs(rq) <= 1e-9 * tn)) atomicAdd(W.listed, 1ull << 56);
-                if (!(fabs(nv2 - 1.0) <= 1e-12)) atomicAdd(W.listed, 1ull << 60);
-#endif
-                bad = bad || !(r2 <= tl * tl && fabs(cw) <= 1e-12 && fabs(rq) <= 1e-9 * tn && fabs(nv2 - 1.0) <= 1e-12);
-            }
-        }
         break;
     }
     // a matrix one of whose vectors failed the residual test joins the list (once; not if the QL kernel listed it already)

@@ -208,6 +208,48 @@ def test_direct_vectors_of_17_to_32_states_list_next_to_nothing_and_chunks_in_fl
         assert np.max(np.abs(H @ V.T - V.T * ev)) < 1e-12 and np.max(np.abs(V.conj() @ V.T - np.eye(22))) < 1e-12
 
 
+def test_models_with_paired_levels_at_every_k_take_the_replay_by_themselves(tb):
+    """Two decoupled identical copies of a random 11-orbital model, orbitals interleaved: every level of the 22-state model is doubly
+    degenerate at every k (the situation of spin-degenerate and Kramers-paired bands).  The twisted factorisation gives both members of
+    a pair the same vector, so k_tw32_vectors would list every matrix.  The library notices at upload (one generic k-point solved:
+    ModelView::pairs_hint) and such a model takes the rotation replay from the start: nothing is listed, and the eigenvectors are
+    eigenvectors, orthonormal inside the degenerate spaces too.  TBK_TW32=3 overrides the hint: every matrix listed, same quality."""
+    from pythtb_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(4)
+    half = 11
+    orb = np.repeat(rng.random((half, 3)), 2, axis=0)
+    m = hp.quiet(tb.tb_model, 3, 3, np.identity(3), orb)
+    m.set_onsite(list(np.repeat(rng.standard_normal(half), 2)))
+    seen = set()
+    while len(seen) < 5 * half:
+        i, j = int(rng.integers(half)), int(rng.integers(half))
+        R = tuple(int(x) for x in rng.integers(-1, 2, size=3))
+        if (i == j and R == (0, 0, 0)) or (i, j, R) in seen or (j, i, tuple(-r for r in R)) in seen:
+            continue
+        seen.add((i, j, R))
+        amp = complex(rng.standard_normal(), rng.standard_normal())
+        for c in (0, 1):
+            m.set_hop(amp, 2 * i + c, 2 * j + c, list(R))
+    mesh, start = [17, 16, 10], [0.05, -0.1, 0.2]
+    npt = int(np.prod(mesh))
+    n = 2 * half
+    for knob, want in ((1, 0), (3, npt)):
+        with _lib.knob("TBK_TW32", knob):
+            w = tb.wf_array(m, mesh)
+            ctx.solver_stats(reset=True)
+            w.solve_on_grid(start)
+            host = w.to_host()
+            assert ctx.solver_stats(reset=True)["listed_matrices"] == want
+        for idx in ((0, 0, 0), (3, 5, 7), (16, 15, 9), (8, 1, 4)):
+            k = np.array(start) + np.array(idx) / (np.array(mesh) - 1.0)
+            H = m._gen_ham(k)
+            V = host[idx]
+            ev = np.linalg.eigvalsh(H)
+            assert np.max(np.abs(ev[0::2] - ev[1::2])) < 1e-12                       # pairs indeed
+            assert np.max(np.abs(H @ V.T - V.T * ev)) < 1e-12 and np.max(np.abs(V.conj() @ V.T - np.eye(n))) < 1e-12
+
+
 def test_large_batch_takes_the_path_by_default(tb):
     """Above 8 x CUs matrices no knob is needed: 4096 k-points of a 20-orbital ribbon, against LAPACK on H(k)."""
     m = _ribbon(tb, 10)
