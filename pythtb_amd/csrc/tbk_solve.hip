@@ -2303,7 +2303,11 @@ static const RegimeRule kRegimeRules[] = {
     {Regime::Ql16, 9, 16, -1, kAnyForm, kPerCU, 8, -1, "cubic16 64^3 with vectors: 12.4 (LDS Jacobi) -> 1.9 ms"},
     // 17..64: tridiagonalise in LDS | lane-per-matrix QL or bisection | replay; the same batch rule
     {Regime::Qlw, 17, 64, 0, kNoMesh, kMatrices, -1, -1, "one 64 x 64: 1.26 -> 0.44 ms; 16384 x n=32: 11.8 -> 1.1 ms"},
-    {Regime::Qlw, 17, 64, -1, kAnyForm, kPerCU, 8, -1, "16384 x n=32 with vectors: 11.7 -> 2.2 ms"},
+    // (round 6: k_hh32 + k_ql32_lanes + k_tw32_vectors overtake the workgroup Jacobi kernels from ~3 matrices per CU with eigenvectors --
+    // profiles/qlw_min_probe.py, ms Jacobi | direct: n=17 x 512 0.18 | 0.20, x 1024 0.20 | 0.20, x 2048 0.39 | 0.21; n=24 x 512 0.27 | 0.28,
+    // x 1024 0.31 | 0.28, x 2048 0.65 | 0.30; n=32 x 512 0.43 | 0.46, x 1024 0.58 | 0.47, x 2048 1.63 | 0.51)
+    {Regime::Qlw, 17, 32, 1, kAnyForm, kPerCU, 3, -1, "2048 x n=32 with vectors: 1.63 (workgroup Jacobi) -> 0.51 ms; 33^3 x n=32: 4.26 (round 5) -> 1.70"},
+    {Regime::Qlw, 17, 64, -1, kAnyForm, kPerCU, 8, -1, "16384 x n=32 with vectors: 11.7 -> 2.2 ms (round 2); 33..64 states"},
     // 40..64 with eigenvectors BELOW that batch: the workgroup-scale direct method of 65..1024 states instead of workgroup Jacobi
     // (ms per call, Jacobi | direct, profiles/trigv_small_batches.py: n=64 x 16 1.18 | 0.87, x 1024 5.35 | 1.89; n=48 x 16 0.67 |
     // 0.63, x 1024 2.13 | 1.17; n=40 x 256 0.50 | 0.57, x 1024 1.69 | 0.92; n=32 x 1024 0.61 | 0.68 stays) -- and 3-6 x smaller errors
