@@ -421,8 +421,10 @@ def test_solver_dispatch_table_routes_the_measured_crossovers():
     assert regime(12, 1, MESH, 300, batch=300) == "wg_lds" and regime(12, 1, MESH, 300, batch=10 ** 5) == "ql16"
     assert regime(12, 0, LIST, 7) == "ql16" and regime(16, 1, LIST, 10 ** 5, rblocks=0) == "wave"
     # 17..64
-    assert regime(32, 1, SUP, 16384) == "qlw" and regime(32, 1, SUP, 2048) == "wg_lds" and regime(20, 1, SUP, 2048) == "wg_lds"
-    assert regime(64, 0, SUP, 1) == "qlw" and regime(20, 1, LIST, 2049) == "qlw"
+    # (17..32 with eigenvectors: the direct kernels of round 6 from 3 matrices per CU -- 2048 x n=32 1.63 -> 0.51 ms; 33..64 from 8)
+    assert regime(32, 1, SUP, 16384) == "qlw" and regime(32, 1, SUP, 2048) == "qlw" and regime(20, 1, SUP, 769) == "qlw"
+    assert regime(32, 1, SUP, 768) == "wg_lds" and regime(20, 1, SUP, 768) == "wg_lds" and regime(33, 1, SUP, 2048) == "wg_lds"
+    assert regime(64, 0, SUP, 1) == "qlw" and regime(20, 1, LIST, 2049) == "qlw" and regime(33, 1, LIST, 2049) == "qlw"
     # ... and 40..64 with eigenvectors below the QL batch take the direct method of 65+ states instead of workgroup Jacobi
     assert regime(64, 1, SUP, 16) == "trigv" and regime(48, 1, LIST, 2048) == "trigv" and regime(48, 1, LIST, 2049) == "qlw"
     assert regime(47, 1, SUP, 512) == "wg_lds" and regime(47, 1, SUP, 513) == "trigv" and regime(39, 1, SUP, 1024) == "wg_lds"
