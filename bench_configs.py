@@ -386,6 +386,16 @@ def single_gpu(which, reps):
         w24 = tb.wf_array(m24, [33, 33, 33])
         res["dense24_32cubed_solve_on_grid_ms"] = wall(lambda: w24.solve_on_grid([0.0, 0.0, 0.0]))
         res["dense24_kpts_per_s"] = 32 ** 3 / res["dense24_32cubed_solve_on_grid_ms"] * 1e3
+        # (round 6) the step between 16 and 17 states: random sparse models on 33^3 points, with eigenvectors and without
+        # (k_e16 up to 16 states; k_hh32 + k_ql32_lanes + k_tw32_vectors from 17: profiles/HISTORY.md)
+        for nn in (16, 17, 24, 32):
+            mm = hp.random_model(tb.tb_model, nn, 3, 1, seed=5, nhop=6 * nn, rmax=1)
+            ww = tb.wf_array(mm, [33, 33, 33])
+            ms = wall(lambda ww=ww: ww.solve_on_grid([0.0, 0.0, 0.0]))
+            res["random%d_33cubed_solve_on_grid_ms" % nn] = ms
+            res["random%d_ns_per_point" % nn] = ms * 1e6 / 33 ** 3
+            kk = rng.uniform(-0.5, 0.5, (33 ** 3, 3))
+            res["random%d_33cubed_solve_all_eigenvalues_ms_incl_pcie" % nn] = wall(lambda mm=mm, kk=kk: mm.solve_all(kk))
         out.append(res)
     for o in out:
         print(json.dumps(o))
