@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void k_tw32_vectors(const int n, const int64_t 
 
     const int j16 = lane & 15, g = lane >> 4;
     constexpr int KS = NM / 4;                            // k-steps of 4 over the NM rows / columns that can be real
-    constexpr int NT = NM / 8;                            // 16-double tiles of a row of Q (2 NM doubles)
+    constexpr int NT = (NM + 7) / 8;                      // 16-double tiles of a row of Q (2 NM doubles)
     // (REFL: matrix 1 first -- its record is staged over its own image and the (d, e) region behind it, then matrix 0's over image 0
     // and the start of image 1, which is dead by then)
 #pragma unroll

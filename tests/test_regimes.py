@@ -70,7 +70,10 @@ REGIMES = [
     (18, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<24>"),
     (25, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<32>"),
     (32, 100, {"TBK_QLW_MIN": 0}, "tridiagonal path, k_hh32<32>"),
-    (17, 101, {"TBK_QLW_MIN": 0}, "tridiagonal path: k_hh32<24> leaves the reflector record, k_tw32_vectors<24, record>"),
+    (17, 101, {"TBK_QLW_MIN": 0}, "tridiagonal path: k_hh32<20> leaves the reflector record, k_ql32_lanes<20>, k_tw32_vectors<20, record>"),
+    (20, 101, {"TBK_QLW_MIN": 0}, "the same at the top of the 20-row forms"),
+    (21, 101, {"TBK_QLW_MIN": 0}, "k_hh32<24> / k_ql32_lanes<24> / k_tw32_vectors<24, record>"),
+    (18, 101, {"TBK_QLW_MIN": 0, "TBK_TW16_GAPTOL": "1e300"}, "k_tw32_vectors<20> lists every matrix: Q out, replay over the list"),
     (27, 101, {"TBK_QLW_MIN": 0, "TBK_QLW_STREAMS": 3}, "... three chunks in flight on the side streams (default: two from 16384 matrices)"),
     (19, 101, {"TBK_QLW_MIN": 0, "TBK_QLW_STREAMS": 2, "TBK_TW16_GAPTOL": "3e-2"}, "... two chunks in flight, some matrices listed"),
     (20, 101, {"TBK_QLW_MIN": 0, "TBK_QL32": 0}, "... the QL iteration with (d, e) in LDS (k_tridiag_ql_lanes) instead of k_ql32_lanes<24>"),
@@ -124,6 +127,8 @@ EVAL_ONLY = [
     (24, 100, {"TBK_QLW_BISECT": 0}, "tridiagonalise in LDS + lane-per-matrix QL"),
     (29, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<32, eigenvalues only> + lane-per-matrix QL in registers (k_ql32_lanes)"),
     (23, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<24, eigenvalues only> + k_ql32_lanes<24>"),
+    (18, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<20, eigenvalues only> + k_ql32_lanes<20>"),
+    (20, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<20, eigenvalues only> + k_ql32_lanes<20>"),
     (26, 100, {"TBK_QLW_BISECT": 0, "TBK_QLW_STREAMS": 3}, "... three chunks in flight"),
     (29, 100, {"TBK_QLW_BISECT": 0, "TBK_QL32": 0}, "k_hh32<32, eigenvalues only> + k_tridiag_ql_lanes"),
     (19, 100, {"TBK_HH32": 0}, "k_tridiag_lds + bisection"),
