@@ -6,7 +6,7 @@ cd /root/repo/pythtb_amd/csrc
   echo '#include "tbk_internal.h"'; echo '#include "tbk_solve_dev.h"'
   sed -n '/^struct QlwWork {/,/^};/p' tbk_solve_qlw.inl
   echo '#include "tbk_solve_ql32.inl"'
-  for a in "1, 20" "1, 24" "1, 32" "0, 32"; do
+  for a in "1, 28" "1, 24" "1, 32" "0, 32"; do
     echo "template __global__ void k_ql32_lanes<$a>(const int, const int64_t, const int64_t, const int64_t, const QlwWork, double*, const GridArgs, int*);"
   done
 } > ql32_dev.hip

@@ -11,7 +11,7 @@ cd /root/repo/pythtb_amd/csrc
   grep "^__host__ __device__ constexpr int hh32_rec" tbk_solve_hh32.inl
   sed -n '/^__device__ __forceinline__ double hh32_xhalf/,/^}/p' tbk_solve_hh32.inl
   echo '#include "tbk_solve_tw32.inl"'
-  echo 'template __global__ void k_tw32_vectors<1, 20, true>(const int, const int64_t, const int64_t, const int64_t, const QlwWork, cd*, const WfsView);'
+  echo 'template __global__ void k_tw32_vectors<1, 28, true>(const int, const int64_t, const int64_t, const int64_t, const QlwWork, cd*, const WfsView);'
   echo 'template __global__ void k_tw32_vectors<1, 32, false>(const int, const int64_t, const int64_t, const int64_t, const QlwWork, cd*, const WfsView);'
   echo 'template __global__ void k_tw32_vectors<1, 32, true>(const int, const int64_t, const int64_t, const int64_t, const QlwWork, cd*, const WfsView);'
 } > tw32_dev.hip

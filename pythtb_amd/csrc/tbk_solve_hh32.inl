@@ -67,7 +67,7 @@ __host__ __device__ constexpr int hh32_rec_size(const int NMAX) { return hh32_re
 template <int MODE, int VEC, int NMAX>
 __global__ __launch_bounds__(64) HH32_OCC void k_hh32(const ModelView mv, const int64_t nk, const ListArgs L, const GridArgs G, const int64_t id0,
                                               const int64_t nchunk, double2* __restrict__ de, cd* __restrict__ refl = nullptr) {
-    static_assert(NMAX == 20 || NMAX == 24 || NMAX == 32, "k_hh32: 17..20, 21..24 or 25..32 states");
+    static_assert(NMAX == 20 || NMAX == 24 || NMAX == 28 || NMAX == 32, "k_hh32: 17..20, 21..24, 25..28 or 29..32 states");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int HC = NMAX / 2;
     const int n = mv.nsta, ld = n | 1;

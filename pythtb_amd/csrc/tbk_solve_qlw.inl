@@ -759,7 +759,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     const int scap = VEC ? 8 * n : 0;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t per = (size_t)n * sizeof(double2) + (size_t)cap * sizeof(double2) + (size_t)scap * sizeof(unsigned) + sizeof(int) + (size_t)n * sizeof(int) +
-                       (VEC && n <= 32 ? (size_t)n * sizeof(double) + 16 + (size_t)hh32_rec_size(n <= 20 ? 20 : n <= 24 ? 24 : 32) * sizeof(cd) : 0);
+                       (VEC && n <= 32 ? (size_t)n * sizeof(double) + 16 + (size_t)hh32_rec_size(n <= 20 ? 20 : n <= 24 ? 24 : n <= 28 ? 28 : 32) * sizeof(cd) : 0);
     const size_t budget = (size_t)(K.qlw_ws_mb > 0 ? K.qlw_ws_mb : 4096) << 20;
     // n <= 32 with eigenvectors: the vectors from the twisted factorisation (k_tw32_vectors), the replay for the listed matrices only
     // (not for models whose levels come in pairs at a generic k -- ModelView::pairs_hint -- unless TBK_TW32=3: every matrix would be listed)
@@ -771,8 +771,8 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     // (at 17 states with AND without eigenvectors: the eigenvalues of the two forms of a call stay the same bits)
     const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && (n >= 18 || ((K.tw32 == 1 || K.tw32 == 3) && K.qlw_replay_reg != 0))));
     const bool refl = tw32 && hh32 && K.tw32 != 2;
-    // (17..20 states: forms of the three kernels with 20 rows / positions / lanes' worth of unrolled work -- the record format follows)
-    const int nm32 = n <= 20 ? 20 : n <= 24 ? 24 : 32;
+    // (17..20 and 25..28 states: forms of the three kernels with 20 / 28 rows / positions / lanes' worth of unrolled work -- the record format follows)
+    const int nm32 = n <= 20 ? 20 : n <= 24 ? 24 : n <= 28 ? 28 : 32;
     // n <= 32 on k_ql32_lanes: the QL kernel is ONE dependent chain per wavefront on half a wavefront per SIMD -- a quarter of the call during
     // which the chip idles.  Chunks on the context's side streams (the scheme of launch_tw16): a chunk's QL runs beside its
     // neighbours' tridiagonalisation and vectors.  (Round 6 tried this with the replay kernels and gained nothing: every stage was
@@ -880,9 +880,12 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         if (hh32 && refl) {
             if (n <= 20) hipLaunchKernelGGL((k_hh32<MODE, 2, 20>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
             else if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, 2, 24>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
+            else if (n <= 28) hipLaunchKernelGGL((k_hh32<MODE, 2, 28>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
             else hipLaunchKernelGGL((k_hh32<MODE, 2, 32>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
         } else if (hh32 && !VEC && n <= 20) {
             if constexpr (!VEC) hipLaunchKernelGGL((k_hh32<MODE, 0, 20>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
+        } else if (hh32 && !VEC && n > 24 && n <= 28) {
+            if constexpr (!VEC) hipLaunchKernelGGL((k_hh32<MODE, 0, 28>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
         } else if (hh32) {
             if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, VEC ? 1 : 0, 24>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
             else hipLaunchKernelGGL((k_hh32<MODE, VEC ? 1 : 0, 32>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, (cd*)nullptr);
@@ -906,6 +909,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
             const dim3 gq((unsigned)((nc + 63) / 64));
             if (ql32 && n <= 20) hipLaunchKernelGGL((k_ql32_lanes<MODE, 20>), gq, dim3(64), 0, sq, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
             else if (ql32 && n <= 24) hipLaunchKernelGGL((k_ql32_lanes<MODE, 24>), gq, dim3(64), 0, sq, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
+            else if (ql32 && n <= 28) hipLaunchKernelGGL((k_ql32_lanes<MODE, 28>), gq, dim3(64), 0, sq, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
             else if (ql32) hipLaunchKernelGGL((k_ql32_lanes<MODE, 32>), gq, dim3(64), 0, sq, n, nk, id0, nc, W, L.eval, G, ctx->flags_dev);
             else if (tw32)
                 hipLaunchKernelGGL((k_tridiag_ql_lanes<MODE, 2>), dim3((unsigned)((nc + 63) / 64)), dim3(64), lds2, sq, n, nk, id0, nc, W,
@@ -925,6 +929,10 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
                     hipLaunchKernelGGL((k_tw32_vectors<MODE, 20, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                     listed_ql();
                     hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24, true>), dim3(b32), dim3(256), 0, sq, n, nk, id0, nc, W, evec, G.wv);
+                } else if (n > 24 && n <= 28 && refl) {
+                    hipLaunchKernelGGL((k_tw32_vectors<MODE, 28, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
+                    listed_ql();
+                    hipLaunchKernelGGL((k_ql_replay_reg<MODE, 32, true>), dim3(b32), dim3(256), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                 } else if (n <= 24) {
                     if (refl) hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                     else hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, false>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);

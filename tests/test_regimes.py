@@ -73,6 +73,9 @@ REGIMES = [
     (17, 101, {"TBK_QLW_MIN": 0}, "tridiagonal path: k_hh32<20> leaves the reflector record, k_ql32_lanes<20>, k_tw32_vectors<20, record>"),
     (20, 101, {"TBK_QLW_MIN": 0}, "the same at the top of the 20-row forms"),
     (21, 101, {"TBK_QLW_MIN": 0}, "k_hh32<24> / k_ql32_lanes<24> / k_tw32_vectors<24, record>"),
+    (26, 101, {"TBK_QLW_MIN": 0}, "k_hh32<28> / k_ql32_lanes<28> / k_tw32_vectors<28, record>"),
+    (28, 101, {"TBK_QLW_MIN": 0}, "the same at the top of the 28-row forms"),
+    (27, 101, {"TBK_QLW_MIN": 0, "TBK_TW16_GAPTOL": "1e300"}, "k_tw32_vectors<28> lists every matrix: Q out, replay over the list"),
     (18, 101, {"TBK_QLW_MIN": 0, "TBK_TW16_GAPTOL": "1e300"}, "k_tw32_vectors<20> lists every matrix: Q out, replay over the list"),
     (27, 101, {"TBK_QLW_MIN": 0, "TBK_QLW_STREAMS": 3}, "... three chunks in flight on the side streams (default: two from 16384 matrices)"),
     (19, 101, {"TBK_QLW_MIN": 0, "TBK_QLW_STREAMS": 2, "TBK_TW16_GAPTOL": "3e-2"}, "... two chunks in flight, some matrices listed"),
@@ -128,6 +131,7 @@ EVAL_ONLY = [
     (29, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<32, eigenvalues only> + lane-per-matrix QL in registers (k_ql32_lanes)"),
     (23, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<24, eigenvalues only> + k_ql32_lanes<24>"),
     (18, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<20, eigenvalues only> + k_ql32_lanes<20>"),
+    (27, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<28, eigenvalues only> + k_ql32_lanes<28>"),
     (20, 100, {"TBK_QLW_BISECT": 0}, "k_hh32<20, eigenvalues only> + k_ql32_lanes<20>"),
     (26, 100, {"TBK_QLW_BISECT": 0, "TBK_QLW_STREAMS": 3}, "... three chunks in flight"),
     (29, 100, {"TBK_QLW_BISECT": 0, "TBK_QL32": 0}, "k_hh32<32, eigenvalues only> + k_tridiag_ql_lanes"),

@@ -50,7 +50,7 @@ def _special(n, rng):
     return out
 
 
-@pytest.mark.parametrize("n", [17, 20, 21, 23, 25, 31, 32, 33, 40, 47, 48, 49, 63, 64])
+@pytest.mark.parametrize("n", [17, 20, 21, 23, 25, 28, 29, 31, 32, 33, 40, 47, 48, 49, 63, 64])
 def test_supplied_matrices_against_numpy(n):
     from pythtb_amd import _lib
     rng = np.random.default_rng(100 + n)
