@@ -250,6 +250,39 @@ def test_models_with_paired_levels_at_every_k_take_the_replay_by_themselves(tb):
             assert np.max(np.abs(H @ V.T - V.T * ev)) < 1e-12 and np.max(np.abs(V.conj() @ V.T - np.eye(n))) < 1e-12
 
 
+@pytest.mark.parametrize("n", [19, 22, 27, 32])
+def test_structured_matrices_of_17_to_32_states(n):
+    """profiles/tw32_fuzz.py in small: direct sums of random blocks (T splits), identical blocks (levels degenerate ACROSS blocks: each
+    vector must stay inside its own block), blocks coupled by 1e-18 .. 1e-6, the same under a diagonal unitary -- against numpy."""
+    rng = np.random.default_rng(300 + n)
+    nk = 96
+
+    def herm(k, m):
+        a = rng.standard_normal((k, m, m)) + 1j * rng.standard_normal((k, m, m))
+        return a + a.conj().transpose(0, 2, 1)
+    cut, half = int(rng.integers(3, n - 3)), n // 2
+    two = np.zeros((nk, n, n), dtype=complex)
+    two[:, :cut, :cut], two[:, cut:, cut:] = herm(nk, cut), herm(nk, n - cut)
+    b = herm(nk, half)
+    same = np.zeros((nk, n, n), dtype=complex)
+    same[:, :half, :half], same[:, half:2 * half, half:2 * half] = b, b
+    if n % 2:
+        same[:, -1, -1] = rng.standard_normal(nk)
+    near = two.copy()
+    near[:, cut - 1, cut] = near[:, cut, cut - 1] = 10.0 ** rng.uniform(-18, -6, nk)
+    ph = np.exp(2j * np.pi * rng.random((nk, n)))
+    from pythtb_amd import _lib
+    for h in (two, same, near, ph[:, :, None] * same * ph.conj()[:, None, :]):
+        with _lib.knob("TBK_QLW_MIN", 0):
+            ev, vec = _eigh_batch(h)
+        ref = np.linalg.eigvalsh(h).T
+        nrm = np.abs(ref).max(axis=0)
+        V = vec.transpose(1, 0, 2)
+        assert (np.abs(ev - ref) / nrm).max() < 5e-14
+        assert (np.abs(np.einsum("kij,kbj->kbi", h, V) - V * ev.T[:, :, None]).reshape(nk, -1).max(axis=1) / nrm).max() < 5e-14
+        assert np.abs(np.einsum("kbi,kci->kbc", V.conj(), V) - np.eye(n)).max() < 5e-14
+
+
 def test_large_batch_takes_the_path_by_default(tb):
     """Above 8 x CUs matrices no knob is needed: 4096 k-points of a 20-orbital ribbon, against LAPACK on H(k)."""
     m = _ribbon(tb, 10)
