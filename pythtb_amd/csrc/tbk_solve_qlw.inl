@@ -60,6 +60,7 @@ struct QlwWork {           // chunk workspace (device pointers; see launch_qlw)
     int* count;            //                  their number
     double gaptol;
     unsigned long long* listed;   // the context's count of listed matrices (tbk_ctx_solver_stats)
+    int all_q;             //                  k_tw32_vectors<.., true>: Q only (every matrix of the call takes the rotation replay)
     cd* refl;              // [nchunk][hh32_rec_size(NM)]  the reflector records of k_hh32<.., 2, NM> (nullptr: Q sits in the output array)
 };
 
@@ -771,6 +772,10 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     // (at 17 states with AND without eigenvectors: the eigenvalues of the two forms of a call stay the same bits)
     const bool hh32 = n <= 32 && (K.hh32 == 2 || (K.hh32 != 0 && (n >= 18 || ((K.tw32 == 1 || K.tw32 == 3) && K.qlw_replay_reg != 0))));
     const bool refl = tw32 && hh32 && K.tw32 != 2;
+    // models with paired levels at every k (pairs_hint): the replay for every matrix, but Q from the reflector record (k_hh32<.., 2>, then
+    // k_tw32_vectors with W.all_q) instead of accumulated in k_hh32 -- 0.67 of that kernel's 1.75 ms per 36 k matrices of 32 states
+    // against ~0.25 ms
+    const bool hintq = VEC && n <= 32 && MODE != 2 && mv.pairs_hint && K.tw32 == 1 && K.qlw_replay_reg != 0 && hh32;
     // (17..20 and 25..28 states: forms of the three kernels with 20 / 28 rows / positions / lanes' worth of unrolled work -- the record format follows)
     const int nm32 = n <= 20 ? 20 : n <= 24 ? 24 : n <= 28 ? 28 : 32;
     // n <= 32 on k_ql32_lanes: the QL kernel is ONE dependent chain per wavefront on half a wavefront per SIMD -- a quarter of the call during
@@ -789,7 +794,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
     const size_t wone = al((size_t)chunk * n * sizeof(double2)) + 256 + al((size_t)chunk * cap * sizeof(double2)) +
                           al((size_t)chunk * scap * sizeof(unsigned)) + al((size_t)chunk * sizeof(int)) + al((size_t)chunk * n * sizeof(int)) + 1024 +
                           (tw32 ? al((size_t)chunk * n * sizeof(double)) + al((size_t)chunk * sizeof(uint2)) + al((size_t)chunk * sizeof(int)) + 256 : 0) +
-                          (refl ? al((size_t)chunk * hh32_rec_size(nm32) * sizeof(cd)) : 0);
+                          (refl || hintq ? al((size_t)chunk * hh32_rec_size(nm32) * sizeof(cd)) : 0);
     const size_t wbytes = wone * ns;
     if (wbytes > ctx->work_bytes) {
         TBK_HIP(hipStreamSynchronize(ctx->stream));
@@ -830,6 +835,10 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         W.listed = (unsigned long long*)(ctx->flags_dev + TBK_FLAG_LISTED);
         if (refl) W.refl = (cd*)p;
     }
+    if (hintq) {
+        W.refl = (cd*)p;
+        W.all_q = 1;
+    }
     Wsl[sl] = W;
     }
     hipStream_t st[3] = {ctx->stream, ctx->stream, ctx->stream};
@@ -869,7 +878,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         TBK_HIP(hipFuncSetAttribute((const void*)k_ql_backtransform<MODE, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     cd* evec = MODE == 1 ? nullptr : L.evec;
-    const size_t lds_hh = hh32_lds_bytes(n, MODE == 2 ? 0 : mv.nR, !VEC || refl);
+    const size_t lds_hh = hh32_lds_bytes(n, MODE == 2 ? 0 : mv.nR, !VEC || refl || hintq);
     // the chunks; an error inside leaves through the join below like success does (see launch_tw16)
     auto run_chunks = [&]() -> int {
     int which = 0;
@@ -877,7 +886,7 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         const int64_t nc = std::min<int64_t>(chunk, nk - id0);
         const QlwWork& W = Wsl[which];
         hipStream_t sq = st[which];
-        if (hh32 && refl) {
+        if (hh32 && (refl || hintq)) {
             if (n <= 20) hipLaunchKernelGGL((k_hh32<MODE, 2, 20>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
             else if (n <= 24) hipLaunchKernelGGL((k_hh32<MODE, 2, 24>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
             else if (n <= 28) hipLaunchKernelGGL((k_hh32<MODE, 2, 28>), dim3((unsigned)nc), dim3(64), lds_hh, sq, mv, nk, L, G, id0, nc, W.de, W.refl);
@@ -946,6 +955,13 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
                 }
             } else if (rw == 32 && K.qlw_replay_reg != 0) {
                 const unsigned b32 = (unsigned)((nc * 32 + 255) / 256);
+                if (hintq) {                             // Q = H_0 .. H_{n-3} D from the record into the output array, for the replay
+                    const unsigned b2 = (unsigned)((nc + 1) / 2);
+                    if (n <= 20) hipLaunchKernelGGL((k_tw32_vectors<MODE, 20, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
+                    else if (n <= 24) hipLaunchKernelGGL((k_tw32_vectors<MODE, 24, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
+                    else if (n <= 28) hipLaunchKernelGGL((k_tw32_vectors<MODE, 28, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
+                    else hipLaunchKernelGGL((k_tw32_vectors<MODE, 32, true>), dim3(b2), dim3(64), 0, sq, n, nk, id0, nc, W, evec, G.wv);
+                }
                 if (n <= 24)
                     hipLaunchKernelGGL((k_ql_replay_reg<MODE, 24>), dim3(b32), dim3(256), 0, sq, n, nk, id0, nc, W, evec, G.wv);
                 else

@@ -78,12 +78,16 @@ __global__ __launch_bounds__(64) void k_tw32_vectors(const int n, const int64_t 
     const int64_t slot = live ? slot_u : nchunk - 1;
 
     // ---- (a) twisted factorisation of T - lambda_j within the unreduced block of position j
-    const uint2 mt = W.meta[slot];                       // {split mask (bit i: e_i negligible in T; bit n-1 set), flagged}
+    // (W.all_q: only Q is wanted -- every matrix of the model goes through the rotation replay, ModelView::pairs_hint; stages (a), (b)
+    // are skipped and V = I in position order, as for a listed matrix)
+    const bool allq = REFL && W.all_q != 0;
+    uint2 mt{~0u, 0u};
+    if (!allq) mt = W.meta[slot];                        // {split mask (bit i: e_i negligible in T; bit n-1 set), flagged}
     const unsigned split = mt.x | (n < 32 ? ~0u << n : 0u);
     {
         double2 t{0.0, 0.0};
         int rk = j;
-        if (j < n) {
+        if (j < n && !allq) {
             t = W.de[(int64_t)j * nchunk + slot];
             rk = W.rank[(int64_t)j * nchunk + slot];
         }
@@ -91,12 +95,13 @@ __global__ __launch_bounds__(64) void k_tw32_vectors(const int n, const int64_t 
         Xd[mat * 32 + j] = t;
         Rk[mat * 32 + j] = rk;
     }
-    const double lam = j < n ? W.lam[(int64_t)j * nchunk + slot] : 0.0;
+    const double lam = j < n && !allq ? W.lam[(int64_t)j * nchunk + slot] : 0.0;
     TW_LDS_ORDER();
     bool bad = false;
     double lamv = lam;
     // (a second pass with the Rayleigh-quotient correction lambda + gamma_r / |z|^2 when a vector of the wavefront fails the residual
     // test: a listed matrix costs a whole lane-per-matrix QL chain with its record, ~0.15 ms per chunk whatever their number)
+    if (!allq)
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         const double lam = lamv;
@@ -200,8 +205,8 @@ __global__ __launch_bounds__(64) void k_tw32_vectors(const int n, const int64_t 
         const unsigned m0 = (unsigned)bal, m1 = (unsigned)(bal >> 32);
         const unsigned fl0 = (unsigned)__builtin_amdgcn_readlane((int)mt.y, 0), fl1 = (unsigned)__builtin_amdgcn_readlane((int)mt.y, 32);
         if (j == 0 && live && (mat ? m1 : m0) != 0 && mt.y == 0) W.list[atomicAdd(W.count, 1)] = (int)slot;
-        skip_m[0] = m0 != 0 || fl0 != 0;
-        skip_m[1] = m1 != 0 || fl1 != 0 || slot0 + 1 >= nchunk;
+        skip_m[0] = m0 != 0 || fl0 != 0 || allq;
+        skip_m[1] = m1 != 0 || fl1 != 0 || slot0 + 1 >= nchunk || allq;
     }
     constexpr int RSZ = hh32_rec_size(NM), NL = (RSZ + 63) / 64;
     if constexpr (REFL) {

@@ -208,16 +208,17 @@ def test_direct_vectors_of_17_to_32_states_list_next_to_nothing_and_chunks_in_fl
         assert np.max(np.abs(H @ V.T - V.T * ev)) < 1e-12 and np.max(np.abs(V.conj() @ V.T - np.eye(22))) < 1e-12
 
 
-def test_models_with_paired_levels_at_every_k_take_the_replay_by_themselves(tb):
-    """Two decoupled identical copies of a random 11-orbital model, orbitals interleaved: every level of the 22-state model is doubly
+@pytest.mark.parametrize("half", [9, 11, 13, 16])
+def test_models_with_paired_levels_at_every_k_take_the_replay_by_themselves(tb, half):
+    """Two decoupled identical copies of a random model of `half` orbitals, orbitals interleaved: every level of the model is doubly
     degenerate at every k (the situation of spin-degenerate and Kramers-paired bands).  The twisted factorisation gives both members of
     a pair the same vector, so k_tw32_vectors would list every matrix.  The library notices at upload (one generic k-point solved:
-    ModelView::pairs_hint) and such a model takes the rotation replay from the start: nothing is listed, and the eigenvectors are
+    ModelView::pairs_hint) and such a model takes the rotation replay from the start (Q from k_hh32's reflector record through
+    k_tw32_vectors in its Q-only form): nothing is listed, and the eigenvectors are
     eigenvectors, orthonormal inside the degenerate spaces too.  TBK_TW32=3 overrides the hint: every matrix listed, same quality."""
     from pythtb_amd import _lib
     ctx = _lib.default_context()
-    rng = np.random.default_rng(4)
-    half = 11
+    rng = np.random.default_rng(4 + half)
     orb = np.repeat(rng.random((half, 3)), 2, axis=0)
     m = hp.quiet(tb.tb_model, 3, 3, np.identity(3), orb)
     m.set_onsite(list(np.repeat(rng.standard_normal(half), 2)))
