@@ -908,7 +908,10 @@ static int launch_qlw(tbk_ctx* ctx, const ModelView& mv, int n, int64_t nk, cons
         // eigenvalues only, batches that leave the lane-per-matrix QL kernel a few wavefronts of pure latency: one thread per
         // EIGENVALUE instead (bisection, tbk_solve_trig.inl); TBK_QLW_BISECT=0 | 1 forces either
         bool bisect = false;
-        if constexpr (!VEC && MODE != 1) bisect = K.qlw_bisect >= 0 ? K.qlw_bisect == 1 : nc < (int64_t)ctx->cus * 16;
+        // (with k_ql32_lanes the crossover sits lower for 17..32 states -- profiles/bisect_crossover_probe.py, ms bisection | QL: n = 17 x 2048
+        // 0.20 | 0.16, n = 24 x 2048 0.29 | 0.26, x 4096 0.48 | 0.30, n = 32 x 2048 0.39 | 0.44, x 4096 0.57 | 0.48)
+        const int bis_per_cu = ql32 ? (n <= 20 ? 6 : n <= 24 ? 8 : 12) : 16;
+        if constexpr (!VEC && MODE != 1) bisect = K.qlw_bisect >= 0 ? K.qlw_bisect == 1 : nc < (int64_t)ctx->cus * bis_per_cu;
         if (bisect)
             hipLaunchKernelGGL(k_tridiag_bisect, dim3((unsigned)nc), dim3(64), (size_t)n * sizeof(double2) + 32 * sizeof(double), sq, n,
                                nk, id0, (const double2*)W.de, L.eval, (int64_t)1, nc, ctx->flags_dev);
